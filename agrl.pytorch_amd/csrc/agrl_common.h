@@ -1,0 +1,94 @@
+// Shared device/host helpers for libagrl_hip.so (gfx950 only: 64-lane wavefronts are assumed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/agrl_hip.h"
+
+#define AGRL_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- error plumbing: thread-local message, int status ------------------------------------------
+void agrl_set_error(const char* fmt, ...);
+
+#define AGRL_CHECK_ARG(cond, ...)       \
+    do {                                \
+        if (!(cond)) {                  \
+            agrl_set_error(__VA_ARGS__); \
+            return 1;                   \
+        }                               \
+    } while (0)
+
+#define AGRL_CHECK_LAUNCH(name)                                                   \
+    do {                                                                          \
+        hipError_t e__ = hipGetLastError();                                       \
+        if (e__ != hipSuccess) {                                                  \
+            agrl_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return 2;                                                             \
+        }                                                                         \
+    } while (0)
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved; matches torch .to(bfloat16)) ------------
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+    union {
+        uint32_t u;
+        float f;
+    } x;
+    x.u = ((uint32_t)v) << 16;
+    return x.f;
+}
+
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {
+    union {
+        uint32_t u;
+        float f;
+    } x;
+    x.f = f;
+    uint32_t u = x.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+// ---- wavefront reductions (64 lanes) -------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <typename T>
+struct DT;
+template <>
+struct DT<float> {
+    static constexpr int code = AGRL_F32;
+    static constexpr int epc = 4;  // elements per 16-byte chunk
+    __device__ static inline float ld(const float* p) { return *p; }
+    __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <>
+struct DT<bf16_t> {
+    static constexpr int code = AGRL_BF16;
+    static constexpr int epc = 8;
+    __device__ static inline float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static inline void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,364 @@
+// Implicit-GEMM convolution / linear / distance-matrix kernel for gfx950 (MI355X).
+//
+// One kernel family covers every dense contraction of the hot path:
+//   * Bottleneck convs (1x1, 3x3, stride 1|2) + folded BN + residual + ReLU   (vmgn.py:45-65)
+//   * GraphLayer Linear(2048,2048,bias=False)                                  (vmgn.py:148)
+//   * query x gallery distance matrix                                          (metrics/distance.py:59-89)
+//
+// GEMM view:  out[m][n] = epi( sum_k X[m][k] * Wt[n][k] ),  m = output pixel (n,oh,ow) of an NHWC
+// tensor, n = output channel, k = (r, s, cin) of an OHWI weight. Both operands are "K-contiguous",
+// so 16-byte chunks of K are the unit of staging: a k-tile is 128 bytes per row (64 bf16 / 32 fp32),
+// which lies inside one filter tap because Cin % (128/sizeof(T)) == 0.
+//
+// MI355X mapping
+//   * 256 threads = 4 wavefronts (2 x 2), block tile BM x BN, wave tile (BM/2) x (BN/2)
+//   * MFMA 16x16: bf16 -> v_mfma_f32_16x16x32_bf16, fp32 -> v_mfma_f32_16x16x4_f32 (exact fp32 fma
+//     chain); the WEIGHT fragment is the A operand and the PIXEL fragment the B operand, so a lane
+//     ends up holding 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores
+//   * global -> registers -> LDS staging, double-buffered LDS, one barrier per k-tile; the loads of
+//     tile t+1 are issued before the MFMAs of tile t
+//   * LDS rows are 128 B; 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7): ds_read_b128
+//     fragment reads and ds_write_b128 staging writes are both bank-conflict free
+//   * blockIdx -> tile map keeps the N-tiles of one M-tile on the same XCD (private L2) so the
+//     gathered activation tile is fetched from HBM once
+#include "agrl_common.h"
+
+struct IgemmParams {
+    const void* x;
+    const void* w;
+    const float* colv;  // per output channel (bias / gallery sq-norm) or nullptr
+    const float* rowv;  // per output pixel (query sq-norm) or nullptr
+    const void* res;    // residual, same layout/dtype as out, or nullptr
+    void* out;
+    float alpha;  // out = alpha*acc + rowv[m] + colv[n] + rowc (+ res) (relu)
+    float rowc;   // constant added when rowv == nullptr (cosine: 1.0)
+    int relu;
+    int M, N, K;
+    int Cin, H, W, OH, OW, R, S, stride, pad;
+    int ldo;     // row stride of out / res in elements
+    int vec_ok;  // 4-wide epilogue accesses are aligned
+};
+
+template <typename T>
+struct Frag;
+
+template <>
+struct Frag<bf16_t> {
+    // one 16-byte chunk = 8 bf16 = a quarter of the 32-deep k-step of v_mfma_f32_16x16x32_bf16
+    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+        bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
+        bf16x8_t bv = __builtin_bit_cast(bf16x8_t, b);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+    }
+};
+
+template <>
+struct Frag<float> {
+    // one 16-byte chunk = 4 fp32; lane group g = lane>>4 feeds hardware-k g of MFMA j with actual
+    // k = 4*chunk + j -- the same assignment for both operands, so the sum over k is complete
+    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+        return c;
+    }
+};
+
+__device__ inline int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename TOUT>
+__device__ inline void store4(TOUT* p, const float v[4]);
+template <>
+__device__ inline void store4<float>(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ inline void store4<bf16_t>(bf16_t* p, const float v[4]) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+template <typename TOUT>
+__device__ inline void load4(const TOUT* p, float v[4]);
+template <>
+__device__ inline void load4<float>(const float* p, float v[4]) {
+    float4 f = *reinterpret_cast<const float4*>(p);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+template <>
+__device__ inline void load4<bf16_t>(const bf16_t* p, float v[4]) {
+    uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = bf16_to_f32((bf16_t)(u.x & 0xffff)); v[1] = bf16_to_f32((bf16_t)(u.x >> 16));
+    v[2] = bf16_to_f32((bf16_t)(u.y & 0xffff)); v[3] = bf16_to_f32((bf16_t)(u.y >> 16));
+}
+
+template <typename TIN, typename TOUT, int BM, int BN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+    constexpr int EPC = DT<TIN>::epc;   // elements per 16-byte chunk
+    constexpr int BKE = 8 * EPC;        // elements per k-tile (128 bytes)
+    constexpr int AI = BM / 32;         // A rows staged per thread
+    constexpr int BI = BN / 32;         // B rows staged per thread
+    constexpr int FM = BM / 32;         // 16-pixel fragments per wave
+    constexpr int FN = BN / 32;         // 16-channel fragments per wave
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BN * 128;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1;
+    const int wn = wave >> 1;
+
+    // ---- XCD-aware block -> tile map: blocks b, b+8, b+16.. run on one XCD (observed b % 8);
+    // give each XCD a contiguous range of tiles, N-tiles of an M-tile adjacent.
+    const int nNt = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, within = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int mt = bid / nNt;
+    const int nt = bid - mt * nNt;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
+
+    // ---- per-thread staging coordinates
+    const int chunk = tid & 7;
+    const int srow = tid >> 3;  // 0..31
+    int a_ih0[AI], a_iw0[AI], a_nbase[AI];
+    bool a_ok[AI];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int gm = m0 + srow + 32 * i;
+        a_ok[i] = gm < p.M;
+        const int gmc = a_ok[i] ? gm : 0;
+        const int n = gmc / ohw;
+        const int rem = gmc - n * ohw;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        a_ih0[i] = oh * p.stride - p.pad;
+        a_iw0[i] = ow * p.stride - p.pad;
+        a_nbase[i] = n * p.H * p.W;
+    }
+    size_t b_off[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        int gn = n0 + srow + 32 * i;
+        gn = gn < p.N ? gn : p.N - 1;
+        b_off[i] = ((size_t)gn * p.K + chunk * EPC) * sizeof(TIN);
+    }
+
+    uint4 ra[AI], rb[BI];
+    int tap_r = 0, tap_s = 0, c0 = 0;  // filter tap and channel offset of the tile being LOADED
+    size_t kbyte = 0;                  // byte offset of that tile along K in the weight rows
+
+    auto load_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int ih = a_ih0[i] + tap_r;
+            const int iw = a_iw0[i] + tap_s;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            if (ok) {
+                const size_t off =
+                    ((size_t)(a_nbase[i] + ih * p.W + iw) * p.Cin + c0 + chunk * EPC) * sizeof(TIN);
+                ra[i] = *reinterpret_cast<const uint4*>(xg + off);
+            } else {
+                ra[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const uint4*>(wg + b_off[i] + kbyte);
+        // advance to the next k-tile
+        kbyte += 128;
+        c0 += BKE;
+        if (c0 == p.Cin) {
+            c0 = 0;
+            if (++tap_s == p.S) {
+                tap_s = 0;
+                ++tap_r;
+            }
+        }
+    };
+    auto store_lds = [&](int buf) {
+        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) *reinterpret_cast<uint4*>(sa + lds_off(srow + 32 * i, chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BI; ++i) *reinterpret_cast<uint4*>(sb + lds_off(srow + 32 * i, chunk)) = rb[i];
+    };
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BKE;
+    load_tiles();
+    store_lds(0);
+    __syncthreads();
+
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tiles();
+        const unsigned char* sa = smem + cur * (A_BYTES + B_BYTES);
+        const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 xf[FM], wf[FN];
+#pragma unroll
+            for (int b = 0; b < FM; ++b)
+                xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+                wf[a] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
+        }
+        if (more) store_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (g = lane>>4, j = lane&15) holds channels 4g..4g+3 of pixel j per fragment
+    TOUT* __restrict__ outp = reinterpret_cast<TOUT*>(p.out);
+    const TOUT* __restrict__ resp = reinterpret_cast<const TOUT*>(p.res);
+    const bool vec_ok = p.vec_ok != 0;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int gm = m0 + wm * (BM / 2) + b * 16 + frow;
+        if (gm >= p.M) continue;
+        const float rv = p.rowv ? p.rowv[gm] : p.rowc;
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int gn = n0 + wn * (BN / 2) + a * 16 + fchunk * 4;
+            if (gn >= p.N) continue;
+            const size_t o = (size_t)gm * p.ldo + gn;
+            float v[4];
+            if (vec_ok && gn + 3 < p.N) {
+                float cv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.colv) {
+                    const float4 c4 = *reinterpret_cast<const float4*>(p.colv + gn);
+                    cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(p.alpha, acc[a][b][r], rv + cv[r]);
+                if (resp) {
+                    float rr[4];
+                    load4<TOUT>(resp + o, rr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                store4<TOUT>(outp + o, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (gn + r < p.N) {
+                        float t = fmaf(p.alpha, acc[a][b][r], rv + (p.colv ? p.colv[gn + r] : 0.f));
+                        if (resp) t += DT<TOUT>::ld(resp + o + r);
+                        if (p.relu) t = fmaxf(t, 0.f);
+                        DT<TOUT>::st(outp + o + r, t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename TIN, typename TOUT>
+static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char* who) {
+    constexpr int BKE = 8 * DT<TIN>::epc;
+    IgemmParams p = p_in;
+    AGRL_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "%s: empty problem (M=%d N=%d K=%d)", who, p.M, p.N, p.K);
+    AGRL_CHECK_ARG(p.Cin % BKE == 0, "%s: Cin=%d must be a multiple of %d for this dtype", who, p.Cin, BKE);
+    AGRL_CHECK_ARG(p.K == p.R * p.S * p.Cin, "%s: K mismatch", who);
+    AGRL_CHECK_ARG((((uintptr_t)p.x) & 15) == 0 && (((uintptr_t)p.w) & 15) == 0,
+                   "%s: operands must be 16-byte aligned", who);
+    p.vec_ok = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 && (!p.colv || (((uintptr_t)p.colv) & 15) == 0) &&
+               (!p.res || (((uintptr_t)p.res) & 15) == 0);
+    if (p.N <= 64) {
+        const int grid = cdiv(p.M, 128) * cdiv(p.N, 64);
+        hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 64>), dim3(grid), dim3(256), 0, stream, p);
+    } else {
+        const int grid = cdiv(p.M, 128) * cdiv(p.N, 128);
+        hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 128>), dim3(grid), dim3(256), 0, stream, p);
+    }
+    AGRL_CHECK_LAUNCH(who);
+    return 0;
+}
+
+extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const void* residual,
+                                  void* out, int N, int H, int W, int Cin, int Cout, int R, int S,
+                                  int stride, int pad, int relu, int dtype, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && w && out, "agrl_conv2d_bn_act: null pointer");
+    AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "agrl_conv2d_bn_act: bad shape");
+    AGRL_CHECK_ARG(R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_conv2d_bn_act: bad filter geometry");
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_conv2d_bn_act: bad dtype %d", dtype);
+    IgemmParams p;
+    p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = relu;
+    p.OH = (H + 2 * pad - R) / stride + 1;
+    p.OW = (W + 2 * pad - S) / stride + 1;
+    AGRL_CHECK_ARG(p.OH > 0 && p.OW > 0, "agrl_conv2d_bn_act: empty output");
+    p.M = N * p.OH * p.OW; p.N = Cout; p.K = R * S * Cin;
+    p.Cin = Cin; p.H = H; p.W = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.ldo = Cout;
+    if (dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
+    return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
+}
+
+extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
+                                  int in_dtype, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && w && y, "agrl_linear_nobias: null pointer");
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16, "agrl_linear_nobias: bad dtype %d", in_dtype);
+    IgemmParams p;
+    p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0;
+    p.M = M; p.N = Nout; p.K = K;
+    p.Cin = K; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.ldo = Nout;
+    if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
+    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
+}
+
+extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist,
+                            int m, int n, int D, int ldd, int metric, int dtype, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(q && g && dist, "agrl_distmat: null pointer");
+    AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && ldd >= n, "agrl_distmat: bad shape m=%d n=%d D=%d ldd=%d", m, n, D, ldd);
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_distmat: bad dtype %d", dtype);
+    IgemmParams p;
+    p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0;
+    if (metric == AGRL_METRIC_EUCLIDEAN) {
+        AGRL_CHECK_ARG(qn && gn, "agrl_distmat: euclidean needs the squared row norms");
+        p.alpha = -2.f; p.rowv = qn; p.colv = gn; p.rowc = 0.f;
+    } else if (metric == AGRL_METRIC_COSINE) {
+        p.alpha = -1.f; p.rowv = nullptr; p.colv = nullptr; p.rowc = 1.f;
+    } else {
+        agrl_set_error("agrl_distmat: unknown metric %d", metric);
+        return 1;
+    }
+    p.M = m; p.N = n; p.K = D;
+    p.Cin = D; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.ldo = ldd;
+    if (dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_distmat");
+    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_distmat");
+}

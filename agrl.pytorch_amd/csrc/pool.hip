@@ -1,0 +1,275 @@
+// Pooling kernels of the per-tracklet tail (all HBM-bound, one pass over the layer4 maps):
+//   agrl_part_pool        : vmgn.py:298-300 (per-frame part of the global pool) + :304-308 (part pooling)
+//   agrl_row_sqnorm       : vmgn.py:276 (feat.norm over channels), distance.py:70-71 (row norms)
+//   agrl_attn_pool_bnneck : vmgn.py:270-278, :313-321 (attention-weighted temporal pooling, BNNeck, cat)
+//   agrl_row_l2_normalize : distance.py:86-87 (F.normalize p=2) / dtype conversion of embeddings
+#include "agrl_common.h"
+
+namespace {
+
+constexpr int MAX_PARTS = 16;
+
+struct PartBins {
+    int nparts;
+    int start[MAX_PARTS];
+    int end[MAX_PARTS];
+};
+
+template <typename T>
+__device__ inline void load_vec(const T* p, float v[DT<T>::epc]);
+template <>
+__device__ inline void load_vec<float>(const float* p, float v[4]) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+}
+template <>
+__device__ inline void load_vec<bf16_t>(const bf16_t* p, float v[8]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
+// grid = (frames, 2): y == 0 -> global sums of x4_1, y == 1 -> part means of x4_2.
+// thread -> one 16-byte channel vector; a wavefront reads 1 KiB contiguous per pixel.
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void part_pool_kernel(const T* __restrict__ x41, const T* __restrict__ x42,
+                                                        float* __restrict__ gsum, float* __restrict__ nodes,
+                                                        bf16_t* __restrict__ nodes_lp, int h, int w, int C,
+                                                        PartBins bins) {
+    constexpr int VEC = DT<T>::epc;
+    const int frame = blockIdx.x;
+    const int which = blockIdx.y;
+    const int P = bins.nparts;
+    for (int c = threadIdx.x * VEC; c < C; c += blockDim.x * VEC) {
+        if (which == 0) {
+            const T* src = x41 + (size_t)frame * h * w * C + c;
+            float acc[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+            const int npix = h * w;
+#pragma unroll 8
+            for (int pix = 0; pix < npix; ++pix) {
+                float v[VEC];
+                load_vec<T>(src + (size_t)pix * C, v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+            }
+            float* dst = gsum + (size_t)frame * C + c;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) dst[j] = acc[j];
+        } else {
+            const T* src = x42 + (size_t)frame * h * w * C + c;
+            float acc[NP][VEC];
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[q][j] = 0.f;
+            for (int y = 0; y < h; ++y) {
+                float rs[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) rs[j] = 0.f;
+#pragma unroll 8
+                for (int xx = 0; xx < w; ++xx) {
+                    float v[VEC];
+                    load_vec<T>(src + (size_t)(y * w + xx) * C, v);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) rs[j] += v[j];
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const bool in = q < P && y >= bins.start[q] && y < bins.end[q];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[q][j] += in ? rs[j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (q < P) {
+                    const float inv = 1.f / (float)((bins.end[q] - bins.start[q]) * w);
+                    float* dst = nodes + ((size_t)frame * P + q) * C + c;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float m = acc[q][j] * inv;
+                        dst[j] = m;
+                        if (nodes_lp) nodes_lp[((size_t)frame * P + q) * C + c + j] = f32_to_bf16(m);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// one wavefront per row
+template <typename T>
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const T* __restrict__ x, float* __restrict__ sqn, int R,
+                                                         int C) {
+    constexpr int VEC = DT<T>::epc;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const T* src = x + (size_t)row * C;
+    float s = 0.f;
+    if ((C % VEC) == 0) {
+        for (int c = lane * VEC; c < C; c += 64 * VEC) {
+            float v[VEC];
+            load_vec<T>(src + c, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s = fmaf(v[j], v[j], s);
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) {
+            const float v = DT<T>::ld(src + c);
+            s = fmaf(v, v, s);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) sqn[row] = s;
+}
+
+// y = x / max(||x||, 1e-12) (or plain conversion); one wavefront per row
+template <typename TOUT>
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ x, TOUT* __restrict__ y, int R,
+                                                            int C, int normalize) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* src = x + (size_t)row * C;
+    float den = 1.f;
+    if (normalize) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = src[c];
+            s = fmaf(v, v, s);
+        }
+        s = wave_sum(s);
+        den = fmaxf(sqrtf(s), 1e-12f);
+    }
+    TOUT* dst = y + (size_t)row * C;
+    for (int c = lane; c < C; c += 64) {
+        const float v = normalize ? src[c] / den : src[c];
+        DT<TOUT>::st(dst + c, v);
+    }
+}
+
+// grid = (B, C/256): thread -> one channel of one tracklet.
+__global__ __launch_bounds__(256) void attn_pool_bnneck_kernel(
+    const float* __restrict__ nodes, const float* __restrict__ sqn, const float* __restrict__ gsum,
+    const float* __restrict__ g_scale, const float* __restrict__ g_shift, const float* __restrict__ a_scale,
+    const float* __restrict__ a_shift, float* __restrict__ out, float* __restrict__ g_f, float* __restrict__ att_f,
+    int S, int P, int C, float inv_ghw) {
+    extern __shared__ __attribute__((aligned(16))) float s_att[];  // S*P attention weights
+    const int b = blockIdx.x;
+    const int V = S * P;
+    // a[s,p] = ||f[s,p]|| / max(sum_s ||f[s,p]||, 1e-12)   (F.normalize p=1 over the frame axis)
+    for (int q = threadIdx.x; q < P; q += blockDim.x) {
+        float tot = 0.f;
+        for (int s = 0; s < S; ++s) tot += sqrtf(sqn[(size_t)b * V + s * P + q]);
+        const float den = fmaxf(tot, 1e-12f);
+        for (int s = 0; s < S; ++s) s_att[s * P + q] = sqrtf(sqn[(size_t)b * V + s * P + q]) / den;
+    }
+    __syncthreads();
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    // attention branch: mean over parts of the attention-weighted sum over frames
+    float att = 0.f;
+    for (int q = 0; q < P; ++q) {
+        float fuse = 0.f;
+        for (int s = 0; s < S; ++s) fuse = fmaf(s_att[s * P + q], nodes[((size_t)b * V + s * P + q) * C + c], fuse);
+        att += fuse;
+    }
+    att /= (float)P;
+    // global branch: mean over (S, h, w)
+    float g = 0.f;
+    for (int s = 0; s < S; ++s) g += gsum[((size_t)b * S + s) * C + c];
+    g *= inv_ghw;
+    if (g_f) g_f[(size_t)b * C + c] = g;
+    if (att_f) att_f[(size_t)b * C + c] = att;
+    out[(size_t)b * 2 * C + c] = fmaf(g, g_scale[c], g_shift[c]);
+    out[(size_t)b * 2 * C + C + c] = fmaf(att, a_scale[c], a_shift[c]);
+}
+
+}  // namespace
+
+extern "C" int agrl_part_pool(const void* x4_1, const void* x4_2, float* gsum, float* nodes, void* nodes_lp, int F,
+                              int h, int w, int C, const int* splits, int n_splits, int dtype,
+                              agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x4_1 && x4_2 && gsum && nodes && splits, "agrl_part_pool: null pointer");
+    AGRL_CHECK_ARG(F > 0 && h > 0 && w > 0 && C > 0 && n_splits > 0, "agrl_part_pool: bad shape");
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_part_pool: bad dtype %d", dtype);
+    PartBins bins;
+    int P = 0;
+    for (int i = 0; i < n_splits; ++i) {
+        const int n = splits[i];
+        AGRL_CHECK_ARG(n > 0 && P + n <= MAX_PARTS, "agrl_part_pool: at most %d parts supported", MAX_PARTS);
+        for (int j = 0; j < n; ++j) {  // AdaptiveAvgPool2d bins: [floor(j*h/n), ceil((j+1)*h/n))
+            bins.start[P] = (j * h) / n;
+            bins.end[P] = ((j + 1) * h + n - 1) / n;
+            ++P;
+        }
+    }
+    bins.nparts = P;
+    for (int i = P; i < MAX_PARTS; ++i) bins.start[i] = bins.end[i] = 0;
+    const int vec = dtype == AGRL_F32 ? 4 : 8;
+    AGRL_CHECK_ARG(C % vec == 0, "agrl_part_pool: C=%d must be a multiple of %d", C, vec);
+    const int threads = 256;
+    dim3 grid(F, 2);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_PP(T, NP)                                                                                         \
+    hipLaunchKernelGGL((part_pool_kernel<T, NP>), grid, dim3(threads), 0, st, (const T*)x4_1, (const T*)x4_2, gsum, \
+                       nodes, (bf16_t*)nodes_lp, h, w, C, bins)
+    if (dtype == AGRL_F32) {
+        if (P <= 8) LAUNCH_PP(float, 8); else LAUNCH_PP(float, 16);
+    } else {
+        if (P <= 8) LAUNCH_PP(bf16_t, 8); else LAUNCH_PP(bf16_t, 16);
+    }
+#undef LAUNCH_PP
+    AGRL_CHECK_LAUNCH("agrl_part_pool");
+    return 0;
+}
+
+extern "C" int agrl_row_sqnorm(const void* x, float* sqn, int R, int C, int dtype, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && sqn && R > 0 && C > 0, "agrl_row_sqnorm: bad arguments");
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_row_sqnorm: bad dtype %d", dtype);
+    if (dtype == AGRL_F32)
+        hipLaunchKernelGGL(row_sqnorm_kernel<float>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, sqn, R, C);
+    else
+        hipLaunchKernelGGL(row_sqnorm_kernel<bf16_t>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, sqn, R, C);
+    AGRL_CHECK_LAUNCH("agrl_row_sqnorm");
+    return 0;
+}
+
+extern "C" int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int normalize, int out_dtype,
+                                     agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && y && R > 0 && C > 0, "agrl_row_l2_normalize: bad arguments");
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_row_l2_normalize: bad dtype %d", out_dtype);
+    if (out_dtype == AGRL_F32)
+        hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           (float*)y, R, C, normalize);
+    else
+        hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x,
+                           (bf16_t*)y, R, C, normalize);
+    AGRL_CHECK_LAUNCH("agrl_row_l2_normalize");
+    return 0;
+}
+
+extern "C" int agrl_attn_pool_bnneck(const float* nodes, const float* sqn, const float* gsum, const float* g_scale,
+                                     const float* g_shift, const float* a_scale, const float* a_shift, float* out,
+                                     float* g_f, float* att_f, int B, int S, int P, int C, int hw,
+                                     agrl_stream_t stream) {
+    AGRL_CHECK_ARG(nodes && sqn && gsum && g_scale && g_shift && a_scale && a_shift && out,
+                   "agrl_attn_pool_bnneck: null pointer");
+    AGRL_CHECK_ARG(B > 0 && S > 0 && P > 0 && C > 0 && hw > 0, "agrl_attn_pool_bnneck: bad shape");
+    const size_t lds = (size_t)S * P * sizeof(float);
+    AGRL_CHECK_ARG(lds <= 64 * 1024, "agrl_attn_pool_bnneck: S*P too large");
+    dim3 grid(B, cdiv(C, 256));
+    hipLaunchKernelGGL(attn_pool_bnneck_kernel, grid, dim3(256), lds, (hipStream_t)stream, nodes, sqn, gsum, g_scale,
+                       g_shift, a_scale, a_shift, out, g_f, att_f, S, P, C, 1.f / ((float)S * (float)hw));
+    AGRL_CHECK_LAUNCH("agrl_attn_pool_bnneck");
+    return 0;
+}

@@ -1,0 +1,266 @@
+// Ranking side of the match step, on device:
+//   agrl_rank_topk         np.argsort(distmat[k])[:max_rank]           torchreid/metrics/rank.py:170-172
+//   agrl_rank_mars         evaluate_mars / Compute_AP per query         torchreid/metrics/rank.py:160-212
+//   agrl_triplet_hard_mine batch-hard mining of TripletLoss.forward     torchreid/losses/hard_mine_triplet_loss.py:33-45
+//
+// Top-k is an exact radix select on the order-preserving 32-bit image of the fp32 distance followed by
+// an index-ordered tie fill and a bitonic sort of the k winners on (key, index): the result equals a
+// STABLE argsort truncated to k (ties -> lower gallery index), independent of launch geometry.
+#include "agrl_common.h"
+
+namespace {
+
+__device__ inline uint32_t dist_key(float d) {
+    uint32_t u = __float_as_uint(d);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN sorts last (numpy convention)
+    if (u == 0x80000000u) u = 0;                               // -0.0 == +0.0
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float key_dist(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(u);
+}
+
+// exclusive prefix sum of `flag` over the 256-thread block, plus the block total; s_w: 4+ ints of LDS
+__device__ inline int block_excl_scan(int flag, int* s_w, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag != 0);
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int c = s_w[w];
+        if (w < wave) base += c;
+        total += c;
+    }
+    __syncthreads();
+    return base + within;
+}
+
+__global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict__ dist, int n, int ldd, int k,
+                                                        int kpad, int idx_offset, int32_t* __restrict__ idx_out,
+                                                        float* __restrict__ val_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cand[];  // kpad composites
+    __shared__ int s_hist[256];
+    __shared__ int s_w[4];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_kth, s_cnt;
+    const int tid = threadIdx.x;
+    const float* row = dist + (size_t)blockIdx.x * ldd;
+
+    if (tid == 0) {
+        s_prefix = 0;
+        s_kth = k;
+        s_cnt = 0;
+    }
+    // ---- radix select of the k-th smallest key, 8 bits per pass, MSB first
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        s_hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+        for (int j = tid; j < n; j += 256) {
+            const uint32_t key = dist_key(row[j]);
+            if ((key & himask) == prefix) atomicAdd(&s_hist[(key >> shift) & 0xff], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int kth = s_kth, cum = 0, bin = 0;
+            for (; bin < 256; ++bin) {
+                const int c = s_hist[bin];
+                if (cum + c >= kth) break;
+                cum += c;
+            }
+            s_prefix = prefix | ((uint32_t)bin << shift);
+            s_kth = kth - cum;
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix;  // k-th smallest key
+    const int need_eq = s_kth;    // how many elements equal to T belong to the top-k (lowest indices)
+    // ---- collect: every key < T, and the first need_eq keys == T in index order
+    int eq_seen = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int j = base + tid;
+        uint32_t key = 0xffffffffu;
+        bool lt = false, eq = false;
+        if (j < n) {
+            key = dist_key(row[j]);
+            lt = key < T;
+            eq = key == T;
+        }
+        int tot_eq;
+        const int r_eq = block_excl_scan(eq ? 1 : 0, s_w, tot_eq);
+        const bool take = lt || (eq && eq_seen + r_eq < need_eq);
+        if (take) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            s_cand[pos] = ((unsigned long long)key << 32) | (uint32_t)j;
+        }
+        eq_seen += tot_eq;
+    }
+    __syncthreads();
+    for (int i = k + tid; i < kpad; i += 256) s_cand[i] = ~0ull;
+    __syncthreads();
+    // ---- bitonic sort of kpad composites (ascending)
+    for (int size = 2; size <= kpad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (kpad >> 1); i += 256) {
+                const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = s_cand[lo], b = s_cand[hi];
+                if ((a > b) == up) {
+                    s_cand[lo] = b;
+                    s_cand[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 256) {
+        const unsigned long long c = s_cand[i];
+        idx_out[(size_t)blockIdx.x * k + i] = (int32_t)(uint32_t)(c & 0xffffffffull) + idx_offset;
+        val_out[(size_t)blockIdx.x * k + i] = key_dist((uint32_t)(c >> 32));
+    }
+}
+
+// grid = m queries. Block-reduce ngood over the whole gallery, then lane 0 replays Compute_AP in fp64
+// with the reference's operation order, so ap is bit-identical to the Python floats.
+__global__ __launch_bounds__(256) void rank_mars_kernel(const int32_t* __restrict__ topk, const int32_t* __restrict__ q_pids,
+                                                        const int32_t* __restrict__ q_camids,
+                                                        const int32_t* __restrict__ g_pids,
+                                                        const int32_t* __restrict__ g_camids, int n, int k,
+                                                        double* __restrict__ ap_out, float* __restrict__ cmc_out) {
+    __shared__ int s_part[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int qp = q_pids[q], qc = q_camids[q];
+    int cnt = 0;
+    for (int j = tid; j < n; j += 256) cnt += (g_pids[j] == qp && g_camids[j] != qc) ? 1 : 0;
+    cnt = wave_sum_i(cnt);
+    if ((tid & 63) == 0) s_part[tid >> 6] = cnt;
+    __syncthreads();
+    float* cmc = cmc_out + (size_t)q * k;
+    for (int i = tid; i < k; i += 256) cmc[i] = 0.f;
+    __syncthreads();
+    if (tid != 0) return;
+    const int ngood = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    const int32_t* index = topk + (size_t)q * k;
+    double old_recall = 0.0, old_precision = 1.0, ap = 0.0;
+    int intersect = 0, j = 0, good_now = 0, njunk = 0;
+    int first_hit = -1;  // cmc[first_hit:] = 1
+    for (int t = 0; t < k; ++t) {
+        const int gi = index[t];
+        const int gp = g_pids[gi], gc = g_camids[gi];
+        const bool good = (gp == qp) && (gc != qc);
+        const bool junk = (gp == -1) || ((gp == qp) && (gc == qc));
+        int flag = 0;
+        if (good) {
+            const int from = t - njunk;
+            if (first_hit < 0 || from < first_hit) first_hit = from;
+            flag = 1;
+            ++good_now;
+        }
+        if (junk) {
+            ++njunk;
+            continue;
+        }
+        if (flag) ++intersect;
+        const double recall = (double)intersect / (double)ngood;
+        const double precision = (double)intersect / (double)(j + 1);
+        ap += (recall - old_recall) * (old_precision + precision) / 2;
+        old_recall = recall;
+        old_precision = precision;
+        ++j;
+        if (good_now == ngood) break;
+    }
+    if (first_hit >= 0)
+        for (int i = first_hit; i < k; ++i) cmc[i] = 1.f;
+    ap_out[q] = ap;
+}
+
+// grid = n anchors; each wavefront strides over the candidates j, lanes over the feature dim.
+__global__ __launch_bounds__(256) void triplet_mine_kernel(const float* __restrict__ x, const int32_t* __restrict__ pids,
+                                                           int n, int d, float* __restrict__ dist_ap,
+                                                           float* __restrict__ dist_an, int32_t* __restrict__ idx_ap,
+                                                           int32_t* __restrict__ idx_an) {
+    __shared__ float s_ap[4], s_an[4];
+    __shared__ int s_iap[4], s_ian[4];
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* xi = x + (size_t)i * d;
+    float ni = 0.f;
+    for (int c = lane; c < d; c += 64) ni = fmaf(xi[c], xi[c], ni);
+    ni = wave_sum(ni);
+    const int pi = pids[i];
+    float best_ap = -INFINITY, best_an = INFINITY;
+    int bi_ap = -1, bi_an = -1;
+    for (int j = wave; j < n; j += 4) {
+        const float* xj = x + (size_t)j * d;
+        float dot = 0.f, nj = 0.f;
+        for (int c = lane; c < d; c += 64) {
+            const float a = xi[c], b = xj[c];
+            dot = fmaf(a, b, dot);
+            nj = fmaf(b, b, nj);
+        }
+        dot = wave_sum(dot);
+        nj = wave_sum(nj);
+        const float dd = sqrtf(fmaxf((ni + nj) - 2.f * dot, 1e-12f));
+        if (pids[j] == pi) {
+            if (dd > best_ap) { best_ap = dd; bi_ap = j; }
+        } else {
+            if (dd < best_an) { best_an = dd; bi_an = j; }
+        }
+    }
+    if (lane == 0) {
+        s_ap[wave] = best_ap; s_iap[wave] = bi_ap;
+        s_an[wave] = best_an; s_ian[wave] = bi_an;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ap = -INFINITY, an = INFINITY;
+        int iap = -1, ian = -1;
+        for (int w = 0; w < 4; ++w) {
+            if (s_iap[w] >= 0 && (s_ap[w] > ap || (s_ap[w] == ap && s_iap[w] < iap))) { ap = s_ap[w]; iap = s_iap[w]; }
+            if (s_ian[w] >= 0 && (s_an[w] < an || (s_an[w] == an && s_ian[w] < ian))) { an = s_an[w]; ian = s_ian[w]; }
+        }
+        dist_ap[i] = ap; dist_an[i] = an; idx_ap[i] = iap; idx_an[i] = ian;
+    }
+}
+
+}  // namespace
+
+extern "C" int agrl_rank_topk(const float* dist, int m, int n, int ldd, int k, int idx_offset, int32_t* idx, float* val,
+                              agrl_stream_t stream) {
+    AGRL_CHECK_ARG(dist && idx && val, "agrl_rank_topk: null pointer");
+    AGRL_CHECK_ARG(m > 0 && n > 0 && ldd >= n, "agrl_rank_topk: bad shape m=%d n=%d ldd=%d", m, n, ldd);
+    AGRL_CHECK_ARG(k > 0 && k <= n && k <= 1024, "agrl_rank_topk: need 0 < k <= min(n, 1024), got k=%d n=%d", k, n);
+    int kpad = 2;
+    while (kpad < k) kpad <<= 1;
+    hipLaunchKernelGGL(rank_topk_kernel, dim3(m), dim3(256), (size_t)kpad * 8, (hipStream_t)stream, dist, n, ldd, k,
+                       kpad, idx_offset, idx, val);
+    AGRL_CHECK_LAUNCH("agrl_rank_topk");
+    return 0;
+}
+
+extern "C" int agrl_rank_mars(const int32_t* topk_idx, const int32_t* q_pids, const int32_t* q_camids,
+                              const int32_t* g_pids, const int32_t* g_camids, int m, int n, int k, double* ap,
+                              float* cmc, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(topk_idx && q_pids && q_camids && g_pids && g_camids && ap && cmc, "agrl_rank_mars: null pointer");
+    AGRL_CHECK_ARG(m > 0 && n > 0 && k > 0, "agrl_rank_mars: bad shape");
+    hipLaunchKernelGGL(rank_mars_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, topk_idx, q_pids, q_camids, g_pids,
+                       g_camids, n, k, ap, cmc);
+    AGRL_CHECK_LAUNCH("agrl_rank_mars");
+    return 0;
+}
+
+extern "C" int agrl_triplet_hard_mine(const float* x, const int32_t* pids, int n, int d, float* dist_ap, float* dist_an,
+                                      int32_t* idx_ap, int32_t* idx_an, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && pids && dist_ap && dist_an && idx_ap && idx_an, "agrl_triplet_hard_mine: null pointer");
+    AGRL_CHECK_ARG(n > 0 && d > 0, "agrl_triplet_hard_mine: bad shape");
+    hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, pids, n, d, dist_ap, dist_an,
+                       idx_ap, idx_an);
+    AGRL_CHECK_LAUNCH("agrl_triplet_hard_mine");
+    return 0;
+}

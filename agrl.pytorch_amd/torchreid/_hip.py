@@ -1,0 +1,132 @@
+"""ctypes binding of libagrl_hip.so -- the C-ABI declared in include/agrl_hip.h.
+
+The library is the product: there is NO fallback. ``lib()`` raises ``HipLibraryError`` when the
+shared object is missing or does not export a declared entry point, and every wrapper raises
+``HipKernelError`` carrying ``agrl_last_error()`` when an entry point returns non-zero.
+
+Only device pointers, sizes and the current HIP stream cross this boundary; torch is used by the
+callers for device memory and streams, never for the arithmetic of the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+F32 = 0
+BF16 = 1
+METRIC_EUCLIDEAN = 0
+METRIC_COSINE = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get(
+    "AGRL_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "lib", "libagrl_hip.so"))
+)
+
+
+class HipLibraryError(RuntimeError):
+    """libagrl_hip.so is missing or incomplete."""
+
+
+class HipKernelError(RuntimeError):
+    """An entry point of libagrl_hip.so returned a non-zero status."""
+
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+
+# name -> argtypes; must list every function include/agrl_hip.h declares (tests/test_cabi.py checks)
+SIGNATURES = {
+    "agrl_stem_conv_bn_relu_maxpool": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_linear_nobias": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "agrl_part_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
+    "agrl_graph_gram": [_p, _p, _i, _i, _i, _i, _p],
+    "agrl_graph_finalize": [_p, _i, _p, _p, _i, _i, _i, _i, _p],
+    "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _p],
+    "agrl_row_sqnorm": [_p, _p, _i, _i, _i, _p],
+    "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _p],
+    "agrl_distmat": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_rank_topk": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
+    "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                "libagrl_hip.so not found at %s -- build it with `python __graft_entry__.py` "
+                "(or `make -C agrl.pytorch_amd/csrc`); the HIP path has no fallback" % LIB_PATH
+            )
+        try:
+            h = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the host
+            raise HipLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(h, name)
+            except AttributeError:
+                raise HipLibraryError("%s does not export %s" % (LIB_PATH, name))
+            fn.argtypes = argtypes
+            fn.restype = _i
+        h.agrl_version.restype = _i
+        h.agrl_last_error.restype = C.c_char_p
+        _lib = h
+    return _lib
+
+
+def available() -> bool:
+    try:
+        lib()
+        return True
+    except HipLibraryError:
+        return False
+
+
+def _check(name, status):
+    if status != 0:
+        msg = lib().agrl_last_error()
+        raise HipKernelError("%s failed (%d): %s" % (name, status, msg.decode() if msg else "?"))
+
+
+def stream_ptr(device=None):
+    """The current HIP stream of the calling thread on ``device`` as an integer handle."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_cuda, "HIP entry points take device tensors"
+    assert t.is_contiguous(), "HIP entry points take contiguous tensors"
+    return t.data_ptr()
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError("unsupported dtype %s (float32 / bfloat16 only)" % dt)
+
+
+def call(name, *args):
+    """Invoke an entry point; the last argument (stream) is appended by the caller."""
+    fn = getattr(lib(), name)
+    _check(name, fn(*args))

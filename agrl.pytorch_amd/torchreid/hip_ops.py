@@ -1,0 +1,194 @@
+"""Tensor-level wrappers of the C-ABI entry points (include/agrl_hip.h).
+
+Each function checks shapes/dtypes, allocates the output through torch's caching allocator on the
+input's device, and launches on the calling thread's current HIP stream. No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _hip
+from ._hip import BF16, F32, METRIC_COSINE, METRIC_EUCLIDEAN, call, dtype_code, ptr
+
+
+def _stream(t):
+    return _hip.stream_ptr(t.device)
+
+
+def _dev(t):
+    return torch.cuda.device(t.device)
+
+
+def stem(x_nchw, w_ohwi, bias, out_dtype):
+    """(N,3,H,W) fp32 NCHW -> (N,PH,PW,64) NHWC. vmgn.py:281-284."""
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.size(1) == 3
+    x_nchw = x_nchw.contiguous()
+    N, _, H, W = x_nchw.shape
+    CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
+    out = torch.empty((N, PH, PW, 64), dtype=out_dtype, device=x_nchw.device)
+    with _dev(x_nchw):
+        call("agrl_stem_conv_bn_relu_maxpool", ptr(x_nchw), ptr(w_ohwi), ptr(bias), ptr(out), N, H, W,
+             dtype_code(out_dtype), _stream(x_nchw))
+    return out
+
+
+def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
+    """NHWC conv (BN folded) [+ residual] [+ ReLU]. vmgn.py:45-65."""
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w_ohwi.shape
+    assert Cin == Cin2 and x.dtype == w_ohwi.dtype
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    out = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == out.dtype
+    with _dev(x):
+        call("agrl_conv2d_bn_act", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
+             stride, pad, 1 if relu else 0, dtype_code(x.dtype), _stream(x))
+    return out
+
+
+def linear_nobias(x, w):
+    """(M,K) @ (N,K)^T -> fp32 (M,N). vmgn.py:148."""
+    M, K = x.shape
+    Nout, K2 = w.shape
+    assert K == K2 and x.dtype == w.dtype
+    y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        call("agrl_linear_nobias", ptr(x), ptr(w), ptr(y), M, K, Nout, dtype_code(x.dtype), _stream(x))
+    return y
+
+
+def part_pool(x4_1, x4_2, splits, want_lp):
+    """-> gsum (F,C), nodes (F,P,C) fp32 [, nodes_lp bf16]. vmgn.py:298-308."""
+    F_, h, w, Cc = x4_1.shape
+    assert x4_2.shape == x4_1.shape and x4_1.dtype == x4_2.dtype
+    P = int(sum(splits))
+    gsum = torch.empty((F_, Cc), dtype=torch.float32, device=x4_1.device)
+    nodes = torch.empty((F_, P, Cc), dtype=torch.float32, device=x4_1.device)
+    nodes_lp = torch.empty((F_, P, Cc), dtype=torch.bfloat16, device=x4_1.device) if want_lp else None
+    arr = (C.c_int * len(splits))(*[int(s) for s in splits])
+    with _dev(x4_1):
+        call("agrl_part_pool", ptr(x4_1), ptr(x4_2), ptr(gsum), ptr(nodes), ptr(nodes_lp), F_, h, w, Cc, arr,
+             len(splits), dtype_code(x4_1.dtype), _stream(x4_1))
+    return gsum, nodes, nodes_lp
+
+
+GRAM_CSLICE = 128
+
+
+def graph_matrix(f, adj, use_pose, learn_graph):
+    """f (B,V,C) fp32, adj (B,V,V) fp32 -> G (B,V,V). vmgn.py:114-120, :155-166."""
+    B, V, Cc = f.shape
+    G = torch.empty((B, V, V), dtype=torch.float32, device=f.device)
+    gram = None
+    nz = 0
+    with _dev(f):
+        if learn_graph:
+            nz = Cc // GRAM_CSLICE
+            gram = torch.empty((B, nz, V, V), dtype=torch.float32, device=f.device)
+            call("agrl_graph_gram", ptr(f), ptr(gram), B, V, Cc, GRAM_CSLICE, _stream(f))
+        if use_pose:
+            assert adj is not None and tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32
+            adj = adj.contiguous()
+        call("agrl_graph_finalize", ptr(gram), nz, ptr(adj) if use_pose else None, ptr(G), B, V,
+             1 if use_pose else 0, 1 if learn_graph else 0, _stream(f))
+    return G
+
+
+def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp):
+    """out = (1-gamma) f + gamma lrelu(bn(G h)). vmgn.py:168-172."""
+    B, V, Cc = f.shape
+    out = torch.empty_like(f)
+    out_lp = torch.empty((B, V, Cc), dtype=torch.bfloat16, device=f.device) if want_lp else None
+    with _dev(f):
+        call("agrl_graph_propagate", ptr(f), ptr(h), ptr(G), ptr(bn_scale), ptr(bn_shift), float(gamma), float(slope),
+             ptr(out), ptr(out_lp), B, V, Cc, _stream(f))
+    return out, out_lp
+
+
+def row_sqnorm(x):
+    R, Cc = x.shape
+    out = torch.empty((R,), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        call("agrl_row_sqnorm", ptr(x), ptr(out), R, Cc, dtype_code(x.dtype), _stream(x))
+    return out
+
+
+def attn_pool_bnneck(nodes, sqn, gsum, g_scale, g_shift, a_scale, a_shift, B, S, P, hw, want_feats=False):
+    """-> out (B,2C) [, g_f, att_f (B,C)]. vmgn.py:270-278, :299-301, :313-321."""
+    Cc = nodes.shape[-1]
+    out = torch.empty((B, 2 * Cc), dtype=torch.float32, device=nodes.device)
+    g_f = torch.empty((B, Cc), dtype=torch.float32, device=nodes.device) if want_feats else None
+    att_f = torch.empty((B, Cc), dtype=torch.float32, device=nodes.device) if want_feats else None
+    with _dev(nodes):
+        call("agrl_attn_pool_bnneck", ptr(nodes), ptr(sqn), ptr(gsum), ptr(g_scale), ptr(g_shift), ptr(a_scale),
+             ptr(a_shift), ptr(out), ptr(g_f), ptr(att_f), B, S, P, Cc, hw, _stream(nodes))
+    if want_feats:
+        return out, g_f, att_f
+    return out
+
+
+def row_l2_normalize(x, normalize, out_dtype):
+    R, Cc = x.shape
+    assert x.dtype == torch.float32
+    y = torch.empty((R, Cc), dtype=out_dtype, device=x.device)
+    with _dev(x):
+        call("agrl_row_l2_normalize", ptr(x), ptr(y), R, Cc, 1 if normalize else 0, dtype_code(out_dtype), _stream(x))
+    return y
+
+
+def distmat(q, g, metric, qn=None, gn=None, out=None):
+    """q (m,D), g (n,D) prepared operands (see metrics.distance) -> fp32 (m,n). distance.py:59-89."""
+    m, D = q.shape
+    n, D2 = g.shape
+    assert D == D2 and q.dtype == g.dtype
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=q.device)
+    assert out.stride(1) == 1 and out.dtype == torch.float32
+    code = METRIC_EUCLIDEAN if metric == "euclidean" else METRIC_COSINE
+    with _dev(q):
+        _hip.call("agrl_distmat", ptr(q), ptr(g), ptr(qn), ptr(gn), out.data_ptr(), m, n, D, out.stride(0), code,
+                  dtype_code(q.dtype), _stream(q))
+    return out
+
+
+def rank_topk(dist, k, idx_offset=0):
+    """dist (m,n) fp32 -> idx int32 (m,k), val fp32 (m,k), ascending (distance, index). rank.py:170-172."""
+    m, n = dist.shape
+    assert dist.dtype == torch.float32 and dist.stride(1) == 1
+    idx = torch.empty((m, k), dtype=torch.int32, device=dist.device)
+    val = torch.empty((m, k), dtype=torch.float32, device=dist.device)
+    with _dev(dist):
+        _hip.call("agrl_rank_topk", dist.data_ptr(), m, n, dist.stride(0), k, idx_offset, ptr(idx), ptr(val),
+                  _stream(dist))
+    return idx, val
+
+
+def rank_mars(topk_idx, q_pids, q_camids, g_pids, g_camids):
+    """-> ap fp64 (m), cmc fp32 (m,k). rank.py:160-212."""
+    m, k = topk_idx.shape
+    n = g_pids.numel()
+    ap = torch.empty((m,), dtype=torch.float64, device=topk_idx.device)
+    cmc = torch.empty((m, k), dtype=torch.float32, device=topk_idx.device)
+    for t in (topk_idx, q_pids, q_camids, g_pids, g_camids):
+        assert t.dtype == torch.int32
+    with _dev(topk_idx):
+        call("agrl_rank_mars", ptr(topk_idx), ptr(q_pids), ptr(q_camids), ptr(g_pids), ptr(g_camids), m, n, k, ptr(ap),
+             ptr(cmc), _stream(topk_idx))
+    return ap, cmc
+
+
+def triplet_hard_mine(x, pids):
+    """x (n,d) fp32, pids int32 (n) -> dist_ap, dist_an fp32 (n), idx_ap, idx_an int32 (n)."""
+    n, d = x.shape
+    assert x.dtype == torch.float32 and pids.dtype == torch.int32
+    dap = torch.empty((n,), dtype=torch.float32, device=x.device)
+    dan = torch.empty((n,), dtype=torch.float32, device=x.device)
+    iap = torch.empty((n,), dtype=torch.int32, device=x.device)
+    ian = torch.empty((n,), dtype=torch.int32, device=x.device)
+    with _dev(x):
+        call("agrl_triplet_hard_mine", ptr(x), ptr(pids), n, d, ptr(dap), ptr(dan), ptr(iap), ptr(ian), _stream(x))
+    return dap, dan, iap, ian

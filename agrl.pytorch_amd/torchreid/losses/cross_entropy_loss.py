@@ -1,0 +1,24 @@
+"""Label-smoothed cross entropy (reference: torchreid/losses/cross_entropy_loss.py:8-37). Stock PyTorch:
+the classifier loss is not on the forward-and-match hot path."""
+from __future__ import absolute_import
+from __future__ import division
+
+import torch
+import torch.nn as nn
+
+
+class CrossEntropyLabelSmooth(nn.Module):
+    """``-(sum_c q_c log p_c)`` averaged over the batch, ``q = (1-eps) onehot + eps/K``."""
+
+    def __init__(self, num_classes, epsilon=0.1, use_gpu=True):
+        super(CrossEntropyLabelSmooth, self).__init__()
+        self.num_classes = num_classes
+        self.epsilon = epsilon
+        self.use_gpu = use_gpu
+        self.logsoftmax = nn.LogSoftmax(dim=1)
+
+    def forward(self, inputs, targets):
+        log_probs = self.logsoftmax(inputs)
+        onehot = torch.zeros_like(log_probs).scatter_(1, targets.view(-1, 1).to(log_probs.device), 1)
+        smooth = (1 - self.epsilon) * onehot + self.epsilon / self.num_classes
+        return (-smooth * log_probs).mean(0).sum()

@@ -1,0 +1,58 @@
+"""Batch-hard triplet loss (reference: torchreid/losses/hard_mine_triplet_loss.py:8-50).
+
+The O(n^2) mining -- pairwise distances, hardest positive (max over same id, self included) and hardest
+negative (min over other ids) per anchor -- runs in one gfx950 kernel (``agrl_triplet_hard_mine``) when the
+features are CUDA tensors, replacing the reference's Python loop of 2n masked reductions. The loss value and
+its gradient are then formed by autograd on the 2n selected pairs only, with the reference's distance formula
+``sqrt(clamp(|a|^2 + |b|^2 - 2ab, 1e-12))``. CPU tensors use the stock-torch formulation (no GPU: plumbing).
+"""
+from __future__ import absolute_import
+from __future__ import division
+
+import torch
+import torch.nn as nn
+
+
+def _pair_dist(x, idx):
+    sq = x.pow(2).sum(dim=1)
+    other = x.index_select(0, idx)
+    d2 = sq + sq.index_select(0, idx) - 2 * (x * other).sum(dim=1)
+    return d2.clamp(min=1e-12).sqrt()
+
+
+class TripletLoss(nn.Module):
+    """``margin``: used when ``soft`` is False (MarginRankingLoss); ``soft``: log(1+exp(ap-an))."""
+
+    def __init__(self, margin=0.3, soft=True):
+        super(TripletLoss, self).__init__()
+        self.margin = margin
+        self.soft = soft
+        self.ranking_loss = nn.MarginRankingLoss(margin=margin)
+
+    def mine(self, inputs, targets):
+        """Indices (idx_ap, idx_an) of the hardest positive / negative of every anchor."""
+        n = inputs.size(0)
+        if inputs.is_cuda:
+            from torchreid import hip_ops as ops
+            _, _, idx_ap, idx_an = ops.triplet_hard_mine(inputs.detach().float().contiguous(),
+                                                         targets.detach().to(torch.int32).contiguous())
+            if bool((idx_an < 0).any()):
+                raise RuntimeError('an anchor has no negative in the batch')
+            return idx_ap.long(), idx_an.long()
+        with torch.no_grad():
+            sq = inputs.pow(2).sum(dim=1, keepdim=True)
+            dist = torch.addmm(sq + sq.t(), inputs, inputs.t(), beta=1, alpha=-2).clamp(min=1e-12).sqrt()
+            same = targets.view(n, 1).eq(targets.view(1, n))
+            idx_ap = dist.masked_fill(~same, float('-inf')).argmax(dim=1)
+            if bool(same.all(dim=1).any()):
+                raise RuntimeError('an anchor has no negative in the batch')
+            idx_an = dist.masked_fill(same, float('inf')).argmin(dim=1)
+        return idx_ap, idx_an
+
+    def forward(self, inputs, targets):
+        idx_ap, idx_an = self.mine(inputs, targets)
+        dist_ap = _pair_dist(inputs, idx_ap)
+        dist_an = _pair_dist(inputs, idx_an)
+        if self.soft:
+            return torch.log(1 + torch.exp(dist_ap - dist_an)).mean()
+        return self.ranking_loss(dist_an, dist_ap, torch.ones_like(dist_an))

@@ -1,0 +1,85 @@
+"""Query x gallery distance matrix (reference: torchreid/metrics/distance.py:11-89).
+
+``compute_distance_matrix`` keeps the reference's signature, assertions and error behaviour. Where it runs:
+
+* a GPU is present  -> the gfx950 GEMM of libagrl_hip.so (``agrl_distmat``) with the norm / normalise
+  prologue kernels; CUDA inputs stay on the device, CPU inputs (what the reference's ``test()`` passes,
+  train_vidreid_xent_htri.py:520) are uploaded, computed on the GPU and returned as a CPU tensor.
+  A missing library raises -- there is no silent fallback on a GPU host.
+* no GPU at all     -> stock torch CPU ops (the reference's CPU-runnable plumbing configuration).
+"""
+from __future__ import absolute_import
+from __future__ import print_function
+from __future__ import division
+
+import os
+
+import torch
+from torch.nn import functional as F
+
+# 'fp32' = exact-fp32 MFMA (parity mode); 'bf16' = bf16 operands, fp32 accumulation (throughput mode)
+HIP_PRECISION = os.environ.get('AGRL_HIP_PRECISION', 'fp32')
+
+
+def compute_distance_matrix(input1, input2, metric='euclidean'):
+    """(m, d), (n, d) -> (m, n) distance matrix; ``metric`` is "euclidean" (squared) or "cosine"."""
+    assert isinstance(input1, torch.Tensor)
+    assert isinstance(input2, torch.Tensor)
+    assert input1.dim() == 2, 'Expected 2-D tensor, but got {}-D'.format(input1.dim())
+    assert input2.dim() == 2, 'Expected 2-D tensor, but got {}-D'.format(input2.dim())
+    assert input1.size(1) == input2.size(1)
+
+    if metric == 'euclidean':
+        return euclidean_squared_distance(input1, input2)
+    if metric == 'cosine':
+        return cosine_distance(input1, input2)
+    raise ValueError(
+        'Unknown distance metric: {}. '
+        'Please choose either "euclidean" or "cosine"'.format(metric)
+    )
+
+
+def _use_hip(t):
+    return t.is_cuda or torch.cuda.is_available()
+
+
+def _hip_distmat(input1, input2, metric):
+    from torchreid import hip_ops as ops
+    from torchreid import _hip
+    _hip.lib()
+    home = input1.device
+    dev = home if input1.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    q = input1.detach().to(device=dev, dtype=torch.float32).contiguous()
+    g = input2.detach().to(device=dev, dtype=torch.float32).contiguous()
+    out = hip_distmat_device(q, g, metric, HIP_PRECISION)
+    return out if home == dev else out.to(home)
+
+
+def hip_distmat_device(q, g, metric, precision='fp32', out=None):
+    """Device-resident form: q (m,d), g (n,d) fp32 CUDA tensors -> fp32 (m,n) on the same device."""
+    from torchreid import hip_ops as ops
+    lp = precision == 'bf16'
+    dt = torch.bfloat16 if lp else torch.float32
+    if metric == 'euclidean':
+        qn, gn = ops.row_sqnorm(q), ops.row_sqnorm(g)
+        if lp:
+            q, g = ops.row_l2_normalize(q, False, dt), ops.row_l2_normalize(g, False, dt)
+        return ops.distmat(q, g, 'euclidean', qn, gn, out=out)
+    qh, gh = ops.row_l2_normalize(q, True, dt), ops.row_l2_normalize(g, True, dt)
+    return ops.distmat(qh, gh, 'cosine', out=out)
+
+
+def euclidean_squared_distance(input1, input2):
+    """||a||^2 + ||b||^2 - 2 a.b  (squared distance: no clamp, no sqrt)."""
+    if _use_hip(input1):
+        return _hip_distmat(input1, input2, 'euclidean')
+    sq1 = input1.pow(2).sum(dim=1, keepdim=True)
+    sq2 = input2.pow(2).sum(dim=1, keepdim=True)
+    return torch.addmm(sq1 + sq2.t(), input1, input2.t(), beta=1, alpha=-2)
+
+
+def cosine_distance(input1, input2):
+    """1 - cos(a, b) on L2-normalised rows (norms clamped at 1e-12)."""
+    if _use_hip(input1):
+        return _hip_distmat(input1, input2, 'cosine')
+    return 1 - torch.mm(F.normalize(input1, p=2, dim=1), F.normalize(input2, p=2, dim=1).t())

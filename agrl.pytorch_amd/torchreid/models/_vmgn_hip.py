@@ -1,0 +1,158 @@
+"""MI355X execution of the VMGN eval forward (reference call site: train_vidreid_xent_htri.py:469/:499
+-> GSTA.forward, vmgn.py:292-321) through the C-ABI of libagrl_hip.so.
+
+Data layout in HBM
+    frames        fp32 NCHW (B*S,3,H,W)  as handed over by the driver (read once by the stem kernel)
+    activations   NHWC (B*S, h, w, C) in the compute dtype (fp32 parity mode / bf16 throughput mode)
+    conv weights  OHWI (Cout, R, S, Cin), eval BatchNorm folded in, compute dtype; bias fp32
+    part nodes    fp32 (B, V = S*P, 2048) (+ a bf16 copy as the Linear's operand in bf16 mode)
+    graph         fp32 (B, V, V)
+    embedding     fp32 (B, 4096) = cat(BN(global), BN(attention))
+
+The packed weights are cached per (device, precision) and rebuilt when any parameter / buffer changed
+(data pointer or in-place version), unless ``model.hip_static_weights`` is set.
+"""
+from __future__ import annotations
+
+import torch
+
+from torchreid import hip_ops as ops
+from torchreid import _hip
+
+_PRECISIONS = {'fp32': torch.float32, 'bf16': torch.bfloat16}
+
+
+def _fold_conv_bn(conv, bn, dtype):
+    """conv (no bias) followed by eval BatchNorm2d -> (OHWI weight in dtype, fp32 bias)."""
+    w = conv.weight.detach().float()
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    w = (w * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous()
+    return w.to(dtype).contiguous(), shift.contiguous()
+
+
+def _fold_bn1d(bn):
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _pack_stage(stage, dtype):
+    blocks = []
+    for unit in stage:
+        blk = {
+            'c1': _fold_conv_bn(unit.conv1, unit.bn1, dtype),
+            'c2': _fold_conv_bn(unit.conv2, unit.bn2, dtype),
+            'c3': _fold_conv_bn(unit.conv3, unit.bn3, dtype),
+            'stride': unit.conv2.stride[0],
+            'ds': None,
+        }
+        if unit.downsample is not None:
+            blk['ds'] = _fold_conv_bn(unit.downsample[0], unit.downsample[1], dtype)
+            blk['ds_stride'] = unit.downsample[0].stride[0]
+        blocks.append(blk)
+    return blocks
+
+
+def _fingerprint(model):
+    return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+
+
+def pack_weights(model, device, precision):
+    """BN-fold + re-layout every weight of the eval forward for ``device``; cached on the model."""
+    if precision not in _PRECISIONS:
+        raise ValueError("hip_precision must be 'fp32' or 'bf16', got {!r}".format(precision))
+    key = (device.index if device.index is not None else torch.cuda.current_device(), precision)
+    cached = model._hip_packs.get(key)
+    if cached is not None and (model.hip_static_weights or cached['fingerprint'] == _fingerprint(model)):
+        return cached
+    first = next(model.parameters())
+    if first.device != device:
+        raise RuntimeError('model parameters live on {} but the input is on {}'.format(first.device, device))
+    dtype = _PRECISIONS[precision]
+    with torch.no_grad():
+        stem_w, stem_b = _fold_conv_bn(model.conv1, model.bn1, torch.float32)
+        pack = {
+            'dtype': dtype,
+            'stem': (stem_w, stem_b),
+            'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype),
+            'l4_1': _pack_stage(model.layer4_1, dtype),
+            'l4_2': _pack_stage(model.layer4_2, dtype),
+            'graph': [],
+            'g_bn': _fold_bn1d(model.global_bottleneck),
+            'a_bn': _fold_bn1d(model.att_bottleneck),
+        }
+        for layer in model.graph_layers:
+            scale, shift = _fold_bn1d(layer.bn)
+            pack['graph'].append({
+                'w': layer.linear.weight.detach().to(dtype).contiguous(),
+                'scale': scale, 'shift': shift,
+                'gamma': float(layer.gamma), 'slope': float(layer.relu.negative_slope),
+                'use_pose': bool(layer.use_pose), 'learn_graph': bool(layer.learn_graph),
+            })
+    pack['fingerprint'] = _fingerprint(model)
+    model._hip_packs[key] = pack
+    return pack
+
+
+def _run_block(x, blk):
+    y = ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
+    y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
+    shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
+    return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)
+
+
+def hip_featuremaps(model, frames, pack):
+    """(F,3,H,W) fp32 NCHW -> x4_1, x4_2 NHWC (F,h,w,2048). reference vmgn.py:280-290."""
+    a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+    for blk in pack['trunk']:
+        a = _run_block(a, blk)
+    x4_1 = a
+    for blk in pack['l4_1']:
+        x4_1 = _run_block(x4_1, blk)
+    x4_2 = a
+    for blk in pack['l4_2']:
+        x4_2 = _run_block(x4_2, blk)
+    return x4_1, x4_2
+
+
+def hip_graph_layers(nodes, nodes_lp, adj, pack):
+    """GraphLayer x num_gb on (B,V,C) fp32 nodes. reference vmgn.py:311-312 -> :142-172."""
+    lp = pack['dtype'] == torch.bfloat16
+    B, V, C = nodes.shape
+    n_layers = len(pack['graph'])
+    for i, g in enumerate(pack['graph']):
+        operand = nodes_lp if lp else nodes
+        h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
+        G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+        nodes, nodes_lp = ops.graph_propagate(nodes, h, G, g['scale'], g['shift'], g['gamma'], g['slope'],
+                                              want_lp=lp and i + 1 < n_layers)
+    return nodes
+
+
+def hip_forward(model, x, adj, return_feats=False):
+    """Eval forward on the GPU: (B,S,3,H,W) fp32, (B,V,V) fp32 -> (B,4096) fp32."""
+    _hip.lib()  # fail loudly before touching anything if the extension is missing
+    if x.dtype != torch.float32:
+        raise TypeError('frames must be float32, got {}'.format(x.dtype))
+    B, S, Cc, H, W = x.shape
+    P = model.total_split
+    V = S * P
+    if tuple(adj.shape) != (B, V, V):
+        raise ValueError('adj must be {} for S={} and {} parts, got {}'.format((B, V, V), S, P, tuple(adj.shape)))
+    pack = pack_weights(model, x.device, model.hip_precision)
+    lp = pack['dtype'] == torch.bfloat16
+    with torch.no_grad():
+        frames = x.reshape(B * S, Cc, H, W)
+        x4_1, x4_2 = hip_featuremaps(model, frames, pack)
+        F_, h, w, C = x4_1.shape
+        gsum, nodes, nodes_lp = ops.part_pool(x4_1, x4_2, model.total_split_list, want_lp=lp)
+        del x4_1, x4_2
+        nodes = nodes.view(B, V, C)
+        if nodes_lp is not None:
+            nodes_lp = nodes_lp.view(B, V, C)
+        adj32 = adj.detach().to(torch.float32).contiguous()
+        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack)
+        sqn = ops.row_sqnorm(nodes.view(B * V, C))
+        return ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
+                                    pack['a_bn'][1], B, S, P, h * w, want_feats=return_feats)

@@ -1,0 +1,170 @@
+/*
+ * agrl_hip.h -- C ABI of libagrl_hip.so: the MI355X (gfx950) kernels of AGRL's per-tracklet
+ * forward-and-match hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (the Python host side allocates
+ *     through torch); the library allocates nothing and keeps no global mutable state
+ *   - every entry point is re-entrant, takes the HIP stream to launch on (hipStream_t passed as
+ *     void*), never synchronises the device, and returns 0 on success / non-zero on error;
+ *     agrl_last_error() returns a thread-local message for the last non-zero return
+ *   - activations are NHWC ("pixel-major"): x[n][h][w][c]; conv weights are OHWI:
+ *     w[cout][r][s][cin] with eval-mode BatchNorm already folded in (scale into w, shift into bias)
+ *   - dtype codes: AGRL_F32 = 0 (exact-fp32 MFMA, the parity mode), AGRL_BF16 = 1 (bf16 MFMA with
+ *     fp32 accumulation, the throughput mode)
+ *
+ * Each entry point cites the reference call site it replaces (paths relative to the reference
+ * tree weleen/AGRL.pytorch).
+ */
+#ifndef AGRL_HIP_H
+#define AGRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGRL_F32 0
+#define AGRL_BF16 1
+
+#define AGRL_METRIC_EUCLIDEAN 0 /* squared euclidean, torchreid/metrics/distance.py:59-73 */
+#define AGRL_METRIC_COSINE 1    /* 1 - cos,          torchreid/metrics/distance.py:76-89 */
+
+typedef void* agrl_stream_t; /* hipStream_t */
+
+/* library version (major*10000 + minor*100 + patch) and last error of the calling thread */
+int agrl_version(void);
+const char* agrl_last_error(void);
+
+/* ---- conv stages ------------------------------------------------------------------------- */
+
+/* Stem: conv 7x7/2 pad 3 (3->64, BN folded) + ReLU + maxpool 3x3/2 pad 1.
+ * Replaces torchreid/models/vmgn.py:281-284 (GSTA.featuremaps: conv1, bn1, relu, maxpool).
+ *   x    : fp32 NCHW (N,3,H,W) -- the layout the reference driver hands to model(imgs, adj)
+ *   w    : fp32 (64, 7, 7, 3) OHWI, BN folded; bias fp32 (64)
+ *   out  : NHWC (N, PH, PW, 64) of out_dtype, PH = ((H+6-7)/2+1 +2-3)/2+1 (64x32 for 256x128) */
+int agrl_stem_conv_bn_relu_maxpool(const float* x, const float* w, const float* bias, void* out,
+                                   int N, int H, int W, int out_dtype, agrl_stream_t stream);
+
+/* Implicit-GEMM convolution (1x1 or 3x3, stride 1|2) + folded BN + optional residual + optional
+ * ReLU, NHWC in / NHWC out. One call == one (conv, bn[, +residual][, relu]) group of
+ * Bottleneck.forward, torchreid/models/vmgn.py:45-65 (and the downsample branch :58-59).
+ *   x (N,H,W,Cin) dtype ; w (Cout,R,S,Cin) dtype ; bias fp32 (Cout) ;
+ *   residual NULL or (N,OH,OW,Cout) dtype ; out (N,OH,OW,Cout) dtype
+ *   Cin must be a multiple of 64 (bf16) / 32 (fp32). */
+int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const void* residual,
+                       void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                       int pad, int relu, int dtype, agrl_stream_t stream);
+
+/* y = x @ w^T (no bias): x (M,K) in_dtype, w (Nout,K) in_dtype, y (M,Nout) fp32.
+ * Replaces GraphLayer's nn.Linear(2048,2048,bias=False), torchreid/models/vmgn.py:148. */
+int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
+                       int in_dtype, agrl_stream_t stream);
+
+/* ---- pooling ------------------------------------------------------------------------------- */
+
+/* Part pooling + per-frame global pooling, one pass over the two layer4 maps.
+ * Replaces torchreid/models/vmgn.py:298-300 (AdaptiveAvgPool3d over (S,h,w); here the per-frame
+ * sums, finished by agrl_attn_pool_bnneck) and :304-308 (AdaptiveAvgPool2d((n,1)) for each n in
+ * total_split_list, cat, transpose).
+ *   x4_1, x4_2 : NHWC (F, h, w, C) of dtype, F = B*S frames
+ *   splits     : host array of n_splits part counts (e.g. {4,2,1}); P = sum(splits)
+ *   gsum       : fp32 (F, C)   sum over (h,w) of x4_1 per frame (NOT yet divided)
+ *   nodes      : fp32 (F, P, C) part means of x4_2, node index = frame*P + part
+ *   nodes_lp   : NULL or bf16 (F, P, C) copy of nodes (A operand of the bf16 Linear) */
+int agrl_part_pool(const void* x4_1, const void* x4_2, float* gsum, float* nodes, void* nodes_lp,
+                   int F, int h, int w, int C, const int* splits, int n_splits, int dtype,
+                   agrl_stream_t stream);
+
+/* ---- adaptive graph convolution (GraphLayer) -------------------------------------------------- */
+
+/* Partial Gram matrices of the node features: gram_part[b][z][i][j] = sum over the z-th channel
+ * slice of f[b,i,c]*f[b,j,c]. First half of GraphLayer.get_sim_matrix (dist_method='l2'),
+ * torchreid/models/vmgn.py:114-118.  f fp32 (B,V,C); gram_part fp32 (B, nz, V, V); nz = C/cslice */
+int agrl_graph_gram(const float* f, float* gram_part, int B, int V, int C, int cslice,
+                    agrl_stream_t stream);
+
+/* Finish the adaptive graph: sum the Gram partials, d = sqrt(clamp(n_i+n_j-2g_ij, 1e-12)),
+ * sim = 2/(exp(d)+1), row-L1-normalise sim and adj, G = (adj^ + sim^)/2 (or one of them).
+ * torchreid/models/vmgn.py:118-120 and :155-166.
+ *   adj fp32 (B,V,V) or NULL when use_pose == 0; gram_part may be NULL when learn_graph == 0
+ *   G   fp32 (B,V,V) */
+int agrl_graph_finalize(const float* gram_part, int nz, const float* adj, float* G, int B, int V,
+                        int use_pose, int learn_graph, agrl_stream_t stream);
+
+/* Message pass + BatchNorm1d(eval) + LeakyReLU + residual mix:
+ *   out[b,v,c] = (1-gamma)*f[b,v,c] + gamma*lrelu(bn_scale[c]*(sum_u G[b,v,u]*h[b,u,c]) + bn_shift[c])
+ * torchreid/models/vmgn.py:168-172.
+ *   f,h fp32 (B,V,C); G fp32 (B,V,V); out fp32 (B,V,C); out_lp NULL or bf16 copy of out (the A
+ *   operand of the next layer's bf16 Linear). Deterministic: no atomics. */
+int agrl_graph_propagate(const float* f, const float* h, const float* G, const float* bn_scale,
+                         const float* bn_shift, float gamma, float slope, float* out, void* out_lp,
+                         int B, int V, int C, agrl_stream_t stream);
+
+/* ---- attention temporal pooling + BNNeck tail -------------------------------------------------- */
+
+/* sqn[r] = sum_c x[r,c]^2 for R rows of C fp32 (one wavefront per row).
+ * First step of GSTA._attention_op (feat.norm(p=2, dim=3)), torchreid/models/vmgn.py:276. */
+int agrl_row_sqnorm(const void* x, float* sqn, int R, int C, int dtype, agrl_stream_t stream);
+
+/* a[s,p] = ||f[b,s,p]|| / max(sum_s ||f[b,s,p]||, 1e-12); att_f[b,c] = mean_p sum_s a[s,p] f[b,s,p,c];
+ * g_f[b,c] = sum_s gsum[b*S+s,c] / (S*hw); out[b] = cat(BN_g(g_f), BN_att(att_f)).
+ * torchreid/models/vmgn.py:270-278, :299-301, :313-321 (eval return).
+ *   nodes fp32 (B,S,P,C); sqn fp32 (B,S,P); gsum fp32 (B*S,C); g_scale/g_shift/a_scale/a_shift
+ *   fp32 (C) = eval BatchNorm1d folded to scale/shift; out fp32 (B, 2C);
+ *   g_f, att_f: NULL or fp32 (B,C) pre-BN features (the train-mode f_list, vmgn.py:346-355). */
+int agrl_attn_pool_bnneck(const float* nodes, const float* sqn, const float* gsum,
+                          const float* g_scale, const float* g_shift, const float* a_scale,
+                          const float* a_shift, float* out, float* g_f, float* att_f, int B, int S,
+                          int P, int C, int hw, agrl_stream_t stream);
+
+/* ---- distance matrix + ranking ------------------------------------------------------------------ */
+
+/* y[r,:] = x[r,:] / max(||x[r,:]||_2, 1e-12)  (F.normalize p=2), x fp32 (R,C) -> y out_dtype.
+ * torchreid/metrics/distance.py:86-87. With normalize == 0 it is a plain dtype conversion. */
+int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int normalize, int out_dtype,
+                          agrl_stream_t stream);
+
+/* dist (m,n) fp32 between q (m,D) and g (n,D) of dtype.
+ *   euclidean: qn[i] + gn[j] - 2 q_i.g_j (squared, no clamp/sqrt), distance.py:59-73;
+ *              qn, gn = fp32 squared row norms (agrl_row_sqnorm of the fp32 embeddings)
+ *   cosine   : 1 - q^_i.g^_j with q^, g^ already L2-normalised rows (qn, gn ignored, may be NULL),
+ *              distance.py:76-89
+ *   ldd = row stride of dist in elements (>= n), so a rank can write its gallery shard's columns
+ *   straight into the full matrix. */
+int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist,
+                 int m, int n, int D, int ldd, int metric, int dtype, agrl_stream_t stream);
+
+/* Per query row: the k smallest distances in ascending (distance, gallery index) order -- i.e.
+ * np.argsort(dist[i])[:k] with ties broken towards the lower index -- torchreid/metrics/rank.py:170-172.
+ *   dist fp32 (m, n) row stride ldd; idx int32 (m,k) (gallery index + idx_offset); val fp32 (m,k).
+ *   NaNs sort last. Requires k <= 1024, k <= n. */
+int agrl_rank_topk(const float* dist, int m, int n, int ldd, int k, int idx_offset, int32_t* idx,
+                   float* val, agrl_stream_t stream);
+
+/* MARS evaluation of every query from its top-k list: evaluate_mars + Compute_AP,
+ * torchreid/metrics/rank.py:160-212.
+ *   topk_idx int32 (m,k) global gallery indices (ascending distance); q_pids,q_camids int32 (m);
+ *   g_pids,g_camids int32 (n)
+ *   ap fp64 (m); cmc fp32 (m,k) (0/1). A query with no good match gets ap = NaN (the reference
+ *   raises ZeroDivisionError there unless its whole top-k is junk, rank.py:203). */
+int agrl_rank_mars(const int32_t* topk_idx, const int32_t* q_pids, const int32_t* q_camids,
+                   const int32_t* g_pids, const int32_t* g_camids, int m, int n, int k, double* ap,
+                   float* cmc, agrl_stream_t stream);
+
+/* ---- batch-hard triplet mining (train step, BASELINE config 4) ----------------------------------- */
+
+/* dist = sqrt(clamp(||x_i||^2+||x_j||^2-2x_i.x_j, 1e-12)); per anchor hardest positive (max over
+ * same pid, self included) and hardest negative (min over other pids).
+ * torchreid/losses/hard_mine_triplet_loss.py:33-45.
+ *   x fp32 (n,d); pids int32 (n); dist_ap, dist_an fp32 (n); idx_ap, idx_an int32 (n) argmax/argmin
+ *   (lowest index on ties). */
+int agrl_triplet_hard_mine(const float* x, const int32_t* pids, int n, int d, float* dist_ap,
+                           float* dist_an, int32_t* idx_ap, int32_t* idx_an, agrl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGRL_HIP_H */

@@ -1,0 +1,274 @@
+"""GPU parity tests, kernel by kernel, through the C-ABI (libagrl_hip.so) against the CPU oracle.
+
+fp32 (exact-fp32 MFMA) must agree with the oracle to ~1e-5 relative; the north-star bar is 1e-3.
+bf16 is the throughput mode: operands rounded to bf16, fp32 accumulation -> tolerance 2e-2 of the output scale.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vmgn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def rel_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp(min=1e-30)).item()
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, R, stride, residual, relu
+    (3, 10, 7, 64, 64, 1, 1, False, True),      # ragged M (210 pixels), small N tile
+    (2, 16, 8, 64, 256, 1, 1, True, True),      # conv3 + residual
+    (2, 16, 8, 128, 128, 3, 1, False, True),    # 3x3 pad 1
+    (2, 16, 8, 128, 128, 3, 2, False, True),    # 3x3 stride 2
+    (2, 16, 8, 256, 512, 1, 2, False, False),   # downsample 1x1 stride 2, no relu
+    (1, 9, 5, 512, 200, 3, 1, True, False),     # ragged N (200 channels), odd spatial
+    (4, 16, 8, 1024, 512, 1, 1, False, True),   # deep K
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bn_act(case, dtype):
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, Cout, R, stride, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, R, R), generator=g) / np.sqrt(Cin * R * R)
+    b = torch.randn((Cout,), generator=g)
+    pad = R // 2
+    if dtype == torch.bfloat16:  # the kernel sees bf16-rounded operands; so does the reference
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, bias=b, stride=stride, padding=pad)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        if dtype == torch.bfloat16:
+            res = res.bfloat16().float()
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    out = ops.conv_bn_act(nhwc(x, dtype), w.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV), b.to(DEV), stride, pad,
+                          relu, residual=None if res is None else nhwc(res, dtype))
+    torch.cuda.synchronize()
+    got = out.float().permute(0, 3, 1, 2)
+    e = rel_err(got, ref)
+    print("conv", case, dtype, "rel err %.3e" % e)
+    assert e < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 256, 128), (3, 64, 48), (1, 37, 29)])
+def test_stem(shape, dtype):
+    from torchreid import hip_ops as ops
+    N, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((N, 3, H, W), generator=g)
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.1
+    b = torch.randn((64,), generator=g) * 0.1
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w, bias=b, stride=2, padding=3)), 3, 2, 1)
+    out = ops.stem(x.to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), dtype)
+    torch.cuda.synchronize()
+    e = rel_err(out.float().permute(0, 3, 1, 2), ref)
+    print("stem", shape, dtype, "rel err %.3e" % e)
+    assert e < (1e-5 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 4, 16, 8, 2048, [4, 2, 1]), (1, 3, 14, 7, 512, [4, 2, 1]), (2, 2, 16, 8, 256, [8, 4, 2, 1]), (1, 2, 16, 8, 256, [4])])
+def test_part_pool(cfg, dtype):
+    from torchreid import hip_ops as ops
+    B, S, h, w, C, splits = cfg
+    g = torch.Generator().manual_seed(11)
+    x41 = torch.rand((B * S, C, h, w), generator=g)
+    x42 = torch.rand((B * S, C, h, w), generator=g)
+    if dtype == torch.bfloat16:
+        x41, x42 = x41.bfloat16().float(), x42.bfloat16().float()
+    gsum, nodes, nodes_lp = ops.part_pool(nhwc(x41, dtype), nhwc(x42, dtype), splits, want_lp=True)
+    torch.cuda.synchronize()
+    ref_nodes = O.part_nodes(x42, B, S, splits)
+    ref_g = O.global_feature(x41, B, S)
+    e1 = rel_err(nodes.view(B, -1, C), ref_nodes)
+    e2 = rel_err(gsum.view(B, S, C).sum(1) / (S * h * w), ref_g)
+    e3 = rel_err(nodes_lp.float().view(B, -1, C), ref_nodes)
+    print("part_pool", cfg, dtype, "%.3e %.3e %.3e" % (e1, e2, e3))
+    assert e1 < 1e-5 and e2 < 1e-5 and e3 < 5e-3
+
+
+@pytest.mark.parametrize("V", [28, 56, 112, 20])
+@pytest.mark.parametrize("mode", [(True, True), (True, False), (False, True)])
+def test_graph_layer(V, mode):
+    from torchreid import hip_ops as ops
+    from recipe import synthetic_adj
+    use_pose, learn_graph = mode
+    B, C = 3, 2048
+    g = torch.Generator().manual_seed(V)
+    # node features: correlated positive vectors, some pairs close enough that the learned graph is not the identity
+    base = torch.rand((B, 1, C), generator=g)
+    f = base + 0.02 * torch.randn((B, V, C), generator=g)
+    if V % 7 == 0:
+        adj = synthetic_adj(B, V // 7, seed=V)
+    else:
+        adj = (torch.rand((B, V, V), generator=g) > 0.5).float()
+        adj[0, 3] = 0  # an all-zero row
+    W = torch.randn((C, C), generator=g) * 0.02
+    sd = {"gl.linear.weight": W, "gl.bn.weight": 0.8 + 0.4 * torch.rand(C, generator=g), "gl.bn.bias": 0.1 * torch.randn(C, generator=g),
+          "gl.bn.running_mean": 0.1 * torch.randn(C, generator=g), "gl.bn.running_var": 0.5 + torch.rand(C, generator=g)}
+    ref = O.graph_layer(f, adj, sd, "gl", use_pose, learn_graph)
+    refG = O.graph_matrix(f, adj, use_pose, learn_graph)
+    fd, adjd = f.to(DEV), adj.to(DEV)
+    h = ops.linear_nobias(fd.view(B * V, C), W.to(DEV)).view(B, V, C)
+    G = ops.graph_matrix(fd, adjd, use_pose, learn_graph)
+    scale = sd["gl.bn.weight"] / torch.sqrt(sd["gl.bn.running_var"] + 1e-5)
+    shift = sd["gl.bn.bias"] - sd["gl.bn.running_mean"] * scale
+    out, out_lp = ops.graph_propagate(fd, h, G, scale.to(DEV), shift.to(DEV), 0.1, 0.1, want_lp=True)
+    torch.cuda.synchronize()
+    eh = rel_err(h, f @ W.t())
+    eG = rel_err(G, refG)
+    eo = rel_err(out, ref)
+    # the message term alone (what the kernel adds on top of 0.9 f)
+    em = rel_err(out.cpu() - 0.9 * f, ref - 0.9 * f)
+    print("graph V=%d mode=%s  h %.3e  G %.3e  out %.3e  msg %.3e  offdiag mass %.3e" % (
+        V, mode, eh, eG, eo, em, (refG.sum(2) - refG.diagonal(dim1=1, dim2=2)).mean().item()))
+    assert eh < 1e-5 and eG < 1e-4 and eo < 1e-5 and em < 1e-3
+    assert rel_err(out_lp.float(), ref) < 5e-3
+
+
+def test_attention_tail():
+    from torchreid import hip_ops as ops
+    B, S, P, C, hw = 3, 8, 7, 2048, 128
+    g = torch.Generator().manual_seed(3)
+    nodes = torch.rand((B, S, P, C), generator=g)
+    nodes[1, 2] = 0  # a frame whose nodes are all zero
+    gsum = torch.rand((B * S, C), generator=g) * hw
+    sd = {}
+    for name in ("global_bottleneck", "att_bottleneck"):
+        sd[name + ".weight"] = 0.8 + 0.4 * torch.rand(C, generator=g)
+        sd[name + ".bias"] = 0.1 * torch.randn(C, generator=g)
+        sd[name + ".running_mean"] = 0.1 * torch.randn(C, generator=g)
+        sd[name + ".running_var"] = 0.5 + torch.rand(C, generator=g)
+    att_f = O.attention_pool(nodes)
+    g_f = gsum.view(B, S, C).sum(1) / (S * hw)
+    ref = torch.cat([O._bn(g_f, sd, "global_bottleneck"), O._bn(att_f, sd, "att_bottleneck")], 1)
+
+    def fold(n):
+        sc = sd[n + ".weight"] / torch.sqrt(sd[n + ".running_var"] + 1e-5)
+        return sc.to(DEV), (sd[n + ".bias"] - sd[n + ".running_mean"] * sc).to(DEV)
+
+    nd = nodes.to(DEV)
+    sqn = ops.row_sqnorm(nd.view(B * S * P, C))
+    gs, gsh = fold("global_bottleneck")
+    as_, ash = fold("att_bottleneck")
+    out, gf, af = ops.attn_pool_bnneck(nd, sqn, gsum.to(DEV), gs, gsh, as_, ash, B, S, P, hw, want_feats=True)
+    torch.cuda.synchronize()
+    print("tail", rel_err(out, ref), rel_err(gf, g_f), rel_err(af, att_f))
+    assert rel_err(out, ref) < 1e-5 and rel_err(gf, g_f) < 1e-5 and rel_err(af, att_f) < 1e-5
+
+
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("shape", [(37, 101, 4096), (5, 300, 96), (130, 257, 2048)])
+def test_distmat(shape, metric):
+    from torchreid.metrics.distance import hip_distmat_device
+    m, n, D = shape
+    g = torch.Generator().manual_seed(m)
+    q = torch.randn((m, D), generator=g)
+    gal = torch.randn((n, D), generator=g)
+    ref = O.euclidean_squared(q.double(), gal.double()) if metric == "euclidean" else O.cosine(q.double(), gal.double())
+    got = hip_distmat_device(q.to(DEV), gal.to(DEV), metric, "fp32")
+    got_lp = hip_distmat_device(q.to(DEV), gal.to(DEV), metric, "bf16")
+    torch.cuda.synchronize()
+    e, elp = rel_err(got, ref), rel_err(got_lp, ref)
+    print("distmat", shape, metric, "fp32 %.3e bf16 %.3e" % (e, elp))
+    assert e < 1e-5 and elp < 1e-2
+
+
+def test_distmat_public_api_and_errors():
+    from torchreid import metrics
+    q, gal = torch.randn(7, 64), torch.randn(60, 64)
+    d_cpu_in = metrics.compute_distance_matrix(q, gal, "euclidean")  # CPU in -> CPU out, computed on the GPU
+    assert not d_cpu_in.is_cuda and d_cpu_in.shape == (7, 60)
+    assert rel_err(d_cpu_in, O.euclidean_squared(q, gal)) < 1e-5
+    d_dev = metrics.compute_distance_matrix(q.to(DEV), gal.to(DEV), "cosine")
+    assert d_dev.is_cuda and rel_err(d_dev, O.cosine(q, gal)) < 1e-5
+    with pytest.raises(ValueError):
+        metrics.compute_distance_matrix(q, gal, "manhattan")
+    with pytest.raises(AssertionError):
+        metrics.compute_distance_matrix(q, gal[:, :32])
+
+
+@pytest.mark.parametrize("shape", [(30, 300, 50), (4, 64, 64), (3, 12180, 50), (2, 5000, 1000)])
+def test_rank_topk_exact(shape):
+    from torchreid import hip_ops as ops
+    m, n, k = shape
+    rng = np.random.RandomState(n)
+    d = rng.rand(m, n).astype(np.float32)
+    d[0, : n // 2] = np.float32(0.25)          # massive ties
+    d[1, 5] = np.nan
+    d[1, 7] = -np.inf
+    d[2 % m, ::3] = -d[2 % m, ::3]             # negatives
+    if m > 3:
+        d[3] = np.round(d[3] * 8) / 8           # few distinct values
+    idx, val = ops.rank_topk(torch.from_numpy(d).to(DEV), k)
+    torch.cuda.synchronize()
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    for r in range(m):
+        ref = O.stable_topk(d[r], k)
+        assert np.array_equal(idx[r], ref), (r, idx[r][:10], ref[:10])
+        assert np.array_equal(val[r], d[r][ref], equal_nan=True)
+
+
+def test_rank_mars_bit_exact():
+    from torchreid import metrics
+    rng = np.random.RandomState(7)
+    m, n = 40, 400
+    d = rng.rand(m, n).astype(np.float32)
+    q_pids = rng.randint(0, 10, m)
+    g_pids = rng.randint(0, 10, n)
+    g_pids[rng.rand(n) < 0.05] = -1
+    q_cam = rng.randint(0, 6, m)
+    g_cam = rng.randint(0, 6, n)
+    cmc_ref, map_ref, ap_ref, _, _ = O.evaluate_mars(d, q_pids, g_pids, q_cam, g_cam, 50, return_all=True)
+    cmc, mAP = metrics.evaluate_rank(d, q_pids, g_pids, q_cam, g_cam, use_metric_mars=True)
+    assert mAP == map_ref, (mAP, map_ref)            # fp64, same operation order -> identical
+    assert np.array_equal(cmc, cmc_ref)
+    d_dev = torch.from_numpy(d).to(DEV)
+    cmc2, mAP2 = metrics.evaluate_rank(d_dev, q_pids, g_pids, q_cam, g_cam, use_metric_mars=True)
+    assert mAP2 == map_ref and np.array_equal(cmc2, cmc_ref)
+    assert metrics.evaluate_rank(d, q_pids, g_pids, q_cam, g_cam) is None
+    with pytest.raises(ValueError):
+        metrics.evaluate_rank(d[:, :30], q_pids, g_pids[:30], q_cam, g_cam[:30], use_metric_mars=True)
+    q_bad = q_pids.copy()
+    q_bad[0] = 999  # no match in the gallery
+    with pytest.raises(ZeroDivisionError):
+        metrics.evaluate_rank(d, q_bad, g_pids, q_cam, g_cam, use_metric_mars=True)
+
+
+def test_triplet_mining_and_loss():
+    from torchreid import losses, hip_ops as ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((32, 2048), generator=g)
+    pids = torch.arange(8).repeat_interleave(4)
+    loss_ref, dap_ref, dan_ref, iap_ref, ian_ref = O.triplet_hard(x, pids, soft=True)
+    dap, dan, iap, ian = ops.triplet_hard_mine(x.to(DEV), pids.to(torch.int32).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(iap.cpu().long(), iap_ref) and torch.equal(ian.cpu().long(), ian_ref)
+    assert rel_err(dap, dap_ref) < 1e-5 and rel_err(dan, dan_ref) < 1e-5
+    xd = x.to(DEV).requires_grad_(True)
+    loss = losses.TripletLoss(soft=True)(xd, pids.to(DEV))
+    loss.backward()
+    xr = x.clone().requires_grad_(True)
+    O.triplet_hard(xr, pids, soft=True)[0].backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-4
+    hard = losses.TripletLoss(margin=0.3, soft=False)(x.to(DEV), pids.to(DEV))
+    assert abs(hard.item() - O.triplet_hard(x, pids, 0.3, soft=False)[0].item()) < 1e-5

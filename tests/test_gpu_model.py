@@ -1,0 +1,107 @@
+"""End-to-end GPU parity of the vmgn eval forward (the drop-in boundary) against the CPU oracle."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vmgn_oracle as O
+from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(num_classes=5, **kw):
+    from torchreid import models
+    cfg = dict(num_classes=num_classes, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+               pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=False, num_parts=3, bnneck=True)
+    cfg.update(kw)
+    m = models.init_model("vmgn", **cfg)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    return m.eval(), sd
+
+
+def rel(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return ((got - ref).abs().max() / ref.abs().max()).item()
+
+
+@pytest.mark.parametrize("cfg", [(2, 4, True, True), (1, 8, True, True), (2, 4, True, False), (2, 4, False, True)])
+def test_vmgn_eval_fp32_matches_oracle(cfg):
+    B, S, use_pose, learn_graph = cfg
+    m, sd = build(use_pose=use_pose, learn_graph=learn_graph)
+    x, adj = synthetic_clips(B, S, seed=S), synthetic_adj(B, S, seed=S)
+    with torch.no_grad():
+        ref = O.vmgn_eval(x, adj, sd, use_pose=use_pose, learn_graph=learn_graph)
+    m = m.to(DEV)
+    m.hip_precision = "fp32"
+    got = m(x.to(DEV), adj.to(DEV))
+    torch.cuda.synchronize()
+    assert got.shape == (B, 4096) and got.dtype == torch.float32 and got.is_cuda
+    e = rel(got, ref)
+    print("vmgn fp32", cfg, "max rel err %.3e  (|ref|max %.3f, tracklet spread %.3e)" % (
+        e, ref.abs().max().item(), (ref[0] - ref[-1]).abs().max().item()))
+    assert e < 1e-3  # north-star bar; measured ~1e-5
+
+
+def test_vmgn_eval_bf16_close_and_ranking_preserved():
+    B, S = 4, 4
+    m, sd = build()
+    x, adj = synthetic_clips(B, S, seed=9, identities=[0, 0, 1, 2]), synthetic_adj(B, S, seed=9)
+    with torch.no_grad():
+        ref = O.vmgn_eval(x, adj, sd)
+    m = m.to(DEV)
+    m.hip_precision = "bf16"
+    got = m(x.to(DEV), adj.to(DEV))
+    torch.cuda.synchronize()
+    e = rel(got, ref)
+    print("vmgn bf16 max rel err %.3e" % e)
+    assert e < 5e-2
+    # the nearest neighbour of tracklet 0 is its same-identity twin under both precisions
+    d_ref = O.cosine(ref, ref) + 10 * torch.eye(B)
+    d_got = O.cosine(got.float().cpu(), got.float().cpu()) + 10 * torch.eye(B)
+    assert d_ref[0].argmin().item() == 1 and d_got[0].argmin().item() == 1
+
+
+def test_weight_cache_tracks_parameter_updates():
+    m, sd = build()
+    m = m.to(DEV)
+    x, adj = synthetic_clips(1, 4).to(DEV), synthetic_adj(1, 4).to(DEV)
+    a = m(x, adj).clone()
+    with torch.no_grad():
+        m.att_bottleneck.weight.mul_(2.0)
+    b = m(x, adj)
+    torch.cuda.synchronize()
+    assert not torch.allclose(a[:, 2048:], b[:, 2048:])
+    assert torch.allclose(a[:, :2048], b[:, :2048])
+
+
+def test_bad_adj_shape_raises():
+    m, _ = build()
+    m = m.to(DEV)
+    with pytest.raises(ValueError):
+        m(synthetic_clips(1, 4).to(DEV), torch.ones(1, 20, 20, device=DEV))
+
+
+def test_throughput_probe():
+    """Not an assertion on speed: prints a first timing of the full forward at the BASELINE config-2 shape."""
+    m, _ = build()
+    m = m.to(DEV)
+    m.hip_static_weights = True
+    B, S = 32, 8
+    x = torch.randn(B, S, 3, 256, 128, device=DEV)
+    adj = synthetic_adj(B, S).to(DEV)
+    for prec in ("fp32", "bf16"):
+        m.hip_precision = prec
+        for _ in range(2):
+            m(x, adj)
+        torch.cuda.synchronize()
+        t = time.time()
+        n = 5
+        for _ in range(n):
+            m(x, adj)
+        torch.cuda.synchronize()
+        dt = (time.time() - t) / n
+        print("forward B=32 S=8 %s: %.2f ms  -> %.0f frames/s" % (prec, dt * 1e3, B * S / dt))
