@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const T* __restrict__ x
 // y = x / max(||x||, 1e-12) (or plain conversion); one wavefront per row
 template <typename TOUT>
 __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ x, TOUT* __restrict__ y, int R,
-                                                            int C, int normalize) {
+                                                            int C, int ldy, int normalize) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= R) return;
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restr
         s = wave_sum(s);
         den = fmaxf(sqrtf(s), 1e-12f);
     }
-    TOUT* dst = y + (size_t)row * C;
-    for (int c = lane; c < C; c += 64) {
-        const float v = normalize ? src[c] / den : src[c];
+    TOUT* dst = y + (size_t)row * ldy;
+    for (int c = lane; c < ldy; c += 64) {
+        const float v = c < C ? (normalize ? src[c] / den : src[c]) : 0.f;  // zero padding up to ldy
         DT<TOUT>::st(dst + c, v);
     }
 }
@@ -244,16 +244,16 @@ extern "C" int agrl_row_sqnorm(const void* x, float* sqn, int R, int C, int dtyp
     return 0;
 }
 
-extern "C" int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int normalize, int out_dtype,
+extern "C" int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int ldy, int normalize, int out_dtype,
                                      agrl_stream_t stream) {
-    AGRL_CHECK_ARG(x && y && R > 0 && C > 0, "agrl_row_l2_normalize: bad arguments");
+    AGRL_CHECK_ARG(x && y && R > 0 && C > 0 && ldy >= C, "agrl_row_l2_normalize: bad arguments");
     AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_row_l2_normalize: bad dtype %d", out_dtype);
     if (out_dtype == AGRL_F32)
         hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x,
-                           (float*)y, R, C, normalize);
+                           (float*)y, R, C, ldy, normalize);
     else
         hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x,
-                           (bf16_t*)y, R, C, normalize);
+                           (bf16_t*)y, R, C, ldy, normalize);
     AGRL_CHECK_LAUNCH("agrl_row_l2_normalize");
     return 0;
 }

@@ -49,7 +49,7 @@ SIGNATURES = {
     "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _p],
     "agrl_row_sqnorm": [_p, _p, _i, _i, _i, _p],
     "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _p],
+    "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_distmat": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "agrl_rank_topk": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
@@ -126,7 +126,22 @@ def dtype_code(dt):
     raise TypeError("unsupported dtype %s (float32 / bfloat16 only)" % dt)
 
 
+# Optional launch timing: set ``PROFILE`` to a list and every entry-point call appends
+# (name, start_event, end_event, tag); the events are recorded on the stream the kernel is launched on
+# (the last argument of every entry point). Used by bench.py for the live roofline numbers.
+PROFILE = None
+PROFILE_TAG = None
+
+
 def call(name, *args):
-    """Invoke an entry point; the last argument (stream) is appended by the caller."""
+    """Invoke an entry point (its last argument is the HIP stream handle)."""
     fn = getattr(lib(), name)
+    if PROFILE is None:
+        _check(name, fn(*args))
+        return
+    stream = torch.cuda.ExternalStream(args[-1]) if args[-1] else torch.cuda.current_stream()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record(stream)
     _check(name, fn(*args))
+    end.record(stream)
+    PROFILE.append((name, start, end, PROFILE_TAG))

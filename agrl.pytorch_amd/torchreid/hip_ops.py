@@ -131,12 +131,20 @@ def attn_pool_bnneck(nodes, sqn, gsum, g_scale, g_shift, a_scale, a_shift, B, S,
     return out
 
 
-def row_l2_normalize(x, normalize, out_dtype):
+def k_multiple(dtype):
+    """K granularity of the GEMM kernel: one 128-byte k-tile."""
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+def row_l2_normalize(x, normalize, out_dtype, pad_to=1):
+    """fp32 (R,C) -> (R, Cpad) out_dtype, Cpad = C rounded up to ``pad_to``, padding columns zero."""
     R, Cc = x.shape
     assert x.dtype == torch.float32
-    y = torch.empty((R, Cc), dtype=out_dtype, device=x.device)
+    ld = -(-Cc // pad_to) * pad_to
+    y = torch.empty((R, ld), dtype=out_dtype, device=x.device)
     with _dev(x):
-        call("agrl_row_l2_normalize", ptr(x), ptr(y), R, Cc, 1 if normalize else 0, dtype_code(out_dtype), _stream(x))
+        call("agrl_row_l2_normalize", ptr(x), ptr(y), R, Cc, ld, 1 if normalize else 0, dtype_code(out_dtype),
+             _stream(x))
     return y
 
 

@@ -60,12 +60,13 @@ def hip_distmat_device(q, g, metric, precision='fp32', out=None):
     from torchreid import hip_ops as ops
     lp = precision == 'bf16'
     dt = torch.bfloat16 if lp else torch.float32
+    km = ops.k_multiple(dt)
     if metric == 'euclidean':
         qn, gn = ops.row_sqnorm(q), ops.row_sqnorm(g)
-        if lp:
-            q, g = ops.row_l2_normalize(q, False, dt), ops.row_l2_normalize(g, False, dt)
+        if lp or q.size(1) % km:
+            q, g = ops.row_l2_normalize(q, False, dt, km), ops.row_l2_normalize(g, False, dt, km)
         return ops.distmat(q, g, 'euclidean', qn, gn, out=out)
-    qh, gh = ops.row_l2_normalize(q, True, dt), ops.row_l2_normalize(g, True, dt)
+    qh, gh = ops.row_l2_normalize(q, True, dt, km), ops.row_l2_normalize(g, True, dt, km)
     return ops.distmat(qh, gh, 'cosine', out=out)
 
 

@@ -1,0 +1,95 @@
+"""One-process-per-GPU data parallelism for the forward-and-match path.
+
+The reference's only parallelism is single-process ``nn.DataParallel`` (train_vidreid_xent_htri.py:318), whose
+scatter/gather funnels everything through GPU 0. On an 8-GPU xGMI node this build shards instead:
+
+  * tracklets : each rank runs the eval forward on its slice of the batch (weights replicated, no traffic)
+  * exchange  : ONE collective per batch -- an RCCL all-gather of the (b_local, 4096) embeddings
+  * gallery   : each rank keeps a contiguous shard of gallery rows resident and computes the distance columns
+                of that shard for ALL queries; a per-shard top-k plus a second small all-gather of the
+                (index, distance) candidates gives every rank the global top-k for the ranking step
+
+``torch.distributed`` (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests) only moves bytes; the arithmetic
+is the HIP kernels. The per-rank compute is passed in as callables so the CPU tests can exercise the
+sharding/merge logic under gloo without a GPU.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous, balanced split of ``n`` items: the first ``n % world`` ranks get one extra. -> (lo, hi)"""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def all_gather_rows(local):
+    """All-gather of equally-sized row blocks: (b, D) on every rank -> (b*world, D), rank-major."""
+    world = world_size()
+    if world == 1:
+        return local
+    out = torch.empty((local.size(0) * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def all_gather_ragged_rows(local, counts):
+    """All-gather of row blocks with per-rank row counts ``counts`` (list, same on every rank)."""
+    world = world_size()
+    if world == 1:
+        return local
+    cap = max(counts)
+    padded = local.new_zeros((cap,) + tuple(local.shape[1:]))
+    padded[: local.size(0)] = local
+    gathered = all_gather_rows(padded).view((world, cap) + tuple(local.shape[1:]))
+    return torch.cat([gathered[r, : counts[r]] for r in range(world)], dim=0)
+
+
+def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn):
+    """Global top-k of every query against a gallery sharded by rows across ranks.
+
+    ``distmat_fn(q, g) -> (m, n_local)`` and ``topk_fn(d, k) -> (idx (m,k') int, val (m,k'))`` (ascending
+    (distance, index), ties towards the lower index) are the per-rank kernels. Returns (idx (m,k) global gallery
+    indices, val (m,k)), identical on every rank and identical to a single-GPU top-k of the full matrix:
+    shards are contiguous and rank-ordered, so 'position in the concatenated candidate list' orders ties exactly
+    like 'global gallery index'."""
+    d_local = distmat_fn(q_all, gallery_shard)
+    k_local = min(k, d_local.size(1))
+    idx, val = topk_fn(d_local, k_local)
+    idx = idx.to(torch.int64) + shard_lo
+    world = world_size()
+    if world == 1:
+        return idx, val
+    if k_local < k:  # a shard smaller than k: pad with +inf candidates
+        pad = k - k_local
+        idx = torch.cat([idx, idx.new_full((idx.size(0), pad), -1)], dim=1)
+        val = torch.cat([val, val.new_full((val.size(0), pad), float("inf"))], dim=1)
+    m = idx.size(0)
+    # (world, m, k) -> (m, world*k), rank-major inside each query row
+    cand_idx = all_gather_rows(idx.view(1, m, k)).permute(1, 0, 2).reshape(m, world * k).contiguous()
+    cand_val = all_gather_rows(val.view(1, m, k)).permute(1, 0, 2).reshape(m, world * k).contiguous()
+    pos, best = topk_fn(cand_val, k)
+    return torch.gather(cand_idx, 1, pos.to(torch.int64)), best

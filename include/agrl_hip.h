@@ -122,9 +122,10 @@ int agrl_attn_pool_bnneck(const float* nodes, const float* sqn, const float* gsu
 
 /* ---- distance matrix + ranking ------------------------------------------------------------------ */
 
-/* y[r,:] = x[r,:] / max(||x[r,:]||_2, 1e-12)  (F.normalize p=2), x fp32 (R,C) -> y out_dtype.
- * torchreid/metrics/distance.py:86-87. With normalize == 0 it is a plain dtype conversion. */
-int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int normalize, int out_dtype,
+/* y[r,:C] = x[r,:] / max(||x[r,:]||_2, 1e-12)  (F.normalize p=2), x fp32 (R,C) -> y out_dtype with row
+ * stride ldy >= C; columns C..ldy-1 are written as zeros (K padding for agrl_distmat).
+ * torchreid/metrics/distance.py:86-87. With normalize == 0 it is a plain dtype conversion / padding copy. */
+int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int ldy, int normalize, int out_dtype,
                           agrl_stream_t stream);
 
 /* dist (m,n) fp32 between q (m,D) and g (n,D) of dtype.
@@ -132,8 +133,9 @@ int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int normalize, 
  *              qn, gn = fp32 squared row norms (agrl_row_sqnorm of the fp32 embeddings)
  *   cosine   : 1 - q^_i.g^_j with q^, g^ already L2-normalised rows (qn, gn ignored, may be NULL),
  *              distance.py:76-89
- *   ldd = row stride of dist in elements (>= n), so a rank can write its gallery shard's columns
- *   straight into the full matrix. */
+ *   D must be a multiple of 64 (bf16) / 32 (fp32): pad the operands with zero columns (agrl_row_l2_normalize's
+ *   ldy) otherwise. ldd = row stride of dist in elements (>= n), so a rank can write its gallery shard's
+ *   columns straight into the full matrix. */
 int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist,
                  int m, int n, int D, int ldd, int metric, int dtype, agrl_stream_t stream);
 

@@ -253,3 +253,28 @@ def pose_adjacency(part_sets, num_split=4, pyramid_part=True):
                 if a != b:
                     adj[a, b] = 1
     return adj
+
+
+def pose_part_sets(pose, height, num_split=4, threshold=0.1):
+    """Keypoints -> body-part stripe sets of ONE frame, generate_graph, dataset_loader.py:308-331.
+
+    ``pose``: (18,3) array of (x, y, confidence) AlphaPose keypoints, or None when no person was detected.
+    Each confident keypoint's y is bucketed into one of ``num_split`` horizontal stripes (1-based,
+    bisect_right on the stripe borders, clamped to [1, num_split]); a part spanning several stripes is made
+    contiguous."""
+    import bisect
+
+    if pose is None:
+        return {}
+    borders = list(np.arange(0, height + 1, height / num_split))
+    groups = {"head": [0, 1, 14, 15, 16, 17], "body": [2, 3, 4, 5, 6, 7], "leg": [8, 9, 10, 11, 12, 13]}
+    out = {}
+    for name, ids in groups.items():
+        for kp in ids:
+            if pose[kp, 2] > threshold:
+                sid = min(num_split, max(1, bisect.bisect_right(borders, pose[kp, 1])))
+                out.setdefault(name, set()).add(sid)
+    for name, ids in out.items():
+        if len(ids) > 1:
+            ids.update(range(min(ids), max(ids) + 1))
+    return out

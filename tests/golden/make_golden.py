@@ -1,0 +1,192 @@
+"""Generates tests/golden/*.npz by running the REFERENCE implementation (weleen/AGRL.pytorch, mounted read-only at
+/root/reference) in the build container. Run:  python tests/golden/make_golden.py
+
+The reference is imported by file path with three harness-side shims (nothing in the reference is modified and no
+reference source is copied into this repository):
+  1. ``init_pretrained_weights`` is replaced by a no-op (it would download ImageNet weights);
+  2. a stub ``sklearn.metrics.base`` module is installed (removed from scikit-learn >= 0.24; the reference's
+     rank.py imports it at module level for a dead-code branch);
+  3. stub ``torchvision`` / ``torchreid.transforms`` modules are installed so dataset_loader.py (home of
+     generate_graph / adj_graph) imports; the stubs are never called.
+Only small data (inputs that cannot be re-derived from seeds, and expected outputs) is written. Weights and most
+inputs come from tests/recipe.py seeds so the same tensors can be rebuilt anywhere.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("AGRL_REFERENCE_ROOT", "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)  # the reference's (empty-__init__) torchreid package; this build's package is NOT on the path
+
+from recipe import recipe_state_dict, recipe_tensor, synthetic_adj, synthetic_clips  # noqa: E402
+
+
+def load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def install_shims():
+    base = types.ModuleType("sklearn.metrics.base")
+    from sklearn.metrics import _base
+    base._average_binary_score = _base._average_binary_score
+    sys.modules["sklearn.metrics.base"] = base
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tv.transforms = tvt
+    tvt.functional = tvf
+    tvt.__dict__.update({n: object for n in ("Compose", "ToTensor", "Normalize", "Resize", "RandomCrop")})
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    tr = types.ModuleType("torchreid.transforms")
+    tr.ImageData = object
+    sys.modules["torchreid.transforms"] = tr
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def main():
+    torch.set_num_threads(8)
+    install_shims()
+    ref_vmgn = load("ref_vmgn", "torchreid/models/vmgn.py")
+    ref_vmgn.init_pretrained_weights = lambda *a, **k: None
+    ref_dist = load("ref_distance", "torchreid/metrics/distance.py")
+    ref_rank = load("ref_rank", "torchreid/metrics/rank.py")
+    ref_trip = load("ref_triplet", "torchreid/losses/hard_mine_triplet_loss.py")
+    ref_dl = load("ref_dataset_loader", "torchreid/dataset_loader.py")
+
+    # ---- F1: GraphLayer (vmgn.py:68-172) ----------------------------------------------------------------
+    for tag, V, C, use_pose, learn in [("v28", 28, 256, True, True), ("v56", 56, 2048, True, True),
+                                        ("v56_pose", 56, 256, True, False), ("v56_learn", 56, 256, False, True),
+                                        ("v112", 112, 256, True, True)]:
+        B = 1 if C == 2048 else 2
+        layer = ref_vmgn.GraphLayer(C, C, learn_graph=learn, use_pose=use_pose)
+        sd = recipe_state_dict({"linear.weight": (C, C), "bn.weight": (C,), "bn.bias": (C,), "bn.running_mean": (C,),
+                                "bn.running_var": (C,)}, seed=11)
+        sd["linear.weight"] = recipe_tensor("graph_layers.0.linear.weight", (C, C), 11)
+        layer.load_state_dict(sd, strict=False)
+        layer.eval()
+        g = torch.Generator().manual_seed(V * 7 + C)
+        f = torch.rand((B, 1, C), generator=g) + 0.02 * torch.randn((B, V, C), generator=g)
+        adj = synthetic_adj(B, V // 7, seed=V)
+        with torch.no_grad():
+            out = layer(f, adj)
+            sim = layer.get_sim_matrix(f)
+        save("graph_layer_" + tag, f=f if C <= 256 else np.zeros(0), adj=adj, out=out, sim=sim,
+             meta=np.array([B, V, C, int(use_pose), int(learn), V * 7 + C, 11]))
+
+    # ---- F2: pooling + attention tail (vmgn.py:270-278, :298-321) on small feature maps ----------------------
+    model = ref_vmgn.vmgn(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=False)
+    sd_full = recipe_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd_full)
+    model.eval()
+    B, S, c, h, w = 2, 4, 2048, 16, 8
+    g = torch.Generator().manual_seed(21)
+    x41 = torch.rand((B * S, c, h, w), generator=g)
+    x42 = torch.rand((B * S, c, h, w), generator=g)
+    adj = synthetic_adj(B, S, seed=21)
+    with torch.no_grad():
+        g_f = model.global_avg_pool(x41.view(B, S, c, h, w).transpose(1, 2).contiguous()).view(B, -1)
+        v_f = [model.parts_avgpool[i](x42).view(B, S, c, n) for i, n in enumerate(model.total_split_list)]
+        nodes = torch.cat(v_f, dim=3).transpose(2, 3).contiguous().view(B, S * model.total_split, c)
+        f = nodes
+        for i in range(model.num_gb):
+            f = model.graph_layers[i](f, adj)
+        att_f = model._attention_op(f.view(B, S, model.total_split, c)).mean(dim=1).view(B, -1)
+        out = torch.cat([model.global_bottleneck(g_f), model.att_bottleneck(att_f)], dim=1)
+    save("tail", g_f=g_f, nodes=nodes[:, :, :64], nodes_out=f[:, :, :64], att_f=att_f, out=out,
+         meta=np.array([B, S, c, h, w, 21]))
+
+    # ---- F3: full vmgn eval forward (vmgn.py:292-321), config-1 shape --------------------------------------
+    for tag, B, S, seed in [("b2s4", 2, 4, 4), ("b1s8", 1, 8, 8)]:
+        x, adj = synthetic_clips(B, S, seed=seed), synthetic_adj(B, S, seed=seed)
+        with torch.no_grad():
+            y = model(x, adj)
+            x4_1, x4_2 = model.featuremaps(x.view(B * S, 3, 256, 128))
+        save("vmgn_eval_" + tag, out=y, x4_1_mean=x4_1.mean(dim=(2, 3)), x4_2_mean=x4_2.mean(dim=(2, 3)),
+             meta=np.array([B, S, seed, 0]))
+
+    # ---- F8: train-mode outputs with the consistent loss (vmgn.py:323-357) ---------------------------------
+    model_t = ref_vmgn.vmgn(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                            pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)
+    model_t.load_state_dict(sd_full)
+    model_t.train()
+    x, adj = synthetic_clips(2, 8, seed=31), synthetic_adj(2, 8, seed=31)
+    torch.manual_seed(1234)
+    outs, feats = model_t(x, adj)
+    save("vmgn_train_b2s8", **{"logit%d" % i: o for i, o in enumerate(outs)}, **{"feat%d" % i: f_ for i, f_ in enumerate(feats)},
+         meta=np.array([2, 8, 31, 1234]))
+
+    # ---- F4: distance matrices (distance.py:59-89) ------------------------------------------------------
+    g = torch.Generator().manual_seed(41)
+    q, gal = torch.randn((37, 4096), generator=g), torch.randn((101, 4096), generator=g)
+    save("distmat", euclidean=ref_dist.compute_distance_matrix(q, gal, "euclidean"),
+         cosine=ref_dist.compute_distance_matrix(q, gal, "cosine"), meta=np.array([37, 101, 4096, 41]))
+
+    # ---- F5: MARS ranking (rank.py:160-212) --------------------------------------------------------------
+    rng = np.random.RandomState(51)
+    m, n = 30, 300
+    dist = rng.rand(m, n).astype(np.float32)
+    q_pids, g_pids = rng.randint(0, 8, m), rng.randint(0, 8, n)
+    g_pids[rng.rand(n) < 0.05] = -1
+    q_cam, g_cam = rng.randint(0, 6, m), rng.randint(0, 6, n)
+    cmc, mAP = ref_rank.evaluate_rank(dist, q_pids, g_pids, q_cam, g_cam, max_rank=50, use_metric_mars=True)
+    aps = []
+    for k in range(m):  # per-query AP through the reference's Compute_AP
+        good = np.where((q_pids[k] == g_pids) & (q_cam[k] != g_cam))[0]
+        junk = np.where((g_pids == -1) | ((q_pids[k] == g_pids) & (q_cam[k] == g_cam)))[0]
+        aps.append(ref_rank.Compute_AP(good, junk, np.argsort(dist[k])[:50])[0])
+    save("rank_mars", dist=dist, q_pids=q_pids, g_pids=g_pids, q_camids=q_cam, g_camids=g_cam, cmc=cmc, mAP=np.float64(mAP),
+         ap=np.array(aps, dtype=np.float64))
+
+    # ---- F6: batch-hard triplet loss (hard_mine_triplet_loss.py:24-50) ----------------------------------
+    g = torch.Generator().manual_seed(61)
+    feats = torch.randn((16, 2048), generator=g)
+    pids = torch.arange(4).repeat_interleave(4)
+    res = {}
+    for soft in (True, False):
+        fx = feats.clone().requires_grad_(True)
+        loss = ref_trip.TripletLoss(margin=0.3, soft=soft)(fx, pids)
+        loss.backward()
+        res["loss_soft" if soft else "loss_margin"] = loss.detach()
+        res["grad_soft" if soft else "grad_margin"] = fx.grad
+    save("triplet", pids=pids, meta=np.array([16, 2048, 61]), **res)
+
+    # ---- F7: pose adjacency (dataset_loader.py:218-388) -------------------------------------------------
+    rng = np.random.RandomState(71)
+    S, width, height = 8, 128, 256
+    paths, poses, pose_arr = [], {}, np.zeros((S, 18, 3), dtype=np.float32)
+    detected = np.ones(S, dtype=bool)
+    for t in range(S):
+        path = "data/mars/bbox_test/0001/0001C1T0001F%03d.jpg" % (t + 1)
+        paths.append(path)
+        kp = np.stack([rng.rand(18) * width, rng.rand(18) * height, rng.rand(18)], axis=1).astype(np.float32)
+        pose_arr[t] = kp
+        if t == 3:
+            detected[t] = False  # no pose entry for this frame -> all-zero block
+        else:
+            poses[path.split("/")[-1]] = kp
+    ims = [torch.zeros(3, 256, 128) for _ in range(S)]
+    adj = ref_dl.generate_graph(ims, im_paths=paths, im_sizes=[(width, height)] * S, poses=poses, num_split=4,
+                                num_parts=3, num_scale=1, pyramid_part=True)
+    save("pose_adjacency", poses=pose_arr, detected=detected, adj=adj, meta=np.array([S, width, height, 4]))
+
+
+if __name__ == "__main__":
+    main()

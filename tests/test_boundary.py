@@ -1,0 +1,154 @@
+"""Drop-in boundary without a GPU: registry, factory kwargs, state-dict keys, return
+conventions, error behaviour, import side effects, C-ABI exports."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make(**kw):
+    from torchreid import models
+    cfg = dict(num_classes=7, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1, pyramid_part=True,
+               use_pose=True, learn_graph=True, consistent_loss=False, num_parts=3, bnneck=True)
+    cfg.update(kw)
+    return models.init_model("vmgn", **cfg)
+
+
+def test_registry_and_unknown_model(tmp_path):
+    from torchreid import models
+    assert "vmgn" in models.get_names()
+    with pytest.raises(KeyError):
+        models.init_model("nope")
+    make(save_dir=str(tmp_path))  # the factory's source file is copied next to the logs
+    assert os.path.isfile(os.path.join(str(tmp_path), "vmgn.py"))
+
+
+def test_state_dict_contract():
+    m = make()
+    sd = m.state_dict()
+    assert len(sd) == 402
+    assert sd["conv1.weight"].shape == (64, 3, 7, 7)
+    assert sd["graph_layers.1.linear.weight"].shape == (2048, 2048)
+    assert sd["global_classifier.weight"].shape == (7, 2048) and sd["att_classifier.weight"].shape == (7, 2048)
+    counts = {p: sum(k.startswith(p + ".") for k in sd) for p in ("layer1", "layer2", "layer3", "layer4_1", "layer4_2")}
+    assert counts == {"layer1": 60, "layer2": 78, "layer3": 114, "layer4_1": 60, "layer4_2": 60}
+    assert not m.global_bottleneck.bias.requires_grad and not m.att_bottleneck.bias.requires_grad
+    assert abs(sum(p.numel() for p in m.parameters()) - 46.88e6) < 0.03e6
+    # layer4_2 starts as a copy of layer4_1
+    assert torch.equal(sd["layer4_1.0.conv1.weight"], sd["layer4_2.0.conv1.weight"])
+    assert m.layer4_1[0].conv2.stride == (1, 1)  # last stride hard-wired to 1
+
+
+def test_factory_asserts():
+    with pytest.raises(AssertionError):
+        make(use_pose=False, learn_graph=False)
+    with pytest.raises(AssertionError):
+        make(num_split=3)
+
+
+def test_eval_and_train_return_conventions():
+    m = make(num_gb=1)
+    x, adj = torch.randn(2, 5, 3, 64, 32), torch.ones(2, 35, 35)
+    m.eval()
+    with torch.no_grad():
+        y = m(x, adj)
+    assert y.shape == (2, 4096)
+    m.train()
+    outs, feats = m(x, adj)
+    assert [tuple(o.shape) for o in outs] == [(2, 7)] * 2 and [tuple(f.shape) for f in feats] == [(2, 2048)] * 2
+    m.loss = {"xent"}
+    assert isinstance(m(x, adj), list)
+    m.loss = {"htri"}
+    with pytest.raises(KeyError):
+        m(x, adj)
+    mc = make(num_gb=1, consistent_loss=True)
+    mc.train()
+    outs, feats = mc(x, adj)
+    assert len(outs) == 5 and len(feats) == 5
+    sum(o.sum() for o in outs).backward()  # autograd reaches the backbone
+    assert mc.conv1.weight.grad is not None
+
+
+def test_leaf_module_hooks_fire_on_cpu_forward():
+    m = make(num_gb=1).eval()
+    seen = []
+    hooks = [mod.register_forward_hook(lambda mod, i, o: seen.append(type(mod).__name__))
+             for mod in m.modules() if len(list(mod.children())) == 0]
+    with torch.no_grad():
+        m(torch.randn(1, 4, 3, 64, 32), torch.ones(1, 28, 28))
+    for h in hooks:
+        h.remove()
+    assert seen.count("Conv2d") == 63 and "Linear" in seen and "AdaptiveAvgPool3d" in seen
+
+
+def test_metrics_contract_without_gpu():
+    from torchreid import metrics
+    q, g = torch.randn(4, 16), torch.randn(60, 16)
+    with pytest.raises(ValueError):
+        metrics.compute_distance_matrix(q, g, "l1")
+    with pytest.raises(AssertionError):
+        metrics.compute_distance_matrix(q.numpy(), g)
+    with pytest.raises(AssertionError):
+        metrics.compute_distance_matrix(q[0], g)
+    with pytest.raises(NotImplementedError):
+        metrics.evaluate_rank(np.zeros((4, 60)), np.zeros(4), np.zeros(60), np.zeros(4), np.zeros(60), use_metric_market1501=True)
+    acc = metrics.accuracy([torch.eye(4), torch.eye(4).flip(0)], torch.arange(4), topk=(1, 2))
+    assert acc.shape == (2, 2) and acc[0, 0] == 1.0 and acc[1, 0] == 0.0
+
+
+def test_samplers_star_import_binds_driver_names():
+    ns = {}
+    exec("from torchreid.samplers import *", ns)
+    for name in ("np", "torch", "random", "copy", "RandomIdentitySampler", "RandomIdentitySamplerV1"):
+        assert name in ns
+    data = [(None, pid, 0) for pid in range(6) for _ in range(5)]
+    s = ns["RandomIdentitySampler"](data, batch_size=8, num_instances=4)
+    order = list(iter(s))
+    assert len(order) % 8 == 0 and len(order) == len(s)
+    for i in range(0, len(order), 4):
+        assert len({data[j][1] for j in order[i:i + 4]}) == 1
+
+
+def test_losses_contract():
+    from torchreid import losses
+    x = torch.randn(8, 32, requires_grad=True)
+    y = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3])
+    ce = losses.CrossEntropyLabelSmooth(4, use_gpu=False)
+    logits = torch.randn(8, 4)
+    smooth = 0.9 * torch.nn.functional.one_hot(y, 4).float() + 0.1 / 4
+    assert torch.allclose(ce(logits, y), (-smooth * torch.log_softmax(logits, 1)).sum(1).mean(), atol=1e-6)
+    val = losses.DeepSupervision(losses.TripletLoss(), [x, 2 * x], y)
+    val.backward()
+    assert x.grad is not None
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """The C-ABI library loads (no GPU needed) and exports exactly what include/agrl_hip.h declares."""
+    from torchreid import _hip
+    header = open(os.path.join(ROOT, "include", "agrl_hip.h")).read()
+    declared = set(re.findall(r"\b(agrl_[a-z0-9_]+)\s*\(", header))
+    assert declared >= {"agrl_conv2d_bn_act", "agrl_graph_propagate", "agrl_distmat", "agrl_rank_topk"}
+    if not os.path.exists(_hip.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "agrl.pytorch_amd", "csrc"), "-j8"])
+    lib = _hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(_hip.SIGNATURES) == declared - {"agrl_version", "agrl_last_error"}
+    assert lib.agrl_version() >= 100
+    # argument validation happens before any launch, so it is checkable without a GPU
+    assert lib.agrl_distmat(None, None, None, None, None, 1, 1, 64, 1, 0, 0, None) != 0
+    assert b"null pointer" in lib.agrl_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from torchreid import _hip
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libagrl_hip.so")
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.lib()
+    assert not _hip.available()

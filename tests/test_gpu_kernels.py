@@ -133,14 +133,21 @@ def test_graph_layer(V, mode):
     shift = sd["gl.bn.bias"] - sd["gl.bn.running_mean"] * scale
     out, out_lp = ops.graph_propagate(fd, h, G, scale.to(DEV), shift.to(DEV), 0.1, 0.1, want_lp=True)
     torch.cuda.synchronize()
-    eh = rel_err(h, f @ W.t())
-    eG = rel_err(G, refG)
-    eo = rel_err(out, ref)
-    # the message term alone (what the kernel adds on top of 0.9 f)
-    em = rel_err(out.cpu() - 0.9 * f, ref - 0.9 * f)
-    print("graph V=%d mode=%s  h %.3e  G %.3e  out %.3e  msg %.3e  offdiag mass %.3e" % (
-        V, mode, eh, eG, eo, em, (refG.sum(2) - refG.diagonal(dim1=1, dim2=2)).mean().item()))
-    assert eh < 1e-5 and eG < 1e-4 and eo < 1e-5 and em < 1e-3
+    # fp64 ground truth: in fp32 the diagonal d2_ii = n_i + n_i - 2 g_ii is pure cancellation noise (its value
+    # depends on the BLAS summation order), and sqrt() amplifies it to a ~1e-2 relative change of sim_ii.
+    # The kernel takes n_i from the Gram diagonal (d2_ii == 0 exactly), i.e. the exact-arithmetic value.
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref64 = O.graph_layer(f.double(), adj.double(), sd64, "gl", use_pose, learn_graph)
+    refG64 = O.graph_matrix(f.double(), adj.double(), use_pose, learn_graph)
+    eh = rel_err(h, f.double() @ W.double().t())
+    eG, eG32 = rel_err(G, refG64), rel_err(G, refG)
+    eo, eo32 = rel_err(out, ref64), rel_err(out, ref)
+    em = rel_err(out.cpu().double() - 0.9 * f.double(), ref64 - 0.9 * f.double())
+    print("graph V=%d mode=%s  h %.3e | vs fp64: G %.3e out %.3e msg %.3e | vs fp32 oracle: G %.3e out %.3e | oracle32 vs 64: G %.3e | offdiag mass %.3e" % (
+        V, mode, eh, eG, eo, em, eG32, eo32, rel_err(refG, refG64), (refG.sum(2) - refG.diagonal(dim1=1, dim2=2)).mean().item()))
+    # G: node features are deliberately close (d2 ~ 1.6 from norms ~ 680), so fp32 d2 itself carries ~1e-4 rel
+    assert eh < 1e-5 and eG < 5e-4 and eo < 1e-5 and em < 1e-4
+    assert eo32 < 1e-3  # the north-star bar against the fp32 reference arithmetic
     assert rel_err(out_lp.float(), ref) < 5e-3
 
 

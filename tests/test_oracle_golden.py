@@ -1,0 +1,159 @@
+"""Pins the CPU oracle (oracle/vmgn_oracle.py) to golden vectors captured from the reference implementation
+itself (tests/golden/make_golden.py, run in the build container where /root/reference is mounted).
+No GPU, no reference needed at test time."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vmgn_oracle as O
+from recipe import recipe_state_dict, recipe_tensor, synthetic_adj, synthetic_clips
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def close(a, b, tol):
+    a, b = torch.as_tensor(np.asarray(a)).double(), torch.as_tensor(np.asarray(b)).double()
+    err = ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item()
+    assert err < tol, err
+    return err
+
+
+def vmgn_state_dict():
+    from torchreid import models
+    m = models.init_model("vmgn", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2,
+                          num_scale=1, pyramid_part=True, use_pose=True, learn_graph=True)
+    return m, recipe_state_dict(m.state_dict(), seed=0)
+
+
+@pytest.mark.parametrize("tag", ["v28", "v56", "v56_pose", "v56_learn", "v112"])
+def test_graph_layer(tag):
+    z = gold("graph_layer_" + tag)
+    B, V, C, use_pose, learn, fseed, wseed = [int(v) for v in z["meta"]]
+    sd = recipe_state_dict({"gl.bn.weight": (C,), "gl.bn.bias": (C,), "gl.bn.running_mean": (C,), "gl.bn.running_var": (C,)}, seed=wseed)
+    # the generator drew BN tensors under the keys 'bn.*' and the weight under 'graph_layers.0.linear.weight'
+    for leaf in ("weight", "bias", "running_mean", "running_var"):
+        sd["gl.bn." + leaf] = recipe_tensor("bn." + leaf, (C,), wseed)
+    sd["gl.linear.weight"] = recipe_tensor("graph_layers.0.linear.weight", (C, C), wseed)
+    g = torch.Generator().manual_seed(fseed)
+    f = torch.rand((B, 1, C), generator=g) + 0.02 * torch.randn((B, V, C), generator=g)
+    if z["f"].size:
+        assert np.array_equal(z["f"], f.numpy())
+    adj = torch.from_numpy(z["adj"])
+    assert torch.equal(adj, synthetic_adj(B, V // 7, seed=V))
+    close(O.sim_matrix(f), z["sim"], 2e-2)  # the fp32 diagonal is cancellation noise (see test_gpu_kernels)
+    offdiag = ~np.eye(V, dtype=bool)[None].repeat(B, 0)
+    close(O.sim_matrix(f).numpy()[offdiag], z["sim"][offdiag], 1e-3)
+    close(O.graph_layer(f, adj, sd, "gl", bool(use_pose), bool(learn)), z["out"], 1e-5)
+
+
+def test_tail():
+    z = gold("tail")
+    B, S, c, h, w, seed = [int(v) for v in z["meta"]]
+    _, sd = vmgn_state_dict()
+    g = torch.Generator().manual_seed(seed)
+    x41 = torch.rand((B * S, c, h, w), generator=g)
+    x42 = torch.rand((B * S, c, h, w), generator=g)
+    adj = synthetic_adj(B, S, seed=seed)
+    out, parts = O.tail(x41, x42, adj, sd, B, S, [4, 2, 1], 2, return_parts=True)
+    close(parts["g_f"], z["g_f"], 1e-6)
+    close(parts["nodes"][:, :, :64], z["nodes"], 1e-6)
+    # uniform-random maps give near-identical part nodes: the learned graph is then sensitive to the fp32
+    # cancellation noise of d2 (restatement and reference reduce in different orders) -> 1e-4 instead of 1e-5
+    close(parts["nodes_out"][:, :, :64], z["nodes_out"], 1e-4)
+    close(parts["att_f"], z["att_f"], 1e-4)
+    close(out, z["out"], 1e-4)
+
+
+@pytest.mark.parametrize("tag", ["b2s4", "b1s8"])
+def test_vmgn_eval(tag):
+    z = gold("vmgn_eval_" + tag)
+    B, S, seed, wseed = [int(v) for v in z["meta"]]
+    m, sd = vmgn_state_dict()
+    x, adj = synthetic_clips(B, S, seed=seed), synthetic_adj(B, S, seed=seed)
+    with torch.no_grad():
+        x4_1, x4_2 = O.featuremaps(x.view(B * S, 3, 256, 128), sd)
+        close(x4_1.mean(dim=(2, 3)), z["x4_1_mean"], 1e-5)
+        close(x4_2.mean(dim=(2, 3)), z["x4_2_mean"], 1e-5)
+        close(O.tail(x4_1, x4_2, adj, sd, B, S, [4, 2, 1], 2), z["out"], 1e-5)
+        # the drop-in module's stock-torch path (what runs for CPU tensors) gives the same answer
+        m.load_state_dict(sd)
+        m.eval()
+        close(m(x, adj), z["out"], 1e-5)
+
+
+def test_vmgn_train_outputs_match_reference():
+    z = gold("vmgn_train_b2s8")
+    B, S, seed, rng_seed = [int(v) for v in z["meta"]]
+    from torchreid import models
+    m = models.init_model("vmgn", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2,
+                          num_scale=1, pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)
+    m.load_state_dict(recipe_state_dict(m.state_dict(), seed=0))
+    m.train()
+    x, adj = synthetic_clips(B, S, seed=seed), synthetic_adj(B, S, seed=seed)
+    torch.manual_seed(rng_seed)
+    outs, feats = m(x, adj)
+    assert len(outs) == 5 and len(feats) == 5
+    for i in range(5):
+        close(outs[i].detach(), z["logit%d" % i], 1e-4)
+        close(feats[i].detach(), z["feat%d" % i], 1e-4)
+
+
+def test_distmat():
+    z = gold("distmat")
+    m, n, D, seed = [int(v) for v in z["meta"]]
+    g = torch.Generator().manual_seed(seed)
+    q, gal = torch.randn((m, D), generator=g), torch.randn((n, D), generator=g)
+    close(O.euclidean_squared(q, gal), z["euclidean"], 1e-6)
+    close(O.cosine(q, gal), z["cosine"], 1e-6)
+    from torchreid.metrics import distance
+    if not torch.cuda.is_available():  # the host path of the drop-in (no GPU present)
+        close(distance.compute_distance_matrix(q, gal, "euclidean"), z["euclidean"], 1e-6)
+        close(distance.compute_distance_matrix(q, gal, "cosine"), z["cosine"], 1e-6)
+
+
+def test_rank_mars_bit_exact():
+    z = gold("rank_mars")
+    cmc, mAP, ap, _, _ = O.evaluate_mars(z["dist"], z["q_pids"], z["g_pids"], z["q_camids"], z["g_camids"], 50, return_all=True)
+    assert mAP == float(z["mAP"])
+    assert np.array_equal(cmc, z["cmc"])
+    assert np.array_equal(ap, z["ap"])
+    if not torch.cuda.is_available():
+        from torchreid import metrics
+        cmc2, mAP2 = metrics.evaluate_rank(z["dist"], z["q_pids"], z["g_pids"], z["q_camids"], z["g_camids"], use_metric_mars=True)
+        assert mAP2 == float(z["mAP"]) and np.array_equal(cmc2, z["cmc"])
+
+
+def test_triplet():
+    z = gold("triplet")
+    n, d, seed = [int(v) for v in z["meta"]]
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn((n, d), generator=g)
+    pids = torch.from_numpy(z["pids"])
+    for soft, key in ((True, "soft"), (False, "margin")):
+        x = feats.clone().requires_grad_(True)
+        loss = O.triplet_hard(x, pids, 0.3, soft)[0]
+        loss.backward()
+        assert abs(loss.item() - float(z["loss_" + key])) < 1e-6
+        close(x.grad, z["grad_" + key], 1e-4)
+        from torchreid import losses
+        x2 = feats.clone().requires_grad_(True)
+        loss2 = losses.TripletLoss(0.3, soft)(x2, pids)  # CPU tensors: host path of the drop-in
+        loss2.backward()
+        assert abs(loss2.item() - float(z["loss_" + key])) < 1e-6
+        close(x2.grad, z["grad_" + key], 1e-4)
+
+
+def test_pose_adjacency():
+    z = gold("pose_adjacency")
+    S, width, height, num_split = [int(v) for v in z["meta"]]
+    sets = [O.pose_part_sets(z["poses"][t] if z["detected"][t] else None, height, num_split) for t in range(S)]
+    adj = O.pose_adjacency(sets, num_split, True)
+    assert np.array_equal(adj, z["adj"])
+    assert np.array_equal(adj, adj.T) and adj.diagonal().sum() == 0
+    assert adj[3 * 7:(3 + 1) * 7].sum() == 0  # the undetected frame is an all-zero block
