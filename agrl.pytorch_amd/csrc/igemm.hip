@@ -15,8 +15,11 @@
 //   * MFMA 16x16: bf16 -> v_mfma_f32_16x16x32_bf16, fp32 -> v_mfma_f32_16x16x4_f32 (exact fp32 fma
 //     chain); the WEIGHT fragment is the A operand and the PIXEL fragment the B operand, so a lane
 //     ends up holding 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores
-//   * global -> registers -> LDS staging, double-buffered LDS, one barrier per k-tile; the loads of
-//     tile t+1 are issued before the MFMAs of tile t
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write), double-buffered LDS,
+//     one barrier per k-tile; the DMA of tile t+1 is issued before the MFMAs of tile t; padded / out-of-range
+//     chunks are DMA'd from a 16-byte zero block
+//   * bf16 epilogue: the residual tile is DMA'd into the idle staging buffer during the last k-tile, combined
+//     in fp32 in place, and the finished tile leaves as whole rows (16 B per lane, full cache lines)
 //   * LDS rows are 128 B; 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7): ds_read_b128
 //     fragment reads and ds_write_b128 staging writes are both bank-conflict free
 //   * blockIdx -> tile map keeps the N-tiles of one M-tile on the same XCD (private L2) so the
@@ -94,22 +97,34 @@ __device__ inline void load4<bf16_t>(const bf16_t* p, float v[4]) {
     v[2] = bf16_to_f32((bf16_t)(u.y & 0xffff)); v[3] = bf16_to_f32((bf16_t)(u.y >> 16));
 }
 
-template <typename TIN, typename TOUT, int BM, int BN>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+// 16 zero bytes in device memory: the DMA source of every padded / out-of-range chunk
+__device__ __attribute__((aligned(16))) uint4 g_zero16;
+
+__device__ inline void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
+    // LDS-DMA: lane L's 16 bytes land at lds_wave_base + 16*L (wave-uniform base), no VGPR round trip
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename TIN, typename TOUT, int BM, int BN, bool LDS_EPI>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int EPC = DT<TIN>::epc;   // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;        // elements per k-tile (128 bytes)
-    constexpr int AI = BM / 32;         // A rows staged per thread
-    constexpr int BI = BN / 32;         // B rows staged per thread
+    constexpr int AJ = BM / 32;         // 8-row DMA pieces per wave for the pixel tile
+    constexpr int BJ = BN / 32;         // ... for the weight tile
     constexpr int FM = BM / 32;         // 16-pixel fragments per wave
     constexpr int FN = BN / 32;         // 16-channel fragments per wave
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1;
     const int wn = wave >> 1;
 
@@ -130,55 +145,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
     const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
 
-    // ---- per-thread staging coordinates
-    const int chunk = tid & 7;
-    const int srow = tid >> 3;  // 0..31
-    int a_ih0[AI], a_iw0[AI], a_nbase[AI];
-    bool a_ok[AI];
+    // ---- per-lane DMA coordinates. DMA piece j of this wave covers tile rows wave*(BM/4) + 8j .. +7:
+    // lane L -> row + (L>>3), physical chunk L&7, which holds global chunk (L&7) ^ ((row>>1)&7).
+    const int lrow = lane >> 3;
+    const int lchk = lane & 7;
+    int a_ih0[AJ], a_iw0[AJ], a_nbase[AJ], a_coff[AJ];
+    bool a_ok[AJ];
     const int ohw = p.OH * p.OW;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int gm = m0 + srow + 32 * i;
-        a_ok[i] = gm < p.M;
-        const int gmc = a_ok[i] ? gm : 0;
+    for (int j = 0; j < AJ; ++j) {
+        const int row = wave * (BM / 4) + j * 8 + lrow;
+        const int gm = m0 + row;
+        a_ok[j] = gm < p.M;
+        const int gmc = a_ok[j] ? gm : 0;
         const int n = gmc / ohw;
         const int rem = gmc - n * ohw;
         const int oh = rem / p.OW;
         const int ow = rem - oh * p.OW;
-        a_ih0[i] = oh * p.stride - p.pad;
-        a_iw0[i] = ow * p.stride - p.pad;
-        a_nbase[i] = n * p.H * p.W;
+        a_ih0[j] = oh * p.stride - p.pad;
+        a_iw0[j] = ow * p.stride - p.pad;
+        a_nbase[j] = n * p.H * p.W;
+        a_coff[j] = (lchk ^ ((row >> 1) & 7)) * EPC;
     }
-    size_t b_off[BI];
+    size_t b_off[BJ];
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-        int gn = n0 + srow + 32 * i;
+    for (int j = 0; j < BJ; ++j) {
+        const int row = wave * (BN / 4) + j * 8 + lrow;
+        int gn = n0 + row;
         gn = gn < p.N ? gn : p.N - 1;
-        b_off[i] = ((size_t)gn * p.K + chunk * EPC) * sizeof(TIN);
+        b_off[j] = ((size_t)gn * p.K + (lchk ^ ((row >> 1) & 7)) * EPC) * sizeof(TIN);
     }
 
-    uint4 ra[AI], rb[BI];
-    int tap_r = 0, tap_s = 0, c0 = 0;  // filter tap and channel offset of the tile being LOADED
+    int tap_r = 0, tap_s = 0, c0 = 0;  // filter tap and channel offset of the tile being STAGED
     size_t kbyte = 0;                  // byte offset of that tile along K in the weight rows
 
-    auto load_tiles = [&]() {
+    auto stage = [&](int buf) {
+        unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / 4) * 128;
+        unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / 4) * 128;
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int ih = a_ih0[i] + tap_r;
-            const int iw = a_iw0[i] + tap_s;
-            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            if (ok) {
-                const size_t off =
-                    ((size_t)(a_nbase[i] + ih * p.W + iw) * p.Cin + c0 + chunk * EPC) * sizeof(TIN);
-                ra[i] = *reinterpret_cast<const uint4*>(xg + off);
-            } else {
-                ra[i] = make_uint4(0, 0, 0, 0);
-            }
+        for (int j = 0; j < AJ; ++j) {
+            const int ih = a_ih0[j] + tap_r;
+            const int iw = a_iw0[j] + tap_s;
+            const bool ok = a_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const size_t off = ((size_t)(a_nbase[j] + ih * p.W + iw) * p.Cin + c0 + a_coff[j]) * sizeof(TIN);
+            dma16(ok ? xg + off : zsrc, sa + j * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < BI; ++i) rb[i] = *reinterpret_cast<const uint4*>(wg + b_off[i] + kbyte);
-        // advance to the next k-tile
+        for (int j = 0; j < BJ; ++j) dma16(wg + b_off[j] + kbyte, sb + j * 1024);
         kbyte += 128;
         c0 += BKE;
         if (c0 == p.Cin) {
@@ -189,14 +204,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             }
         }
     };
-    auto store_lds = [&](int buf) {
-        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) *reinterpret_cast<uint4*>(sa + lds_off(srow + 32 * i, chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BI; ++i) *reinterpret_cast<uint4*>(sb + lds_off(srow + 32 * i, chunk)) = rb[i];
-    };
 
     f32x4_t acc[FN][FM];
 #pragma unroll
@@ -204,18 +211,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // ---- LDS-staged epilogue geometry (bf16 output): the out tile is BM rows of BN*2 bytes, 16-byte chunk c of
+    // row r stored at chunk c ^ (r & (CPR-1)); the residual tile is DMA'd into the same image beforehand.
+    constexpr int CPR = BN * 2 / 16;        // chunks per out-tile row (16 for BN=128, 8 for BN=64)
+    constexpr int ROWB = BN * 2;            // bytes per out-tile row
+    constexpr int RPI = 64 / CPR;           // rows per DMA piece
+    constexpr int RJ = BM / (4 * RPI);      // residual DMA pieces per wave
+    const TOUT* __restrict__ resp = reinterpret_cast<const TOUT*>(p.res);
+    auto stage_residual = [&](int buf) {
+        unsigned char* so = smem + buf * BUF_BYTES;
+        const unsigned char* rg = reinterpret_cast<const unsigned char*>(p.res);
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) {
+            const int row0 = (wave * RJ + j) * RPI;
+            const int row = row0 + lane / CPR;
+            const int gch = (lane % CPR) ^ (row & (CPR - 1));
+            const int gm = m0 + row;
+            const int gn = n0 + gch * 8;
+            const bool ok = gm < p.M && gn < p.N;  // N % 8 == 0 is guaranteed on this path
+            dma16(ok ? rg + ((size_t)gm * p.ldo + gn) * 2 : zsrc, so + row0 * ROWB);
+        }
+    };
+
     const int nk = p.K / BKE;
-    load_tiles();
-    store_lds(0);
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tiles();
-        const unsigned char* sa = smem + cur * (A_BYTES + B_BYTES);
+        if (kt + 1 < nk) {
+            stage(cur ^ 1);
+        } else if (LDS_EPI && resp) {
+            stage_residual(cur ^ 1);
+        }
+        const unsigned char* sa = smem + cur * BUF_BYTES;
         const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -231,36 +263,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int b = 0; b < FM; ++b) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
         }
-        if (more) store_lds(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     // ---- epilogue: lane (g = lane>>4, j = lane&15) holds channels 4g..4g+3 of pixel j per fragment
     TOUT* __restrict__ outp = reinterpret_cast<TOUT*>(p.out);
-    const TOUT* __restrict__ resp = reinterpret_cast<const TOUT*>(p.res);
-    const bool vec_ok = p.vec_ok != 0;
+    if constexpr (LDS_EPI) {
+        // phase 1: combine in fp32, round once, park the bf16 tile in the free staging buffer (in place over the
+        // residual image: every lane overwrites exactly the 8 bytes it just read)
+        unsigned char* so = smem + ((nk & 1) ? BUF_BYTES : 0);  // buffer (last cur) ^ 1
 #pragma unroll
-    for (int b = 0; b < FM; ++b) {
-        const int gm = m0 + wm * (BM / 2) + b * 16 + frow;
-        if (gm >= p.M) continue;
-        const float rv = p.rowv ? p.rowv[gm] : p.rowc;
+        for (int b = 0; b < FM; ++b) {
+            const int prow = wm * (BM / 2) + b * 16 + frow;
+            const int gm = m0 + prow;
+            const float rv = p.rowv ? p.rowv[gm < p.M ? gm : 0] : p.rowc;
 #pragma unroll
-        for (int a = 0; a < FN; ++a) {
-            const int gn = n0 + wn * (BN / 2) + a * 16 + fchunk * 4;
-            if (gn >= p.N) continue;
-            const size_t o = (size_t)gm * p.ldo + gn;
-            float v[4];
-            if (vec_ok && gn + 3 < p.N) {
+            for (int a = 0; a < FN; ++a) {
+                const int c = wn * (BN / 2) + a * 16 + fchunk * 4;
+                const int gn = n0 + c;
                 float cv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.colv) {
+                if (p.colv && gn < p.N) {
                     const float4 c4 = *reinterpret_cast<const float4*>(p.colv + gn);
                     cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
                 }
+                unsigned char* slot = so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1);
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(p.alpha, acc[a][b][r], rv + cv[r]);
                 if (resp) {
                     float rr[4];
-                    load4<TOUT>(resp + o, rr);
+                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), rr);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += rr[r];
                 }
@@ -268,15 +301,66 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
-                store4<TOUT>(outp + o, v);
-            } else {
+                store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+            }
+        }
+        __syncthreads();
+        // phase 2: whole 16-byte chunks, a wavefront writes 4 (BN=128) / 8 (BN=64) complete rows per instruction
+        constexpr int RPT = 256 / CPR;  // rows covered by the 256 threads per pass
+        const int pch = tid % CPR;
+        const int r0 = tid / CPR;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (gn + r < p.N) {
-                        float t = fmaf(p.alpha, acc[a][b][r], rv + (p.colv ? p.colv[gn + r] : 0.f));
-                        if (resp) t += DT<TOUT>::ld(resp + o + r);
-                        if (p.relu) t = fmaxf(t, 0.f);
-                        DT<TOUT>::st(outp + o + r, t);
+        for (int i = 0; i < BM / RPT; ++i) {
+            const int row = r0 + i * RPT;
+            const int gch = pch ^ (row & (CPR - 1));
+            const int gm = m0 + row;
+            const int gn = n0 + gch * 8;
+            if (gm < p.M && gn < p.N) {
+                const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * p.ldo + gn) * 2) = v;
+            }
+        }
+    } else {
+        const bool vec_ok = p.vec_ok != 0;
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int gm = m0 + wm * (BM / 2) + b * 16 + frow;
+            if (gm >= p.M) continue;
+            const float rv = p.rowv ? p.rowv[gm] : p.rowc;
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int gn = n0 + wn * (BN / 2) + a * 16 + fchunk * 4;
+                if (gn >= p.N) continue;
+                const size_t o = (size_t)gm * p.ldo + gn;
+                float v[4];
+                if (vec_ok && gn + 3 < p.N) {
+                    float cv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (p.colv) {
+                        const float4 c4 = *reinterpret_cast<const float4*>(p.colv + gn);
+                        cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(p.alpha, acc[a][b][r], rv + cv[r]);
+                    if (resp) {
+                        float rr[4];
+                        load4<TOUT>(resp + o, rr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    store4<TOUT>(outp + o, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (gn + r < p.N) {
+                            float t = fmaf(p.alpha, acc[a][b][r], rv + (p.colv ? p.colv[gn + r] : 0.f));
+                            if (resp) t += DT<TOUT>::ld(resp + o + r);
+                            if (p.relu) t = fmaxf(t, 0.f);
+                            DT<TOUT>::st(outp + o + r, t);
+                        }
                     }
                 }
             }
@@ -295,13 +379,21 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
                    "%s: operands must be 16-byte aligned", who);
     p.vec_ok = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 && (!p.colv || (((uintptr_t)p.colv) & 15) == 0) &&
                (!p.res || (((uintptr_t)p.res) & 15) == 0);
-    if (p.N <= 64) {
-        const int grid = cdiv(p.M, 128) * cdiv(p.N, 64);
-        hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 64>), dim3(grid), dim3(256), 0, stream, p);
-    } else {
-        const int grid = cdiv(p.M, 128) * cdiv(p.N, 128);
-        hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 128>), dim3(grid), dim3(256), 0, stream, p);
+    // bf16 outputs whose rows are whole 16-byte chunks take the LDS-staged (fully coalesced) epilogue
+    const bool lds_epi = sizeof(TOUT) == 2 && (p.N % 8) == 0 && (p.ldo % 8) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
+                         (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.colv || (((uintptr_t)p.colv) & 15) == 0);
+    const bool narrow = p.N <= 64;
+    const int grid = cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128);
+    if constexpr (sizeof(TOUT) == 2) {
+        if (lds_epi) {
+            if (narrow) hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 64, true>), dim3(grid), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 128, true>), dim3(grid), dim3(256), 0, stream, p);
+            AGRL_CHECK_LAUNCH(who);
+            return 0;
+        }
     }
+    if (narrow) hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 64, false>), dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 128, false>), dim3(grid), dim3(256), 0, stream, p);
     AGRL_CHECK_LAUNCH(who);
     return 0;
 }

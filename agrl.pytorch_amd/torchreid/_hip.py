@@ -144,4 +144,6 @@ def call(name, *args):
     start.record(stream)
     _check(name, fn(*args))
     end.record(stream)
+    global PROFILE_TAG
     PROFILE.append((name, start, end, PROFILE_TAG))
+    PROFILE_TAG = None

@@ -44,6 +44,10 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
     out = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
     if residual is not None:
         assert residual.shape == out.shape and residual.dtype == out.dtype
+    if _hip.PROFILE is not None:
+        e = x.element_size()
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * OH * OW * Cout * R * S * Cin,
+                            "bytes": e * (x.numel() + w_ohwi.numel() + out.numel() * (2 if residual is not None else 1))}
     with _dev(x):
         call("agrl_conv2d_bn_act", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
              stride, pad, 1 if relu else 0, dtype_code(x.dtype), _stream(x))
@@ -56,6 +60,8 @@ def linear_nobias(x, w):
     Nout, K2 = w.shape
     assert K == K2 and x.dtype == w.dtype
     y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * K * Nout, "bytes": x.element_size() * (x.numel() + w.numel()) + 4 * y.numel()}
     with _dev(x):
         call("agrl_linear_nobias", ptr(x), ptr(w), ptr(y), M, K, Nout, dtype_code(x.dtype), _stream(x))
     return y
@@ -103,6 +109,8 @@ def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp):
     B, V, Cc = f.shape
     out = torch.empty_like(f)
     out_lp = torch.empty((B, V, Cc), dtype=torch.bfloat16, device=f.device) if want_lp else None
+    if _hip.PROFILE is not None:  # read f + read h + read G(adj-sized) + write out
+        _hip.PROFILE_TAG = {"flops": 2.0 * B * V * V * Cc, "bytes": 4.0 * (3 * B * V * Cc + B * V * V)}
     with _dev(f):
         call("agrl_graph_propagate", ptr(f), ptr(h), ptr(G), ptr(bn_scale), ptr(bn_shift), float(gamma), float(slope),
              ptr(out), ptr(out_lp), B, V, Cc, _stream(f))
@@ -157,6 +165,8 @@ def distmat(q, g, metric, qn=None, gn=None, out=None):
         out = torch.empty((m, n), dtype=torch.float32, device=q.device)
     assert out.stride(1) == 1 and out.dtype == torch.float32
     code = METRIC_EUCLIDEAN if metric == "euclidean" else METRIC_COSINE
+    if _hip.PROFILE is not None:  # (m+n)*D*e + m*n*4
+        _hip.PROFILE_TAG = {"flops": 2.0 * m * n * D, "bytes": q.element_size() * (m + n) * D + 4.0 * m * n}
     with _dev(q):
         _hip.call("agrl_distmat", ptr(q), ptr(g), ptr(qn), ptr(gn), out.data_ptr(), m, n, D, out.stride(0), code,
                   dtype_code(q.dtype), _stream(q))

@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the per-tracklet forward-and-match hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on): MARS-shaped synthetic clips, seq_len 8,
+32 tracklets per GPU per step (256 frames of 256x128), VMGN eval forward (ResNet50 two-branch + 2 graph layers +
+attention pooling) in bf16, then the cosine distance of the step's embeddings against the resident gallery
+(12 180 x 4096, row-sharded over the ranks). One "step" = forward + [RCCL all-gather of embeddings, N > 1] +
+distance matrix against the rank's gallery shard. Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see the task contract): value = whole-job frames/s (all ranks), plus
+  roofline     : the dominant kernel (implicit-GEMM conv, MFMA-bound), achieved = algorithmic flops per launch /
+                 average launch duration measured with HIP events on the launch stream, vs the dense MFMA peak
+  cpu_baseline : the CPU oracle (oracle/vmgn_oracle.py, torch CPU kernels) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+GALLERY_ROWS = 12180  # MARS gallery of the reference tree
+FEATURE_DIM = 4096
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="tracklets per GPU per step")
+    ap.add_argument("--seq-len", type=int, default=8)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--metric", default="cosine", choices=["cosine", "euclidean"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU-baseline work")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_model(device, precision):
+    from recipe import recipe_state_dict
+    from torchreid import models
+    m = models.init_model("vmgn", num_classes=625, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2,
+                          num_scale=1, pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=False,
+                          num_parts=3, bnneck=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m.eval()
+    m.hip_precision = precision
+    m.hip_static_weights = True
+    return m.to(device), sd
+
+
+def cpu_baseline(sd, S, metric, gallery_cpu, min_seconds):
+    """The oracle on this host's cores: same step (forward + distmat against the full gallery), fewer tracklets."""
+    from oracle import vmgn_oracle as O
+    from recipe import synthetic_adj, synthetic_clips
+    bs = 4
+    x, adj = synthetic_clips(bs, S, seed=123), synthetic_adj(bs, S, seed=123)
+    fn = O.cosine if metric == "cosine" else O.euclidean_squared
+    with torch.no_grad():
+        O.vmgn_eval(x[:1], adj[:1], sd)  # warm the thread pool / allocator
+        frames, t0 = 0, time.time()
+        while time.time() - t0 < min_seconds:
+            emb = O.vmgn_eval(x, adj, sd)
+            fn(emb, gallery_cpu)
+            frames += bs * S
+        dt = time.time() - t0
+    return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frames (batches of %d tracklets x %d frames, fwd+GCN+%s distmat vs %d gallery rows) in %.1f s, "
+                      "oracle/vmgn_oracle.py on torch CPU fp32" % (frames, bs, S, metric, gallery_cpu.size(0), dt)}
+
+
+def main():
+    args = parse()
+    from torchreid import _hip, parallel
+    from torchreid.metrics.distance import hip_distmat_device
+    from torchreid import hip_ops as ops
+
+    rank, world, local_rank = parallel.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    _hip.lib()
+
+    from recipe import synthetic_adj
+    B, S = args.batch, args.seq_len
+    model, sd = build_model(device, args.precision)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(0xFF + rank)
+    clips = torch.randn((B, S, 3, 256, 128), device=device, generator=gen)
+    adj = synthetic_adj(B, S, seed=rank).to(device)
+    g_all = torch.Generator().manual_seed(7)
+    gallery_cpu = torch.randn((GALLERY_ROWS, FEATURE_DIM), generator=g_all)
+    lo, hi = parallel.shard_bounds(GALLERY_ROWS, rank, world)
+    lp = args.precision == "bf16"
+    dt_g = torch.bfloat16 if lp else torch.float32
+    # resident gallery shard, prepared once (normalised rows for cosine / norms for euclidean)
+    g_shard = gallery_cpu[lo:hi].to(device)
+    if args.metric == "cosine":
+        g_op, g_norm = ops.row_l2_normalize(g_shard, True, dt_g), None
+    else:
+        g_norm = ops.row_sqnorm(g_shard)
+        g_op = ops.row_l2_normalize(g_shard, False, dt_g) if lp else g_shard
+    dist_out = torch.empty((B * world, hi - lo), dtype=torch.float32, device=device)
+
+    def step():
+        emb = model(clips, adj)                       # (B, 4096) fp32
+        q_all = parallel.all_gather_rows(emb)         # RCCL all-gather over xGMI when world > 1
+        if args.metric == "cosine":
+            q_op = ops.row_l2_normalize(q_all, True, dt_g)
+            return ops.distmat(q_op, g_op, "cosine", out=dist_out)
+        qn = ops.row_sqnorm(q_all)
+        q_op = ops.row_l2_normalize(q_all, False, dt_g) if lp else q_all
+        return ops.distmat(q_op, g_op, "euclidean", qn, g_norm, out=dist_out)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    frames = B * S * world * args.steps
+    result = {
+        "metric": "frames/sec (fwd+GCN+distmat), MARS seq_len=8",
+        "value": round(frames / elapsed, 1),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.precision,
+        "data": "synthetic",
+        "config": {"workload": "MARS seq_len=8 bs=32/GPU %s fwd+distmat (BASELINE configs[1]): 256x128 frames, VMGN "
+                               "ResNet50x2-branch + 2 graph layers, %s distmat vs resident %d x 4096 gallery" %
+                               (args.precision, args.metric, GALLERY_ROWS),
+                   "global_batch": B * world, "seq_len": S, "frames_per_step": B * S * world,
+                   "gallery_rows_per_gpu": hi - lo, "parallelism": "dp%d" % world},
+    }
+
+    # ---- live per-kernel timing (HIP events on the launch stream), rank 0 only
+    if rank == 0:
+        _hip.PROFILE = []
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        prof, _hip.PROFILE = _hip.PROFILE, None
+        agg = {}
+        for name, s_ev, e_ev, tag in prof:
+            a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            a["ms"] += s_ev.elapsed_time(e_ev)
+            a["launches"] += 1
+            if tag:
+                a["flops"] += tag["flops"]
+                a["bytes"] += tag["bytes"]
+        kernels = {}
+        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            sec = a["ms"] * 1e-3
+            kernels[name] = {"ms_per_step": round(a["ms"] / args.profile_steps, 4),
+                             "launches_per_step": a["launches"] // args.profile_steps,
+                             "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2)}
+            if a["flops"]:
+                kernels[name]["tflops"] = round(a["flops"] / sec / 1e12, 2)
+                kernels[name]["gbs"] = round(a["bytes"] / sec / 1e9, 1)
+        dom = "agrl_conv2d_bn_act"
+        a = agg[dom]
+        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.precision, {}).get("igemm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "mfma", "kernel": "igemm_kernel (agrl_conv2d_bn_act)", "achieved": round(achieved, 2),
+                              "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                              "flops_per_launch": round(a["flops"] / a["launches"], 1),
+                              "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2)}
+        for name, label in (("agrl_graph_propagate", "gcn_message_pass"), ("agrl_distmat", "distmat")):
+            if name in agg and agg[name]["bytes"]:
+                gbs = agg[name]["bytes"] / (agg[name]["ms"] * 1e-3) / 1e9
+                result["roofline_" + label] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                               "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        result["kernels"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(sd, S, args.metric, gallery_cpu, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
