@@ -59,48 +59,63 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Finalize. grid = B, 256 threads; one wavefront per graph row.
+// Finalize. grid = (B, ceil(V/4)), 256 threads: one wavefront per graph row, so B*V/4 workgroups are in
+// flight and every row's loads are independent (the first version, one workgroup per tracklet walking its
+// rows, was latency-bound at ~70 us).
 __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __restrict__ gram_part, int nz,
                                                              const float* __restrict__ adj, float* __restrict__ G,
                                                              int V, int use_pose, int learn_graph) {
-    extern __shared__ __attribute__((aligned(16))) float s_g[];  // V*V gram, then V norms
+    extern __shared__ __attribute__((aligned(16))) float s_n[];  // V squared norms (Gram diagonal)
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* s_n = s_g + V * V;
+    const float* gp = gram_part + (size_t)b * nz * V * V;
     if (learn_graph) {
-        const float* gp = gram_part + (size_t)b * nz * V * V;
-        for (int e = tid; e < V * V; e += 256) {
+        for (int j = tid; j < V; j += 256) {
             float s = 0.f;
-            for (int z = 0; z < nz; ++z) s += gp[(size_t)z * V * V + e];
-            s_g[e] = s;
+            for (int z = 0; z < nz; ++z) s += gp[(size_t)z * V * V + (size_t)j * V + j];
+            s_n[j] = s;
         }
-        __syncthreads();
-        for (int i = tid; i < V; i += 256) s_n[i] = s_g[i * V + i];
         __syncthreads();
     }
-    for (int i = wave; i < V; i += 4) {
-        // similarity row: 2 / (exp(sqrt(clamp(n_j + n_i - 2 g_ij, 1e-12))) + 1), then /max(sum,1e-12)
-        float ssum = 0.f, asum = 0.f;
-        for (int j = lane; j < V; j += 64) {
+    const int i = blockIdx.y * 4 + wave;
+    if (i >= V) return;
+    constexpr int JPL = 4;  // columns per lane held in registers: V <= 256
+    float sim[JPL], av[JPL];
+    float ssum = 0.f, asum = 0.f;
+#pragma unroll
+    for (int q = 0; q < JPL; ++q) {
+        const int j = lane + 64 * q;
+        sim[q] = 0.f;
+        av[q] = 0.f;
+        if (j < V) {
             if (learn_graph) {
-                float d2 = (s_n[j] + s_n[i]) - 2.f * s_g[i * V + j];
+                float g = 0.f;
+                for (int z = 0; z < nz; ++z) g += gp[(size_t)z * V * V + (size_t)i * V + j];
+                // similarity: 2 / (exp(sqrt(clamp(n_j + n_i - 2 g_ij, 1e-12))) + 1)
+                float d2 = (s_n[j] + s_n[i]) - 2.f * g;
                 d2 = fmaxf(d2, 1e-12f);
-                const float sim = 2.f / (expf(sqrtf(d2)) + 1.f);
-                s_g[i * V + j] = sim;
-                ssum += fabsf(sim);
+                sim[q] = 2.f / (expf(sqrtf(d2)) + 1.f);
+                ssum += fabsf(sim[q]);
             }
-            if (use_pose) asum += fabsf(adj[((size_t)b * V + i) * V + j]);
+            if (use_pose) {
+                av[q] = adj[((size_t)b * V + i) * V + j];
+                asum += fabsf(av[q]);
+            }
         }
-        ssum = wave_sum(ssum);
-        asum = wave_sum(asum);
-        const float sden = fmaxf(ssum, 1e-12f), aden = fmaxf(asum, 1e-12f);
-        for (int j = lane; j < V; j += 64) {
+    }
+    ssum = wave_sum(ssum);
+    asum = wave_sum(asum);
+    const float sden = fmaxf(ssum, 1e-12f), aden = fmaxf(asum, 1e-12f);
+#pragma unroll
+    for (int q = 0; q < JPL; ++q) {
+        const int j = lane + 64 * q;
+        if (j < V) {
             float g;
             if (learn_graph) {
-                g = s_g[i * V + j] / sden;
-                if (use_pose) g = (adj[((size_t)b * V + i) * V + j] / aden + g) / 2.f;
+                g = sim[q] / sden;
+                if (use_pose) g = (av[q] / aden + g) / 2.f;
             } else {
-                g = adj[((size_t)b * V + i) * V + j] / aden;
+                g = av[q] / aden;
             }
             G[((size_t)b * V + i) * V + j] = g;
         }
@@ -108,46 +123,83 @@ __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Propagate. grid = (B, C/256); thread -> one channel; the thread's h column sits in LDS (private to
-// the thread: no barrier needed), graph rows come through the scalar cache (wave-uniform addresses),
-// RB output rows are register-blocked so each LDS read feeds RB FMAs.
-template <int RB>
-__global__ __launch_bounds__(256) void graph_propagate_kernel(const float* __restrict__ f, const float* __restrict__ h,
-                                                              const float* __restrict__ G,
-                                                              const float* __restrict__ bn_scale,
-                                                              const float* __restrict__ bn_shift, float one_minus_gamma,
-                                                              float gamma, float slope, float* __restrict__ out,
-                                                              bf16_t* __restrict__ out_lp, int V, int C) {
-    extern __shared__ __attribute__((aligned(16))) float s_h[];  // [V][256]
+// Propagate. grid = (B, C/128), 128 threads; thread -> one channel. The graph is staged in LDS transposed
+// (GT[u][v]) so the 8 graph values a register block needs are two broadcast ds_read_b128; the thread's h column
+// sits in a thread-private LDS column (VT == 0; a register-resident variant VT > 0 exists but spills).
+// 8 output rows are register-blocked: each h value feeds 8 FMAs.
+constexpr int PROP_THREADS = 128;
+constexpr int PROP_RB = 8;
+
+template <int VT>  // VT > 0: compile-time V, h in registers; VT == 0: generic, h in LDS
+__global__ __launch_bounds__(PROP_THREADS) void graph_propagate_kernel(
+    const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
+    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int Vrt, int C) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int V = VT > 0 ? VT : Vrt;
+    const int Vp = (V + PROP_RB - 1) & ~(PROP_RB - 1);
+    float* s_gt = s_mem;            // [V][Vp] transposed graph, zero padded columns
+    float* s_h = s_mem + V * Vp;    // generic path only: [V][PROP_THREADS]
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int c = blockIdx.y * 256 + tid;
+    const int c = blockIdx.y * PROP_THREADS + tid;
     const bool live = c < C;
     const int cc = live ? c : C - 1;
-    const float* hb = h + (size_t)b * V * C + cc;
-    for (int u = 0; u < V; ++u) s_h[u * 256 + tid] = hb[(size_t)u * C];
-    const float sc = bn_scale[cc], sh = bn_shift[cc];
     const float* Gb = G + (size_t)b * V * V;
+    for (int e = tid; e < V * Vp; e += PROP_THREADS) {
+        const int u = e / Vp, v = e - u * Vp;
+        s_gt[e] = v < V ? Gb[(size_t)v * V + u] : 0.f;
+    }
+    const float* hb = h + (size_t)b * V * C + cc;
+    float hreg[VT > 0 ? VT : 1];
+    if constexpr (VT > 0) {
+#pragma unroll
+        for (int u = 0; u < VT; ++u) hreg[u] = hb[(size_t)u * C];
+    } else {
+        for (int u = 0; u < V; ++u) s_h[u * PROP_THREADS + tid] = hb[(size_t)u * C];
+    }
+    const float sc = bn_scale[cc], sh = bn_shift[cc];
     const float* fb = f + (size_t)b * V * C + cc;
-    for (int v0 = 0; v0 < V; v0 += RB) {
-        float acc[RB];
+    __syncthreads();
+    for (int v0 = 0; v0 < V; v0 += PROP_RB) {
+        float acc[PROP_RB], fv[PROP_RB];
 #pragma unroll
-        for (int k = 0; k < RB; ++k) acc[k] = 0.f;
-        const float* grow[RB];
+        for (int k = 0; k < PROP_RB; ++k) {
+            acc[k] = 0.f;
+            fv[k] = fb[(size_t)(v0 + k < V ? v0 + k : V - 1) * C];  // residual input, in flight under the FMA sweep
+        }
+        if constexpr (VT > 0) {
 #pragma unroll
-        for (int k = 0; k < RB; ++k) grow[k] = Gb + (size_t)(v0 + k < V ? v0 + k : V - 1) * V;
-        for (int u = 0; u < V; ++u) {
-            const float hv = s_h[u * 256 + tid];
-#pragma unroll
-            for (int k = 0; k < RB; ++k) acc[k] = fmaf(grow[k][u], hv, acc[k]);
+            for (int u = 0; u < VT; ++u) {
+                const float4 g0 = *reinterpret_cast<const float4*>(&s_gt[u * Vp + v0]);
+                const float4 g1 = *reinterpret_cast<const float4*>(&s_gt[u * Vp + v0 + 4]);
+                const float hv = hreg[u];
+                acc[0] = fmaf(g0.x, hv, acc[0]); acc[1] = fmaf(g0.y, hv, acc[1]);
+                acc[2] = fmaf(g0.z, hv, acc[2]); acc[3] = fmaf(g0.w, hv, acc[3]);
+                acc[4] = fmaf(g1.x, hv, acc[4]); acc[5] = fmaf(g1.y, hv, acc[5]);
+                acc[6] = fmaf(g1.z, hv, acc[6]); acc[7] = fmaf(g1.w, hv, acc[7]);
+            }
+        } else {
+            // unrolled by 4: 12 LDS reads are issued before the first FMA needs its operands (one wave per SIMD
+            // has nobody else to hide the ~100-cycle LDS latency behind)
+#pragma unroll 4
+            for (int u = 0; u < V; ++u) {
+                const float4 g0 = *reinterpret_cast<const float4*>(&s_gt[u * Vp + v0]);
+                const float4 g1 = *reinterpret_cast<const float4*>(&s_gt[u * Vp + v0 + 4]);
+                const float hv = s_h[u * PROP_THREADS + tid];
+                acc[0] = fmaf(g0.x, hv, acc[0]); acc[1] = fmaf(g0.y, hv, acc[1]);
+                acc[2] = fmaf(g0.z, hv, acc[2]); acc[3] = fmaf(g0.w, hv, acc[3]);
+                acc[4] = fmaf(g1.x, hv, acc[4]); acc[5] = fmaf(g1.y, hv, acc[5]);
+                acc[6] = fmaf(g1.z, hv, acc[6]); acc[7] = fmaf(g1.w, hv, acc[7]);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < RB; ++k) {
+        for (int k = 0; k < PROP_RB; ++k) {
             const int v = v0 + k;
             if (v < V && live) {
                 float y = fmaf(acc[k], sc, sh);
                 y = y > 0.f ? y : slope * y;
-                const float o = one_minus_gamma * fb[(size_t)v * C] + gamma * y;
+                const float o = one_minus_gamma * fv[k] + gamma * y;
                 const size_t idx = ((size_t)b * V + v) * C + c;
                 out[idx] = o;
                 if (out_lp) out_lp[idx] = f32_to_bf16(o);
@@ -178,10 +230,9 @@ extern "C" int agrl_graph_finalize(const float* gram_part, int nz, const float* 
     AGRL_CHECK_ARG(use_pose || learn_graph, "agrl_graph_finalize: use_pose or learn_graph must be set");
     AGRL_CHECK_ARG(!use_pose || adj, "agrl_graph_finalize: use_pose needs adj");
     AGRL_CHECK_ARG(!learn_graph || (gram_part && nz > 0), "agrl_graph_finalize: learn_graph needs the Gram partials");
-    const size_t lds = ((size_t)V * V + V) * sizeof(float);
-    AGRL_CHECK_ARG(lds <= 160 * 1024, "agrl_graph_finalize: V=%d too large", V);
-    hipLaunchKernelGGL(graph_finalize_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, gram_part, nz, adj, G, V,
-                       use_pose, learn_graph);
+    AGRL_CHECK_ARG(V <= 256, "agrl_graph_finalize: V=%d > 256 not supported", V);
+    hipLaunchKernelGGL(graph_finalize_kernel, dim3(B, cdiv(V, 4)), dim3(256), (size_t)V * sizeof(float),
+                       (hipStream_t)stream, gram_part, nz, adj, G, V, use_pose, learn_graph);
     AGRL_CHECK_LAUNCH("agrl_graph_finalize");
     return 0;
 }
@@ -191,17 +242,26 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
                                     int V, int C, agrl_stream_t stream) {
     AGRL_CHECK_ARG(f && h && G && bn_scale && bn_shift && out, "agrl_graph_propagate: null pointer");
     AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0, "agrl_graph_propagate: bad shape");
-    const size_t lds = (size_t)V * 256 * sizeof(float);
+    const int Vp = (V + PROP_RB - 1) & ~(PROP_RB - 1);
+    const bool fixed = false;  // register-resident h (VT > 0) spills: hipcc hoists every LDS graph read; keep h in LDS
+    const size_t lds = ((size_t)V * Vp + (fixed ? 0 : (size_t)V * PROP_THREADS)) * sizeof(float);
     AGRL_CHECK_ARG(lds <= 160 * 1024, "agrl_graph_propagate: V=%d too large", V);
     // (1 - gamma) is evaluated in double like the reference's Python float, then rounded once
     const float omg = (float)(1.0 - (double)gamma);
-    if (lds > 64 * 1024) {  // per-device attribute, idempotent: set it whenever the launch needs it
-        hipError_t e = hipFuncSetAttribute((const void*)graph_propagate_kernel<8>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_propagate: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(graph_propagate_kernel<8>, dim3(B, cdiv(C, 256)), dim3(256), lds, (hipStream_t)stream, f, h, G,
-                       bn_scale, bn_shift, omg, gamma, slope, out, (bf16_t*)out_lp, V, C);
+    const dim3 grid(B, cdiv(C, PROP_THREADS));
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_PROP(VT)                                                                                              \
+    do {                                                                                                             \
+        if (lds > 64 * 1024) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute((const void*)graph_propagate_kernel<VT>,                              \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);              \
+            AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_propagate: cannot raise dynamic LDS: %s", hipGetErrorString(e)); \
+        }                                                                                                            \
+        hipLaunchKernelGGL(graph_propagate_kernel<VT>, grid, dim3(PROP_THREADS), lds, st, f, h, G, bn_scale, bn_shift, \
+                           omg, gamma, slope, out, (bf16_t*)out_lp, V, C);                                           \
+    } while (0)
+    LAUNCH_PROP(0);
+#undef LAUNCH_PROP
     AGRL_CHECK_LAUNCH("agrl_graph_propagate");
     return 0;
 }

@@ -24,6 +24,8 @@
 //     fragment reads and ds_write_b128 staging writes are both bank-conflict free
 //   * blockIdx -> tile map keeps the N-tiles of one M-tile on the same XCD (private L2) so the
 //     gathered activation tile is fetched from HBM once
+#include <stdlib.h>
+
 #include "agrl_common.h"
 
 struct IgemmParams {
@@ -40,6 +42,7 @@ struct IgemmParams {
     int Cin, H, W, OH, OW, R, S, stride, pad;
     int ldo;     // row stride of out / res in elements
     int vec_ok;  // 4-wide epilogue accesses are aligned
+    int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 2 skip MFMAs, 4 skip epilogue phase 1
 };
 
 template <typename T>
@@ -104,11 +107,25 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 __device__ __attribute__((aligned(16))) uint4 g_zero16;
 
 __device__ inline void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
-    // LDS-DMA: lane L's 16 bytes land at lds_wave_base + 16*L (wave-uniform base), no VGPR round trip
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_wave_base, 16, 0, 0);
+    // LDS-DMA: lane L's 16 bytes land at lds_wave_base + 16*L (wave-uniform base), no VGPR round trip.
+    // Issued through inline asm on purpose: hipcc tracks the builtin as an LDS write and then puts
+    // s_waitcnt vmcnt(0) in front of the next ds_read, which would drain the ring every k-tile; hidden in asm, the
+    // counted waits below are the only ones. M0 (the LDS destination base) is saved/restored in the same statement.
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)lds_wave_base);
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_addr)
+        : "memory");
 }
 
-template <typename TIN, typename TOUT, int BM, int BN, bool LDS_EPI>
+template <int N>
+__device__ inline void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename TIN, typename TOUT, int BM, int BN, bool LDS_EPI, int NS>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int EPC = DT<TIN>::epc;   // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;        // elements per k-tile (128 bytes)
@@ -120,7 +137,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int B_BYTES = BN * 128;
     constexpr int BUF_BYTES = A_BYTES + B_BYTES;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+    constexpr int DPT = AJ + BJ;        // DMA instructions per thread per k-tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -233,19 +251,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
     };
 
-    const int nk = p.K / BKE;
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // per-channel vector (bias) of this lane's 4 channels per fragment: fetched now so its latency hides under the
+    // main loop instead of stalling the epilogue (it was ~1/3 of the short-K layers' time)
+    float cvr[FN][4];
+    if constexpr (LDS_EPI) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int gn = n0 + wn * (BN / 2) + a * 16 + (lane >> 4) * 4;
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.colv && gn < p.N) c4 = *reinterpret_cast<const float4*>(p.colv + gn);
+            cvr[a][0] = c4.x; cvr[a][1] = c4.y; cvr[a][2] = c4.z; cvr[a][3] = c4.w;
+        }
+    }
 
+    // ---- main loop: NS-deep LDS ring, NS-1 k-tiles of DMA in flight, ONE raw barrier per k-tile and a COUNTED
+    // vmcnt so the younger tiles' DMA stays in flight across the barrier (a plain __syncthreads() would drain it)
+    const int nk = p.K / BKE;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s);
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
+    int cur = 0, last_fill = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            stage(cur ^ 1);
-        } else if (LDS_EPI && resp) {
-            stage_residual(cur ^ 1);
+        // tiles issued after tile kt so far: min(NS-2, nk-1-kt); everything older must have landed
+        const int younger = min(NS - 2, nk - 1 - kt);
+        if (NS >= 3 && younger == 1) wait_vmcnt<DPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the buffer read in iteration kt-1 is free now: refill it with tile kt+NS-1, or with the residual tile
+        int fill = cur + NS - 1;
+        fill = fill >= NS ? fill - NS : fill;
+        last_fill = fill;
+        if (kt + NS - 1 < nk) {
+            stage(fill);
+        } else if (LDS_EPI && resp && kt == nk - 1) {
+            stage_residual(fill);
         }
         const unsigned char* sa = smem + cur * BUF_BYTES;
         const unsigned char* sb = sa + A_BYTES;
@@ -261,18 +303,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
+                for (int b = 0; b < FM; ++b)
+                    if (!(p.dbg & 2)) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = cur + 1 == NS ? 0 : cur + 1;
     }
+    // `last_fill` = the slot freed in the last iteration: it holds the residual tile and will hold the out tile
+    wait_vmcnt<0>();
+    __syncthreads();
 
     // ---- epilogue: lane (g = lane>>4, j = lane&15) holds channels 4g..4g+3 of pixel j per fragment
     TOUT* __restrict__ outp = reinterpret_cast<TOUT*>(p.out);
     if constexpr (LDS_EPI) {
         // phase 1: combine in fp32, round once, park the bf16 tile in the free staging buffer (in place over the
         // residual image: every lane overwrites exactly the 8 bytes it just read)
-        unsigned char* so = smem + ((nk & 1) ? BUF_BYTES : 0);  // buffer (last cur) ^ 1
+        unsigned char* so = smem + last_fill * BUF_BYTES;
+        if (!(p.dbg & 4))
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
             const int prow = wm * (BM / 2) + b * 16 + frow;
@@ -281,12 +327,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
                 const int c = wn * (BN / 2) + a * 16 + fchunk * 4;
-                const int gn = n0 + c;
-                float cv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.colv && gn < p.N) {
-                    const float4 c4 = *reinterpret_cast<const float4*>(p.colv + gn);
-                    cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
-                }
+                const float* cv = cvr[a];
                 unsigned char* slot = so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1);
                 float v[4];
 #pragma unroll
@@ -315,7 +356,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             const int gch = pch ^ (row & (CPR - 1));
             const int gm = m0 + row;
             const int gn = n0 + gch * 8;
-            if (gm < p.M && gn < p.N) {
+            if (gm < p.M && gn < p.N && !(p.dbg & 1)) {
                 const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
                 *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * p.ldo + gn) * 2) = v;
             }
@@ -377,23 +418,42 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     AGRL_CHECK_ARG(p.K == p.R * p.S * p.Cin, "%s: K mismatch", who);
     AGRL_CHECK_ARG((((uintptr_t)p.x) & 15) == 0 && (((uintptr_t)p.w) & 15) == 0,
                    "%s: operands must be 16-byte aligned", who);
+    p.dbg = 0;
+    if (const char* e = getenv("AGRL_IGEMM_DBG")) p.dbg = atoi(e);
     p.vec_ok = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 && (!p.colv || (((uintptr_t)p.colv) & 15) == 0) &&
                (!p.res || (((uintptr_t)p.res) & 15) == 0);
     // bf16 outputs whose rows are whole 16-byte chunks take the LDS-staged (fully coalesced) epilogue
     const bool lds_epi = sizeof(TOUT) == 2 && (p.N % 8) == 0 && (p.ldo % 8) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
                          (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.colv || (((uintptr_t)p.colv) & 15) == 0);
     const bool narrow = p.N <= 64;
-    const int grid = cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128);
+    // ring depth 2 at two workgroups per CU beats deeper rings at one (measured: 6.4 vs 9.1 ms per forward)
+    int ns = 2;
+    if (const char* e = getenv("AGRL_IGEMM_NS")) ns = atoi(e);
+    // short K loops (<= 2 k-tiles) are pure load->store latency chains: 64-row tiles halve the LDS footprint so
+    // three workgroups fit a CU
+    int bm = (p.K / BKE) <= 2 ? 64 : 128;
+    if (const char* e = getenv("AGRL_IGEMM_BM")) bm = atoi(e);
+    const int grid = cdiv(p.M, bm) * cdiv(p.N, narrow ? 64 : 128);
+#define LAUNCH_IG(BM_, BN_, EPI_, NS_) \
+    hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_>), dim3(grid), dim3(256), 0, stream, p)
+#define LAUNCH_NS(BN_, EPI_)                                  \
+    do {                                                      \
+        if (bm == 64) LAUNCH_IG(64, BN_, EPI_, 2);            \
+        else if (ns == 3) LAUNCH_IG(128, BN_, EPI_, 3);       \
+        else LAUNCH_IG(128, BN_, EPI_, 2);                    \
+    } while (0)
+    bool done = false;
     if constexpr (sizeof(TOUT) == 2) {
         if (lds_epi) {
-            if (narrow) hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 64, true>), dim3(grid), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 128, true>), dim3(grid), dim3(256), 0, stream, p);
-            AGRL_CHECK_LAUNCH(who);
-            return 0;
+            if (narrow) LAUNCH_NS(64, true); else LAUNCH_NS(128, true);
+            done = true;
         }
     }
-    if (narrow) hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 64, false>), dim3(grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, 128, 128, false>), dim3(grid), dim3(256), 0, stream, p);
+    if (!done) {
+        if (narrow) LAUNCH_NS(64, false); else LAUNCH_NS(128, false);
+    }
+#undef LAUNCH_NS
+#undef LAUNCH_IG
     AGRL_CHECK_LAUNCH(who);
     return 0;
 }

@@ -1,0 +1,172 @@
+// bf16-MFMA stem: conv 7x7/2 (3->64, BN folded) + ReLU + maxpool 3x3/2, fused. vmgn.py:281-284.
+//
+// The 7x7x3 filter is turned into a K = 7 x 32 contraction that needs NO im2col: the input patch sits in LDS as
+// bf16 [y][x][4] (3 channels + a zero), so for a fixed filter row r the 7 taps x 4 channels an output pixel
+// needs are 28 CONTIGUOUS bf16; padding that to 32 (the extra pixel meets zero weights) makes one k-step of
+// v_mfma_f32_16x16x32_bf16 per filter row, and every lane's 8-element operand slice is one aligned ds_read_b128
+// straight out of the patch. 1.5x redundant MFMA work buys zero gather instructions.
+//
+// One 256-thread workgroup -> an 8x8 tile of POOLED pixels x 64 channels of one frame:
+//   patch 39x40x4 bf16 (12.5 KB) + packed weights 64 x 232 bf16 (29 KB, LDS-DMA)      -> LDS
+//   conv tile 17x17 = 289 positions x 64 ch: 19 position fragments over 4 waves, 7 k-steps, +bias, ReLU
+//   -> bf16 conv tile in LDS (overlaying patch+weights) -> 3x3/2 max -> NHWC store (128 B per pooled pixel)
+#include "agrl_common.h"
+
+namespace {
+constexpr int PT = 8;                 // pooled tile edge
+constexpr int CT = 2 * PT + 1;        // conv tile edge 17
+constexpr int NPOS = CT * CT;         // 289
+constexpr int NFRAG = (NPOS + 15) / 16;  // 19
+constexpr int FPW = (NFRAG + 3) / 4;  // position fragments per wave: 5
+constexpr int IT = 2 * (CT - 1) + 7;  // input patch edge 39
+constexpr int PWP = 40;               // padded patch width (pixels)
+constexpr int PATCH_BYTES = IT * PWP * 8;      // 12480
+constexpr int WROW_BYTES = 464;                // 7*32 bf16 = 448 + 16 pad (odd number of 16-B slots: conflict-free)
+constexpr int W_BYTES = 64 * WROW_BYTES;       // 29696 = 29 KiB
+constexpr int CTILE_BYTES = NPOS * 128;        // 36992
+constexpr int LDS_BYTES = PATCH_BYTES + W_BYTES;  // 42176 >= CTILE_BYTES
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
+                                                        int W, int CH, int CW, int PH, int PW, int tiles_w, int tiles_hw) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    unsigned char* s_patch = smem;
+    unsigned char* s_w = smem + PATCH_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / tiles_hw;
+    const int trem = blockIdx.x - n * tiles_hw;
+    const int ph0 = (trem / tiles_w) * PT;
+    const int pw0 = (trem % tiles_w) * PT;
+    const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1;
+    const int iy0 = 2 * cr0 - 3, ix0 = 2 * cc0 - 3;
+
+    // weights: 29 one-KiB DMA pieces, contiguous
+    for (int piece = wave; piece < W_BYTES / 1024; piece += 4)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(wpk + piece * 1024 + lane * 16), (lds_void_t*)(s_w + piece * 1024), 16, 0, 0);
+    // patch: one pixel (3 channels -> 4 bf16) per thread iteration
+    const float* xn = x + (size_t)n * 3 * H * W;
+    for (int e = tid; e < IT * PWP; e += 256) {
+        const int py = e / PWP, px = e - py * PWP;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (px < IT && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const size_t o = (size_t)iy * W + ix;
+            v0 = xn[o];
+            v1 = xn[(size_t)H * W + o];
+            v2 = xn[2 * (size_t)H * W + o];
+        }
+        uint2 u;
+        u.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+        u.y = (uint32_t)f32_to_bf16(v2);
+        *reinterpret_cast<uint2*>(s_patch + e * 8) = u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 15, g = lane >> 4;
+    int a_off[FPW];  // byte offset of this lane's patch slice at filter row 0
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        int pos = (wave + 4 * i) * 16 + frow;
+        pos = pos < NPOS ? pos : NPOS - 1;
+        const int cy = pos / CT, cx = pos - cy * CT;
+        a_off[i] = ((2 * cy) * PWP + 2 * cx + 2 * g) * 8;
+    }
+    f32x4_t acc[FPW][4];
+#pragma unroll
+    for (int i = 0; i < FPW; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[i][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        uint4 wf[4], xf[FPW];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            wf[a] = *reinterpret_cast<const uint4*>(s_w + (a * 16 + frow) * WROW_BYTES + r * 64 + g * 16);
+#pragma unroll
+        for (int i = 0; i < FPW; ++i) xf[i] = *reinterpret_cast<const uint4*>(s_patch + a_off[i] + r * (PWP * 8));
+#pragma unroll
+        for (int i = 0; i < FPW; ++i)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                acc[i][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[a]),
+                                                                    __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][a], 0, 0, 0);
+    }
+    __syncthreads();  // every wave is done with patch + weights: the conv tile may overlay them
+
+    // conv tile [pos][64 ch] bf16, 8-byte slot s of row p stored at slot s ^ (p & 15)
+    unsigned char* s_ct = smem;
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int pos = (wave + 4 * i) * 16 + frow;
+        if (pos < NPOS) {
+            const int cy = pos / CT, cx = pos - cy * CT;
+            const bool in = (unsigned)(cr0 + cy) < (unsigned)CH && (unsigned)(cc0 + cx) < (unsigned)CW;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int ch = a * 16 + g * 4;
+                const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+                const float v0 = in ? fmaxf(acc[i][a][0] + bv.x, 0.f) : 0.f;
+                const float v1 = in ? fmaxf(acc[i][a][1] + bv.y, 0.f) : 0.f;
+                const float v2 = in ? fmaxf(acc[i][a][2] + bv.z, 0.f) : 0.f;
+                const float v3 = in ? fmaxf(acc[i][a][3] + bv.w, 0.f) : 0.f;
+                uint2 u;
+                u.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+                u.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                *reinterpret_cast<uint2*>(s_ct + pos * 128 + (((ch >> 2) ^ (pos & 15)) << 3)) = u;
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3x3/2 max pool: thread -> 4 channels (one 8-byte slot) of pooled pixels (tid>>4) + 16 i
+    const int cq = tid & 15;
+#pragma unroll
+    for (int i = 0; i < (PT * PT) / 16; ++i) {
+        const int pp = (tid >> 4) + 16 * i;
+        const int py = pp / PT, px = pp - py * PT;
+        const int ph = ph0 + py, pw = pw0 + px;
+        if (ph < PH && pw < PW) {
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;  // post-ReLU values are >= 0
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int pos = (2 * py + dy) * CT + 2 * px + dx;
+                    const uint2 u = *reinterpret_cast<const uint2*>(s_ct + pos * 128 + ((cq ^ (pos & 15)) << 3));
+                    m0 = fmaxf(m0, __uint_as_float(u.x << 16));
+                    m1 = fmaxf(m1, __uint_as_float(u.x & 0xffff0000u));
+                    m2 = fmaxf(m2, __uint_as_float(u.y << 16));
+                    m3 = fmaxf(m3, __uint_as_float(u.y & 0xffff0000u));
+                }
+            uint2 o;  // already bf16-representable: plain truncation is exact
+            o.x = (__float_as_uint(m0) >> 16) | (__float_as_uint(m1) & 0xffff0000u);
+            o.y = (__float_as_uint(m2) >> 16) | (__float_as_uint(m3) & 0xffff0000u);
+            *reinterpret_cast<uint2*>(out + (((size_t)n * PH + ph) * PW + pw) * 64 + cq * 4) = o;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w_packed, const float* bias, void* out,
+                                                   int N, int H, int W, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && w_packed && bias && out, "agrl_stem_bf16: null pointer");
+    AGRL_CHECK_ARG(N > 0 && H >= 7 && W >= 7, "agrl_stem_bf16: bad shape N=%d H=%d W=%d", N, H, W);
+    AGRL_CHECK_ARG((((uintptr_t)w_packed) & 15) == 0 && (((uintptr_t)bias) & 15) == 0 && (((uintptr_t)out) & 7) == 0,
+                   "agrl_stem_bf16: misaligned pointer");
+    const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
+    const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
+    const int tiles_h = cdiv(PH, PT), tiles_w = cdiv(PW, PT);
+    const long long grid = (long long)N * tiles_h * tiles_w;
+    AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_bf16: grid too large");
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x,
+                       (const unsigned char*)w_packed, bias, (bf16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w);
+    AGRL_CHECK_LAUNCH("agrl_stem_bf16");
+    return 0;
+}

@@ -75,6 +75,7 @@ def pack_weights(model, device, precision):
         pack = {
             'dtype': dtype,
             'stem': (stem_w, stem_b),
+            'stem_lp': ops.pack_stem_weights_bf16(stem_w) if dtype == torch.bfloat16 else None,
             'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype),
             'l4_1': _pack_stage(model.layer4_1, dtype),
             'l4_2': _pack_stage(model.layer4_2, dtype),
@@ -104,7 +105,10 @@ def _run_block(x, blk):
 
 def hip_featuremaps(model, frames, pack):
     """(F,3,H,W) fp32 NCHW -> x4_1, x4_2 NHWC (F,h,w,2048). reference vmgn.py:280-290."""
-    a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+    if pack['stem_lp'] is not None:
+        a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1])
+    else:
+        a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
     for blk in pack['trunk']:
         a = _run_block(a, blk)
     x4_1 = a

@@ -84,6 +84,24 @@ def test_stem(shape, dtype):
     assert e < (1e-5 if dtype == torch.float32 else 8e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 256, 128), (3, 64, 48), (1, 37, 29), (1, 224, 112)])
+def test_stem_bf16_mfma(shape):
+    from torchreid import hip_ops as ops
+    N, H, W = shape
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((N, 3, H, W), generator=g)
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.1
+    b = torch.randn((64,), generator=g) * 0.1
+    # the kernel rounds pixels and weights to bf16 and accumulates in fp32: so does the reference here
+    ref = F.max_pool2d(F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), bias=b, stride=2, padding=3)), 3, 2, 1)
+    wpk = ops.pack_stem_weights_bf16(w.permute(0, 2, 3, 1).contiguous().to(DEV))
+    out = ops.stem_bf16(x.to(DEV), wpk, b.to(DEV))
+    torch.cuda.synchronize()
+    e = rel_err(out.float().permute(0, 3, 1, 2), ref)
+    print("stem bf16 mfma", shape, "rel err %.3e" % e)
+    assert e < 5e-3  # one bf16 rounding of the output
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(2, 4, 16, 8, 2048, [4, 2, 1]), (1, 3, 14, 7, 512, [4, 2, 1]), (2, 2, 16, 8, 256, [8, 4, 2, 1]), (1, 2, 16, 8, 256, [4])])
 def test_part_pool(cfg, dtype):
