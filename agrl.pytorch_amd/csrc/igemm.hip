@@ -42,7 +42,7 @@ struct IgemmParams {
     int Cin, H, W, OH, OW, R, S, stride, pad;
     int ldo;     // row stride of out / res in elements
     int vec_ok;  // 4-wide epilogue accesses are aligned
-    int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 2 skip MFMAs, 4 skip epilogue phase 1
+    int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
 };
 
 template <typename T>
@@ -199,19 +199,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     int tap_r = 0, tap_s = 0, c0 = 0;  // filter tap and channel offset of the tile being STAGED
     size_t kbyte = 0;                  // byte offset of that tile along K in the weight rows
 
-    auto stage = [&](int buf) {
-        unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / 4) * 128;
-        unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / 4) * 128;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
+    // one 1-KiB DMA piece of the k-tile being staged: pieces 0..AJ-1 are pixel rows, AJ..AJ+BJ-1 weight rows
+    auto stage_piece = [&](int buf, int idx) {
+        if (idx < AJ) {
+            const int j = idx;
+            unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / 4) * 128;
             const int ih = a_ih0[j] + tap_r;
             const int iw = a_iw0[j] + tap_s;
             const bool ok = a_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const size_t off = ((size_t)(a_nbase[j] + ih * p.W + iw) * p.Cin + c0 + a_coff[j]) * sizeof(TIN);
             dma16(ok ? xg + off : zsrc, sa + j * 1024);
+        } else {
+            const int j = idx - AJ;
+            unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / 4) * 128;
+            dma16(wg + b_off[j] + kbyte, sb + j * 1024);
         }
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) dma16(wg + b_off[j] + kbyte, sb + j * 1024);
+    };
+    auto stage_advance = [&]() {
         kbyte += 128;
         c0 += BKE;
         if (c0 == p.Cin) {
@@ -221,6 +225,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                 ++tap_r;
             }
         }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AJ + BJ; ++i) stage_piece(buf, i);
+        stage_advance();
     };
 
     f32x4_t acc[FN][FM];
@@ -276,7 +285,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         // tiles issued after tile kt so far: min(NS-2, nk-1-kt); everything older must have landed
         const int younger = min(NS - 2, nk - 1 - kt);
-        if (NS >= 3 && younger == 1) wait_vmcnt<DPT>();
+        if (p.dbg & 32) {
+        } else if (NS >= 3 && younger == 1) wait_vmcnt<DPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -284,11 +294,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         int fill = cur + NS - 1;
         fill = fill >= NS ? fill - NS : fill;
         last_fill = fill;
-        if (kt + NS - 1 < nk) {
+        // The DMA pieces of the next k-tile are interleaved with the MFMA groups (one piece per FM MFMAs): a burst of
+        // 8 back-to-back pieces fills the memory pipeline's queue and stalls the wave for ~500 cycles, spread out they
+        // ride under the matrix work. sched_barrier pins that order.
+        bool do_stage = kt + NS - 1 < nk && !(p.dbg & 8);
+        if (do_stage && (p.dbg & 64)) {  // A/B switch: burst-issue the whole k-tile up front
             stage(fill);
-        } else if (LDS_EPI && resp && kt == nk - 1) {
-            stage_residual(fill);
+            do_stage = false;
         }
+        if (!do_stage && LDS_EPI && resp && kt == nk - 1) stage_residual(fill);
+        constexpr int GROUPS = 2 * FN;
+        constexpr int PPG = (DPT + GROUPS - 1) / GROUPS;
         const unsigned char* sa = smem + cur * BUF_BYTES;
         const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
@@ -301,11 +317,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             for (int a = 0; a < FN; ++a)
                 wf[a] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
 #pragma unroll
-            for (int a = 0; a < FN; ++a)
+            for (int a = 0; a < FN; ++a) {
+                if (do_stage) {
 #pragma unroll
-                for (int b = 0; b < FM; ++b)
-                    if (!(p.dbg & 2)) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
+                    for (int q = 0; q < PPG; ++q) {
+                        const int idx = (kk * FN + a) * PPG + q;
+                        if (idx < DPT) stage_piece(fill, idx);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (do_stage) stage_advance();
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
     // `last_fill` = the slot freed in the last iteration: it holds the residual tile and will hold the out tile
@@ -409,6 +434,224 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form (bf16 output, LDS epilogue). Same 4 waves / 2 x 2 MFMA layout, but each workgroup walks tiles
+// T = vid, vid+G, ... and the waves take fixed side roles:
+//   waves 0,1 ("loaders")  issue every LDS-DMA (k-tiles, residual, bias) and are the only ones that wait on vmcnt
+//   waves 2,3 ("drainers") issue every global store of the finished tiles and never wait on them
+// On gfx950 loads and stores retire in order on ONE per-wave counter, so a wave that stores and then waits for a
+// DMA stalls until its stores have drained to HBM; with the roles split the loaders' counter only ever holds DMA
+// and the store drain of tile T overlaps the whole of tile T+G. The first k-tile of tile T+G is issued while
+// tile T is still in its epilogue, so no tile starts with an exposed L2/HBM round trip either.
+// Barriers per tile: nk (ring) + 2 (residual landed / out tile complete); every wave executes every one.
+__device__ inline void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename TIN, int BM, int BN, int NL>  // NL = number of loader waves (2: split roles, 4: everybody)
+__global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p, int ntiles) {
+    constexpr int EPC = DT<TIN>::epc;
+    constexpr int BKE = 8 * EPC;
+    constexpr int AJ = BM / (8 * NL), BJ = BN / (8 * NL);  // 8-row DMA pieces per loader wave
+    constexpr int FM = BM / 32, FN = BN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int CPR = BN * 2 / 16, ROWB = BN * 2, RPI = 64 / CPR;
+    constexpr int RJ = BM / (NL * RPI);         // residual DMA pieces per loader wave
+    static_assert(BM * ROWB <= BUF_BYTES, "out tile must fit one ring slot");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES + 1024];
+    unsigned char* s_bias = smem + 2 * BUF_BYTES;  // BN floats (<= 512 B), one DMA piece
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave < NL;
+    const bool drainer = NL == 4 || wave >= 2;
+    const int wm = wave & 1;
+    const int wn = wave >> 1;
+    const int nNt = (p.N + BN - 1) / BN;
+    const int nk = p.K / BKE;
+    const int G = gridDim.x;
+    int vid = blockIdx.x;
+    {
+        const int q = G >> 3, r = G & 7;
+        const int xcd = vid & 7, within = vid >> 3;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int slot_step = (nk - 1) & 1;  // k-tile 0 of the next tile lands in the slot of this tile's last k-tile
+
+    const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+    const int lrow = lane >> 3;
+    const int lchk = lane & 7;
+
+    // ---- loader state. This kernel serves the pointwise case only (1x1, stride 1, no padding: 36 of the 52 convs,
+    // the Linear and the distance matrix), where pixel m of the GEMM is row m of the input matrix and no
+    // (n, oh, ow) decomposition has to be carried: the staging "coordinates" are just the tile origin.
+    int sm0 = 0, sn0 = 0;
+    auto make_coord = [&](int T) {
+        const int mt = T / nNt, nt = T - mt * nNt;
+        sm0 = mt * BM;
+        sn0 = nt * BN;
+    };
+    const unsigned coff0 = (lchk ^ (lrow >> 1)) * EPC * sizeof(TIN);        // even 8-row pieces
+    const unsigned coff1 = (lchk ^ ((lrow >> 1) + 4)) * EPC * sizeof(TIN);  // odd 8-row pieces
+    const size_t a_row_bytes = (size_t)p.Cin * sizeof(TIN);
+    unsigned kbyte = 0;  // byte offset of the k-tile being staged inside a row of X / W (K == Cin here)
+    auto stage = [&](int buf) {  // loaders only
+        unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / NL) * 128;
+        unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / NL) * 128;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int gm = sm0 + wave * (BM / NL) + j * 8 + lrow;
+            const unsigned char* src = xg + (size_t)gm * a_row_bytes + kbyte + ((j & 1) ? coff1 : coff0);
+            dma16(gm < p.M ? src : zsrc, sa + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            int gn = sn0 + wave * (BN / NL) + j * 8 + lrow;
+            gn = gn < p.N ? gn : p.N - 1;
+            dma16(wg + (size_t)gn * a_row_bytes + kbyte + ((j & 1) ? coff1 : coff0), sb + j * 1024);
+        }
+        kbyte += 128;
+    };
+    const bool has_res = p.res != nullptr;
+    auto stage_residual_bias = [&](int buf, int cm0, int cn0) {  // loaders only, for the tile being computed
+        unsigned char* so = smem + buf * BUF_BYTES;
+        const unsigned char* rg = reinterpret_cast<const unsigned char*>(p.res);
+        if (has_res) {
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                const int row0 = (wave * RJ + j) * RPI;
+                const int row = row0 + lane / CPR;
+                const int gch = (lane % CPR) ^ (row & (CPR - 1));
+                const int gm = cm0 + row;
+                const int gn = cn0 + gch * 8;
+                const bool ok = gm < p.M && gn < p.N;
+                dma16(ok ? rg + ((size_t)gm * p.ldo + gn) * 2 : zsrc, so + row0 * ROWB);
+            }
+        }
+        if (wave == 0) {  // BN floats of bias: lanes 0 .. BN/4-1
+            const int gn = cn0 + lane * 4;
+            const bool ok = p.colv != nullptr && lane < BN / 4 && gn < p.N;
+            dma16(ok ? reinterpret_cast<const unsigned char*>(p.colv + gn) : zsrc, s_bias);
+        }
+    };
+
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+    int s0 = 0;  // ring slot holding k-tile 0 of the current tile
+    if (vid < ntiles) {
+        make_coord(vid);
+        if (loader) stage(0);
+    }
+    for (int T = vid; T < ntiles; T += G) {
+        const int cm0 = sm0, cn0 = sn0;  // the tile being computed / written (sm0/sn0 move on to the next one)
+        const bool has_next = T + G < ntiles;
+        if (nk == 1 && has_next) {  // this tile's only k-tile is already in flight: retarget the staging coordinates
+            make_coord(T + G);
+            kbyte = 0;
+        }
+
+        f32x4_t acc[FN][FM];
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        int cur = s0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (loader) wait_vmcnt<0>();  // the loaders' queue holds nothing but DMA: k-tile kt has landed
+            wg_barrier();                 // ... for everybody; and the other slot is no longer being read
+            if (kt + 1 < nk) {
+                if (loader) stage(cur ^ 1);
+                if (kt + 2 == nk && has_next) {  // last k-tile issued: retarget the staging coordinates
+                    make_coord(T + G);
+                    kbyte = 0;
+                }
+            } else if (loader) {
+                stage_residual_bias(cur ^ 1, cm0, cn0);
+            }
+            const unsigned char* sa = smem + cur * BUF_BYTES;
+            const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 xf[FM], wf[FN];
+#pragma unroll
+                for (int b = 0; b < FM; ++b)
+                    xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+                    wf[a] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b)
+                        if (!(p.dbg & 2)) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
+            }
+            cur ^= 1;
+        }
+        // cur = slot with the residual image (becomes the out tile); cur ^ 1 = slot of the last k-tile
+        if (loader) wait_vmcnt<0>();
+        wg_barrier();
+        if (loader && has_next) stage(cur ^ 1);  // next tile's first k-tile flies under this tile's epilogue
+
+        unsigned char* so = smem + cur * BUF_BYTES;
+        if (!(p.dbg & 4)) {
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int prow = wm * (BM / 2) + b * 16 + frow;
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    const int c = wn * (BN / 2) + a * 16 + fchunk * 4;
+                    const float4 cv = *reinterpret_cast<const float4*>(s_bias + c * 4);
+                    unsigned char* slot = so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1);
+                    float v[4];
+                    v[0] = fmaf(p.alpha, acc[a][b][0], p.rowc + cv.x);
+                    v[1] = fmaf(p.alpha, acc[a][b][1], p.rowc + cv.y);
+                    v[2] = fmaf(p.alpha, acc[a][b][2], p.rowc + cv.z);
+                    v[3] = fmaf(p.alpha, acc[a][b][3], p.rowc + cv.w);
+                    if (has_res) {
+                        float rr[4];
+                        load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), rr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+                }
+            }
+        }
+        wg_barrier();  // out tile complete
+        if (drainer) {
+            // drain: whole 16-byte chunks, full rows (with split roles these stores are never waited for)
+            constexpr int ND = NL == 4 ? 256 : 128;  // drainer lanes
+            const int dt = NL == 4 ? tid : tid - 128;
+            const int pch = dt % CPR;
+            const int r0 = dt / CPR;
+            constexpr int RPP = ND / CPR;  // rows per pass
+#pragma unroll
+            for (int i = 0; i < BM / RPP; ++i) {
+                const int row = r0 + i * RPP;
+                const int gch = pch ^ (row & (CPR - 1));
+                const int gm = cm0 + row;
+                const int gn = cn0 + gch * 8;
+                if (gm < p.M && gn < p.N && !(p.dbg & 1)) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
+                    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * p.ldo + gn) * 2) = v;
+                }
+            }
+        }
+        s0 ^= slot_step;
+    }
+}
+
 template <typename TIN, typename TOUT>
 static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char* who) {
     constexpr int BKE = 8 * DT<TIN>::epc;
@@ -443,6 +686,30 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
         else LAUNCH_IG(128, BN_, EPI_, 2);                    \
     } while (0)
     bool done = false;
+    if constexpr (sizeof(TOUT) == 2) {
+        // persistent tiles pay off where a tile is short (<= 8 k-tiles): its first DMA round trip and its store
+        // drain are a large share of the tile; long K loops run better as independent workgroups (A/B measured)
+        int persist = (p.K / BKE) <= 8 ? 1 : 0;
+        if (const char* e = getenv("AGRL_IGEMM_PERSIST")) persist = atoi(e);
+        const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+        if (lds_epi && persist && !p.rowv && pointwise) {
+            const int ntiles = cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128);
+            int wgs = 512;  // two resident workgroups per CU
+            if (const char* e = getenv("AGRL_IGEMM_WGS")) wgs = atoi(e);
+            const int g = ntiles < wgs ? ntiles : wgs;
+            int nl = 4;
+            if (const char* e = getenv("AGRL_IGEMM_NL")) nl = atoi(e);
+            if (nl == 2) {
+                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 2>), dim3(g), dim3(256), 0, stream, p, ntiles);
+                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 2>), dim3(g), dim3(256), 0, stream, p, ntiles);
+            } else {
+                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 4>), dim3(g), dim3(256), 0, stream, p, ntiles);
+                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 4>), dim3(g), dim3(256), 0, stream, p, ntiles);
+            }
+            AGRL_CHECK_LAUNCH(who);
+            return 0;
+        }
+    }
     if constexpr (sizeof(TOUT) == 2) {
         if (lds_epi) {
             if (narrow) LAUNCH_NS(64, true); else LAUNCH_NS(128, true);

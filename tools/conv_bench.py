@@ -7,13 +7,18 @@ import torch
 from torchreid import hip_ops as ops
 dev = "cuda:0"
 SHAPES = [  # N, H, W, Cin, Cout, R, stride, res
+    (256, 64, 32, 64, 128, 1, 1, False),
     (256, 64, 32, 64, 256, 1, 1, False),
-    (256, 64, 32, 64, 256, 1, 1, True),
+    (256, 64, 32, 64, 512, 1, 1, False),
+    (256, 64, 32, 128, 128, 1, 1, False),
+    (256, 64, 32, 128, 128, 1, 1, True),
     (256, 64, 32, 256, 64, 1, 1, False),
     (256, 16, 8, 512, 2048, 1, 1, True),
     (256, 16, 8, 2048, 512, 1, 1, False),
     (256, 16, 8, 512, 512, 3, 1, False),
 ]
+if len(sys.argv) > 1:
+    SHAPES = [SHAPES[int(i)] for i in sys.argv[1].split(",")]
 for (N, H, W, Cin, Cout, R, stride, res) in SHAPES:
     x = torch.randn((N, H, W, Cin), device=dev).bfloat16()
     w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).bfloat16()
