@@ -675,6 +675,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     // short K loops (<= 2 k-tiles) are pure load->store latency chains: 64-row tiles halve the LDS footprint so
     // three workgroups fit a CU
     int bm = (p.K / BKE) <= 2 ? 64 : 128;
+    if (cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128) < 400) bm = 64;  // too few 128-row tiles to fill 256 CUs twice
     if (const char* e = getenv("AGRL_IGEMM_BM")) bm = atoi(e);
     const int grid = cdiv(p.M, bm) * cdiv(p.N, narrow ? 64 : 128);
 #define LAUNCH_IG(BM_, BN_, EPI_, NS_) \

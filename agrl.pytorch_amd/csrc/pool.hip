@@ -130,26 +130,33 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const T* __restrict__ x
     if (lane == 0) sqn[row] = s;
 }
 
-// y = x / max(||x||, 1e-12) (or plain conversion); one wavefront per row
+// y = x / max(||x||, 1e-12) (or plain conversion); one 256-thread workgroup per row, float4 loads
 template <typename TOUT>
 __global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ x, TOUT* __restrict__ y, int R,
                                                             int C, int ldy, int normalize) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= R) return;
+    __shared__ float s_part[4];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = x + (size_t)row * C;
+    const bool vec = (C & 3) == 0 && ((((uintptr_t)src) & 15) == 0);
     float den = 1.f;
     if (normalize) {
         float s = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float v = src[c];
-            s = fmaf(v, v, s);
+        if (vec) {
+            for (int c = tid * 4; c < C; c += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c);
+                s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+            }
+        } else {
+            for (int c = tid; c < C; c += 256) s = fmaf(src[c], src[c], s);
         }
         s = wave_sum(s);
-        den = fmaxf(sqrtf(s), 1e-12f);
+        if (lane == 0) s_part[wave] = s;
+        __syncthreads();
+        den = fmaxf(sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])), 1e-12f);
     }
     TOUT* dst = y + (size_t)row * ldy;
-    for (int c = lane; c < ldy; c += 64) {
+    for (int c = tid; c < ldy; c += 256) {
         const float v = c < C ? (normalize ? src[c] / den : src[c]) : 0.f;  // zero padding up to ldy
         DT<TOUT>::st(dst + c, v);
     }
@@ -249,10 +256,10 @@ extern "C" int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int 
     AGRL_CHECK_ARG(x && y && R > 0 && C > 0 && ldy >= C, "agrl_row_l2_normalize: bad arguments");
     AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_row_l2_normalize: bad dtype %d", out_dtype);
     if (out_dtype == AGRL_F32)
-        hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x,
+        hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, x,
                            (float*)y, R, C, ldy, normalize);
     else
-        hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x,
+        hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, x,
                            (bf16_t*)y, R, C, ldy, normalize);
     AGRL_CHECK_LAUNCH("agrl_row_l2_normalize");
     return 0;

@@ -1,0 +1,106 @@
+"""Device-resident evaluation harness: the dataflow of the reference's ``test()``
+(train_vidreid_xent_htri.py:450-542) with everything after the data loader kept on the GPU.
+
+    reference test()                                   this harness
+    ------------------------------------------------   ---------------------------------------------------------
+    model(imgs, adj) per batch            (:469,:499)   same call (the HIP eval forward)
+    dense/skipdense clip pooling          (:471-476)    ``pool_clips`` (mean / max over a tracklet's clips)
+    features.data.cpu(); torch.cat        (:477-511)    embeddings stay in HBM; RCCL all-gather when sharded
+    compute_distance_matrix on CPU        (:520)        ``agrl_distmat`` against the rank's gallery shard
+    evaluate_rank(use_metric_mars=True)   (:531)        ``agrl_rank_topk`` + candidate merge + ``agrl_rank_mars``
+    returns cmc[0], mAP                   (:542)        returns (cmc, mAP) (+ the top-k lists on request)
+
+With ``torch.distributed`` initialised (one process per GPU) the tracklet batches and the gallery rows are sharded
+over the ranks (torchreid/parallel.py); every rank returns the same (cmc, mAP).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from torchreid import hip_ops as ops
+from torchreid import parallel
+from torchreid.metrics.distance import hip_distmat_device
+
+
+def pool_clips(features, num_clips, pool="avg"):
+    """(tracklets*num_clips, D) -> (tracklets, D): mean or max over each tracklet's clips
+    (reference: features.view(n, 1, -1) then mean/max over dim 0, train_vidreid_xent_htri.py:471-476)."""
+    if num_clips == 1:
+        return features
+    f = features.view(-1, num_clips, features.size(-1))
+    return f.mean(dim=1) if pool == "avg" else f.max(dim=1)[0]
+
+
+@torch.no_grad()
+def extract_features(model, batches, pool="avg"):
+    """``batches`` yields (imgs, pids, camids, adj) like the reference's loaders; imgs is (b,S,3,H,W) or, for the
+    dense samplers, (b,n,S,3,H,W) with adj (b,n,V,V). Returns (features (N,D) on the model's device, pids, camids)."""
+    device = next(model.parameters()).device
+    model.eval()
+    feats, pids, camids = [], [], []
+    for imgs, pid, camid, adj in batches:
+        imgs, adj = imgs.to(device, non_blocking=True), adj.to(device, non_blocking=True)
+        clips = 1
+        if imgs.dim() == 6:
+            b, clips = imgs.shape[:2]
+            imgs = imgs.reshape((b * clips,) + tuple(imgs.shape[2:]))
+            adj = adj.reshape((b * clips,) + tuple(adj.shape[2:]))
+        feats.append(pool_clips(model(imgs, adj), clips, pool))
+        pids.extend(np.asarray(pid).tolist())
+        camids.extend(np.asarray(camid).tolist())
+    return torch.cat(feats, 0), np.asarray(pids), np.asarray(camids)
+
+
+def _i32(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+
+@torch.no_grad()
+def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosine", max_rank=50,
+                   precision="fp32", return_topk=False):
+    """Distance matrix + MARS ranking on the device. ``qf``: ALL query embeddings (m,D); ``gf``: this rank's gallery
+    rows when a process group is active (rows ``shard_bounds(n, rank, world)`` of the gallery), else the whole
+    gallery. ``g_pids``/``g_camids`` always describe the WHOLE gallery. Returns (cmc ndarray (max_rank,), mAP float)."""
+    device = qf.device
+    world = parallel.world_size()
+    n = len(g_pids)
+    if max_rank > n:
+        raise ValueError("max_rank={} exceeds the gallery size {}".format(max_rank, n))
+    lo = parallel.shard_bounds(n, torch.distributed.get_rank(), world)[0] if world > 1 else 0
+
+    def dist_fn(q, g):
+        return hip_distmat_device(q, g, dist_metric, precision)
+
+    def topk_fn(d, k):
+        return ops.rank_topk(d, k)
+
+    idx, val = parallel.sharded_topk(qf.float().contiguous(), gf.float().contiguous(), lo, max_rank, dist_fn, topk_fn)
+    ap, cmc = ops.rank_mars(idx.to(torch.int32).contiguous(), _i32(q_pids, device), _i32(q_camids, device),
+                            _i32(g_pids, device), _i32(g_camids, device))
+    ap = ap.cpu().numpy()
+    if np.isnan(ap).any():
+        raise ZeroDivisionError("query {} has no cross-camera match in the gallery".format(int(np.isnan(ap).argmax())))
+    out = (np.mean(cmc.cpu().numpy().astype(np.float64), axis=0), float(np.mean(ap)))
+    if return_topk:
+        return out + (idx.cpu().numpy(), val.cpu().numpy())
+    return out
+
+
+@torch.no_grad()
+def evaluate(model, query_batches, gallery_batches, dist_metric="cosine", pool="avg", max_rank=50,
+             ranks=(1, 5, 10, 20), verbose=False):
+    """Single-process form of the reference's ``test()``: returns (rank1, mAP) and, like the reference, can print the
+    CMC table. For the sharded form run ``extract_features`` on each rank's slice and call ``match_and_rank``."""
+    qf, q_pids, q_camids = extract_features(model, query_batches, pool)
+    gf, g_pids, g_camids = extract_features(model, gallery_batches, pool)
+    cmc, mAP = match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric, max_rank,
+                              getattr(model, "hip_precision", "fp32"))
+    if verbose:
+        print("Results ----------")
+        print("mAP: {:.2%}".format(mAP))
+        print("CMC curve")
+        for r in ranks:
+            print("Rank-{:<3}: {:.2%}".format(r, cmc[r - 1]))
+        print("------------------")
+    return cmc[0], mAP

@@ -90,3 +90,16 @@ def synthetic_adj(B, S, seed=0, num_split=4, pyramid_part=True):
     rng = np.random.RandomState(2000 + seed)
     adjs = [pose_adjacency(synthetic_part_sets(S, rng, num_split), num_split, pyramid_part) for _ in range(B)]
     return torch.from_numpy(np.stack(adjs))
+
+
+def calibrate_bnneck(sd, g_f, att_f):
+    """Give the two BNNeck layers running statistics that match the synthetic data (as training would): the
+    embeddings become centred / unit-variance per dimension, so cosine distances between identities are O(1)
+    instead of ~1e-4 (random-init features share a dominant common component)."""
+    sd = dict(sd)
+    for name, f in (("global_bottleneck", g_f), ("att_bottleneck", att_f)):
+        sd[name + ".running_mean"] = f.mean(dim=0).clone()
+        sd[name + ".running_var"] = f.var(dim=0, unbiased=False).clamp(min=1e-8).clone()
+        sd[name + ".weight"] = torch.ones_like(sd[name + ".weight"])
+        sd[name + ".bias"] = torch.zeros_like(sd[name + ".bias"])
+    return sd

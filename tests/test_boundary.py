@@ -152,3 +152,19 @@ def test_missing_library_fails_loudly(monkeypatch):
     with pytest.raises(_hip.HipLibraryError):
         _hip.lib()
     assert not _hip.available()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/torchreid"), reason="reference tree only exists in the build container")
+def test_reference_overlay_resolves_out_of_scope_modules():
+    """With AGRL_REFERENCE_ROOT set, sub-modules this build does not provide fall through to the reference tree
+    while models/metrics/losses stay ours (route A)."""
+    code = (
+        "import torchreid, torchreid.models, torchreid.metrics, torchreid.lr_scheduler, torchreid.optimizers;"
+        "import torchreid.utils.avgmeter, torchreid.utils.reidtools;"
+        "print(torchreid.models.__file__); print(torchreid.lr_scheduler.__file__);"
+        "print(torchreid.utils.avgmeter.__file__); print(torchreid.utils.reidtools.__file__)"
+    )
+    env = dict(os.environ, AGRL_REFERENCE_ROOT="/root/reference", PYTHONPATH=os.path.join(ROOT, "agrl.pytorch_amd"))
+    out = subprocess.check_output(["python", "-c", code], env=env, cwd="/tmp").decode().split()
+    assert "agrl.pytorch_amd" in out[0] and out[1].startswith("/root/reference")
+    assert out[2].startswith("/root/reference") and "agrl.pytorch_amd" in out[3]

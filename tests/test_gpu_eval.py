@@ -1,0 +1,132 @@
+"""The test()-equivalent pipeline on the GPU vs the CPU oracle on identical synthetic weights and synthetic
+MARS-shaped tracklets: embeddings -> distance matrix -> MARS ranking -> Rank-1 / mAP ("matched Rank-1/mAP")."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vmgn_oracle as O
+from recipe import calibrate_bnneck, recipe_state_dict, synthetic_adj, synthetic_clips
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+N_ID, S = 12, 4
+G_PER_ID, Q_PER_ID = 5, 1
+
+
+def make_split(rng):
+    """query: 1 tracklet per identity (camera 0); gallery: 5 per identity on cameras 0..4 + a few junk (pid -1)."""
+    q_pids = np.arange(N_ID)
+    q_cams = np.zeros(N_ID, dtype=np.int64)
+    g_pids = np.repeat(np.arange(N_ID), G_PER_ID)
+    g_cams = np.tile(np.arange(G_PER_ID), N_ID)
+    g_pids = np.concatenate([g_pids, -np.ones(4, dtype=np.int64)])
+    g_cams = np.concatenate([g_cams, rng.randint(0, 5, 4)])
+    return q_pids, q_cams, g_pids, g_cams
+
+
+def batches(pids, cams, seed, bs=8):
+    idents = [p if p >= 0 else 1000 + i for i, p in enumerate(pids)]  # junk tracklets get their own pattern
+    for i in range(0, len(pids), bs):
+        sl = slice(i, i + bs)
+        b = len(pids[sl])
+        yield (synthetic_clips(b, S, seed=seed + i, identities=idents[sl]), pids[sl], cams[sl], synthetic_adj(b, S, seed=seed + i))
+
+
+@pytest.fixture(scope="module")
+def world():
+    from torchreid import models
+    rng = np.random.RandomState(5)
+    q_pids, q_cams, g_pids, g_cams = make_split(rng)
+    m = models.init_model("vmgn", num_classes=N_ID, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2,
+                          num_scale=1, pyramid_part=True, use_pose=True, learn_graph=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+
+    def oracle_parts(pids, cams, seed):
+        g, a = [], []
+        for x, _, _, adj in batches(pids, cams, seed):
+            B = x.shape[0]
+            x4_1, x4_2 = O.featuremaps(x.view(B * S, 3, 256, 128), sd)
+            _, parts = O.tail(x4_1, x4_2, adj, sd, B, S, [4, 2, 1], 2, return_parts=True)
+            g.append(parts["g_f"])
+            a.append(parts["att_f"])
+        return torch.cat(g), torch.cat(a)
+
+    with torch.no_grad():
+        qg, qa = oracle_parts(q_pids, q_cams, 100)
+        gg, ga = oracle_parts(g_pids, g_cams, 500)
+        sd = calibrate_bnneck(sd, torch.cat([qg, gg]), torch.cat([qa, ga]))
+        qf = torch.cat([O._bn(qg, sd, "global_bottleneck"), O._bn(qa, sd, "att_bottleneck")], 1)
+        gf = torch.cat([O._bn(gg, sd, "global_bottleneck"), O._bn(ga, sd, "att_bottleneck")], 1)
+    m.load_state_dict(sd)
+    m.eval()
+    ref = {}
+    for metric, fn in (("cosine", O.cosine), ("euclidean", O.euclidean_squared)):
+        d = fn(qf, gf).numpy()
+        cmc, mAP, ap, _, order = O.evaluate_mars(d, q_pids, g_pids, q_cams, g_cams, 50, return_all=True)
+        srt = np.sort(d, axis=1)
+        ref[metric] = dict(d=d, cmc=cmc, mAP=mAP, order=order, min_gap=float(np.min(np.diff(srt[:, :51], axis=1))),
+                           scale=float(np.abs(d).max()))
+    return dict(model=m.to(DEV), qf=qf, gf=gf, ref=ref, split=(q_pids, q_cams, g_pids, g_cams))
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+def test_fp32_pipeline_matches_oracle_rank1_map_and_indices(world, metric):
+    from torchreid import evaluation
+    m = world["model"]
+    m.hip_precision = "fp32"
+    q_pids, q_cams, g_pids, g_cams = world["split"]
+    qf, _, _ = evaluation.extract_features(m, batches(q_pids, q_cams, 100))
+    gf, _, _ = evaluation.extract_features(m, batches(g_pids, g_cams, 500))
+    ref = world["ref"][metric]
+    e_q = ((qf.cpu() - world["qf"]).abs().max() / world["qf"].abs().max()).item()
+    cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, "fp32", return_topk=True)
+    # ranking indices are only well defined where neighbouring distances differ by more than the fp32 error
+    err = np.abs(val - np.take_along_axis(ref["d"], ref["order"], 1)).max()
+    print("%s: embedding rel err %.2e, top-50 distance abs err %.2e, oracle min gap %.2e, Rank-1 %.3f mAP %.4f (oracle %.3f %.4f)" % (
+        metric, e_q, err, ref["min_gap"], cmc[0], mAP, ref["cmc"][0], ref["mAP"]))
+    assert e_q < 1e-3
+    assert err < 1e-3 * ref["scale"]
+    near_ties = 0
+    for r in range(idx.shape[0]):
+        if not np.array_equal(idx[r], ref["order"][r]):
+            # any disagreement must be a swap between distances closer than the combined rounding error
+            bad = np.where(idx[r] != ref["order"][r])[0]
+            assert np.all(np.abs(ref["d"][r, idx[r][bad]] - ref["d"][r, ref["order"][r][bad]]) < 2 * err + 1e-6)
+            near_ties += 1
+    print("rows with near-tie swaps: %d / %d" % (near_ties, idx.shape[0]))
+    if ref["min_gap"] > 4 * err:
+        assert near_ties == 0
+        assert mAP == ref["mAP"] and np.array_equal(cmc, ref["cmc"])
+    assert abs(cmc[0] - ref["cmc"][0]) < 1e-9 and abs(mAP - ref["mAP"]) < 1e-6
+
+
+def test_bf16_pipeline_keeps_rank1_and_map(world):
+    from torchreid import evaluation
+    m = world["model"]
+    m.hip_precision = "bf16"
+    q_pids, q_cams, g_pids, g_cams = world["split"]
+    ref = world["ref"]["cosine"]
+
+    def loader(p, c, s):
+        return batches(p, c, s)
+
+    r1, mAP = evaluation.evaluate(m, loader(q_pids, q_cams, 100), loader(g_pids, g_cams, 500), "cosine")
+    print("bf16: Rank-1 %.3f mAP %.4f (oracle %.3f %.4f)" % (r1, mAP, ref["cmc"][0], ref["mAP"]))
+    m.hip_precision = "fp32"
+    assert abs(r1 - ref["cmc"][0]) <= 1.0 / N_ID + 1e-9
+    assert abs(mAP - ref["mAP"]) < 0.03
+
+
+def test_dense_clip_pooling_path(world):
+    from torchreid import evaluation
+    m = world["model"]
+    m.hip_precision = "fp32"
+    x = synthetic_clips(6, S, seed=3)
+    adj = synthetic_adj(6, S, seed=3)
+    flat, _, _ = evaluation.extract_features(m, [(x, np.arange(6), np.zeros(6), adj)])
+    dense, pids, _ = evaluation.extract_features(m, [(x.view(2, 3, S, 3, 256, 128), np.arange(2), np.zeros(2), adj.view(2, 3, 28, 28))], pool="avg")
+    assert dense.shape == (2, 4096) and len(pids) == 2
+    assert torch.allclose(dense, flat.view(2, 3, -1).mean(1), atol=1e-6)
+    dmax, _, _ = evaluation.extract_features(m, [(x.view(2, 3, S, 3, 256, 128), np.arange(2), np.zeros(2), adj.view(2, 3, 28, 28))], pool="max")
+    assert torch.allclose(dmax, flat.view(2, 3, -1).max(1)[0], atol=1e-6)
