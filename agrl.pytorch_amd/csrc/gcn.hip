@@ -6,6 +6,8 @@
 //
 // The Linear h = f W^T between them is agrl_linear_nobias (igemm.hip).
 // Everything is deterministic: no atomics, fixed summation order.
+#include <stdlib.h>
+
 #include "agrl_common.h"
 
 namespace {
@@ -208,6 +210,117 @@ __global__ __launch_bounds__(PROP_THREADS) void graph_propagate_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Propagate, MFMA form (V <= 128). grid = (B, C/128), 256 threads. Per workgroup: D'[c][v] = sum_u H[u][c] G[v][u]
+// for a 128-channel slab, with v_mfma_f32_16x16x4_f32 (exact fp32): A operand = H^T (rows = channels), B operand =
+// G^T (cols = graph rows), so a lane ends with 4 consecutive channels of one node -> float4 epilogue.
+//   H slab  : V4 rows x 512 B, LDS-DMA straight from HBM (rows >= V from a zero block), 2 rows per 1-KiB piece
+//   G^T     : [V4][NVF*16] fp32, zero padded
+//   f       : this lane's residual inputs are fetched before the MFMA sweep and consumed in the epilogue
+// wave w owns channel fragments {2w, 2w+1} of the slab and all NVF node fragments.
+typedef __attribute__((address_space(3))) void gcn_lds_void_t;
+typedef __attribute__((address_space(1))) const void gcn_gbl_void_t;
+__device__ __attribute__((aligned(16))) uint4 g_gcn_zero16;
+
+template <int NVF>
+__global__ __launch_bounds__(256) void graph_propagate_mfma_kernel(
+    const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
+    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int V, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int V4 = (V + 3) & ~3;
+    constexpr int VP = NVF * 16;
+    float* s_h = reinterpret_cast<float*>(s_raw);                 // [V4 (even-padded)][128]
+    const int hrows = (V4 + 1) & ~1;
+    float* s_gt = s_h + hrows * 128;                              // [V4][VP]
+    const int b = blockIdx.x;
+    const int c0 = blockIdx.y * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // H slab by LDS-DMA: piece p holds rows 2p (lanes 0-31) and 2p+1 (lanes 32-63), 512 B each
+    const unsigned char* hb = reinterpret_cast<const unsigned char*>(h + (size_t)b * V * C + c0);
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_gcn_zero16);
+    for (int p = wave; p < hrows / 2; p += 4) {
+        const int row = 2 * p + (lane >> 5);
+        const unsigned char* src = row < V ? hb + (size_t)row * C * 4 + (lane & 31) * 16 : zsrc;
+        __builtin_amdgcn_global_load_lds((gcn_gbl_void_t*)src, (gcn_lds_void_t*)(s_raw + p * 1024), 16, 0, 0);
+    }
+    // G^T, zero padded in both directions
+    const float* Gb = G + (size_t)b * V * V;
+    for (int e = tid; e < V4 * VP; e += 256) {
+        const int u = e / VP, v = e - u * VP;
+        s_gt[e] = (u < V && v < V) ? Gb[(size_t)v * V + u] : 0.f;
+    }
+    // residual inputs + BN constants of this lane's outputs
+    const int vl = lane & 15, g4 = lane >> 4;
+    float4 fin[2][NVF];
+    float4 sc[2], sh[2];
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+        const int c = c0 + (wave * 2 + cf) * 16 + g4 * 4;
+        sc[cf] = *reinterpret_cast<const float4*>(bn_scale + c);
+        sh[cf] = *reinterpret_cast<const float4*>(bn_shift + c);
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) {
+            const int v = vf * 16 + vl;
+            fin[cf][vf] = v < V ? *reinterpret_cast<const float4*>(f + ((size_t)b * V + v) * C + c)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    f32x4_t acc[2][NVF];
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) acc[cf][vf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int nt = V4 >> 2;
+    for (int t = 0; t < nt; ++t) {
+        const int u = 4 * t + g4;
+        float a[2], bq[NVF];
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf) a[cf] = s_h[u * 128 + (wave * 2 + cf) * 16 + vl];
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) bq[vf] = s_gt[u * VP + vf * 16 + vl];
+#pragma unroll
+        for (int cf = 0; cf < 2; ++cf)
+#pragma unroll
+            for (int vf = 0; vf < NVF; ++vf)
+                acc[cf][vf] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cf], bq[vf], acc[cf][vf], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cf = 0; cf < 2; ++cf) {
+        const int c = c0 + (wave * 2 + cf) * 16 + g4 * 4;
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) {
+            const int v = vf * 16 + vl;
+            if (v < V) {
+                const float scv[4] = {sc[cf].x, sc[cf].y, sc[cf].z, sc[cf].w};
+                const float shv[4] = {sh[cf].x, sh[cf].y, sh[cf].z, sh[cf].w};
+                const float fv[4] = {fin[cf][vf].x, fin[cf][vf].y, fin[cf][vf].z, fin[cf][vf].w};
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float y = fmaf(acc[cf][vf][r], scv[r], shv[r]);
+                    y = y > 0.f ? y : slope * y;
+                    o[r] = one_minus_gamma * fv[r] + gamma * y;
+                }
+                const size_t idx = ((size_t)b * V + v) * C + c;
+                *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
+                if (out_lp) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    *reinterpret_cast<uint2*>(out_lp + idx) = pk;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int agrl_graph_gram(const float* f, float* gram_part, int B, int V, int C, int cslice,
@@ -242,6 +355,29 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
                                     int V, int C, agrl_stream_t stream) {
     AGRL_CHECK_ARG(f && h && G && bn_scale && bn_shift && out, "agrl_graph_propagate: null pointer");
     AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0, "agrl_graph_propagate: bad shape");
+    // (1 - gamma) is evaluated in double like the reference's Python float, then rounded once
+    const float omg_m = (float)(1.0 - (double)gamma);
+    if (V <= 128 && (C % 128) == 0 && !getenv("AGRL_GCN_VALU")) {
+        const int V4 = (V + 3) & ~3;
+        const int hrows = (V4 + 1) & ~1;
+        const int nvf = V <= 64 ? 4 : 8;
+        const size_t lds_m = (size_t)hrows * 512 + (size_t)V4 * nvf * 16 * 4;
+        const dim3 grid_m(B, C / 128);
+        if (nvf == 4) {
+            hipLaunchKernelGGL(graph_propagate_mfma_kernel<4>, grid_m, dim3(256), lds_m, (hipStream_t)stream, f, h, G,
+                               bn_scale, bn_shift, omg_m, gamma, slope, out, (bf16_t*)out_lp, V, C);
+        } else {
+            if (lds_m > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)graph_propagate_mfma_kernel<8>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_propagate: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+            }
+            hipLaunchKernelGGL(graph_propagate_mfma_kernel<8>, grid_m, dim3(256), lds_m, (hipStream_t)stream, f, h, G,
+                               bn_scale, bn_shift, omg_m, gamma, slope, out, (bf16_t*)out_lp, V, C);
+        }
+        AGRL_CHECK_LAUNCH("agrl_graph_propagate");
+        return 0;
+    }
     const int Vp = (V + PROP_RB - 1) & ~(PROP_RB - 1);
     const bool fixed = false;  // register-resident h (VT > 0) spills: hipcc hoists every LDS graph read; keep h in LDS
     const size_t lds = ((size_t)V * Vp + (fixed ? 0 : (size_t)V * PROP_THREADS)) * sizeof(float);

@@ -42,6 +42,7 @@ struct IgemmParams {
     int Cin, H, W, OH, OW, R, S, stride, pad;
     int ldo;     // row stride of out / res in elements
     int vec_ok;  // 4-wide epilogue accesses are aligned
+    int ksplit;  // > 1: blockIdx.y selects a K slice and raw fp32 partials go to out + z*M*ldo (pointwise only)
     int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
 };
 
@@ -198,6 +199,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     int tap_r = 0, tap_s = 0, c0 = 0;  // filter tap and channel offset of the tile being STAGED
     size_t kbyte = 0;                  // byte offset of that tile along K in the weight rows
+    int nk = p.K / BKE;
+    if (p.ksplit > 1) {  // split-K (pointwise problems only): this workgroup owns k-tiles [z*nk/ks, (z+1)*nk/ks)
+        const int per = nk / p.ksplit;
+        c0 = blockIdx.y * per * BKE;
+        kbyte = (size_t)blockIdx.y * per * 128;
+        nk = per;
+    }
 
     // one 1-KiB DMA piece of the k-tile being staged: pieces 0..AJ-1 are pixel rows, AJ..AJ+BJ-1 weight rows
     auto stage_piece = [&](int buf, int idx) {
@@ -275,7 +283,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     // ---- main loop: NS-deep LDS ring, NS-1 k-tiles of DMA in flight, ONE raw barrier per k-tile and a COUNTED
     // vmcnt so the younger tiles' DMA stays in flight across the barrier (a plain __syncthreads() would drain it)
-    const int nk = p.K / BKE;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s);
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
     // ---- epilogue: lane (g = lane>>4, j = lane&15) holds channels 4g..4g+3 of pixel j per fragment
     TOUT* __restrict__ outp = reinterpret_cast<TOUT*>(p.out);
+    if (p.ksplit > 1) outp += (size_t)blockIdx.y * p.M * p.ldo;
     if constexpr (LDS_EPI) {
         // phase 1: combine in fp32, round once, park the bf16 tile in the free staging buffer (in place over the
         // residual image: every lane overwrites exactly the 8 bytes it just read)
@@ -662,6 +670,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     AGRL_CHECK_ARG((((uintptr_t)p.x) & 15) == 0 && (((uintptr_t)p.w) & 15) == 0,
                    "%s: operands must be 16-byte aligned", who);
     p.dbg = 0;
+    if (p.ksplit < 1) p.ksplit = 1;
     if (const char* e = getenv("AGRL_IGEMM_DBG")) p.dbg = atoi(e);
     p.vec_ok = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 && (!p.colv || (((uintptr_t)p.colv) & 15) == 0) &&
                (!p.res || (((uintptr_t)p.res) & 15) == 0);
@@ -679,7 +688,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     if (const char* e = getenv("AGRL_IGEMM_BM")) bm = atoi(e);
     const int grid = cdiv(p.M, bm) * cdiv(p.N, narrow ? 64 : 128);
 #define LAUNCH_IG(BM_, BN_, EPI_, NS_) \
-    hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_>), dim3(grid), dim3(256), 0, stream, p)
+    hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, stream, p)
 #define LAUNCH_NS(BN_, EPI_)                                  \
     do {                                                      \
         if (bm == 64) LAUNCH_IG(64, BN_, EPI_, 2);            \
@@ -735,7 +744,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_conv2d_bn_act: bad dtype %d", dtype);
     IgemmParams p;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
-    p.alpha = 1.f; p.rowc = 0.f; p.relu = relu;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1;
     p.OH = (H + 2 * pad - R) / stride + 1;
     p.OW = (W + 2 * pad - S) / stride + 1;
     AGRL_CHECK_ARG(p.OH > 0 && p.OW > 0, "agrl_conv2d_bn_act: empty output");
@@ -752,7 +761,7 @@ extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M,
     AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16, "agrl_linear_nobias: bad dtype %d", in_dtype);
     IgemmParams p;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
-    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1;
     p.M = M; p.N = Nout; p.K = K;
     p.Cin = K; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.ldo = Nout;
@@ -760,13 +769,26 @@ extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M,
     return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
 }
 
-extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist,
-                            int m, int n, int D, int ldd, int metric, int dtype, agrl_stream_t stream) {
+// out[m][n] = alpha * sum_z ws[z][m][n] + rowv[m] (or rowc) + colv[n]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, float* __restrict__ out,
+                                                            int M, int N, int ldo, float alpha, const float* __restrict__ rowv,
+                                                            const float* __restrict__ colv, float rowc) {
+    const size_t total = (size_t)M * N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int m = (int)(e / N), n = (int)(e - (size_t)m * N);
+        float s = 0.f;
+        for (int z = 0; z < ksplit; ++z) s += ws[(size_t)z * total + e];
+        out[(size_t)m * ldo + n] = fmaf(alpha, s, (rowv ? rowv[m] : rowc) + (colv ? colv[n] : 0.f));
+    }
+}
+
+extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist, int m, int n, int D,
+                            int ldd, int metric, int dtype, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
     AGRL_CHECK_ARG(q && g && dist, "agrl_distmat: null pointer");
     AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && ldd >= n, "agrl_distmat: bad shape m=%d n=%d D=%d ldd=%d", m, n, D, ldd);
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_distmat: bad dtype %d", dtype);
     IgemmParams p;
-    p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0;
+    p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0; p.ksplit = 1;
     if (metric == AGRL_METRIC_EUCLIDEAN) {
         AGRL_CHECK_ARG(qn && gn, "agrl_distmat: euclidean needs the squared row norms");
         p.alpha = -2.f; p.rowv = qn; p.colv = gn; p.rowc = 0.f;
@@ -779,6 +801,26 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
     p.M = m; p.N = n; p.K = D;
     p.Cin = D; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.ldo = ldd;
+    // streaming form (few queries against a long gallery): too few output tiles to fill 256 CUs -> split K over
+    // workgroups, fp32 partials in the caller's workspace, deterministic reduce + epilogue afterwards
+    const int bke = dtype == AGRL_F32 ? 32 : 64;
+    const int nk = D / bke;
+    const int tiles = cdiv(m, 64) * cdiv(n, 128);
+    int ks = 1;
+    while (ks < 8 && tiles * ks < 512 && nk % (ks * 2) == 0 && nk / (ks * 2) >= 4) ks *= 2;
+    if (ks > 1 && workspace && workspace_bytes >= (size_t)ks * m * n * sizeof(float) && D % bke == 0) {
+        IgemmParams ps = p;
+        ps.out = workspace; ps.ldo = n; ps.alpha = 1.f; ps.rowv = nullptr; ps.colv = nullptr; ps.rowc = 0.f; ps.ksplit = ks;
+        int rc = dtype == AGRL_F32 ? launch_igemm<float, float>(ps, (hipStream_t)stream, "agrl_distmat")
+                                   : launch_igemm<bf16_t, float>(ps, (hipStream_t)stream, "agrl_distmat");
+        if (rc) return rc;
+        const size_t total = (size_t)m * n;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, ks,
+                           dist, m, n, ldd, p.alpha, p.rowv, p.colv, p.rowc);
+        AGRL_CHECK_LAUNCH("agrl_distmat(reduce)");
+        return 0;
+    }
     if (dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_distmat");
     return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_distmat");
 }

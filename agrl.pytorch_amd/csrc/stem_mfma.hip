@@ -23,8 +23,8 @@ constexpr int PWP = 40;               // padded patch width (pixels)
 constexpr int PATCH_BYTES = IT * PWP * 8;      // 12480
 constexpr int WROW_BYTES = 464;                // 7*32 bf16 = 448 + 16 pad (odd number of 16-B slots: conflict-free)
 constexpr int W_BYTES = 64 * WROW_BYTES;       // 29696 = 29 KiB
-constexpr int CTILE_BYTES = NPOS * 128;        // 36992
-constexpr int LDS_BYTES = PATCH_BYTES + W_BYTES;  // 42176 >= CTILE_BYTES
+constexpr int LDS_BYTES = PATCH_BYTES + W_BYTES;  // 42176 >= the 289 x 128 B conv tile that later overlays it
+static_assert(NPOS * 128 <= LDS_BYTES, "conv tile must fit");
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;

@@ -192,9 +192,12 @@ def distmat(q, g, metric, qn=None, gn=None, out=None):
     code = METRIC_EUCLIDEAN if metric == "euclidean" else METRIC_COSINE
     if _hip.PROFILE is not None:  # (m+n)*D*e + m*n*4
         _hip.PROFILE_TAG = {"flops": 2.0 * m * n * D, "bytes": q.element_size() * (m + n) * D + 4.0 * m * n}
+    ws = None
+    if m * 64 <= n:  # streaming form: hand the kernel scratch for its split-K partials
+        ws = torch.empty((8 * m * n,), dtype=torch.float32, device=q.device)
     with _dev(q):
         _hip.call("agrl_distmat", ptr(q), ptr(g), ptr(qn), ptr(gn), out.data_ptr(), m, n, D, out.stride(0), code,
-                  dtype_code(q.dtype), _stream(q))
+                  dtype_code(q.dtype), ptr(ws), 0 if ws is None else ws.numel() * 4, _stream(q))
     return out
 
 

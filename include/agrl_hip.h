@@ -141,9 +141,12 @@ int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int ldy, int no
  *              distance.py:76-89
  *   D must be a multiple of 64 (bf16) / 32 (fp32): pad the operands with zero columns (agrl_row_l2_normalize's
  *   ldy) otherwise. ldd = row stride of dist in elements (>= n), so a rank can write its gallery shard's
- *   columns straight into the full matrix. */
+ *   columns straight into the full matrix.
+ *   workspace (optional, may be NULL): device scratch of workspace_bytes; with >= 8*m*n*4 bytes the streaming form
+ *   (few queries, long gallery) is split over K across workgroups and reduced deterministically. */
 int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist,
-                 int m, int n, int D, int ldd, int metric, int dtype, agrl_stream_t stream);
+                 int m, int n, int D, int ldd, int metric, int dtype, void* workspace,
+                 size_t workspace_bytes, agrl_stream_t stream);
 
 /* Per query row: the k smallest distances in ascending (distance, gallery index) order -- i.e.
  * np.argsort(dist[i])[:k] with ties broken towards the lower index -- torchreid/metrics/rank.py:170-172.

@@ -141,7 +141,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert set(_hip.SIGNATURES) == declared - {"agrl_version", "agrl_last_error"}
     assert lib.agrl_version() >= 100
     # argument validation happens before any launch, so it is checkable without a GPU
-    assert lib.agrl_distmat(None, None, None, None, None, 1, 1, 64, 1, 0, 0, None) != 0
+    assert lib.agrl_distmat(None, None, None, None, None, 1, 1, 64, 1, 0, 0, None, 0, None) != 0
     assert b"null pointer" in lib.agrl_last_error()
 
 
