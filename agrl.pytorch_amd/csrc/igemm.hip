@@ -126,13 +126,14 @@ __device__ inline void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename TIN, typename TOUT, int BM, int BN, bool LDS_EPI, int NS>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+template <typename TIN, typename TOUT, int BM, int BN, bool LDS_EPI, int NS, int NW>  // NW waves: (NW/2) x 2 grid
+__global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
+    constexpr int WM = NW / 2;          // wave rows
     constexpr int EPC = DT<TIN>::epc;   // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;        // elements per k-tile (128 bytes)
-    constexpr int AJ = BM / 32;         // 8-row DMA pieces per wave for the pixel tile
-    constexpr int BJ = BN / 32;         // ... for the weight tile
-    constexpr int FM = BM / 32;         // 16-pixel fragments per wave
+    constexpr int AJ = BM / (8 * NW);   // 8-row DMA pieces per wave for the pixel tile
+    constexpr int BJ = BN / (8 * NW);   // ... for the weight tile
+    constexpr int FM = BM / (16 * WM);  // 16-pixel fragments per wave
     constexpr int FN = BN / 32;         // 16-channel fragments per wave
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1;
-    const int wn = wave >> 1;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
 
     // ---- XCD-aware block -> tile map: blocks b, b+8, b+16.. run on one XCD (observed b % 8);
     // give each XCD a contiguous range of tiles, N-tiles of an M-tile adjacent.
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-        const int row = wave * (BM / 4) + j * 8 + lrow;
+        const int row = wave * (BM / NW) + j * 8 + lrow;
         const int gm = m0 + row;
         a_ok[j] = gm < p.M;
         const int gmc = a_ok[j] ? gm : 0;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     size_t b_off[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-        const int row = wave * (BN / 4) + j * 8 + lrow;
+        const int row = wave * (BN / NW) + j * 8 + lrow;
         int gn = n0 + row;
         gn = gn < p.N ? gn : p.N - 1;
         b_off[j] = ((size_t)gn * p.K + (lchk ^ ((row >> 1) & 7)) * EPC) * sizeof(TIN);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     auto stage_piece = [&](int buf, int idx) {
         if (idx < AJ) {
             const int j = idx;
-            unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / 4) * 128;
+            unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / NW) * 128;
             const int ih = a_ih0[j] + tap_r;
             const int iw = a_iw0[j] + tap_s;
             const bool ok = a_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             dma16(ok ? xg + off : zsrc, sa + j * 1024);
         } else {
             const int j = idx - AJ;
-            unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / 4) * 128;
+            unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / NW) * 128;
             dma16(wg + b_off[j] + kbyte, sb + j * 1024);
         }
     };
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     constexpr int CPR = BN * 2 / 16;        // chunks per out-tile row (16 for BN=128, 8 for BN=64)
     constexpr int ROWB = BN * 2;            // bytes per out-tile row
     constexpr int RPI = 64 / CPR;           // rows per DMA piece
-    constexpr int RJ = BM / (4 * RPI);      // residual DMA pieces per wave
+    constexpr int RJ = BM / (NW * RPI);     // residual DMA pieces per wave
     const TOUT* __restrict__ resp = reinterpret_cast<const TOUT*>(p.res);
     auto stage_residual = [&](int buf) {
         unsigned char* so = smem + buf * BUF_BYTES;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
             uint4 xf[FM], wf[FN];
 #pragma unroll
             for (int b = 0; b < FM; ++b)
-                xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fchunk));
+                xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / WM) + b * 16 + frow, kk * 4 + fchunk));
 #pragma unroll
             for (int a = 0; a < FN; ++a)
                 wf[a] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         if (!(p.dbg & 4))
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
-            const int prow = wm * (BM / 2) + b * 16 + frow;
+            const int prow = wm * (BM / WM) + b * 16 + frow;
             const int gm = m0 + prow;
             const float rv = p.rowv ? p.rowv[gm < p.M ? gm : 0] : p.rowc;
 #pragma unroll
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         }
         __syncthreads();
         // phase 2: whole 16-byte chunks, a wavefront writes 4 (BN=128) / 8 (BN=64) complete rows per instruction
-        constexpr int RPT = 256 / CPR;  // rows covered by the 256 threads per pass
+        constexpr int RPT = 64 * NW / CPR;  // rows covered by the workgroup per pass
         const int pch = tid % CPR;
         const int r0 = tid / CPR;
 #pragma unroll
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const bool vec_ok = p.vec_ok != 0;
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
-            const int gm = m0 + wm * (BM / 2) + b * 16 + frow;
+            const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
             if (gm >= p.M) continue;
             const float rv = p.rowv ? p.rowv[gm] : p.rowc;
 #pragma unroll
@@ -458,12 +459,14 @@ __device__ inline void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <typename TIN, int BM, int BN, int NL>  // NL = number of loader waves (2: split roles, 4: everybody)
-__global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p, int ntiles) {
+template <typename TIN, int BM, int BN, int NW>  // NW waves, (NW/2) x 2 MFMA grid; every wave stages, computes, drains
+__global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParams p, int ntiles) {
+    constexpr int NL = NW;
+    constexpr int WM = NW / 2;
     constexpr int EPC = DT<TIN>::epc;
     constexpr int BKE = 8 * EPC;
     constexpr int AJ = BM / (8 * NL), BJ = BN / (8 * NL);  // 8-row DMA pieces per loader wave
-    constexpr int FM = BM / 32, FN = BN / 32;
+    constexpr int FM = BM / (16 * WM), FN = BN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int CPR = BN * 2 / 16, ROWB = BN * 2, RPI = 64 / CPR;
     constexpr int RJ = BM / (NL * RPI);         // residual DMA pieces per loader wave
@@ -476,9 +479,9 @@ __global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave < NL;
-    const bool drainer = NL == 4 || wave >= 2;
-    const int wm = wave & 1;
-    const int wn = wave >> 1;
+    const bool drainer = true;
+    const int wm = wave % WM;
+    const int wn = wave / WM;
     const int nNt = (p.N + BN - 1) / BN;
     const int nk = p.K / BKE;
     const int G = gridDim.x;
@@ -505,8 +508,6 @@ __global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p,
         sm0 = mt * BM;
         sn0 = nt * BN;
     };
-    const unsigned coff0 = (lchk ^ (lrow >> 1)) * EPC * sizeof(TIN);        // even 8-row pieces
-    const unsigned coff1 = (lchk ^ ((lrow >> 1) + 4)) * EPC * sizeof(TIN);  // odd 8-row pieces
     const size_t a_row_bytes = (size_t)p.Cin * sizeof(TIN);
     unsigned kbyte = 0;  // byte offset of the k-tile being staged inside a row of X / W (K == Cin here)
     auto stage = [&](int buf) {  // loaders only
@@ -514,15 +515,17 @@ __global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p,
         unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / NL) * 128;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int gm = sm0 + wave * (BM / NL) + j * 8 + lrow;
-            const unsigned char* src = xg + (size_t)gm * a_row_bytes + kbyte + ((j & 1) ? coff1 : coff0);
+            const int row = wave * (BM / NL) + j * 8 + lrow;
+            const int gm = sm0 + row;
+            const unsigned char* src = xg + (size_t)gm * a_row_bytes + kbyte + (lchk ^ ((row >> 1) & 7)) * 16;
             dma16(gm < p.M ? src : zsrc, sa + j * 1024);
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
-            int gn = sn0 + wave * (BN / NL) + j * 8 + lrow;
+            const int row = wave * (BN / NL) + j * 8 + lrow;
+            int gn = sn0 + row;
             gn = gn < p.N ? gn : p.N - 1;
-            dma16(wg + (size_t)gn * a_row_bytes + kbyte + ((j & 1) ? coff1 : coff0), sb + j * 1024);
+            dma16(wg + (size_t)gn * a_row_bytes + kbyte + (lchk ^ ((row >> 1) & 7)) * 16, sb + j * 1024);
         }
         kbyte += 128;
     };
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p,
                 uint4 xf[FM], wf[FN];
 #pragma unroll
                 for (int b = 0; b < FM; ++b)
-                    xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fchunk));
+                    xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / WM) + b * 16 + frow, kk * 4 + fchunk));
 #pragma unroll
                 for (int a = 0; a < FN; ++a)
                     wf[a] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p,
         if (!(p.dbg & 4)) {
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
-                const int prow = wm * (BM / 2) + b * 16 + frow;
+                const int prow = wm * (BM / WM) + b * 16 + frow;
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
                     const int c = wn * (BN / 2) + a * 16 + fchunk * 4;
@@ -639,8 +642,8 @@ __global__ __launch_bounds__(256) void igemm_persist_kernel(const IgemmParams p,
         wg_barrier();  // out tile complete
         if (drainer) {
             // drain: whole 16-byte chunks, full rows (with split roles these stores are never waited for)
-            constexpr int ND = NL == 4 ? 256 : 128;  // drainer lanes
-            const int dt = NL == 4 ? tid : tid - 128;
+            constexpr int ND = 64 * NW;  // drainer lanes
+            const int dt = tid;
             const int pch = dt % CPR;
             const int r0 = dt / CPR;
             constexpr int RPP = ND / CPR;  // rows per pass
@@ -687,8 +690,17 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     if (cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128) < 400) bm = 64;  // too few 128-row tiles to fill 256 CUs twice
     if (const char* e = getenv("AGRL_IGEMM_BM")) bm = atoi(e);
     const int grid = cdiv(p.M, bm) * cdiv(p.N, narrow ? 64 : 128);
+    int nw = 8;  // 8-wave workgroups (4 x 2 wave grid) beat 4-wave ones by 3-14 % at equal tile size (A/B measured)
+    if (const char* e = getenv("AGRL_IGEMM_NW")) nw = atoi(e);
 #define LAUNCH_IG(BM_, BN_, EPI_, NS_) \
-    hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, stream, p)
+    do {                                                                                                          \
+        if (nw == 8)                                                                                              \
+            hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_, 8>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), \
+                               dim3(512), 0, stream, p);                                                          \
+        else                                                                                                      \
+            hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_, 4>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), \
+                               dim3(256), 0, stream, p);                                                          \
+    } while (0)
 #define LAUNCH_NS(BN_, EPI_)                                  \
     do {                                                      \
         if (bm == 64) LAUNCH_IG(64, BN_, EPI_, 2);            \
@@ -707,11 +719,11 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
             int wgs = 512;  // two resident workgroups per CU
             if (const char* e = getenv("AGRL_IGEMM_WGS")) wgs = atoi(e);
             const int g = ntiles < wgs ? ntiles : wgs;
-            int nl = 4;
-            if (const char* e = getenv("AGRL_IGEMM_NL")) nl = atoi(e);
-            if (nl == 2) {
-                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 2>), dim3(g), dim3(256), 0, stream, p, ntiles);
-                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 2>), dim3(g), dim3(256), 0, stream, p, ntiles);
+            int pnw = 8;
+            if (const char* e = getenv("AGRL_IGEMM_NW")) pnw = atoi(e);
+            if (pnw == 8) {
+                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 8>), dim3(g), dim3(512), 0, stream, p, ntiles);
+                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 8>), dim3(g), dim3(512), 0, stream, p, ntiles);
             } else {
                 if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 4>), dim3(g), dim3(256), 0, stream, p, ntiles);
                 else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 4>), dim3(g), dim3(256), 0, stream, p, ntiles);
