@@ -6,9 +6,9 @@
 // v_mfma_f32_16x16x32_bf16 per filter row, and every lane's 8-element operand slice is one aligned ds_read_b128
 // straight out of the patch. 1.5x redundant MFMA work buys zero gather instructions.
 //
-// One 256-thread workgroup -> an 8x8 tile of POOLED pixels x 64 channels of one frame:
+// One 512-thread workgroup -> an 8x8 tile of POOLED pixels x 64 channels of one frame:
 //   patch 39x40x4 bf16 (12.5 KB) + packed weights 64 x 232 bf16 (29 KB, LDS-DMA)      -> LDS
-//   conv tile 17x17 = 289 positions x 64 ch: 19 position fragments over 4 waves, 7 k-steps, +bias, ReLU
+//   conv tile 17x17 = 289 positions x 64 ch: 19 position fragments over 8 waves, 7 k-steps, +bias, ReLU
 //   -> bf16 conv tile in LDS (overlaying patch+weights) -> 3x3/2 max -> NHWC store (128 B per pooled pixel)
 #include "agrl_common.h"
 
@@ -17,7 +17,9 @@ constexpr int PT = 8;                 // pooled tile edge
 constexpr int CT = 2 * PT + 1;        // conv tile edge 17
 constexpr int NPOS = CT * CT;         // 289
 constexpr int NFRAG = (NPOS + 15) / 16;  // 19
-constexpr int FPW = (NFRAG + 3) / 4;  // position fragments per wave: 5
+constexpr int NWV = 8;                // waves per workgroup
+constexpr int NTH = 64 * NWV;
+constexpr int FPW = (NFRAG + NWV - 1) / NWV;  // position fragments per wave: 3
 constexpr int IT = 2 * (CT - 1) + 7;  // input patch edge 39
 constexpr int PWP = 40;               // padded patch width (pixels)
 constexpr int PATCH_BYTES = IT * PWP * 8;      // 12480
@@ -29,7 +31,7 @@ static_assert(NPOS * 128 <= LDS_BYTES, "conv tile must fit");
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
+__global__ __launch_bounds__(NTH) void stem_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
                                                         int W, int CH, int CW, int PH, int PW, int tiles_w, int tiles_hw) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -47,24 +49,35 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const int iy0 = 2 * cr0 - 3, ix0 = 2 * cc0 - 3;
 
     // weights: 29 one-KiB DMA pieces, contiguous
-    for (int piece = wave; piece < W_BYTES / 1024; piece += 4)
+    for (int piece = wave; piece < W_BYTES / 1024; piece += NWV)
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(wpk + piece * 1024 + lane * 16), (lds_void_t*)(s_w + piece * 1024), 16, 0, 0);
-    // patch: one pixel (3 channels -> 4 bf16) per thread iteration
+    // patch: one pixel (3 channels -> 4 bf16) per thread per pass; all loads of all passes are issued before the
+    // first one is consumed (a load->convert->store loop would serialise 7 HBM round trips)
     const float* xn = x + (size_t)n * 3 * H * W;
-    for (int e = tid; e < IT * PWP; e += 256) {
+    constexpr int NPASS = (IT * PWP + NTH - 1) / NTH;  // 4
+    float pv[NPASS][3];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int e = tid + NTH * i;
         const int py = e / PWP, px = e - py * PWP;
         const int iy = iy0 + py, ix = ix0 + px;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-        if (px < IT && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        pv[i][0] = pv[i][1] = pv[i][2] = 0.f;
+        if (e < IT * PWP && px < IT && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
             const size_t o = (size_t)iy * W + ix;
-            v0 = xn[o];
-            v1 = xn[(size_t)H * W + o];
-            v2 = xn[2 * (size_t)H * W + o];
+            pv[i][0] = xn[o];
+            pv[i][1] = xn[(size_t)H * W + o];
+            pv[i][2] = xn[2 * (size_t)H * W + o];
         }
-        uint2 u;
-        u.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-        u.y = (uint32_t)f32_to_bf16(v2);
-        *reinterpret_cast<uint2*>(s_patch + e * 8) = u;
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int e = tid + NTH * i;
+        if (e < IT * PWP) {
+            uint2 u;
+            u.x = (uint32_t)f32_to_bf16(pv[i][0]) | ((uint32_t)f32_to_bf16(pv[i][1]) << 16);
+            u.y = (uint32_t)f32_to_bf16(pv[i][2]);
+            *reinterpret_cast<uint2*>(s_patch + e * 8) = u;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -73,7 +86,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     int a_off[FPW];  // byte offset of this lane's patch slice at filter row 0
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
-        int pos = (wave + 4 * i) * 16 + frow;
+        int pos = (wave + NWV * i) * 16 + frow;
         pos = pos < NPOS ? pos : NPOS - 1;
         const int cy = pos / CT, cx = pos - cy * CT;
         a_off[i] = ((2 * cy) * PWP + 2 * cx + 2 * g) * 8;
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     unsigned char* s_ct = smem;
 #pragma unroll
     for (int i = 0; i < FPW; ++i) {
-        const int pos = (wave + 4 * i) * 16 + frow;
+        const int pos = (wave + NWV * i) * 16 + frow;
         if (pos < NPOS) {
             const int cy = pos / CT, cx = pos - cy * CT;
             const bool in = (unsigned)(cr0 + cy) < (unsigned)CH && (unsigned)(cc0 + cx) < (unsigned)CW;
@@ -128,8 +141,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     // 3x3/2 max pool: thread -> 4 channels (one 8-byte slot) of pooled pixels (tid>>4) + 16 i
     const int cq = tid & 15;
 #pragma unroll
-    for (int i = 0; i < (PT * PT) / 16; ++i) {
-        const int pp = (tid >> 4) + 16 * i;
+    for (int i = 0; i < (PT * PT * 16) / NTH; ++i) {
+        const int pp = (tid >> 4) + (NTH / 16) * i;
         const int py = pp / PT, px = pp - py * PT;
         const int ph = ph0 + py, pw = pw0 + px;
         if (ph < PH && pw < PW) {
@@ -165,7 +178,7 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w
     const int tiles_h = cdiv(PH, PT), tiles_w = cdiv(PW, PT);
     const long long grid = (long long)N * tiles_h * tiles_w;
     AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_bf16: grid too large");
-    hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)grid), dim3(NTH), 0, (hipStream_t)stream, x,
                        (const unsigned char*)w_packed, bias, (bf16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w);
     AGRL_CHECK_LAUNCH("agrl_stem_bf16");
     return 0;
