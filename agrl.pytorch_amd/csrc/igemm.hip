@@ -43,6 +43,14 @@ struct IgemmParams {
     int ldo;     // row stride of out / res in elements
     int vec_ok;  // 4-wide epilogue accesses are aligned
     int ksplit;  // > 1: blockIdx.y selects a K slice and raw fp32 partials go to out + z*M*ldo (pointwise only)
+    // fused pooling epilogue (persistent kernel only; a tile must be exactly one frame: BM == OH*OW):
+    int pool_nparts;      // 0 = off; else number of row bins summed per frame
+    int pool_mean;        // 1: write bin means, 0: write bin sums
+    int pool_store_out;   // 0: the activation tile itself is not written to HBM
+    int pool_w;           // pixels per image row
+    int pool_start[16], pool_end[16];  // bins in image rows [start, end)
+    float* pool_out;      // fp32 (frames, nparts, N)
+    void* pool_out_lp;    // optional bf16 copy
     int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
 };
 
@@ -459,7 +467,7 @@ __device__ inline void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <typename TIN, int BM, int BN, int NW>  // NW waves, (NW/2) x 2 MFMA grid; every wave stages, computes, drains
+template <typename TIN, int BM, int BN, int NW, bool POOL>  // NW waves, (NW/2) x 2 MFMA grid; POOL: fused frame pooling
 __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParams p, int ntiles) {
     constexpr int NL = NW;
     constexpr int WM = NW / 2;
@@ -640,8 +648,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
             }
         }
         wg_barrier();  // out tile complete
-        if (drainer) {
-            // drain: whole 16-byte chunks, full rows (with split roles these stores are never waited for)
+        if (drainer && (!POOL || p.pool_store_out)) {
+            // drain: whole 16-byte chunks, full rows
             constexpr int ND = 64 * NW;  // drainer lanes
             const int dt = tid;
             const int pch = dt % CPR;
@@ -656,6 +664,57 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                 if (gm < p.M && gn < p.N && !(p.dbg & 1)) {
                     const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
                     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * p.ldo + gn) * 2) = v;
+                }
+            }
+        }
+        if constexpr (POOL) {
+            // fused part / global pooling of the finished frame (vmgn.py:298-308), two LDS stages:
+            //  A: every thread sums 4 consecutive pixel rows of one 8-channel group        (512 threads, 128 rows)
+            //  B: thread (group, bin) adds the 4-row partials that fall into its row bin   (16 x nparts threads)
+            const int gch = tid % CPR;
+            const int rg = tid / CPR;  // 0..31
+            float part8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rg * 4 + i;
+                const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + ((gch ^ (row & (CPR - 1))) << 4));
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    part8[2 * j] += __uint_as_float(w4[j] << 16);
+                    part8[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+                }
+            }
+            wg_barrier();  // everybody holds its partial: the tile image may be overwritten
+            float* sp = reinterpret_cast<float*>(so);  // [32 row groups][CPR][8] fp32 = 16 KB (BN = 128)
+            *reinterpret_cast<float4*>(sp + (rg * CPR + gch) * 8) = make_float4(part8[0], part8[1], part8[2], part8[3]);
+            *reinterpret_cast<float4*>(sp + (rg * CPR + gch) * 8 + 4) = make_float4(part8[4], part8[5], part8[6], part8[7]);
+            wg_barrier();
+            const int q = rg;
+            if (q < p.pool_nparts && cn0 + gch * 8 < p.N) {
+                const int g_lo = p.pool_start[q] * p.pool_w, g_hi = p.pool_end[q] * p.pool_w;  // pixel rows
+                float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int g = 0; g < 32; ++g) {
+                    const bool in = g * 4 >= g_lo && g * 4 < g_hi;  // bins are multiples of 4 pixels (checked by the host)
+                    const float4 lo = *reinterpret_cast<const float4*>(sp + (g * CPR + gch) * 8);
+                    const float4 hi = *reinterpret_cast<const float4*>(sp + (g * CPR + gch) * 8 + 4);
+                    acc8[0] += in ? lo.x : 0.f; acc8[1] += in ? lo.y : 0.f; acc8[2] += in ? lo.z : 0.f; acc8[3] += in ? lo.w : 0.f;
+                    acc8[4] += in ? hi.x : 0.f; acc8[5] += in ? hi.y : 0.f; acc8[6] += in ? hi.z : 0.f; acc8[7] += in ? hi.w : 0.f;
+                }
+                const float sc = p.pool_mean ? 1.f / (float)(g_hi - g_lo) : 1.f;
+                const size_t o = ((size_t)(cm0 / BM) * p.pool_nparts + q) * p.N + cn0 + gch * 8;
+                float4 lo4 = make_float4(acc8[0] * sc, acc8[1] * sc, acc8[2] * sc, acc8[3] * sc);
+                float4 hi4 = make_float4(acc8[4] * sc, acc8[5] * sc, acc8[6] * sc, acc8[7] * sc);
+                *reinterpret_cast<float4*>(p.pool_out + o) = lo4;
+                *reinterpret_cast<float4*>(p.pool_out + o + 4) = hi4;
+                if (p.pool_out_lp) {
+                    uint4 pk;
+                    pk.x = (uint32_t)f32_to_bf16(lo4.x) | ((uint32_t)f32_to_bf16(lo4.y) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(lo4.z) | ((uint32_t)f32_to_bf16(lo4.w) << 16);
+                    pk.z = (uint32_t)f32_to_bf16(hi4.x) | ((uint32_t)f32_to_bf16(hi4.y) << 16);
+                    pk.w = (uint32_t)f32_to_bf16(hi4.z) | ((uint32_t)f32_to_bf16(hi4.w) << 16);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.pool_out_lp) + o) = pk;
                 }
             }
         }
@@ -713,6 +772,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
         // drain are a large share of the tile; long K loops run better as independent workgroups (A/B measured)
         int persist = (p.K / BKE) <= 8 ? 1 : 0;
         if (const char* e = getenv("AGRL_IGEMM_PERSIST")) persist = atoi(e);
+        if (p.pool_nparts > 0) persist = 1;  // the fused pooling epilogue lives in the persistent kernel
         const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
         if (lds_epi && persist && !p.rowv && pointwise) {
             const int ntiles = cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128);
@@ -721,12 +781,16 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
             const int g = ntiles < wgs ? ntiles : wgs;
             int pnw = 8;
             if (const char* e = getenv("AGRL_IGEMM_NW")) pnw = atoi(e);
-            if (pnw == 8) {
-                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 8>), dim3(g), dim3(512), 0, stream, p, ntiles);
-                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 8>), dim3(g), dim3(512), 0, stream, p, ntiles);
+            if (p.pool_nparts > 0) pnw = 8;  // the pooling epilogue exists for the 8-wave 128x128 instantiation only
+            if (p.pool_nparts > 0) {
+                AGRL_CHECK_ARG(!narrow, "%s: fused pooling needs more than 64 output channels", who);
+                hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 8, true>), dim3(g), dim3(512), 0, stream, p, ntiles);
+            } else if (pnw == 8) {
+                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 8, false>), dim3(g), dim3(512), 0, stream, p, ntiles);
+                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 8, false>), dim3(g), dim3(512), 0, stream, p, ntiles);
             } else {
-                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 4>), dim3(g), dim3(256), 0, stream, p, ntiles);
-                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 4>), dim3(g), dim3(256), 0, stream, p, ntiles);
+                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 4, false>), dim3(g), dim3(256), 0, stream, p, ntiles);
+                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 4, false>), dim3(g), dim3(256), 0, stream, p, ntiles);
             }
             AGRL_CHECK_LAUNCH(who);
             return 0;
@@ -756,7 +820,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_conv2d_bn_act: bad dtype %d", dtype);
     IgemmParams p;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
-    p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
     p.OH = (H + 2 * pad - R) / stride + 1;
     p.OW = (W + 2 * pad - S) / stride + 1;
     AGRL_CHECK_ARG(p.OH > 0 && p.OW > 0, "agrl_conv2d_bn_act: empty output");
@@ -767,13 +831,43 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
 }
 
+extern "C" int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const float* bias, const void* residual, void* out,
+                                       float* pool_out, void* pool_out_lp, int N, int H, int W, int Cin, int Cout,
+                                       int relu, const int* splits, int n_splits, int mean, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && w && pool_out && splits, "agrl_conv1x1_bn_act_pool: null pointer");
+    AGRL_CHECK_ARG(H * W == 128, "agrl_conv1x1_bn_act_pool: a frame must be exactly 128 pixels (got %dx%d)", H, W);
+    AGRL_CHECK_ARG(Cout > 64 && Cout % 8 == 0 && Cin % 64 == 0, "agrl_conv1x1_bn_act_pool: unsupported channel counts");
+    IgemmParams p;
+    p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1;
+    p.OH = H; p.OW = W;
+    p.M = N * H * W; p.N = Cout; p.K = Cin;
+    p.Cin = Cin; p.H = H; p.W = W; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.ldo = Cout;
+    int P = 0;
+    for (int i = 0; i < n_splits; ++i) {
+        const int n = splits[i];
+        AGRL_CHECK_ARG(n > 0 && P + n <= 16, "agrl_conv1x1_bn_act_pool: at most 16 bins");
+        for (int j = 0; j < n; ++j) {  // AdaptiveAvgPool2d bins over image rows
+            p.pool_start[P] = (j * H) / n;
+            p.pool_end[P] = ((j + 1) * H + n - 1) / n;
+            ++P;
+        }
+    }
+    for (int i = P; i < 16; ++i) p.pool_start[i] = p.pool_end[i] = 0;
+    p.pool_nparts = P; p.pool_mean = mean; p.pool_store_out = out != nullptr; p.pool_w = W;
+    p.pool_out = pool_out; p.pool_out_lp = pool_out_lp;
+    if (!out) p.out = pool_out;  // never dereferenced as activations; keeps the alignment checks meaningful
+    return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv1x1_bn_act_pool");
+}
+
 extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
                                   int in_dtype, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && w && y, "agrl_linear_nobias: null pointer");
     AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16, "agrl_linear_nobias: bad dtype %d", in_dtype);
     IgemmParams p;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
-    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     p.M = M; p.N = Nout; p.K = K;
     p.Cin = K; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.ldo = Nout;
@@ -800,7 +894,7 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
     AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && ldd >= n, "agrl_distmat: bad shape m=%d n=%d D=%d ldd=%d", m, n, D, ldd);
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_distmat: bad dtype %d", dtype);
     IgemmParams p;
-    p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0; p.ksplit = 1;
+    p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     if (metric == AGRL_METRIC_EUCLIDEAN) {
         AGRL_CHECK_ARG(qn && gn, "agrl_distmat: euclidean needs the squared row norms");
         p.alpha = -2.f; p.rowv = qn; p.colv = gn; p.rowc = 0.f;

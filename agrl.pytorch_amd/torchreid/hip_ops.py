@@ -79,6 +79,25 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
     return out
 
 
+def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=True):
+    """Last 1x1 conv of a layer4 branch with the frame pooling fused in (bf16, 128-pixel frames): the 2048-channel map
+    is never written. -> pooled fp32 (F, P, Cout) [, bf16 copy]. vmgn.py:45-65 + :298-308."""
+    N, H, W, Cin = x.shape
+    Cout = w_ohwi.shape[0]
+    assert x.dtype == torch.bfloat16 and tuple(w_ohwi.shape[1:3]) == (1, 1) and H * W == 128
+    P = int(sum(splits))
+    pooled = torch.empty((N, P, Cout), dtype=torch.float32, device=x.device)
+    pooled_lp = torch.empty((N, P, Cout), dtype=torch.bfloat16, device=x.device) if want_lp else None
+    arr = (C.c_int * len(splits))(*[int(s) for s in splits])
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * Cout * Cin,
+                            "bytes": 2.0 * (x.numel() + w_ohwi.numel() + (residual.numel() if residual is not None else 0)) + 4.0 * pooled.numel()}
+    with _dev(x):
+        call("agrl_conv1x1_bn_act_pool", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), None, ptr(pooled), ptr(pooled_lp),
+             N, H, W, Cin, Cout, 1 if relu else 0, arr, len(splits), 1 if mean else 0, _stream(x))
+    return pooled, pooled_lp
+
+
 def linear_nobias(x, w):
     """(M,K) @ (N,K)^T -> fp32 (M,N). vmgn.py:148."""
     M, K = x.shape

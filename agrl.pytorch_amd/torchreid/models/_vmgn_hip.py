@@ -96,10 +96,14 @@ def pack_weights(model, device, precision):
     return pack
 
 
-def _run_block(x, blk):
+def _run_block(x, blk, pool=None):
+    """One Bottleneck. ``pool`` = (splits, mean, want_lp): fuse the frame pooling into the last conv's epilogue and
+    return the pooled tensors instead of the activation map (which is then never written to HBM)."""
     y = ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
     y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
+    if pool is not None:
+        return ops.conv1x1_bn_act_pool(y, blk['c3'][0], blk['c3'][1], shortcut, pool[0], pool[1], pool[2])
     return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)
 
 
@@ -118,6 +122,27 @@ def hip_featuremaps(model, frames, pack):
     for blk in pack['l4_2']:
         x4_2 = _run_block(x4_2, blk)
     return x4_1, x4_2
+
+
+def hip_features_pooled(model, frames, pack, splits):
+    """Conv stages with the global / part pooling fused into the last conv of each layer4 branch (bf16, 16x8 maps):
+    -> gsum (F,C) per-frame sums, nodes (F,P,C) fp32, nodes_lp bf16, hw. None when the fusion does not apply."""
+    if pack['dtype'] != torch.bfloat16:
+        return None
+    a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1])
+    for blk in pack['trunk']:
+        a = _run_block(a, blk)
+    if a.shape[1] * a.shape[2] != 128 or pack['l4_1'][0]['stride'] != 1:
+        return None
+    x4_1 = a
+    for blk in pack['l4_1'][:-1]:
+        x4_1 = _run_block(x4_1, blk)
+    gsum, _ = _run_block(x4_1, pack['l4_1'][-1], pool=([1], False, False))
+    x4_2 = a
+    for blk in pack['l4_2'][:-1]:
+        x4_2 = _run_block(x4_2, blk)
+    nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(list(splits), True, True))
+    return gsum.view(gsum.shape[0], gsum.shape[2]), nodes, nodes_lp, 128
 
 
 def hip_graph_layers(nodes, nodes_lp, adj, pack):
@@ -148,10 +173,16 @@ def hip_forward(model, x, adj, return_feats=False):
     lp = pack['dtype'] == torch.bfloat16
     with torch.no_grad():
         frames = x.reshape(B * S, Cc, H, W)
-        x4_1, x4_2 = hip_featuremaps(model, frames, pack)
-        F_, h, w, C = x4_1.shape
-        gsum, nodes, nodes_lp = ops.part_pool(x4_1, x4_2, model.total_split_list, want_lp=lp)
-        del x4_1, x4_2
+        fused = hip_features_pooled(model, frames, pack, model.total_split_list) if model.hip_fuse_pool else None
+        if fused is not None:
+            gsum, nodes, nodes_lp, hw = fused
+            C = nodes.shape[-1]
+        else:
+            x4_1, x4_2 = hip_featuremaps(model, frames, pack)
+            F_, h, w, C = x4_1.shape
+            hw = h * w
+            gsum, nodes, nodes_lp = ops.part_pool(x4_1, x4_2, model.total_split_list, want_lp=lp)
+            del x4_1, x4_2
         nodes = nodes.view(B, V, C)
         if nodes_lp is not None:
             nodes_lp = nodes_lp.view(B, V, C)
@@ -159,4 +190,4 @@ def hip_forward(model, x, adj, return_feats=False):
         nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack)
         sqn = ops.row_sqnorm(nodes.view(B * V, C))
         return ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
-                                    pack['a_bn'][1], B, S, P, h * w, want_feats=return_feats)
+                                    pack['a_bn'][1], B, S, P, hw, want_feats=return_feats)

@@ -172,6 +172,7 @@ class GSTA(nn.Module):
         # MI355X path configuration (not part of the state dict)
         self.hip_precision = os.environ.get('AGRL_HIP_PRECISION', 'fp32')
         self.hip_static_weights = False
+        self.hip_fuse_pool = os.environ.get('AGRL_HIP_FUSE_POOL', '1') != '0'
         self._hip_packs = {}
 
     # ------------------------------------------------------------------ stock-torch path (CPU / train)

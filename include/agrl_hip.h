@@ -64,6 +64,16 @@ int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const vo
                        void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride,
                        int pad, int relu, int dtype, agrl_stream_t stream);
 
+/* Last conv of a layer4 branch with the pooling fused into its epilogue (bf16 only): 1x1 conv + folded BN + residual
+ * + ReLU on frames of exactly 128 pixels (16x8), and per frame the row-bin pooling of the result is written directly:
+ *   mean == 0, splits {1}       -> pool_out (N, 1, Cout) = per-frame sums        (global branch, vmgn.py:298-300)
+ *   mean == 1, splits {4,2,1}   -> pool_out (N, P, Cout) = part means (+ bf16 copy in pool_out_lp) (vmgn.py:304-308)
+ * out may be NULL: the 2048-channel map is then never written to HBM. Same pooling semantics as agrl_part_pool. */
+int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const float* bias, const void* residual,
+                             void* out, float* pool_out, void* pool_out_lp, int N, int H, int W,
+                             int Cin, int Cout, int relu, const int* splits, int n_splits, int mean,
+                             agrl_stream_t stream);
+
 /* y = x @ w^T (no bias): x (M,K) in_dtype, w (Nout,K) in_dtype, y (M,Nout) fp32.
  * Replaces GraphLayer's nn.Linear(2048,2048,bias=False), torchreid/models/vmgn.py:148. */
 int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
