@@ -124,6 +124,16 @@ def hip_featuremaps(model, frames, pack):
     return x4_1, x4_2
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def hip_features_pooled(model, frames, pack, splits):
     """Conv stages with the global / part pooling fused into the last conv of each layer4 branch (bf16, 16x8 maps):
     -> gsum (F,C) per-frame sums, nodes (F,P,C) fp32, nodes_lp bf16, hw. None when the fusion does not apply."""
@@ -134,14 +144,39 @@ def hip_features_pooled(model, frames, pack, splits):
         a = _run_block(a, blk)
     if a.shape[1] * a.shape[2] != 128 or pack['l4_1'][0]['stride'] != 1:
         return None
-    x4_1 = a
-    for blk in pack['l4_1'][:-1]:
-        x4_1 = _run_block(x4_1, blk)
-    gsum, _ = _run_block(x4_1, pack['l4_1'][-1], pool=([1], False, False))
-    x4_2 = a
-    for blk in pack['l4_2'][:-1]:
-        x4_2 = _run_block(x4_2, blk)
-    nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(list(splits), True, True))
+    splits = list(splits)
+    if not model.hip_branch_streams:
+        x4_1 = a
+        for blk in pack['l4_1'][:-1]:
+            x4_1 = _run_block(x4_1, blk)
+        gsum, _ = _run_block(x4_1, pack['l4_1'][-1], pool=([1], False, False))
+        x4_2 = a
+        for blk in pack['l4_2'][:-1]:
+            x4_2 = _run_block(x4_2, blk)
+        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, True))
+    else:
+        # the two layer4 branches are independent: run the global branch on a side stream so its memory-heavy
+        # kernels (conv3 + residual) overlap the other branch's MFMA-heavy ones (3x3) on the same CUs
+        main = torch.cuda.current_stream(a.device)
+        side = _side_stream(a.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            x4_1 = a
+            for blk in pack['l4_1'][:-1]:
+                x4_1 = _run_block(x4_1, blk)
+            gsum, _ = _run_block(x4_1, pack['l4_1'][-1], pool=([1], False, False))
+            del x4_1
+            done = torch.cuda.Event()
+            done.record(side)
+        a.record_stream(side)
+        x4_2 = a
+        for blk in pack['l4_2'][:-1]:
+            x4_2 = _run_block(x4_2, blk)
+        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, True))
+        main.wait_event(done)
+        gsum.record_stream(main)
     return gsum.view(gsum.shape[0], gsum.shape[2]), nodes, nodes_lp, 128
 
 
