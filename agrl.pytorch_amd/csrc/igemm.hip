@@ -722,6 +722,183 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch (bf16). The generic kernel above re-stages
+// the pixel tile for each of the 9 taps (9 x 16 KB of LDS-DMA per 64 input channels) although the taps only shift
+// the same pixels; issuing that DMA is what bounds it (35 % of its time). Here a workgroup owns a 16x8 block of
+// output pixels (one whole frame in layers 3/4), stages the 18x10 halo patch of a 64-channel slab ONCE (23 KB, zero
+// padded by DMA from a zero block) and reads every tap's MFMA fragments straight out of it at a shifted pixel
+// address -- the same trick as the stem. Per slab: 23 + 9 x 16 DMA pieces instead of 9 x 32.
+//   LDS: patch 2 x 23 KB (double-buffered over slabs) + weight ring 2 x BN x 128 B; out tile overlays the patches.
+template <int BN>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const IgemmParams p) {
+    constexpr int NW = 8, WM = 4, BM = 128;
+    constexpr int FM = BM / (16 * WM), FN = BN / 32;
+    constexpr int PW = 10;                       // patch width in pixels (8 + 2)
+    constexpr int PPIX = 18 * PW;                // 180 patch pixels
+    constexpr int PPIECES = (PPIX + 7) / 8;      // 23 DMA pieces of 8 pixel rows
+    constexpr int PATCH_BYTES = PPIECES * 1024;  // 23552
+    constexpr int B_BYTES = BN * 128;
+    constexpr int BJ = BN / 64;                  // weight pieces per wave per tap
+    constexpr int PJ = (PPIECES + NW - 1) / NW;  // patch pieces per wave per slab (3)
+    constexpr int CPR = BN * 2 / 16, ROWB = BN * 2;
+    static_assert(BM * ROWB <= 2 * PATCH_BYTES, "out tile must fit over the patch buffers");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PATCH_BYTES + 2 * B_BYTES];
+    unsigned char* s_b = smem + 2 * PATCH_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+    const int lrow = lane >> 3, lchk = lane & 7;
+
+    const int nNt = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, within = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int mt = bid / nNt;
+    const int nt = bid - mt * nNt;
+    const int n0 = nt * BN;
+    const int tw = p.W >> 3, th = p.H >> 4;
+    const int img = mt / (tw * th);
+    const int trem = mt - img * (tw * th);
+    const int oy0 = (trem / tw) << 4, ox0 = (trem % tw) << 3;
+
+    const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+
+    // ---- DMA coordinates
+    unsigned poff[PJ];
+    bool pok[PJ];
+#pragma unroll
+    for (int i = 0; i < PJ; ++i) {
+        const int piece = wave + NW * i;
+        const int row = piece * 8 + lrow;  // patch pixel index
+        const int py = row / PW, px = row - py * PW;
+        const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+        pok[i] = piece < PPIECES && row < PPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        poff[i] = (unsigned)((((size_t)img * p.H + iy) * p.W + ix) * p.Cin * 2 + ((lchk ^ ((row >> 1) & 7)) << 4));
+    }
+    unsigned boff[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = wave * (BN / NW) + j * 8 + lrow;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        boff[j] = (unsigned)(((size_t)gn * p.K) * 2 + ((lchk ^ ((row >> 1) & 7)) << 4));
+    }
+    auto stage_patch_piece = [&](int slab, int buf, int i) {
+        const int piece = wave + NW * i;
+        if (piece < PPIECES) dma16(pok[i] ? xg + poff[i] + slab * 128 : zsrc, smem + buf * PATCH_BYTES + piece * 1024);
+    };
+    auto stage_b = [&](int slab, int tap, int slot) {
+        const unsigned koff = (unsigned)(tap * p.Cin + slab * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            dma16(wg + boff[j] + koff, s_b + slot * B_BYTES + (wave * (BN / NW) + j * 8) * 128);
+    };
+
+    // bias of this lane's channels, fetched now so the latency hides under the main loop
+    float cvr[FN][4];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int gn = n0 + wn * (BN / 2) + a * 16 + (lane >> 4) * 4;
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.colv && gn < p.N) c4 = *reinterpret_cast<const float4*>(p.colv + gn);
+        cvr[a][0] = c4.x; cvr[a][1] = c4.y; cvr[a][2] = c4.z; cvr[a][3] = c4.w;
+    }
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int pr0[FM];  // patch pixel of this lane's output pixel at tap (0,0)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = wm * (BM / WM) + b * 16 + frow;
+        pr0[b] = (m >> 3) * PW + (m & 7);
+    }
+
+    const int nslab = p.Cin >> 6;
+    const int nk = 9 * nslab;
+#pragma unroll
+    for (int i = 0; i < PJ; ++i) stage_patch_piece(0, 0, i);
+    stage_b(0, 0, 0);
+    int slab = 0, tap = 0;
+    for (int it = 0; it < nk; ++it) {
+        wait_vmcnt<0>();
+        wg_barrier();
+        // next step's weights; next slab's patch, one piece per tap step so the DMA queue never bursts
+        int ntap = tap + 1, nsl = slab;
+        if (ntap == 9) { ntap = 0; ++nsl; }
+        if (it + 1 < nk) stage_b(nsl, ntap, (it + 1) & 1);
+        if (slab + 1 < nslab && tap < PJ) stage_patch_piece(slab + 1, (slab + 1) & 1, tap);
+        const int tr = tap / 3, ts = tap - tr * 3;
+        const unsigned char* sp = smem + (slab & 1) * PATCH_BYTES;
+        const unsigned char* sb = s_b + (it & 1) * B_BYTES;
+        const int shift = tr * PW + ts;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 xf[FM], wf[FN];
+#pragma unroll
+            for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(sp + lds_off(pr0[b] + shift, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+                wf[a] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+        }
+        tap = ntap;
+        slab = nsl;
+    }
+    wait_vmcnt<0>();
+    wg_barrier();  // all fragment reads done: the patch buffers become the out tile
+
+    unsigned char* so = smem;
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int prow = wm * (BM / WM) + b * 16 + frow;
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int c = wn * (BN / 2) + a * 16 + fchunk * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[a][b][r] + cvr[a][r];
+                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            store4<bf16_t>(reinterpret_cast<bf16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
+        }
+    }
+    wg_barrier();
+    constexpr int RPT = 64 * NW / CPR;
+    const int pch = tid % CPR;
+    const int r0 = tid / CPR;
+#pragma unroll
+    for (int i = 0; i < BM / RPT; ++i) {
+        const int row = r0 + i * RPT;
+        const int gch = pch ^ (row & (CPR - 1));
+        const int gn = n0 + gch * 8;
+        if (gn < p.N) {
+            const size_t gm = ((size_t)img * p.H + oy0 + (row >> 3)) * p.W + ox0 + (row & 7);
+            const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (gm * p.ldo + gn) * 2) = v;
+        }
+    }
+}
+
 template <typename TIN, typename TOUT>
 static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char* who) {
     constexpr int BKE = 8 * DT<TIN>::epc;
@@ -828,6 +1005,20 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     p.Cin = Cin; p.H = H; p.W = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.ldo = Cout;
     if (dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
+    const bool patch_ok = R == 3 && S == 3 && stride == 1 && pad == 1 && !residual && (H % 16) == 0 && (W % 8) == 0 &&
+                          (Cin % 64) == 0 && (Cout % 8) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0 &&
+                          (!bias || (((uintptr_t)bias) & 15) == 0) && (size_t)N * H * W * Cin * 2 < (1ull << 32) &&
+                          !getenv("AGRL_CONV3X3_GENERIC");
+    if (patch_ok) {
+        p.dbg = 0; p.vec_ok = 1;
+        const int tiles = N * (H / 16) * (W / 8);
+        if (Cout <= 64)
+            hipLaunchKernelGGL(conv3x3_patch_kernel<64>, dim3(tiles * cdiv(Cout, 64)), dim3(512), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(conv3x3_patch_kernel<128>, dim3(tiles * cdiv(Cout, 128)), dim3(512), 0, (hipStream_t)stream, p);
+        AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 patch)");
+        return 0;
+    }
     return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
 }
 

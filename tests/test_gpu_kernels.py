@@ -34,6 +34,9 @@ CONV_CASES = [
     (2, 16, 8, 256, 512, 1, 2, False, False),   # downsample 1x1 stride 2, no relu
     (1, 9, 5, 512, 200, 3, 1, True, False),     # ragged N (200 channels), odd spatial
     (4, 16, 8, 1024, 512, 1, 1, False, True),   # deep K
+    (2, 32, 16, 64, 64, 3, 1, False, True),     # 3x3 LDS-patch kernel: 4 pixel blocks per frame, narrow N
+    (1, 64, 32, 128, 128, 3, 1, False, True),   # 3x3 patch, 16 blocks per frame, 2 channel slabs
+    (3, 16, 8, 512, 200, 3, 1, False, False),   # 3x3 patch, whole-frame tile, ragged N, 8 slabs
 ]
 
 
