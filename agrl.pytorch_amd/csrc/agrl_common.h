@@ -44,6 +44,11 @@ __host__ __device__ inline float bf16_to_f32(bf16_t v) {
 }
 
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even); the compiler emits it for this cast
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+#else
     union {
         uint32_t u;
         float f;
@@ -53,6 +58,14 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
+#endif
+}
+
+// two floats -> packed bf16 pair (lo in bits 0..15): one v_cvt_pk_bf16_f32
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // ---- wavefront reductions (64 lanes) -------------------------------------------------------------

@@ -312,8 +312,8 @@ __global__ __launch_bounds__(256) void graph_propagate_mfma_kernel(
                 *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
                 if (out_lp) {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+                    pk.x = pack_bf16x2(o[0], o[1]);
+                    pk.y = pack_bf16x2(o[2], o[3]);
                     *reinterpret_cast<uint2*>(out_lp + idx) = pk;
                 }
             }

@@ -91,8 +91,8 @@ __device__ inline void store4<float>(float* p, const float v[4]) {
 template <>
 __device__ inline void store4<bf16_t>(bf16_t* p, const float v[4]) {
     uint2 u;
-    u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = u;
 }
 template <typename TOUT>
@@ -710,10 +710,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                 *reinterpret_cast<float4*>(p.pool_out + o + 4) = hi4;
                 if (p.pool_out_lp) {
                     uint4 pk;
-                    pk.x = (uint32_t)f32_to_bf16(lo4.x) | ((uint32_t)f32_to_bf16(lo4.y) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(lo4.z) | ((uint32_t)f32_to_bf16(lo4.w) << 16);
-                    pk.z = (uint32_t)f32_to_bf16(hi4.x) | ((uint32_t)f32_to_bf16(hi4.y) << 16);
-                    pk.w = (uint32_t)f32_to_bf16(hi4.z) | ((uint32_t)f32_to_bf16(hi4.w) << 16);
+                    pk.x = pack_bf16x2(lo4.x, lo4.y);
+                    pk.y = pack_bf16x2(lo4.z, lo4.w);
+                    pk.z = pack_bf16x2(hi4.x, hi4.y);
+                    pk.w = pack_bf16x2(hi4.z, hi4.w);
                     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.pool_out_lp) + o) = pk;
                 }
             }

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NTH) void stem_mfma_kernel(const float* __restrict_
         const int e = tid + NTH * i;
         if (e < IT * PWP) {
             uint2 u;
-            u.x = (uint32_t)f32_to_bf16(pv[i][0]) | ((uint32_t)f32_to_bf16(pv[i][1]) << 16);
+            u.x = pack_bf16x2(pv[i][0], pv[i][1]);
             u.y = (uint32_t)f32_to_bf16(pv[i][2]);
             *reinterpret_cast<uint2*>(s_patch + e * 8) = u;
         }
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(NTH) void stem_mfma_kernel(const float* __restrict_
                 const float v2 = in ? fmaxf(acc[i][a][2] + bv.z, 0.f) : 0.f;
                 const float v3 = in ? fmaxf(acc[i][a][3] + bv.w, 0.f) : 0.f;
                 uint2 u;
-                u.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-                u.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+                u.x = pack_bf16x2(v0, v1);
+                u.y = pack_bf16x2(v2, v3);
                 *reinterpret_cast<uint2*>(s_ct + pos * 128 + (((ch >> 2) ^ (pos & 15)) << 3)) = u;
             }
         }
