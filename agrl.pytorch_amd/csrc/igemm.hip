@@ -28,111 +28,8 @@
 
 #include "agrl_common.h"
 
-struct IgemmParams {
-    const void* x;
-    const void* w;
-    const float* colv;  // per output channel (bias / gallery sq-norm) or nullptr
-    const float* rowv;  // per output pixel (query sq-norm) or nullptr
-    const void* res;    // residual, same layout/dtype as out, or nullptr
-    void* out;
-    float alpha;  // out = alpha*acc + rowv[m] + colv[n] + rowc (+ res) (relu)
-    float rowc;   // constant added when rowv == nullptr (cosine: 1.0)
-    int relu;
-    int M, N, K;
-    int Cin, H, W, OH, OW, R, S, stride, pad;
-    int ldo;     // row stride of out / res in elements
-    int vec_ok;  // 4-wide epilogue accesses are aligned
-    int ksplit;  // > 1: blockIdx.y selects a K slice and raw fp32 partials go to out + z*M*ldo (pointwise only)
-    // fused pooling epilogue (persistent kernel only; a tile must be exactly one frame: BM == OH*OW):
-    int pool_nparts;      // 0 = off; else number of row bins summed per frame
-    int pool_mean;        // 1: write bin means, 0: write bin sums
-    int pool_store_out;   // 0: the activation tile itself is not written to HBM
-    int pool_w;           // pixels per image row
-    int pool_start[16], pool_end[16];  // bins in image rows [start, end)
-    float* pool_out;      // fp32 (frames, nparts, N)
-    void* pool_out_lp;    // optional bf16 copy
-    int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
-};
+#include "igemm_dev.h"
 
-template <typename T>
-struct Frag;
-
-template <>
-struct Frag<bf16_t> {
-    // one 16-byte chunk = 8 bf16 = a quarter of the 32-deep k-step of v_mfma_f32_16x16x32_bf16
-    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
-        bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
-        bf16x8_t bv = __builtin_bit_cast(bf16x8_t, b);
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
-    }
-};
-
-template <>
-struct Frag<float> {
-    // one 16-byte chunk = 4 fp32; lane group g = lane>>4 feeds hardware-k g of MFMA j with actual
-    // k = 4*chunk + j -- the same assignment for both operands, so the sum over k is complete
-    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
-        return c;
-    }
-};
-
-__device__ inline int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-template <typename TOUT>
-__device__ inline void store4(TOUT* p, const float v[4]);
-template <>
-__device__ inline void store4<float>(float* p, const float v[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <>
-__device__ inline void store4<bf16_t>(bf16_t* p, const float v[4]) {
-    uint2 u;
-    u.x = pack_bf16x2(v[0], v[1]);
-    u.y = pack_bf16x2(v[2], v[3]);
-    *reinterpret_cast<uint2*>(p) = u;
-}
-template <typename TOUT>
-__device__ inline void load4(const TOUT* p, float v[4]);
-template <>
-__device__ inline void load4<float>(const float* p, float v[4]) {
-    float4 f = *reinterpret_cast<const float4*>(p);
-    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-}
-template <>
-__device__ inline void load4<bf16_t>(const bf16_t* p, float v[4]) {
-    uint2 u = *reinterpret_cast<const uint2*>(p);
-    v[0] = bf16_to_f32((bf16_t)(u.x & 0xffff)); v[1] = bf16_to_f32((bf16_t)(u.x >> 16));
-    v[2] = bf16_to_f32((bf16_t)(u.y & 0xffff)); v[3] = bf16_to_f32((bf16_t)(u.y >> 16));
-}
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
-
-// 16 zero bytes in device memory: the DMA source of every padded / out-of-range chunk
-__device__ __attribute__((aligned(16))) uint4 g_zero16;
-
-__device__ inline void dma16(const unsigned char* src, unsigned char* lds_wave_base) {
-    // LDS-DMA: lane L's 16 bytes land at lds_wave_base + 16*L (wave-uniform base), no VGPR round trip.
-    // Issued through inline asm on purpose: hipcc tracks the builtin as an LDS write and then puts
-    // s_waitcnt vmcnt(0) in front of the next ds_read, which would drain the ring every k-tile; hidden in asm, the
-    // counted waits below are the only ones. M0 (the LDS destination base) is saved/restored in the same statement.
-    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void_t*)lds_wave_base);
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(src), "s"(lds_addr)
-        : "memory");
-}
-
-template <int N>
-__device__ inline void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <typename TIN, typename TOUT, int BM, int BN, bool LDS_EPI, int NS, int NW>  // NW waves: (NW/2) x 2 grid
 __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
@@ -461,11 +358,6 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
 // and the store drain of tile T overlaps the whole of tile T+G. The first k-tile of tile T+G is issued while
 // tile T is still in its epilogue, so no tile starts with an exposed L2/HBM round trip either.
 // Barriers per tile: nk (ring) + 2 (residual landed / out tile complete); every wave executes every one.
-__device__ inline void wg_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
 
 template <typename TIN, int BM, int BN, int NW, bool POOL>  // NW waves, (NW/2) x 2 MFMA grid; POOL: fused frame pooling
 __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParams p, int ntiles) {
@@ -944,6 +836,15 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
         else LAUNCH_IG(128, BN_, EPI_, 2);                    \
     } while (0)
     bool done = false;
+    if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
+        // MFMA-bound pointwise layers (long K, enough 256 x 256 tiles to cover the chip): the wide-tile kernel
+        int wide = -1;
+        if (const char* e = getenv("AGRL_IGEMM_WIDE")) wide = atoi(e);
+        if (wide != 0 && lds_epi && igemm_wide_applicable(p)) {
+            const int wtiles = cdiv(p.M, 256) * (p.N / 256);
+            if (wide == 1 || (wtiles >= 224 && p.K >= 512 && p.N >= 512)) return launch_igemm_wide(p, stream, who);
+        }
+    }
     if constexpr (sizeof(TOUT) == 2) {
         // persistent tiles pay off where a tile is short (<= 8 k-tiles): its first DMA round trip and its store
         // drain are a large share of the tile; long K loops run better as independent workgroups (A/B measured)

@@ -1,0 +1,245 @@
+// 256 x 256 tile form of the pointwise (1x1, stride 1) implicit GEMM for the MFMA-bound layers (layer 3/4 convs:
+// M = 32768 pixels, N = 256..2048 channels, K = 256..2048), bf16 in / bf16 out.
+//
+// Why a second tile shape. Every byte of a k-tile goes global -> LDS through the CU's 64 B/clk vector-memory path
+// and comes back out of the LDS through the 256 B/clk read port. For the 128 x 128 tile (igemm.hip) both cost as many
+// cycles as the MFMAs of that k-tile (32 KB in, 96 KB of fragment reads at 8 waves, 515 MFMA cycles), so the matrix
+// pipe can never be more than half busy. A 256 x 256 tile with 64 x 128 wave tiles needs half the bytes per flop on
+// both paths: 64 KB in and 192 KB of fragment reads per 2060 MFMA cycles.
+//
+//   * 512 threads = 8 waves as 4 (pixels) x 2 (channels); wave tile 64 x 128 = 4 x 8 MFMA 16x16x32 fragments,
+//     128 accumulator registers per lane; one workgroup per CU (128 KB of LDS: 2-slot ring of 64 KB k-tiles)
+//   * staging: LDS-DMA, 8 one-KiB pieces per wave per k-tile, one piece per 4 MFMAs in the first half of the k-tile;
+//     fragment reads software-pipelined two MFMA groups ahead; same swizzled
+//     128-byte-row layout and the same weight-as-A-operand fragment assignment as igemm.hip
+//   * epilogue in two column halves through the two ring slots (a 256 x 256 bf16 tile is the whole ring): half h =
+//     the h-th 64 channels of BOTH wave columns, so all 8 waves work in both halves; the residual half-tiles are
+//     DMA'd into the slots, combined in fp32 in place, rounded once and written out as whole 16-byte chunks
+#include <stdlib.h>
+
+#include "igemm_dev.h"
+
+namespace {
+
+constexpr int WBM = 256, WBN = 256;
+
+template <int DBG>  // ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
+__global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
+    constexpr int BM = WBM, BN = WBN, NW = 8, WM = 4;
+    constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
+    constexpr int FN = BN / 32;         // 8 channel fragments per wave
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;  // 64 KB per ring slot
+    constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW);                                  // 4 + 4 DMA pieces per wave
+    constexpr int DPT = AJ + BJ;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM;
+    const int wn = wave / WM;
+
+    // XCD-aware block -> tile map (blocks b, b+8, .. share an XCD): N-tiles of one M-tile are neighbours in one L2
+    const int nNt = p.N / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, within = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int mt = bid / nNt;
+    const int nt = bid - mt * nNt;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+
+    // per-lane DMA sources (32-bit byte offsets; the host checks the operands are < 4 GB): piece j of this wave
+    // covers tile rows wave*32 + 8j .. +7, lane L -> row + (L>>3), physical chunk L&7 = global chunk (L&7)^((row>>1)&7)
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const unsigned row_bytes = (unsigned)p.K * 2u;
+    unsigned a_off[AJ], b_off[BJ];
+    unsigned a_okmask = 0;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        const int row = wave * (BM / NW) + j * 8 + lrow;
+        const int gm = m0 + row;
+        if (gm < p.M) a_okmask |= 1u << j;
+        a_off[j] = (unsigned)(gm < p.M ? gm : 0) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = wave * (BN / NW) + j * 8 + lrow;
+        b_off[j] = (unsigned)(n0 + row) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
+    }
+    unsigned kbyte = 0;  // byte offset of the k-tile being STAGED inside a row
+    auto stage_piece = [&](int buf, int idx) {
+        if (idx < AJ) {
+            unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / NW) * 128;
+            dma16((a_okmask >> idx) & 1u ? xg + a_off[idx] + kbyte : zsrc, sa + idx * 1024);
+        } else {
+            const int j = idx - AJ;
+            unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / NW) * 128;
+            dma16(wg + b_off[j] + kbyte, sb + j * 1024);
+        }
+    };
+
+    // epilogue half-tile image: 256 rows x 256 B; 16-byte chunk c (8 channels) of row r sits at chunk c ^ (r & 15).
+    // Half h holds channels [64h, 64h+64) of wave column 0 as chunks 0-7 and of wave column 1 as chunks 8-15.
+    auto half_col = [&](int h, int vchunk) { return n0 + (vchunk >> 3) * (BN / 2) + h * 64 + (vchunk & 7) * 8; };
+    auto stage_residual_half = [&](int h, unsigned char* so) {
+        const unsigned char* rg = reinterpret_cast<const unsigned char*>(p.res);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // 64 four-row pieces per half, 8 per wave
+            const int row0 = (wave * 8 + j) * 4;
+            const int row = row0 + (lane >> 4);
+            const int vch = (lane & 15) ^ (row & 15);
+            const int gm = m0 + row;
+            dma16(gm < p.M ? rg + ((size_t)gm * p.ldo + half_col(h, vch)) * 2 : zsrc, so + row0 * 256);
+        }
+    };
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K >> 6;
+    const bool has_res = p.res != nullptr;
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) stage_piece(0, i);
+    kbyte += 128;
+
+    const int frow = lane & 15;
+    const int fchunk = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!(DBG & 32)) wait_vmcnt<0>();  // k-tile kt has landed (this wave's pieces; the barrier covers everybody else's)
+        if (!(DBG & 128)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int fill = cur ^ 1;  // read in iteration kt-1, free now
+        const bool do_stage = kt + 1 < nk && !(DBG & 8);
+        if (!do_stage && has_res) stage_residual_half(0, smem + fill * BUF_BYTES);
+        const unsigned char* sa = smem + cur * BUF_BYTES;
+        const unsigned char* sb = sa + A_BYTES;
+        // Software-pipelined fragment reads: 16 groups of 4 MFMAs (group g = k-step g>>3, channel fragment g&7). The
+        // weight fragment of group g+2 and the next k-step's pixel fragments are requested before group g's MFMAs, so
+        // the matrix pipe waits on the LDS only right after the barrier. One DMA piece of the next k-tile rides in each
+        // of groups 0-7: spread out they hide under the matrix work (a burst of 8 stalls the wave on the memory
+        // pipeline's queue) and every piece still has half a k-tile to land. sched_barrier pins that order.
+        uint4 xfr[2][FM], wfr[3];
+        auto ldx = [&](int kk, int b) {
+            if ((DBG & 16) && kt) return make_uint4(kt, kk, b, lane);
+            return *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / WM) + b * 16 + frow, kk * 4 + fchunk));
+        };
+        auto ldw = [&](int g) {
+            if ((DBG & 16) && kt) return make_uint4(kt, g, 1, lane);
+            return *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + (g & 7) * 16 + frow, (g >> 3) * 4 + fchunk));
+        };
+        wfr[0] = ldw(0);
+#pragma unroll
+        for (int b = 0; b < FM; ++b) xfr[0][b] = ldx(0, b);
+        wfr[1] = ldw(1);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            if (g + 2 < 16) wfr[(g + 2) % 3] = ldw(g + 2);
+            if (g >= 2 && g < 2 + FM) xfr[1][g - 2] = ldx(1, g - 2);
+            if (do_stage && g < DPT) stage_piece(fill, g);
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                if (!(DBG & 2)) acc[g & 7][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g >> 3][b], acc[g & 7][b]);
+                else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g >> 3][b].x), "v"(xfr[g >> 3][b].w));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kbyte += 128;
+        cur ^= 1;
+    }
+    // cur = slot F (free since the last iteration: holds residual half 0), cur ^ 1 = slot L (the last k-tile)
+    unsigned char* soF = smem + cur * BUF_BYTES;
+    unsigned char* soL = smem + (cur ^ 1) * BUF_BYTES;
+    wait_vmcnt<0>();
+    wg_barrier();  // every fragment read of slot L is done
+    if (has_res) stage_residual_half(1, soL);
+
+    auto combine_half = [&](int h, unsigned char* so) {
+#pragma unroll
+        for (int aa = 0; aa < FN / 2; ++aa) {
+            const int a = h * (FN / 2) + aa;
+            const int vc = wn * 64 + aa * 16 + fchunk * 4;  // channel inside the half image (0..127)
+            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.colv) cv = *reinterpret_cast<const float4*>(p.colv + n0 + wn * (BN / 2) + a * 16 + fchunk * 4);
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int prow = wm * (BM / WM) + b * 16 + frow;
+                unsigned char* slot = so + prow * 256 + (((vc >> 3) ^ (prow & 15)) << 4) + ((vc & 4) << 1);
+                float v[4];
+                v[0] = acc[a][b][0] + cv.x;
+                v[1] = acc[a][b][1] + cv.y;
+                v[2] = acc[a][b][2] + cv.z;
+                v[3] = acc[a][b][3] + cv.w;
+                if (has_res) {
+                    float rr[4];
+                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), rr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+            }
+        }
+    };
+    auto drain_half = [&](int h, const unsigned char* so) {  // whole 16-byte chunks, 4 full 128-byte lines per wave op
+        const int pch = tid & 15;
+        const int r0 = tid >> 4;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const int row = r0 + i * 32;
+            const int vch = pch ^ (row & 15);
+            const int gm = m0 + row;
+            if (gm < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(so + row * 256 + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * p.ldo + half_col(h, vch)) * 2) = v;
+            }
+        }
+    };
+
+    combine_half(0, soF);
+    wait_vmcnt<0>();  // residual half 1 has landed
+    wg_barrier();     // half 0 complete
+    drain_half(0, soF);
+    combine_half(1, soL);
+    wg_barrier();
+    drain_half(1, soL);
+}
+
+}  // namespace
+
+bool igemm_wide_applicable(const IgemmParams& p) {
+    const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+    if (!pointwise || p.rowv || p.ksplit > 1 || p.pool_nparts > 0) return false;
+    if (p.alpha != 1.f || p.rowc != 0.f) return false;
+    if (p.N % WBN || p.K % 64 || p.ldo % 8) return false;
+    if ((size_t)p.M * p.K * 2 >= (1ull << 32) || (size_t)p.N * p.K * 2 >= (1ull << 32)) return false;
+    const uintptr_t al = (uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.colv;
+    return (al & 15) == 0;
+}
+
+int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who) {
+    const int grid = cdiv(p.M, WBM) * (p.N / WBN);
+    switch (p.dbg) {
+#define WIDE_CASE(D) case D: hipLaunchKernelGGL(igemm_wide_kernel<D>, dim3(grid), dim3(512), 0, stream, p); break
+        WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
+#undef WIDE_CASE
+        default: hipLaunchKernelGGL(igemm_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p);
+    }
+    AGRL_CHECK_LAUNCH(who);
+    return 0;
+}

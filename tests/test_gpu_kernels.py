@@ -70,6 +70,44 @@ def test_conv_bn_act(case, dtype):
     assert e < (1e-5 if dtype == torch.float32 else 1e-2)
 
 
+WIDE_CASES = [
+    # N, H, W, Cin, Cout, residual, relu  -- the 256 x 256 tile kernel (igemm_wide.hip), forced through AGRL_IGEMM_WIDE=1
+    (4, 16, 8, 512, 512, True, True),     # two M tiles x two N tiles, residual halves through both ring slots
+    (3, 10, 7, 256, 256, False, True),    # ragged M (210 pixels < one tile)
+    (5, 16, 8, 128, 768, True, False),    # 2.5 M tiles, 3 N tiles, 2 k-tiles, no relu
+    (2, 16, 8, 2048, 256, False, True),   # 32 k-tiles
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_conv_wide_tile(case, monkeypatch):
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, Cout, use_res, relu = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = (torch.randn((N, Cin, H, W), generator=g)).bfloat16().float()
+    w = (torch.randn((Cout, Cin, 1, 1), generator=g) / np.sqrt(Cin)).bfloat16().float()
+    b = torch.randn((Cout,), generator=g)
+    ref = F.conv2d(x, w, bias=b)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g).bfloat16().float()
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 1, 0, relu)
+    kw = dict(residual=None if res is None else nhwc(res, torch.bfloat16))
+    monkeypatch.setenv("AGRL_IGEMM_WIDE", "1")
+    wide = ops.conv_bn_act(*args, **kw)
+    monkeypatch.setenv("AGRL_IGEMM_WIDE", "0")
+    narrow = ops.conv_bn_act(*args, **kw)
+    torch.cuda.synchronize()
+    e = rel_err(wide.float().permute(0, 3, 1, 2), ref)
+    print("wide conv", case, "rel err %.3e" % e)
+    assert e < 1e-2
+    # same fp32 accumulation order per output (k ascending in 32-deep MFMA steps) -> identical bf16 results
+    assert torch.equal(wide, narrow)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 256, 128), (3, 64, 48), (1, 37, 29)])
 def test_stem(shape, dtype):

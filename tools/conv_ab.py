@@ -22,6 +22,9 @@ SHAPES = [  # N, H, W, Cin, Cout, R, stride, res
     (256, 64, 32, 64, 64, 3, 1, False),
     (256, 32, 16, 128, 128, 3, 1, False),
     (256, 16, 8, 512, 2048, 1, 1, False),
+    (256, 16, 8, 1024, 512, 1, 1, False),
+    (256, 32, 16, 512, 256, 1, 1, False),
+    (256, 32, 16, 512, 128, 1, 1, False),
 ]
 args = sys.argv[1:]
 if "--shapes" in args:
