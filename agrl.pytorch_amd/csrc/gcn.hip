@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "agrl_common.h"
+#include "igemm_dev.h"
 
 namespace {
 
@@ -321,6 +322,198 @@ __global__ __launch_bounds__(256) void graph_propagate_mfma_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Propagate, streaming MFMA form (V <= 64, V % 4 == 0: the MARS / PRID configurations). grid = (B, C/128), 128
+// threads; each WAVE owns 64 channels of one tracklet and streams them HBM -> registers -> MFMA -> HBM, no LDS round
+// trip for h or f:
+//   * h: one 16-byte load per lane per 4 graph rows u: lane (i = lane&15, kg = lane>>4) reads
+//     h[4t+kg][c0 + 4 sigma(i) .. +3] -> 256 contiguous bytes per row, whole cache lines. The four floats feed FOUR
+//     MFMAs (v_mfma_f32_16x16x4_f32, exact fp32) whose row i stands for channel c0 + 4 sigma(i) + j: the channel <->
+//     MFMA-row assignment is free, so it is chosen to match the load; sigma = the 4 x 4 index transpose, which makes
+//     the lanes kg = 0..3 of every epilogue access cover 64 contiguous bytes.
+//   * D_j[row 4 kg + r][col v] = channel c0 + 4 kg + 16 r + j of node v: f is read and the output written as float4s.
+//   * G (V x V, L2-resident) is copied as it lies into LDS by LDS-DMA (B operand G[v][u] by ds_read_b32; rows >= V of
+//     the padded node fragment read whatever follows and only feed output nodes that are never stored).
+// Issue order = arrival order: G, BN constants, h in sweep order, f. EVERY load of the prologue is inline asm with a
+// hand-counted s_waitcnt tied to its destination registers: left to hipcc, the loads get sunk behind one another (G
+// ends up last in the queue, one load lands under a branch with a vmcnt(0) in front of the sweep); this way 46 KB per
+// workgroup is in flight at once and step t of the sweep waits for h row-group t alone, so the matrix work overlaps
+// the rest of the stream.
+__device__ inline f32x4_t gload16(const void* p) {
+    f32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// at most n younger vector-memory operations still in flight (n folds to a constant in the unrolled callers)
+__device__ inline void landed(int n, f32x4_t& v) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(v) : : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(v) : : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(v) : : "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(v) : : "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" : "+v"(v) : : "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(v) : : "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" : "+v"(v) : : "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(v) : : "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" : "+v"(v) : : "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(v) : : "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" : "+v"(v) : : "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" : "+v"(v) : : "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" : "+v"(v) : : "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" : "+v"(v) : : "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" : "+v"(v) : : "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" : "+v"(v) : : "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" : "+v"(v) : : "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" : "+v"(v) : : "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" : "+v"(v) : : "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" : "+v"(v) : : "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" : "+v"(v) : : "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" : "+v"(v) : : "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" : "+v"(v) : : "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" : "+v"(v) : : "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" : "+v"(v) : : "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" : "+v"(v) : : "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" : "+v"(v) : : "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" : "+v"(v) : : "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(29)" : "+v"(v) : : "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(30)" : "+v"(v) : : "memory"); break;
+        case 31: asm volatile("s_waitcnt vmcnt(31)" : "+v"(v) : : "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" : "+v"(v) : : "memory"); break;
+        case 33: asm volatile("s_waitcnt vmcnt(33)" : "+v"(v) : : "memory"); break;
+        case 34: asm volatile("s_waitcnt vmcnt(34)" : "+v"(v) : : "memory"); break;
+        case 35: asm volatile("s_waitcnt vmcnt(35)" : "+v"(v) : : "memory"); break;
+        case 36: asm volatile("s_waitcnt vmcnt(36)" : "+v"(v) : : "memory"); break;
+        case 37: asm volatile("s_waitcnt vmcnt(37)" : "+v"(v) : : "memory"); break;
+        case 38: asm volatile("s_waitcnt vmcnt(38)" : "+v"(v) : : "memory"); break;
+        case 39: asm volatile("s_waitcnt vmcnt(39)" : "+v"(v) : : "memory"); break;
+        case 40: asm volatile("s_waitcnt vmcnt(40)" : "+v"(v) : : "memory"); break;
+        case 41: asm volatile("s_waitcnt vmcnt(41)" : "+v"(v) : : "memory"); break;
+        case 42: asm volatile("s_waitcnt vmcnt(42)" : "+v"(v) : : "memory"); break;
+        case 43: asm volatile("s_waitcnt vmcnt(43)" : "+v"(v) : : "memory"); break;
+        case 44: asm volatile("s_waitcnt vmcnt(44)" : "+v"(v) : : "memory"); break;
+        case 45: asm volatile("s_waitcnt vmcnt(45)" : "+v"(v) : : "memory"); break;
+        case 46: asm volatile("s_waitcnt vmcnt(46)" : "+v"(v) : : "memory"); break;
+        case 47: asm volatile("s_waitcnt vmcnt(47)" : "+v"(v) : : "memory"); break;
+        case 48: asm volatile("s_waitcnt vmcnt(48)" : "+v"(v) : : "memory"); break;
+        case 49: asm volatile("s_waitcnt vmcnt(49)" : "+v"(v) : : "memory"); break;
+        case 50: asm volatile("s_waitcnt vmcnt(50)" : "+v"(v) : : "memory"); break;
+        case 51: asm volatile("s_waitcnt vmcnt(51)" : "+v"(v) : : "memory"); break;
+        case 52: asm volatile("s_waitcnt vmcnt(52)" : "+v"(v) : : "memory"); break;
+        case 53: asm volatile("s_waitcnt vmcnt(53)" : "+v"(v) : : "memory"); break;
+        case 54: asm volatile("s_waitcnt vmcnt(54)" : "+v"(v) : : "memory"); break;
+        case 55: asm volatile("s_waitcnt vmcnt(55)" : "+v"(v) : : "memory"); break;
+        case 56: asm volatile("s_waitcnt vmcnt(56)" : "+v"(v) : : "memory"); break;
+        case 57: asm volatile("s_waitcnt vmcnt(57)" : "+v"(v) : : "memory"); break;
+        case 58: asm volatile("s_waitcnt vmcnt(58)" : "+v"(v) : : "memory"); break;
+        case 59: asm volatile("s_waitcnt vmcnt(59)" : "+v"(v) : : "memory"); break;
+        case 60: asm volatile("s_waitcnt vmcnt(60)" : "+v"(v) : : "memory"); break;
+        case 61: asm volatile("s_waitcnt vmcnt(61)" : "+v"(v) : : "memory"); break;
+        case 62: asm volatile("s_waitcnt vmcnt(62)" : "+v"(v) : : "memory"); break;
+        case 63: asm volatile("s_waitcnt vmcnt(63)" : "+v"(v) : : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); break;
+    }
+}
+__device__ inline void tie(f32x4_t& v) { asm volatile("" : "+v"(v)); }
+
+template <int PS_NT, int NWV>  // V = 4 PS_NT exactly; NWV waves (64 channels each) per workgroup
+__global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
+    const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
+    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int C) {
+    extern __shared__ __attribute__((aligned(16))) float s_g[];  // [16*NVF][V]
+    constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = (blockIdx.y * NWV + wave) * 64;
+    const int i16 = lane & 15, kg = lane >> 4;
+
+    {
+        const unsigned char* Gb = reinterpret_cast<const unsigned char*>(G + (size_t)b * V * V);
+        const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+        constexpr int GBYTES = V * V * 4, NPIECE = (GBYTES + 1023) / 1024;
+#pragma unroll
+        for (int pc = 0; pc < (NPIECE + NWV - 1) / NWV; ++pc) {  // every wave issues the same number of pieces (vmcnt below)
+            const int piece = NWV * pc + wave;
+            const int off = piece * 1024 + lane * 16;
+            const bool real = piece < NPIECE;
+            dma16(real && off < GBYTES ? Gb + off : zsrc,
+                  reinterpret_cast<unsigned char*>(s_g) + (real ? piece : NPIECE) * 1024);  // spare KiB for the odd one
+        }
+    }
+    const size_t node0 = (size_t)b * V;
+    const int cl = c0 + 4 * kg;  // float4 r of this lane = channels cl + 16 r .. +3
+    f32x4_t sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sc[r] = gload16(bn_scale + cl + 16 * r);
+        sh[r] = gload16(bn_shift + cl + 16 * r);
+    }
+    const int sig = 4 * (i16 & 3) + (i16 >> 2);
+    const float* hb = h + (size_t)b * V * C + c0 + 4 * sig;
+    f32x4_t hreg[PS_NT];
+#pragma unroll
+    for (int t = 0; t < PS_NT; ++t) hreg[t] = gload16(hb + (size_t)(4 * t + kg) * C);
+    f32x4_t fin[NVF][4];
+#pragma unroll
+    for (int vf = 0; vf < NVF; ++vf) {
+        const int v = min(vf * 16 + i16, V - 1);  // clamped: nodes >= V are computed on a copy and never stored
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fin[vf][r] = gload16(f + (node0 + v) * C + cl + 16 * r);
+    }
+    constexpr int YOUNGER_THAN_G = 8 + PS_NT + 4 * NVF;
+    wait_vmcnt<YOUNGER_THAN_G>();  // the DMA pieces are the oldest entries of the queue
+    wg_barrier();
+
+    f32x4_t acc[NVF][4];
+#pragma unroll
+    for (int vf = 0; vf < NVF; ++vf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[vf][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < PS_NT; ++t) {
+        float gq[NVF];
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) gq[vf] = s_g[(vf * 16 + i16) * V + 4 * t + kg];
+        landed(PS_NT - 1 - t + 4 * NVF, hreg[t]);
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[vf][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[t][j], gq[vf], acc[vf][j], 0, 0, 0);
+    }
+    // epilogue: D_j row 4 kg + r = channel c0 + 4 sigma(4 kg + r) + j = cl + 16 r + j -> float4 r = {acc[vf][0..3][r]}
+    landed(0, fin[0][0]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        tie(sc[r]);
+        tie(sh[r]);
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) tie(fin[vf][r]);
+    }
+#pragma unroll
+    for (int vf = 0; vf < NVF; ++vf) {
+        const int v = vf * 16 + i16;
+        if (v >= V) continue;
+        float* op = out + (node0 + v) * C + cl;
+        bf16_t* lp = out_lp ? out_lp + (node0 + v) * C + cl : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = fmaf(acc[vf][j][r], sc[r][j], sh[r][j]);
+                y = y > 0.f ? y : slope * y;
+                o[j] = one_minus_gamma * fin[vf][r][j] + gamma * y;
+            }
+            *reinterpret_cast<float4*>(op + 16 * r) = make_float4(o[0], o[1], o[2], o[3]);
+            if (lp) *reinterpret_cast<uint2*>(lp + 16 * r) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int agrl_graph_gram(const float* f, float* gram_part, int B, int V, int C, int cslice,
@@ -357,6 +550,33 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0, "agrl_graph_propagate: bad shape");
     // (1 - gamma) is evaluated in double like the reference's Python float, then rounded once
     const float omg_m = (float)(1.0 - (double)gamma);
+    const bool aligned = ((((uintptr_t)f | (uintptr_t)h | (uintptr_t)out | (uintptr_t)out_lp | (uintptr_t)bn_scale |
+                            (uintptr_t)bn_shift) & 15) == 0);
+    if (V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned && (((uintptr_t)G) & 15) == 0 && !getenv("AGRL_GCN_LDS")) {
+        const int V4 = (V + 3) & ~3;
+        const int nvf = (V + 15) / 16;
+        int nwv = (C % 256) == 0 ? 4 : 2;  // 4-wave workgroups: one wave per SIMD of a CU by construction
+        if (const char* e = getenv("AGRL_GCN_NWV")) nwv = atoi(e) == 2 ? 2 : nwv;
+        const size_t lds_s = (size_t)16 * nvf * V4 * sizeof(float) + 2048;  // padded fragment rows + DMA piece rounding + spare
+#define LAUNCH_PS(NT_)                                                                                                \
+    case NT_:                                                                                                         \
+        if (nwv == 4)                                                                                                 \
+            hipLaunchKernelGGL((graph_propagate_stream_kernel<NT_, 4>), dim3(B, C / 256), dim3(256), lds_s,           \
+                               (hipStream_t)stream, f, h, G, bn_scale, bn_shift, omg_m, gamma, slope, out,            \
+                               (bf16_t*)out_lp, C);                                                                   \
+        else                                                                                                          \
+            hipLaunchKernelGGL((graph_propagate_stream_kernel<NT_, 2>), dim3(B, C / 128), dim3(128), lds_s,           \
+                               (hipStream_t)stream, f, h, G, bn_scale, bn_shift, omg_m, gamma, slope, out,            \
+                               (bf16_t*)out_lp, C);                                                                   \
+        break
+        switch (V4 >> 2) {
+            LAUNCH_PS(1); LAUNCH_PS(2); LAUNCH_PS(3); LAUNCH_PS(4); LAUNCH_PS(5); LAUNCH_PS(6); LAUNCH_PS(7); LAUNCH_PS(8);
+            LAUNCH_PS(9); LAUNCH_PS(10); LAUNCH_PS(11); LAUNCH_PS(12); LAUNCH_PS(13); LAUNCH_PS(14); LAUNCH_PS(15); LAUNCH_PS(16);
+        }
+#undef LAUNCH_PS
+        AGRL_CHECK_LAUNCH("agrl_graph_propagate");
+        return 0;
+    }
     if (V <= 128 && (C % 128) == 0 && !getenv("AGRL_GCN_VALU")) {
         const int V4 = (V + 3) & ~3;
         const int hrows = (V4 + 1) & ~1;

@@ -999,7 +999,10 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
     p.M = m; p.N = n; p.K = D;
     p.Cin = D; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.ldo = ldd;
-    // streaming form (few queries against a long gallery): too few output tiles to fill 256 CUs -> split K over
+    // streaming form (one eval batch of queries against a long gallery): dedicated single-pass kernel
+    if (!getenv("AGRL_DISTMAT_TILED") && distmat_stream_applicable(p, dtype == AGRL_F32 ? 4 : 2))
+        return launch_distmat_stream(p, dtype, (hipStream_t)stream);
+    // otherwise, when there are too few output tiles to fill 256 CUs -> split K over
     // workgroups, fp32 partials in the caller's workspace, deterministic reduce + epilogue afterwards
     const int bke = dtype == AGRL_F32 ? 32 : 64;
     const int nk = D / bke;

@@ -118,3 +118,7 @@ __device__ inline void wg_barrier() {
 // 256 x 256 tile kernel for the MFMA-bound pointwise layers (igemm_wide.hip)
 bool igemm_wide_applicable(const IgemmParams& p);
 int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who);
+
+// streaming distance matrix (few queries x long gallery, distmat_stream.hip)
+bool distmat_stream_applicable(const IgemmParams& p, int elem_size);
+int launch_distmat_stream(const IgemmParams& p, int dtype, hipStream_t stream);

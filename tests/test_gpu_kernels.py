@@ -242,7 +242,7 @@ def test_attention_tail():
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
-@pytest.mark.parametrize("shape", [(37, 101, 4096), (5, 300, 96), (130, 257, 2048), (32, 12180, 4096), (8, 3000, 1024)])
+@pytest.mark.parametrize("shape", [(37, 101, 4096), (5, 300, 96), (130, 257, 2048), (32, 12180, 4096), (8, 3000, 1024), (50, 2500, 512), (20, 2077, 256), (64, 4099, 128)])
 def test_distmat(shape, metric):
     from torchreid.metrics.distance import hip_distmat_device
     m, n, D = shape
