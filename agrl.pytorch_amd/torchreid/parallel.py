@@ -30,8 +30,16 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # AGRL_DIST_BACKEND=gloo lets several ranks share ONE GPU (control-flow tests of the N > 1 path on a 1-GPU box)
+            backend = os.environ.get("AGRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            # bind this process to its GPU BEFORE the communicator exists: RCCL then builds its rings on the right
+            # device and barrier()/collectives never have to guess one
+            device = torch.device("cuda", local_rank)
+            torch.cuda.set_device(device)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 

@@ -91,10 +91,10 @@ def main():
     from torchreid.metrics.distance import hip_distmat_device
     from torchreid import hip_ops as ops
 
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     rank, world, local_rank = parallel.init_from_env()
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     _hip.lib()
 
@@ -119,8 +119,7 @@ def main():
         g_op = ops.row_l2_normalize(g_shard, False, dt_g) if lp else g_shard
     dist_out = torch.empty((B * world, hi - lo), dtype=torch.float32, device=device)
 
-    def step():
-        emb = model(clips, adj)                       # (B, 4096) fp32
+    def match(emb):
         q_all = parallel.all_gather_rows(emb)         # RCCL all-gather over xGMI when world > 1
         if args.metric == "cosine":
             q_op = ops.row_l2_normalize(q_all, True, dt_g)
@@ -128,6 +127,23 @@ def main():
         qn = ops.row_sqnorm(q_all)
         q_op = ops.row_l2_normalize(q_all, False, dt_g) if lp else q_all
         return ops.distmat(q_op, g_op, "euclidean", qn, g_norm, out=dist_out)
+
+    main_stream = torch.cuda.current_stream(device)
+    match_stream = torch.cuda.Stream(device=device) if world > 1 else None
+
+    def step():
+        emb = model(clips, adj)                       # (B, 4096) fp32
+        if match_stream is None:
+            return match(emb)
+        # N > 1: the exchange + match of this batch run on their own HIP stream, so the collective (and the skew
+        # between ranks it absorbs) overlaps the next batch's forward instead of stalling it; every step still does
+        # the same work, and the closing synchronize() waits for both streams.
+        ready = torch.cuda.Event()
+        ready.record(main_stream)
+        with torch.cuda.stream(match_stream):
+            match_stream.wait_event(ready)
+            emb.record_stream(match_stream)
+            return match(emb)
 
     def sync():
         if world > 1:
@@ -167,12 +183,14 @@ def main():
                    "gallery_rows_per_gpu": hi - lo, "parallelism": "dp%d" % world},
     }
 
-    # ---- live per-kernel timing (HIP events on the launch stream), rank 0 only
+    # ---- live per-kernel timing (HIP events on the launch stream). Every rank runs the extra steps (they contain
+    # the collective); only rank 0 records and reports.
     if rank == 0:
         _hip.PROFILE = []
-        for _ in range(args.profile_steps):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(args.profile_steps):
+        step()
+    sync()
+    if rank == 0:
         prof, _hip.PROFILE = _hip.PROFILE, None
         agg = {}
         for name, s_ev, e_ev, tag in prof:
