@@ -1,0 +1,240 @@
+// 3x3 / stride 1 / pad 1 convolution, bf16, with TWO 16x8 pixel blocks (two whole frames in layers 3/4) per
+// workgroup: 256 output pixels x 128 output channels.
+//
+// The one-block kernel (conv3x3_patch_kernel, igemm.hip) stages per 64-channel slab one 23 KB halo patch and
+// 9 x 16 KB of weights for 9 x 515 MFMA cycles: the weight stream is as expensive as the matrix work it feeds, and a
+// step between two barriers is only 16 MFMAs per wave. Doubling the pixel tile halves the weight bytes per flop
+// (2 x 23 + 9 x 16 KB per 9 x 1030 MFMA cycles = 20 B/clk through the CU's 64 B/clk vector-memory path), doubles the
+// matrix work between barriers and widens the wave tile to 64 x 64 (8 fragment reads per 16 MFMAs instead of 6 per 8).
+//
+//   * 512 threads = 8 waves as 4 (pixels) x 2 (channels); wave tile 64 pixels x 64 channels = 4 x 4 MFMA 16x16x32
+//   * LDS: halo patches 2 (slab ring) x 2 (blocks) x 23.5 KB + weight ring 3 x 16 KB = 142 KB; one workgroup per CU.
+//     Weights are requested TWO tap-steps ahead with counted vmcnt waits (a step is ~0.45 us, an L2 round trip under
+//     load is about that long); the next slab's patches ride one piece per tap-step.
+//   * fragment reads software-pipelined inside the step (weight fragment two MFMA groups ahead, the second k-step's
+//     pixel fragments under the first's MFMAs)
+//   * epilogue: bias + ReLU in fp32, bf16 tile parked over the patch buffers, written out as whole 16-byte chunks
+#include <stdlib.h>
+
+#include "igemm_dev.h"
+
+namespace {
+
+__global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, int nblocks) {
+    constexpr int BN = 128, NW = 8, WM = 4, BM = 256;
+    constexpr int FM = BM / (16 * WM), FN = BN / 32;  // 4 x 4 fragments per wave
+    constexpr int PW = 10, PPIX = 18 * PW;            // 18 x 10 halo patch per block
+    constexpr int PPIECES = (PPIX + 7) / 8;           // 23 one-KiB pieces (8 patch pixels each)
+    constexpr int PATCH_BYTES = PPIECES * 1024;       // 23552
+    constexpr int SLAB_BYTES = 2 * PATCH_BYTES;       // both blocks
+    constexpr int PJ = (2 * PPIECES + NW - 1) / NW;   // patch pieces per wave per slab (6, two of the 48 are dummies)
+    constexpr int B_BYTES = BN * 128, WSLOTS = 3;
+    constexpr int BJ = BN / 64;                       // weight pieces per wave per tap-step (2)
+    constexpr int CPR = BN * 2 / 16, ROWB = BN * 2;
+    static_assert(BM * ROWB <= 2 * SLAB_BYTES, "out tile must fit over the patch buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SLAB_BYTES + WSLOTS * B_BYTES + 1024];
+    unsigned char* s_b = smem + 2 * SLAB_BYTES;
+    unsigned char* s_dummy = s_b + WSLOTS * B_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int lrow = lane >> 3, lchk = lane & 7;
+
+    const int nNt = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, within = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int mt = bid / nNt;
+    const int nt = bid - mt * nNt;
+    const int n0 = nt * BN;
+    const int tw = p.W >> 3, th = p.H >> 4;
+    // pixel block bsel of this tile = block 2 mt + bsel in (image, block row, block column) order
+    auto block_origin = [&](int bsel, int& img, int& oy0, int& ox0) {
+        const int blk = min(2 * mt + bsel, nblocks - 1);
+        img = blk / (tw * th);
+        const int trem = blk - img * (tw * th);
+        oy0 = (trem / tw) << 4;
+        ox0 = (trem % tw) << 3;
+    };
+    const bool second_valid = 2 * mt + 1 < nblocks;
+
+    const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+
+    // ---- DMA coordinates. Patch piece index pi = wave + 8 i (i < 6) over the 46 pieces of the two blocks
+    unsigned poff[PJ];
+    bool pok[PJ];
+    int pdst[PJ];
+#pragma unroll
+    for (int i = 0; i < PJ; ++i) {
+        const int pi = wave + NW * i;
+        const int bsel = pi >= PPIECES ? 1 : 0;
+        const int piece = pi - bsel * PPIECES;
+        int img, oy0, ox0;
+        block_origin(bsel, img, oy0, ox0);
+        const int row = piece * 8 + lrow;  // patch pixel index
+        const int py = row / PW, px = row - py * PW;
+        const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+        const bool real = pi < 2 * PPIECES;
+        pok[i] = real && row < PPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W &&
+                 (bsel == 0 || second_valid);
+        poff[i] = (unsigned)((((size_t)img * p.H + iy) * p.W + ix) * p.Cin * 2 + ((lchk ^ ((row >> 1) & 7)) << 4));
+        pdst[i] = real ? bsel * PATCH_BYTES + piece * 1024 : -1;
+    }
+    unsigned boff[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int row = wave * (BN / NW) + j * 8 + lrow;
+        int gn = n0 + row;
+        gn = gn < p.N ? gn : p.N - 1;
+        boff[j] = (unsigned)(((size_t)gn * p.K) * 2 + ((lchk ^ ((row >> 1) & 7)) << 4));
+    }
+    auto stage_patch_piece = [&](int slab, int i) {  // always exactly one DMA (dummies keep every wave's vmcnt equal)
+        dma16(pok[i] ? xg + poff[i] + slab * 128 : zsrc,
+              pdst[i] >= 0 ? smem + (slab & 1) * SLAB_BYTES + pdst[i] : s_dummy);
+    };
+    auto stage_b = [&](int slab, int tap, int slot) {
+        const unsigned koff = (unsigned)(tap * p.Cin + slab * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            dma16(wg + boff[j] + koff, s_b + slot * B_BYTES + (wave * (BN / NW) + j * 8) * 128);
+    };
+
+    f32x4_t acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    // this wave's 64 pixels lie in block wm >> 1 (pixels (wm & 1) * 64 .. + 63 of it)
+    const int pbase = (wm >> 1) * PATCH_BYTES;
+    int pr0[FM];  // patch pixel of this lane's output pixel at tap (0,0)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = (wm & 1) * 64 + b * 16 + frow;
+        pr0[b] = (m >> 3) * PW + (m & 7);
+    }
+
+    const int nslab = p.Cin >> 6;
+    const int nsteps = 9 * nslab;
+    // prologue: slab 0 patches, weights of steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < PJ; ++i) stage_patch_piece(0, i);
+    stage_b(0, 0, 0);
+    stage_b(0, 1, 1);
+
+    int wslot = 0;  // weight ring slot of the current step
+    for (int slab = 0; slab < nslab; ++slab) {
+        const bool next_slab = slab + 1 < nslab;
+        const unsigned char* sp = smem + (slab & 1) * SLAB_BYTES + pbase;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int step = slab * 9 + tap;
+            // Younger than this step's weights in this wave's queue: the weights of step+1 (BJ pieces) and the patch
+            // pieces issued since. Patch pieces of slab+1 are issued in taps 0..PJ-1 of slab; this step's weights were
+            // issued at step-2, so the pieces of steps step-2 (after the weights), step-1 are younger; waiting them
+            // out is harmless except for the count, so count them exactly:
+            //   issue order inside a step: [patch piece (tap < PJ, next_slab)] then [weights of step+2]
+            // => after weights(step): patch(step-1)? , weights(step+1)  -> BJ + (tap-1 in [0,PJ) && had_next ? 1 : 0)
+            // At a slab boundary (tap == 0) the current slab's own patches must have landed too: they are older than
+            // weights(step) except the piece issued at tap PJ-1 <= step-2 ... all older. So the same wait covers them.
+            {
+                const bool more = step + 1 < nsteps;
+                const int ptap = tap - 1;  // the tap of step-1 (same slab unless tap == 0)
+                const bool patch_younger = (tap >= 1) && (ptap < PJ) && next_slab;
+                if (!more) wait_vmcnt<0>();
+                else if (patch_younger) wait_vmcnt<BJ + 1>();
+                else wait_vmcnt<BJ>();
+            }
+            wg_barrier();
+            // refill: next slab's patch piece, then the weights two steps ahead (into the slot read at step-1)
+            if (tap < PJ && next_slab) stage_patch_piece(slab + 1, tap);
+            if (step + 2 < nsteps) {
+                int t2 = tap + 2, s2 = slab;
+                if (t2 >= 9) { t2 -= 9; ++s2; }
+                int slot2 = wslot + 2;
+                slot2 = slot2 >= WSLOTS ? slot2 - WSLOTS : slot2;
+                stage_b(s2, t2, slot2);
+            }
+            const int tr = tap / 3, ts = tap - tr * 3;
+            const int shift = tr * PW + ts;
+            const unsigned char* sb = s_b + wslot * B_BYTES;
+            // 8 groups of 4 MFMAs: group g = (k-step g >> 2, channel fragment g & 3)
+            uint4 xfr[2][FM], wfr[3];
+            auto ldx = [&](int kk, int b) { return *reinterpret_cast<const uint4*>(sp + lds_off(pr0[b] + shift, kk * 4 + fchunk)); };
+            auto ldw = [&](int g) {
+                return *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + (g & 3) * 16 + frow, (g >> 2) * 4 + fchunk));
+            };
+            wfr[0] = ldw(0);
+#pragma unroll
+            for (int b = 0; b < FM; ++b) xfr[0][b] = ldx(0, b);
+            wfr[1] = ldw(1);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g + 2 < 8) wfr[(g + 2) % 3] = ldw(g + 2);
+                if (g < FM) xfr[1][g] = ldx(1, g);
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[g & 3][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g >> 2][b], acc[g & 3][b]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wslot = wslot + 1 == WSLOTS ? 0 : wslot + 1;
+        }
+    }
+    wait_vmcnt<0>();
+    wg_barrier();  // all fragment reads done: the patch buffers become the out tile
+
+    unsigned char* so = smem;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int c = wn * (BN / 2) + a * 16 + fchunk * 4;
+        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.colv && n0 + c < p.N) cv = *reinterpret_cast<const float4*>(p.colv + n0 + c);
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int prow = wm * (BM / WM) + b * 16 + frow;
+            float v[4] = {acc[a][b][0] + cv.x, acc[a][b][1] + cv.y, acc[a][b][2] + cv.z, acc[a][b][3] + cv.w};
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            store4<bf16_t>(reinterpret_cast<bf16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
+        }
+    }
+    wg_barrier();
+    constexpr int RPT = 64 * NW / CPR;  // 32 rows per pass
+    const int pch = tid % CPR;
+    const int r0 = tid / CPR;
+#pragma unroll
+    for (int i = 0; i < BM / RPT; ++i) {
+        const int row = r0 + i * RPT;
+        const int bsel = row >> 7, m = row & 127;
+        if (bsel == 1 && !second_valid) continue;
+        const int gch = pch ^ (row & (CPR - 1));
+        const int gn = n0 + gch * 8;
+        if (gn < p.N) {
+            int img, oy0, ox0;
+            block_origin(bsel, img, oy0, ox0);
+            const size_t gm = ((size_t)img * p.H + oy0 + (m >> 3)) * p.W + ox0 + (m & 7);
+            const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (gm * p.ldo + gn) * 2) = v;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream) {
+    const int nblocks = (p.M / p.OH / p.OW) * (p.H / 16) * (p.W / 8);
+    const int grid = cdiv(nblocks, 2) * cdiv(p.N, 128);
+    hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(grid), dim3(512), 0, stream, p, nblocks);
+    AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 wide)");
+    return 0;
+}

@@ -913,6 +913,14 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     if (patch_ok) {
         p.dbg = 0; p.vec_ok = 1;
         const int tiles = N * (H / 16) * (W / 8);
+        int wide3 = -1;
+        if (const char* e = getenv("AGRL_CONV3X3_WIDE")) wide3 = atoi(e);
+        // two pixel blocks per workgroup for the deep layers (3/4: measured +3..4 %; at Cin = 128 the one-block kernel
+        // at two workgroups per CU is 5 % faster), where that still leaves >= one workgroup per CU
+        if (Cout > 64 && wide3 != 0 && (wide3 == 1 || (Cin >= 256 && cdiv(tiles, 2) * cdiv(Cout, 128) >= 256))) {
+            p.ksplit = 1;
+            return launch_conv3x3_wide(p, (hipStream_t)stream);
+        }
         if (Cout <= 64)
             hipLaunchKernelGGL(conv3x3_patch_kernel<64>, dim3(tiles * cdiv(Cout, 64)), dim3(512), 0, (hipStream_t)stream, p);
         else

@@ -122,3 +122,6 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
 // streaming distance matrix (few queries x long gallery, distmat_stream.hip)
 bool distmat_stream_applicable(const IgemmParams& p, int elem_size);
 int launch_distmat_stream(const IgemmParams& p, int dtype, hipStream_t stream);
+
+// two-block 3x3 kernel (conv3x3_wide.hip)
+int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream);

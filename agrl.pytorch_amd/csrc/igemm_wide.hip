@@ -117,6 +117,58 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
     int cur = 0;
+    if constexpr ((DBG & 4096) != 0) {
+        // ---- ping-pong schedule. The two waves of a SIMD (w and w + 4: wave column 0 / 1) run the same phase
+        // sequence {L: fragment reads (+ DMA issue) | barrier | M: 32 MFMAs | barrier}, column 1 ONE BARRIER LATER:
+        // while one column's waves are in their matrix section the other column's are reading LDS / issuing DMA, so
+        // the matrix pipe never waits for both at once. Phase p = (k-tile p >> 1, k-step p & 1).
+        //   column 0: L_p in barrier interval 2p,   M_p in 2p+1
+        //   column 1: L_p in barrier interval 2p+1, M_p in 2p+2
+        // k-tile kt+1 goes into the slot last read by column 1's L_{2kt-1} (interval 4kt-1): it is issued at the start
+        // of each wave's L_{2kt} (intervals 4kt / 4kt+1) and must be complete before barrier 4kt+4, the first barrier
+        // after which anybody (column 0, L_{2kt+2}) reads it: column 0 waits for its pieces at the end of M_{2kt+1},
+        // column 1 at the end of L_{2kt+1} -- both just before that barrier.
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // k-tile 0 is in LDS for everybody
+        if (wn == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int fill = cur ^ 1;
+            const bool do_stage = kt + 1 < nk;
+            const unsigned char* sa = smem + cur * BUF_BYTES;
+            const unsigned char* sb = sa + A_BYTES;
+            if (do_stage) {
+#pragma unroll
+                for (int i = 0; i < DPT; ++i) stage_piece(fill, i);
+            } else if (has_res) {
+                stage_residual_half(0, smem + fill * BUF_BYTES);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 xf[FM], wf[FN];
+#pragma unroll
+                for (int b = 0; b < FM; ++b)
+                    xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm * (BM / WM) + b * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+                    wf[a] = *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
+                if (kk == 1 && wn == 1) wait_vmcnt<0>();
+                wg_barrier();  // lgkmcnt(0): the fragments are in registers
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+                __builtin_amdgcn_s_setprio(0);
+                if (kk == 1 && wn == 0) wait_vmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            kbyte += 128;
+            cur ^= 1;
+        }
+        if (wn == 0) __builtin_amdgcn_s_barrier();
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         if (!(DBG & 32)) wait_vmcnt<0>();  // k-tile kt has landed (this wave's pieces; the barrier covers everybody else's)
         if (!(DBG & 128)) __builtin_amdgcn_s_barrier();
@@ -236,7 +288,7 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
     const int grid = cdiv(p.M, WBM) * (p.N / WBN);
     switch (p.dbg) {
 #define WIDE_CASE(D) case D: hipLaunchKernelGGL(igemm_wide_kernel<D>, dim3(grid), dim3(512), 0, stream, p); break
-        WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
+        WIDE_CASE(4096); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
 #undef WIDE_CASE
         default: hipLaunchKernelGGL(igemm_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p);
     }

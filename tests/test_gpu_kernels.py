@@ -108,6 +108,38 @@ def test_conv_wide_tile(case, monkeypatch):
     assert torch.equal(wide, narrow)
 
 
+WIDE3_CASES = [
+    # N, H, W, Cin, Cout, relu -- the two-block 3x3 kernel (conv3x3_wide.hip), forced through AGRL_CONV3X3_WIDE=1
+    (3, 16, 8, 128, 128, True),     # odd number of pixel blocks: the last workgroup has one valid block
+    (1, 64, 32, 128, 256, True),    # 16 blocks per frame, two channel tiles, 2 slabs
+    (3, 16, 8, 512, 200, False),    # ragged N, 8 slabs (72 tap-steps), no relu
+    (4, 16, 8, 64, 128, True),      # a single slab: no next-slab patch pieces in the queue
+]
+
+
+@pytest.mark.parametrize("case", WIDE3_CASES)
+def test_conv3x3_wide_tile(case, monkeypatch):
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, Cout, relu = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn((N, Cin, H, W), generator=g).bfloat16().float()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / np.sqrt(9 * Cin)).bfloat16().float()
+    b = torch.randn((Cout,), generator=g)
+    ref = F.conv2d(x, w, bias=b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 1, 1, relu)
+    monkeypatch.setenv("AGRL_CONV3X3_WIDE", "1")
+    wide = ops.conv_bn_act(*args)
+    monkeypatch.setenv("AGRL_CONV3X3_WIDE", "0")
+    narrow = ops.conv_bn_act(*args)
+    torch.cuda.synchronize()
+    e = rel_err(wide.float().permute(0, 3, 1, 2), ref)
+    print("wide 3x3", case, "rel err %.3e" % e)
+    assert e < 1e-2
+    assert torch.equal(wide, narrow)  # same k order per output -> identical bf16 results
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 256, 128), (3, 64, 48), (1, 37, 29)])
 def test_stem(shape, dtype):
