@@ -1,0 +1,214 @@
+// Fused tail of a layer-1 Bottleneck and head of the next one (torchreid/models/vmgn.py:45-65), bf16:
+//
+//     x_out = relu( W3 y2 + b3 + residual )      1x1 conv   64 -> 256, folded BN, the block's output   (written)
+//     z     = relu( W1' x_out + b1' )            1x1 conv  256 ->  64 of the NEXT block, folded BN     (written)
+//
+// Layer 1 works on 64 x 32 maps (524 288 pixels per 256-frame step) with 64 / 256 channels: every conv there is
+// HBM-bound (arithmetic intensity 32-170 flop/B), and the next block's first conv re-reads the 268 MB map the previous
+// kernel has just written. Here that conv is computed from the output tile while it is still in LDS: the map is
+// written once and not read back (-25 % of a block's HBM bytes, one launch less).
+//
+//   * persistent workgroups (one per CU, 8 waves), tiles of 64 pixels; BOTH weight matrices stay resident in LDS
+//     (32 KB + 32 KB) for the whole kernel
+//   * per tile only y2 (8 KB) and the residual (32 KB) come in by LDS-DMA, prefetched one tile ahead (double-buffered);
+//     the residual tile is combined in place (fp32 math, one rounding) and IS the out tile: drained to HBM as whole
+//     16-byte chunks and re-read as the B operand of the second GEMM (row = pixel, 512 B, chunk c at c ^ (row & 31):
+//     conflict-free ds_read_b128)
+//   * waits are counted: the prefetch DMA sits in front of the tile's stores in the queue, so waiting for it leaves
+//     the stores in flight (loads and stores retire in order on one counter)
+#include "igemm_dev.h"
+
+namespace {
+
+struct TailParams {
+    const void* y2;      // (M, 64)   bf16
+    const void* w3;      // (256, 64) bf16, BN folded
+    const float* b3;     // (256)
+    const void* res;     // (M, 256)  bf16
+    void* out;           // (M, 256)  bf16
+    const void* w1n;     // (64, 256) bf16, BN folded (next block's conv1)
+    const float* b1n;    // (64)
+    void* z;             // (M, 64)   bf16
+    int M;
+};
+
+constexpr int TBM = 64, TK1 = 64, TN1 = 256, TK2 = 256, TN2 = 64;
+
+__global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p, int ntiles) {
+    constexpr int W3_BYTES = TN1 * 128;                // 32 KB: 256 rows x 128 B (one 64-deep k-tile)
+    constexpr int W1_KT = TN2 * 128;                   // one k-tile of W1': 64 rows x 128 B
+    constexpr int W1_BYTES = (TK2 / 64) * W1_KT;       // 32 KB: 4 k-tiles
+    constexpr int A_BYTES = TBM * 128;                 // 8 KB y2 tile (also the z staging tile)
+    constexpr int R_BYTES = TBM * TN1 * 2;             // 32 KB residual / out tile, 512-byte rows
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W3_BYTES + W1_BYTES + 2 * A_BYTES + 2 * R_BYTES];
+    unsigned char* s_w3 = smem;
+    unsigned char* s_w1 = s_w3 + W3_BYTES;
+    unsigned char* s_a = s_w1 + W1_BYTES;
+    unsigned char* s_r = s_a + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm2 = wave & 1, wn4 = wave >> 1;  // 2 (pixels) x 4 (channels) wave grid for both GEMMs
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const int G = gridDim.x;
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+    const unsigned char* y2g = reinterpret_cast<const unsigned char*>(p.y2);
+    const unsigned char* resg = reinterpret_cast<const unsigned char*>(p.res);
+
+    // ---- resident weights: W3 rows (wave*32 + 8j + lrow), W1' k-tile (j), rows (wave*8 + lrow)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + j * 8 + lrow;
+        dma16(reinterpret_cast<const unsigned char*>(p.w3) + (size_t)row * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4),
+              s_w3 + (wave * 32 + j * 8) * 128);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 8 + lrow;
+        dma16(reinterpret_cast<const unsigned char*>(p.w1n) + (size_t)row * (TK2 * 2) + j * 128 + ((lchk ^ ((row >> 1) & 7)) << 4),
+              s_w1 + j * W1_KT + wave * 8 * 128);
+    }
+    // ---- per-tile DMA: y2 piece = rows 8 wave .. +7; residual pieces = rows 2 (4 wave + j) + (lane >> 5)
+    auto stage_tile = [&](int T, int slot) {
+        const int m0 = T * TBM;
+        {
+            const int row = wave * 8 + lrow;
+            const int gm = m0 + row;
+            dma16(gm < p.M ? y2g + (size_t)gm * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4) : zsrc,
+                  s_a + slot * A_BYTES + wave * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = wave * 4 + j;
+            const int row = piece * 2 + (lane >> 5);
+            const int gm = m0 + row;
+            const int gch = (lane & 31) ^ (row & 31);
+            dma16(gm < p.M ? resg + ((size_t)gm * TN1 + gch * 8) * 2 : zsrc, s_r + slot * R_BYTES + piece * 1024);
+        }
+    };
+    // biases of this lane's output channels (fixed for the whole kernel)
+    float4 b3v[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) b3v[a] = *reinterpret_cast<const float4*>(p.b3 + wn4 * 64 + a * 16 + fchunk * 4);
+    const float4 b1v = *reinterpret_cast<const float4*>(p.b1n + wn4 * 16 + fchunk * 4);
+
+    int T = blockIdx.x;
+    if (T < ntiles) stage_tile(T, 0);
+    wait_vmcnt<0>();
+    wg_barrier();
+    int slot = 0;
+    for (; T < ntiles; T += G, slot ^= 1) {
+        const int m0 = T * TBM;
+        const bool has_next = T + G < ntiles;
+        if (has_next) stage_tile(T + G, slot ^ 1);  // 5 DMA pieces, at the head of this iteration's queue
+        const unsigned char* sa = s_a + slot * A_BYTES;
+        unsigned char* sr = s_r + slot * R_BYTES;
+        // ---- GEMM 1: 64 px x 256 ch, K = 64. Wave tile 32 px x 64 ch.
+        f32x4_t acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 xf[2], wf[4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm2 * 32 + b * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const uint4*>(s_w3 + lds_off(wn4 * 64 + a * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+        }
+        // bias + residual (in place) + ReLU -> bf16 out tile
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int px = wm2 * 32 + b * 16 + frow;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int c = wn4 * 64 + a * 16 + fchunk * 4;
+                unsigned char* cell = sr + px * 512 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
+                float rr[4];
+                load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
+                float v[4];
+                v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
+                v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
+                v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
+                v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
+                store4<bf16_t>(reinterpret_cast<bf16_t*>(cell), v);
+            }
+        }
+        wg_barrier();  // out tile complete
+        // drain the out tile: 2048 16-byte chunks, 4 per thread, whole 512-byte rows per 32 lanes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 5) + 16 * i;
+            const int pch = tid & 31;
+            const int gm = m0 + row;
+            if (gm < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sr + row * 512 + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * TN1 + (pch ^ (row & 31)) * 8) * 2) = v;
+            }
+        }
+        // ---- GEMM 2: 64 px x 64 ch, K = 256, B operand straight from the out tile. Wave tile 32 px x 16 ch.
+        f32x4_t acc2[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < TK2 / 32; ++ks) {
+            const uint4 wf = *reinterpret_cast<const uint4*>(s_w1 + (ks >> 1) * W1_KT + lds_off(wn4 * 16 + frow, (ks & 1) * 4 + fchunk));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int px = wm2 * 32 + b * 16 + frow;
+                const uint4 xf = *reinterpret_cast<const uint4*>(sr + px * 512 + (((ks * 4 + fchunk) ^ (px & 31)) << 4));
+                acc2[b] = Frag<bf16_t>::mma(wf, xf, acc2[b]);
+            }
+        }
+        // z tile -> the y2 slot of this tile (every wave finished reading it before the barrier above)
+        unsigned char* sz = s_a + slot * A_BYTES;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int px = wm2 * 32 + b * 16 + frow;
+            const int c = wn4 * 16 + fchunk * 4;
+            float v[4];
+            v[0] = fmaxf(acc2[b][0] + b1v.x, 0.f);
+            v[1] = fmaxf(acc2[b][1] + b1v.y, 0.f);
+            v[2] = fmaxf(acc2[b][2] + b1v.z, 0.f);
+            v[3] = fmaxf(acc2[b][3] + b1v.w, 0.f);
+            store4<bf16_t>(reinterpret_cast<bf16_t*>(sz + px * 128 + (((c >> 3) ^ (px & 7)) << 4) + ((c & 4) << 1)), v);
+        }
+        wg_barrier();  // z tile complete; every read of the out tile done
+        {
+            const int row = tid >> 3, pch = tid & 7;
+            const int gm = m0 + row;
+            if (gm < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sz + row * 128 + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.z) + ((size_t)gm * TN2 + (pch ^ (row & 7)) * 8) * 2) = v;
+            }
+        }
+        // the next tile's DMA (issued first) has landed once at most the 5 stores above are still outstanding
+        wait_vmcnt<5>();
+        wg_barrier();
+    }
+}
+
+}  // namespace
+
+extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual, void* out,
+                                    const void* w1_next, const float* b1_next, void* z, int M, int Cmid, int Cout,
+                                    int Cnext, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(y2 && w3 && b3 && residual && out && w1_next && b1_next && z, "agrl_bottleneck_tail: null pointer");
+    AGRL_CHECK_ARG(M > 0, "agrl_bottleneck_tail: empty problem");
+    AGRL_CHECK_ARG(Cmid == TK1 && Cout == TN1 && Cnext == TN2,
+                   "agrl_bottleneck_tail: built for Cmid=64, Cout=256, Cnext=64 (layer 1), got %d/%d/%d", Cmid, Cout, Cnext);
+    const uintptr_t al = (uintptr_t)y2 | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)residual | (uintptr_t)out |
+                         (uintptr_t)w1_next | (uintptr_t)b1_next | (uintptr_t)z;
+    AGRL_CHECK_ARG((al & 15) == 0, "agrl_bottleneck_tail: pointers must be 16-byte aligned");
+    TailParams p;
+    p.y2 = y2; p.w3 = w3; p.b3 = b3; p.res = residual; p.out = out; p.w1n = w1_next; p.b1n = b1_next; p.z = z; p.M = M;
+    const int ntiles = cdiv(M, TBM);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(bottleneck_tail_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
+    AGRL_CHECK_LAUNCH("agrl_bottleneck_tail");
+    return 0;
+}

@@ -96,6 +96,23 @@ def pack_weights(model, device, precision):
     return pack
 
 
+def _run_trunk(a, blocks, fuse_tail=True):
+    """layer1..layer3 Bottlenecks. Where the fused kernel exists (layer 1, bf16) the last conv of block i also
+    produces the first conv of block i+1 from the tile it still holds in LDS (ops.bottleneck_tail)."""
+    z = None  # conv1 output of the current block, when the previous block's tail already computed it
+    for i, blk in enumerate(blocks):
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        y = z if z is not None else ops.conv_bn_act(a, blk['c1'][0], blk['c1'][1], 1, 0, True)
+        y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
+        shortcut = a if blk['ds'] is None else ops.conv_bn_act(a, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
+        if fuse_tail and nxt is not None and ops.bottleneck_tail_supported(y, blk['c3'][0], nxt['c1'][0]):
+            a, z = ops.bottleneck_tail(y, blk['c3'][0], blk['c3'][1], shortcut, nxt['c1'][0], nxt['c1'][1])
+        else:
+            a = ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)
+            z = None
+    return a
+
+
 def _run_block(x, blk, pool=None):
     """One Bottleneck. ``pool`` = (splits, mean, want_lp): fuse the frame pooling into the last conv's epilogue and
     return the pooled tensors instead of the activation map (which is then never written to HBM)."""
@@ -113,8 +130,7 @@ def hip_featuremaps(model, frames, pack):
         a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1])
     else:
         a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
-    for blk in pack['trunk']:
-        a = _run_block(a, blk)
+    a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))
     x4_1 = a
     for blk in pack['l4_1']:
         x4_1 = _run_block(x4_1, blk)
@@ -140,8 +156,7 @@ def hip_features_pooled(model, frames, pack, splits):
     if pack['dtype'] != torch.bfloat16:
         return None
     a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1])
-    for blk in pack['trunk']:
-        a = _run_block(a, blk)
+    a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))
     if a.shape[1] * a.shape[2] != 128 or pack['l4_1'][0]['stride'] != 1:
         return None
     splits = list(splits)

@@ -174,6 +174,7 @@ class GSTA(nn.Module):
         self.hip_static_weights = False
         self.hip_fuse_pool = os.environ.get('AGRL_HIP_FUSE_POOL', '1') != '0'
         self.hip_branch_streams = os.environ.get('AGRL_HIP_BRANCH_STREAMS', '0') != '0'
+        self.hip_fuse_tail = os.environ.get('AGRL_HIP_FUSE_TAIL', '1') != '0'
         self._hip_packs = {}
 
     # ------------------------------------------------------------------ stock-torch path (CPU / train)

@@ -108,6 +108,34 @@ def test_conv_wide_tile(case, monkeypatch):
     assert torch.equal(wide, narrow)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 32), (1, 16, 8), (3, 10, 7), (5, 64, 32)])
+def test_bottleneck_tail(shape):
+    """conv3 + residual + relu of a layer-1 block fused with the next block's conv1 (bottleneck_tail.hip) against the
+    two separate igemm launches (bitwise: same fp32 accumulation order, same roundings) and the fp32 reference."""
+    from torchreid import hip_ops as ops
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * H)
+    y2 = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
+    res = torch.randn((N, 256, H, W), generator=g).bfloat16().float()
+    w3 = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
+    w1 = (torch.randn((64, 256, 1, 1), generator=g) / 16).bfloat16().float()
+    b3, b1 = torch.randn(256, generator=g), torch.randn(64, generator=g)
+    out_ref = F.relu(F.conv2d(y2, w3, bias=b3) + res)
+    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
+    dy2, dres = nhwc(y2, torch.bfloat16), nhwc(res, torch.bfloat16)
+    dw3 = w3.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    dw1 = w1.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    assert ops.bottleneck_tail_supported(dy2, dw3, dw1)
+    out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
+    out2 = ops.conv_bn_act(dy2, dw3, b3.to(DEV), 1, 0, True, residual=dres)
+    z2 = ops.conv_bn_act(out2, dw1, b1.to(DEV), 1, 0, True)
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(z.float().permute(0, 3, 1, 2), z_ref)
+    print("bottleneck tail", shape, "out %.3e z %.3e" % (e1, e2))
+    assert e1 < 1e-2 and e2 < 1e-2
+    assert torch.equal(out, out2) and torch.equal(z, z2)
+
+
 WIDE3_CASES = [
     # N, H, W, Cin, Cout, relu -- the two-block 3x3 kernel (conv3x3_wide.hip), forced through AGRL_CONV3X3_WIDE=1
     (3, 16, 8, 128, 128, True),     # odd number of pixel blocks: the last workgroup has one valid block

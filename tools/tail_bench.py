@@ -1,0 +1,29 @@
+"""Times the fused layer-1 bottleneck tail against the two separate convs it replaces."""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
+    sys.path.insert(0, p)
+import torch
+from torchreid import hip_ops as ops
+dev = "cuda:0"
+N, H, W = 256, 64, 32
+y2 = torch.randn((N, H, W, 64), device=dev).bfloat16()
+res = torch.randn((N, H, W, 256), device=dev).bfloat16()
+w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).bfloat16()
+b3, b1 = torch.randn(256, device=dev), torch.randn(64, device=dev)
+def fused(): return ops.bottleneck_tail(y2, w3, b3, res, w1, b1)
+def split():
+    o = ops.conv_bn_act(y2, w3, b3, 1, 0, True, residual=res)
+    return o, ops.conv_bn_act(o, w1, b1, 1, 0, True)
+for name, fn in (("fused", fused), ("split", split)):
+    ts = []
+    for r in range(8):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10): fn()
+        e.record(); torch.cuda.synchronize()
+        if r >= 2: ts.append(s.elapsed_time(e) * 100)
+    us = statistics.median(ts)
+    gb = 2.0 * (y2.numel() + 2 * res.numel() + N * H * W * 64) / 1e9
+    print("%s %7.1f us  (fused traffic %.0f MB -> %.2f TB/s)" % (name, us, gb * 1e3, gb / us * 1e-3 * 1e3 if False else gb / (us * 1e-6) / 1e3))
