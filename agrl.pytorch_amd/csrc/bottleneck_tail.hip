@@ -29,18 +29,26 @@ struct TailParams {
     const void* w1n;     // (64, 256) bf16, BN folded (next block's conv1)
     const float* b1n;    // (64)
     void* z;             // (M, 64)   bf16
+    const void* xs;      // CAT form: (M, 64) bf16 input of the block's 1x1 stride-1 downsample conv (instead of res)
+    const void* ws;      // CAT form: (256, 64) bf16 downsample weights, BN folded
+    const float* bs;     // CAT form: (256) downsample bias
     int M;
 };
 
 constexpr int TBM = 64, TK1 = 64, TN1 = 256, TK2 = 256, TN2 = 64;
 
+// CAT: the residual is the block's own downsample conv (first block of the layer): computed here as a second k-tile,
+// out = relu([W3 | Ws] [y2 ; xs] + b3 + bs) -- the 268 MB residual map is neither written nor read.
+template <bool CAT>
 __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p, int ntiles) {
-    constexpr int W3_BYTES = TN1 * 128;                // 32 KB: 256 rows x 128 B (one 64-deep k-tile)
+    constexpr int NKT1 = CAT ? 2 : 1;                  // k-tiles of the first GEMM
+    constexpr int W3_BYTES = NKT1 * TN1 * 128;         // 32 / 64 KB: [k-tile][256 rows][128 B]
     constexpr int W1_KT = TN2 * 128;                   // one k-tile of W1': 64 rows x 128 B
     constexpr int W1_BYTES = (TK2 / 64) * W1_KT;       // 32 KB: 4 k-tiles
-    constexpr int A_BYTES = TBM * 128;                 // 8 KB y2 tile (also the z staging tile)
+    constexpr int A_BYTES = NKT1 * TBM * 128;          // 8 / 16 KB input tile (its first 8 KB double as the z staging tile)
     constexpr int R_BYTES = TBM * TN1 * 2;             // 32 KB residual / out tile, 512-byte rows
-    __shared__ __attribute__((aligned(16))) unsigned char smem[W3_BYTES + W1_BYTES + 2 * A_BYTES + 2 * R_BYTES];
+    constexpr int NR = CAT ? 1 : 2;                    // out tile slots: the residual prefetch needs the second one
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W3_BYTES + W1_BYTES + 2 * A_BYTES + NR * R_BYTES];
     unsigned char* s_w3 = smem;
     unsigned char* s_w1 = s_w3 + W3_BYTES;
     unsigned char* s_a = s_w1 + W1_BYTES;
@@ -58,11 +66,13 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
 
     // ---- resident weights: W3 rows (wave*32 + 8j + lrow), W1' k-tile (j), rows (wave*8 + lrow)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = wave * 32 + j * 8 + lrow;
-        dma16(reinterpret_cast<const unsigned char*>(p.w3) + (size_t)row * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4),
-              s_w3 + (wave * 32 + j * 8) * 128);
-    }
+    for (int kt = 0; kt < NKT1; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wave * 32 + j * 8 + lrow;
+            const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(kt == 0 ? p.w3 : p.ws);
+            dma16(wsrc + (size_t)row * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4), s_w3 + kt * (TN1 * 128) + (wave * 32 + j * 8) * 128);
+        }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = wave * 8 + lrow;
@@ -77,7 +87,11 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
             const int gm = m0 + row;
             dma16(gm < p.M ? y2g + (size_t)gm * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4) : zsrc,
                   s_a + slot * A_BYTES + wave * 1024);
+            if constexpr (CAT)
+                dma16(gm < p.M ? reinterpret_cast<const unsigned char*>(p.xs) + (size_t)gm * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4) : zsrc,
+                      s_a + slot * A_BYTES + TBM * 128 + wave * 1024);
         }
+        if constexpr (!CAT)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int piece = wave * 4 + j;
@@ -90,7 +104,13 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
     // biases of this lane's output channels (fixed for the whole kernel)
     float4 b3v[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) b3v[a] = *reinterpret_cast<const float4*>(p.b3 + wn4 * 64 + a * 16 + fchunk * 4);
+    for (int a = 0; a < 4; ++a) {
+        b3v[a] = *reinterpret_cast<const float4*>(p.b3 + wn4 * 64 + a * 16 + fchunk * 4);
+        if constexpr (CAT) {
+            const float4 t = *reinterpret_cast<const float4*>(p.bs + wn4 * 64 + a * 16 + fchunk * 4);
+            b3v[a].x += t.x; b3v[a].y += t.y; b3v[a].z += t.z; b3v[a].w += t.w;
+        }
+    }
     const float4 b1v = *reinterpret_cast<const float4*>(p.b1n + wn4 * 16 + fchunk * 4);
 
     int T = blockIdx.x;
@@ -101,9 +121,9 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
     for (; T < ntiles; T += G, slot ^= 1) {
         const int m0 = T * TBM;
         const bool has_next = T + G < ntiles;
-        if (has_next) stage_tile(T + G, slot ^ 1);  // 5 DMA pieces, at the head of this iteration's queue
+        if (has_next) stage_tile(T + G, slot ^ 1);  // 5 (CAT: 2) DMA pieces, at the head of this iteration's queue
         const unsigned char* sa = s_a + slot * A_BYTES;
-        unsigned char* sr = s_r + slot * R_BYTES;
+        unsigned char* sr = s_r + (CAT ? 0 : slot) * R_BYTES;
         // ---- GEMM 1: 64 px x 256 ch, K = 64. Wave tile 32 px x 64 ch.
         f32x4_t acc[4][2];
 #pragma unroll
@@ -111,12 +131,14 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < 2 * NKT1; ++kk) {
             uint4 xf[2], wf[4];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm2 * 32 + b * 16 + frow, kk * 4 + fchunk));
+            for (int b = 0; b < 2; ++b)
+                xf[b] = *reinterpret_cast<const uint4*>(sa + (kk >> 1) * (TBM * 128) + lds_off(wm2 * 32 + b * 16 + frow, (kk & 1) * 4 + fchunk));
 #pragma unroll
-            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const uint4*>(s_w3 + lds_off(wn4 * 64 + a * 16 + frow, kk * 4 + fchunk));
+            for (int a = 0; a < 4; ++a)
+                wf[a] = *reinterpret_cast<const uint4*>(s_w3 + (kk >> 1) * (TN1 * 128) + lds_off(wn4 * 64 + a * 16 + frow, (kk & 1) * 4 + fchunk));
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -130,8 +152,8 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
             for (int a = 0; a < 4; ++a) {
                 const int c = wn4 * 64 + a * 16 + fchunk * 4;
                 unsigned char* cell = sr + px * 512 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
-                float rr[4];
-                load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
+                float rr[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (!CAT) load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
                 float v[4];
                 v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
                 v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
@@ -194,21 +216,29 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
 
 }  // namespace
 
-extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual, void* out,
+extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual,
+                                    const void* x_short, const void* w_short, const float* b_short, void* out,
                                     const void* w1_next, const float* b1_next, void* z, int M, int Cmid, int Cout,
-                                    int Cnext, agrl_stream_t stream) {
-    AGRL_CHECK_ARG(y2 && w3 && b3 && residual && out && w1_next && b1_next && z, "agrl_bottleneck_tail: null pointer");
+                                    int Cnext, int Cshort, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(y2 && w3 && b3 && out && w1_next && b1_next && z, "agrl_bottleneck_tail: null pointer");
+    AGRL_CHECK_ARG((residual != nullptr) != (x_short != nullptr),
+                   "agrl_bottleneck_tail: pass either the residual map or the downsample conv's input, not both");
+    AGRL_CHECK_ARG(!x_short || (w_short && b_short), "agrl_bottleneck_tail: the downsample form needs its weights and bias");
     AGRL_CHECK_ARG(M > 0, "agrl_bottleneck_tail: empty problem");
-    AGRL_CHECK_ARG(Cmid == TK1 && Cout == TN1 && Cnext == TN2,
-                   "agrl_bottleneck_tail: built for Cmid=64, Cout=256, Cnext=64 (layer 1), got %d/%d/%d", Cmid, Cout, Cnext);
+    AGRL_CHECK_ARG(Cmid == TK1 && Cout == TN1 && Cnext == TN2 && (!x_short || Cshort == TK1),
+                   "agrl_bottleneck_tail: built for Cmid=64, Cout=256, Cnext=64, Cshort=64 (layer 1), got %d/%d/%d/%d", Cmid,
+                   Cout, Cnext, Cshort);
     const uintptr_t al = (uintptr_t)y2 | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)residual | (uintptr_t)out |
-                         (uintptr_t)w1_next | (uintptr_t)b1_next | (uintptr_t)z;
+                         (uintptr_t)w1_next | (uintptr_t)b1_next | (uintptr_t)z | (uintptr_t)x_short | (uintptr_t)w_short |
+                         (uintptr_t)b_short;
     AGRL_CHECK_ARG((al & 15) == 0, "agrl_bottleneck_tail: pointers must be 16-byte aligned");
     TailParams p;
     p.y2 = y2; p.w3 = w3; p.b3 = b3; p.res = residual; p.out = out; p.w1n = w1_next; p.b1n = b1_next; p.z = z; p.M = M;
+    p.xs = x_short; p.ws = w_short; p.bs = b_short;
     const int ntiles = cdiv(M, TBM);
     const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(bottleneck_tail_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
+    if (x_short) hipLaunchKernelGGL(bottleneck_tail_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
+    else hipLaunchKernelGGL(bottleneck_tail_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
     AGRL_CHECK_LAUNCH("agrl_bottleneck_tail");
     return 0;
 }

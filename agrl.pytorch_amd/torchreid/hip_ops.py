@@ -98,26 +98,40 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
     return pooled, pooled_lp
 
 
-def bottleneck_tail_supported(y2, w3, w1_next):
-    """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 shapes in bf16."""
-    return (y2.dtype == torch.bfloat16 and tuple(w3.shape) == (256, 1, 1, 64) and tuple(w1_next.shape) == (64, 1, 1, 256))
+def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
+    """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 shapes in bf16. ``shortcut_conv`` =
+    (weight, stride) of the block's downsample conv when the residual is to be computed in the same pass."""
+    ok = y2.dtype == torch.bfloat16 and tuple(w3.shape) == (256, 1, 1, 64) and tuple(w1_next.shape) == (64, 1, 1, 256)
+    if shortcut_conv is not None:
+        ok = ok and tuple(shortcut_conv[0].shape) == (256, 1, 1, 64) and shortcut_conv[1] == 1
+    return ok
 
 
-def bottleneck_tail(y2, w3, b3, residual, w1_next, b1_next):
-    """out = relu(conv3(y2) + residual), z = relu(conv1_next(out)) in one pass (out never re-read from HBM).
+def bottleneck_tail(y2, w3, b3, residual, w1_next, b1_next, shortcut=None):
+    """out = relu(conv3(y2) + R), z = relu(conv1_next(out)) in one pass (out never re-read from HBM); R = ``residual``
+    or, with ``shortcut`` = (x, w_ds, b_ds), the block's 1x1 stride-1 downsample conv of x computed in the same pass.
     vmgn.py:57-64 (block i) + :48-50 (block i+1). -> out (N,H,W,256), z (N,H,W,64) bf16 NHWC."""
     N, H, W, Cmid = y2.shape
     Cout, Cnext = w3.shape[0], w1_next.shape[0]
-    assert residual.shape == (N, H, W, Cout) and residual.dtype == y2.dtype == torch.bfloat16
+    assert y2.dtype == torch.bfloat16 and (residual is None) != (shortcut is None)
+    xs = ws = bs = None
+    Cshort = 0
+    if shortcut is not None:
+        xs, ws, bs = shortcut
+        assert xs.shape[:3] == y2.shape[:3] and xs.dtype == y2.dtype
+        Cshort = xs.shape[3]
+    else:
+        assert residual.shape == (N, H, W, Cout) and residual.dtype == y2.dtype
     out = torch.empty((N, H, W, Cout), dtype=y2.dtype, device=y2.device)
     z = torch.empty((N, H, W, Cnext), dtype=y2.dtype, device=y2.device)
     M = N * H * W
     if _hip.PROFILE is not None:
-        _hip.PROFILE_TAG = {"flops": 2.0 * M * (Cmid * Cout + Cout * Cnext),
-                            "bytes": 2.0 * (y2.numel() + 2 * out.numel() + z.numel() + w3.numel() + w1_next.numel())}
+        rd = (residual.numel() if residual is not None else xs.numel() + ws.numel())
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * ((Cmid + Cshort) * Cout + Cout * Cnext),
+                            "bytes": 2.0 * (y2.numel() + rd + out.numel() + z.numel() + w3.numel() + w1_next.numel())}
     with _dev(y2):
-        call("agrl_bottleneck_tail", ptr(y2), ptr(w3), ptr(b3), ptr(residual), ptr(out), ptr(w1_next), ptr(b1_next), ptr(z),
-             M, Cmid, Cout, Cnext, _stream(y2))
+        call("agrl_bottleneck_tail", ptr(y2), ptr(w3), ptr(b3), ptr(residual), ptr(xs), ptr(ws), ptr(bs), ptr(out),
+             ptr(w1_next), ptr(b1_next), ptr(z), M, Cmid, Cout, Cnext, Cshort, _stream(y2))
     return out, z
 
 

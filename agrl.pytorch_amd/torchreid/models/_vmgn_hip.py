@@ -104,8 +104,15 @@ def _run_trunk(a, blocks, fuse_tail=True):
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
         y = z if z is not None else ops.conv_bn_act(a, blk['c1'][0], blk['c1'][1], 1, 0, True)
         y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
+        fusable = fuse_tail and nxt is not None and ops.bottleneck_tail_supported(y, blk['c3'][0], nxt['c1'][0])
+        if fusable and blk['ds'] is not None and ops.bottleneck_tail_supported(
+                y, blk['c3'][0], nxt['c1'][0], (blk['ds'][0], blk['ds_stride'])) and a.shape[3] == 64:
+            # first block of layer 1: the downsample conv rides along as a second k-tile (no shortcut map in HBM)
+            a, z = ops.bottleneck_tail(y, blk['c3'][0], blk['c3'][1], None, nxt['c1'][0], nxt['c1'][1],
+                                       shortcut=(a, blk['ds'][0], blk['ds'][1]))
+            continue
         shortcut = a if blk['ds'] is None else ops.conv_bn_act(a, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
-        if fuse_tail and nxt is not None and ops.bottleneck_tail_supported(y, blk['c3'][0], nxt['c1'][0]):
+        if fusable:
             a, z = ops.bottleneck_tail(y, blk['c3'][0], blk['c3'][1], shortcut, nxt['c1'][0], nxt['c1'][1])
         else:
             a = ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)

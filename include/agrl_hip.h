@@ -76,13 +76,18 @@ int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const float* bias, co
 
 /* Fused tail of one layer-1 Bottleneck and head of the next (bf16 only; torchreid/models/vmgn.py:45-65, the
  * conv3/bn3/+residual/relu of block i at :57-64 and the conv1/bn1/relu of block i+1 at :48-50):
- *   out (M,Cout)  = relu(y2 (M,Cmid) @ w3 (Cout,Cmid)^T + b3 + residual (M,Cout))
+ *   out (M,Cout)  = relu(y2 (M,Cmid) @ w3 (Cout,Cmid)^T + b3 + R)
  *   z   (M,Cnext) = relu(out @ w1_next (Cnext,Cout)^T + b1_next)
- * out is written once and never read back from HBM. Built for Cmid = 64, Cout = 256, Cnext = 64 (layer 1);
- * other shapes are rejected (the caller then runs the two convs separately through agrl_conv2d_bn_act). */
-int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual, void* out,
+ * with R = residual (M,Cout) (identity shortcut), or -- first block of the layer, residual == NULL --
+ * R = x_short (M,Cshort) @ w_short (Cout,Cshort)^T + b_short, the block's 1x1 stride-1 downsample conv + BN
+ * (vmgn.py:60-61), computed in the same pass (the shortcut map is then neither written nor read; it is added in fp32
+ * without the intermediate bf16 rounding of a separate conv). out is written once and never read back from HBM.
+ * Built for Cmid = Cshort = 64, Cout = 256, Cnext = 64 (layer 1); other shapes are rejected (the caller then runs the
+ * convs separately through agrl_conv2d_bn_act). */
+int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual,
+                         const void* x_short, const void* w_short, const float* b_short, void* out,
                          const void* w1_next, const float* b1_next, void* z, int M, int Cmid, int Cout,
-                         int Cnext, agrl_stream_t stream);
+                         int Cnext, int Cshort, agrl_stream_t stream);
 
 /* y = x @ w^T (no bias): x (M,K) in_dtype, w (Nout,K) in_dtype, y (M,Nout) fp32.
  * Replaces GraphLayer's nn.Linear(2048,2048,bias=False), torchreid/models/vmgn.py:148. */

@@ -134,6 +134,18 @@ def test_bottleneck_tail(shape):
     print("bottleneck tail", shape, "out %.3e z %.3e" % (e1, e2))
     assert e1 < 1e-2 and e2 < 1e-2
     assert torch.equal(out, out2) and torch.equal(z, z2)
+    # first-block form: the shortcut is the block's 1x1 downsample conv of x0, computed in the same pass
+    x0 = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
+    ws = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
+    bs = torch.randn(256, generator=g)
+    out_ref = F.relu(F.conv2d(y2, w3, bias=b3) + F.conv2d(x0, ws, bias=bs))
+    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
+    out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), None, dw1, b1.to(DEV),
+                                 shortcut=(nhwc(x0, torch.bfloat16), ws.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), bs.to(DEV)))
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(z.float().permute(0, 3, 1, 2), z_ref)
+    print("bottleneck tail + downsample", shape, "out %.3e z %.3e" % (e1, e2))
+    assert e1 < 1e-2 and e2 < 1e-2
 
 
 WIDE3_CASES = [
