@@ -25,6 +25,7 @@ constexpr int WBM = 256, WBN = 256;
 
 template <int DBG>  // ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
+    constexpr bool REGEPI = (DBG & 8192) == 0;  // bit 8192: the LDS-staged two-half epilogue (kept for A/B)
     constexpr int BM = WBM, BN = WBN, NW = 8, WM = 4;
     constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
     constexpr int FN = BN / 32;         // 8 channel fragments per wave
@@ -73,7 +74,15 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int row = wave * (BN / NW) + j * 8 + lrow;
-        b_off[j] = (unsigned)(n0 + row) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
+        int ch = row;
+        if constexpr (REGEPI) {
+            // LDS row a*16 + i of a wave column's 128-channel slab holds channel sigma(a, i) = 32 (a>>1) + 8 (i>>2) +
+            // 4 (a&1) + (i&3): the MFMA result rows 4 f + r of the 8 fragments of a lane are then 32 channels that the
+            // register epilogue reads / writes as 16-byte pieces, 64 contiguous bytes per pixel row and instruction
+            const int rp = row & 127, a = rp >> 4, i = rp & 15;
+            ch = (row & 128) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
+        }
+        b_off[j] = (unsigned)(n0 + ch) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
     }
     unsigned kbyte = 0;  // byte offset of the k-tile being STAGED inside a row
     auto stage_piece = [&](int buf, int idx) {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
             if (do_stage) {
 #pragma unroll
                 for (int i = 0; i < DPT; ++i) stage_piece(fill, i);
-            } else if (has_res) {
+            } else if (has_res && !REGEPI) {
                 stage_residual_half(0, smem + fill * BUF_BYTES);
             }
 #pragma unroll
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         asm volatile("" ::: "memory");
         const int fill = cur ^ 1;  // read in iteration kt-1, free now
         const bool do_stage = kt + 1 < nk && !(DBG & 8);
-        if (!do_stage && has_res) stage_residual_half(0, smem + fill * BUF_BYTES);
+        if (!do_stage && has_res && !REGEPI) stage_residual_half(0, smem + fill * BUF_BYTES);
         const unsigned char* sa = smem + cur * BUF_BYTES;
         const unsigned char* sb = sa + A_BYTES;
         // Software-pipelined fragment reads: 16 groups of 4 MFMAs (group g = k-step g>>3, channel fragment g&7). The
@@ -210,6 +219,60 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         }
         kbyte += 128;
         cur ^= 1;
+    }
+    if constexpr (REGEPI) {
+        // ---- register epilogue: no LDS, no barrier. Lane (f = lane>>4, pixel = lane&15 of fragment b) holds channels
+        // cb + 32 j + {0..7} (cb = n0 + 128 wn + 8 f) in acc[2j][b], acc[2j+1][b]: residual in / result out as one
+        // 16-byte access per (b, j); the four lanes of a pixel cover 64 contiguous bytes per instruction.
+        const int cb = n0 + wn * (BN / 2) + 8 * fchunk;
+        const bf16_t* __restrict__ resp = reinterpret_cast<const bf16_t*>(p.res);
+        bf16_t* __restrict__ outp = reinterpret_cast<bf16_t*>(p.out);
+        uint4 rres[FM][4];
+        if (has_res) {
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int gm = min(m0 + wm * (BM / WM) + b * 16 + frow, p.M - 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rres[b][j] = *reinterpret_cast<const uint4*>(resp + (size_t)gm * p.ldo + cb + 32 * j);
+            }
+        }
+        float4 bia[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bia[j][0] = bia[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.colv) {
+                bia[j][0] = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j);
+                bia[j][1] = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j + 4);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[8];
+                v[0] = acc[2 * j][b][0] + bia[j][0].x; v[1] = acc[2 * j][b][1] + bia[j][0].y;
+                v[2] = acc[2 * j][b][2] + bia[j][0].z; v[3] = acc[2 * j][b][3] + bia[j][0].w;
+                v[4] = acc[2 * j + 1][b][0] + bia[j][1].x; v[5] = acc[2 * j + 1][b][1] + bia[j][1].y;
+                v[6] = acc[2 * j + 1][b][2] + bia[j][1].z; v[7] = acc[2 * j + 1][b][3] + bia[j][1].w;
+                if (has_res) {
+                    const uint32_t w4[4] = {rres[b][j].x, rres[b][j].y, rres[b][j].z, rres[b][j].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += __uint_as_float(w4[e] << 16);
+                        v[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (gm < p.M)
+                    *reinterpret_cast<uint4*>(outp + (size_t)gm * p.ldo + cb + 32 * j) =
+                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            }
+        }
+        return;
     }
     // cur = slot F (free since the last iteration: holds residual half 0), cur ^ 1 = slot L (the last k-tile)
     unsigned char* soF = smem + cur * BUF_BYTES;
@@ -288,7 +351,7 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
     const int grid = cdiv(p.M, WBM) * (p.N / WBN);
     switch (p.dbg) {
 #define WIDE_CASE(D) case D: hipLaunchKernelGGL(igemm_wide_kernel<D>, dim3(grid), dim3(512), 0, stream, p); break
-        WIDE_CASE(4096); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
+        WIDE_CASE(4096); WIDE_CASE(8192); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
 #undef WIDE_CASE
         default: hipLaunchKernelGGL(igemm_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p);
     }
