@@ -843,6 +843,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
         if (wide != 0 && lds_epi && igemm_wide_applicable(p)) {
             const int wtiles = cdiv(p.M, 256) * (p.N / 256);
             if (wide == 1 || (wtiles >= 224 && p.K >= 256)) return launch_igemm_wide(p, stream, who);
+            if (p.pool_nparts > 0 && wide != 0 && wtiles >= 64 && !getenv("AGRL_POOL_PERSIST")) return launch_igemm_wide(p, stream, who);
         }
     }
     if constexpr (sizeof(TOUT) == 2) {

@@ -25,6 +25,7 @@ constexpr int WBM = 256, WBN = 256;
 
 template <int DBG>  // ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
+    constexpr bool POOL = (DBG & 16384) != 0;   // fused frame pooling epilogue (a tile = two whole 16 x 8 frames)
     constexpr bool REGEPI = (DBG & 8192) == 0;  // bit 8192: the LDS-staged two-half epilogue (kept for A/B)
     constexpr int BM = WBM, BN = WBN, NW = 8, WM = 4;
     constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
@@ -245,6 +246,15 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 bia[j][1] = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j + 4);
             }
         }
+        float psum[POOL ? 2 : 1][4][8];
+        if constexpr (POOL) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) psum[q][j][e] = 0.f;
+        }
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
             const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
@@ -267,9 +277,59 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (gm < p.M)
-                    *reinterpret_cast<uint4*>(outp + (size_t)gm * p.ldo + cb + 32 * j) =
-                        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                const uint4 pk = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                if (gm < p.M && (!POOL || p.pool_store_out)) *reinterpret_cast<uint4*>(outp + (size_t)gm * p.ldo + cb + 32 * j) = pk;
+                if constexpr (POOL) {  // pool the bf16-rounded activations (what a separate pooling pass would read)
+                    const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+                    const float live = gm < p.M ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        psum[b >> 1][j][2 * e] += live * __uint_as_float(w4[e] << 16);
+                        psum[b >> 1][j][2 * e + 1] += live * __uint_as_float(w4[e] & 0xffff0000u);
+                    }
+                }
+            }
+        }
+        if constexpr (POOL) {
+            // vmgn.py:298-308. This wave's 64 pixels are image rows 8 (wm & 1) .. +7 of frame (wm >> 1): fragments
+            // b = 0,1 / 2,3 are two QUARTER bins (4 image rows = 32 pixels each). Sum over the 16 pixel lanes of a
+            // fragment (same f), park the quarter sums in LDS, then every output bin is a sum of whole quarters.
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = psum[q][j][e];
+                        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                        psum[q][j][e] = t;
+                    }
+            wg_barrier();  // every wave is past its last fragment read: the ring can be overwritten
+            float* s_q = reinterpret_cast<float*>(smem);  // [2 frames][4 quarters][256 channels]
+            if (frow == 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float* d = s_q + (((wm >> 1) * 4 + 2 * (wm & 1) + q) * BN) + wn * (BN / 2) + 8 * fchunk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        *reinterpret_cast<float4*>(d + 32 * j) = make_float4(psum[q][j][0], psum[q][j][1], psum[q][j][2], psum[q][j][3]);
+                        *reinterpret_cast<float4*>(d + 32 * j + 4) = make_float4(psum[q][j][4], psum[q][j][5], psum[q][j][6], psum[q][j][7]);
+                    }
+                }
+            }
+            wg_barrier();
+            const int P = p.pool_nparts;
+            for (int o = tid; o < 2 * P * BN; o += 512) {
+                const int c = o % BN, fp = o / BN, part = fp % P, fr = fp / P;
+                const int frame = (m0 >> 7) + fr;
+                if (frame * 128 >= p.M) continue;
+                const int q0 = p.pool_start[part] >> 2, q1 = p.pool_end[part] >> 2;  // bins are whole quarters (host-checked)
+                float t = 0.f;
+                for (int q = q0; q < q1; ++q) t += s_q[(fr * 4 + q) * BN + c];
+                if (p.pool_mean) t *= 1.f / (float)((q1 - q0) * 32);
+                const size_t oi = ((size_t)frame * P + part) * p.N + n0 + c;
+                p.pool_out[oi] = t;
+                if (p.pool_out_lp) reinterpret_cast<bf16_t*>(p.pool_out_lp)[oi] = f32_to_bf16(t);
             }
         }
         return;
@@ -339,7 +399,12 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 
 bool igemm_wide_applicable(const IgemmParams& p) {
     const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
-    if (!pointwise || p.rowv || p.ksplit > 1 || p.pool_nparts > 0) return false;
+    if (!pointwise || p.rowv || p.ksplit > 1) return false;
+    if (p.pool_nparts > 0) {  // fused pooling: 16 x 8 frames, two per tile, bins made of whole 4-row quarters
+        if (p.OH != 16 || p.OW != 8 || p.pool_w != 8) return false;
+        for (int i = 0; i < p.pool_nparts; ++i)
+            if ((p.pool_start[i] & 3) || (p.pool_end[i] & 3)) return false;
+    }
     if (p.alpha != 1.f || p.rowc != 0.f) return false;
     if (p.N % WBN || p.K % 64 || p.ldo % 8) return false;
     if ((size_t)p.M * p.K * 2 >= (1ull << 32) || (size_t)p.N * p.K * 2 >= (1ull << 32)) return false;
@@ -349,9 +414,14 @@ bool igemm_wide_applicable(const IgemmParams& p) {
 
 int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who) {
     const int grid = cdiv(p.M, WBM) * (p.N / WBN);
+    if (p.pool_nparts > 0) {
+        hipLaunchKernelGGL(igemm_wide_kernel<16384>, dim3(grid), dim3(512), 0, stream, p);
+        AGRL_CHECK_LAUNCH(who);
+        return 0;
+    }
     switch (p.dbg) {
 #define WIDE_CASE(D) case D: hipLaunchKernelGGL(igemm_wide_kernel<D>, dim3(grid), dim3(512), 0, stream, p); break
-        WIDE_CASE(4096); WIDE_CASE(8192); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
+        WIDE_CASE(16384); WIDE_CASE(4096); WIDE_CASE(8192); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
 #undef WIDE_CASE
         default: hipLaunchKernelGGL(igemm_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p);
     }

@@ -148,6 +148,39 @@ def test_bottleneck_tail(shape):
     assert e1 < 1e-2 and e2 < 1e-2
 
 
+@pytest.mark.parametrize("path", ["wide", "persistent"])
+@pytest.mark.parametrize("cfg", [(6, 512, 512, [4, 2, 1], True), (5, 256, 768, [1], False), (4, 2048, 256, [4, 2, 1], True)])
+def test_conv1x1_pool_fused(cfg, path, monkeypatch):
+    """Last conv of a layer4 branch with the frame pooling fused into its epilogue (the 2048-channel map is never
+    written) against the unfused pair conv_bn_act -> part_pool, both igemm forms."""
+    from torchreid import hip_ops as ops
+    N, Cin, Cout, splits, mean = cfg
+    g = torch.Generator().manual_seed(N + Cin)
+    x = torch.randn((N, 16, 8, Cin), generator=g).bfloat16().to(DEV)
+    w = (torch.randn((Cout, 1, 1, Cin), generator=g) / np.sqrt(Cin)).bfloat16().to(DEV)
+    b = torch.randn((Cout,), generator=g).to(DEV)
+    res = torch.randn((N, 16, 8, Cout), generator=g).bfloat16().to(DEV)
+    monkeypatch.setenv("AGRL_POOL_PERSIST", "1" if path == "persistent" else "0")
+    if path == "wide":
+        monkeypatch.setenv("AGRL_IGEMM_WIDE", "1")
+    pooled, pooled_lp = ops.conv1x1_bn_act_pool(x, w, b, res, splits, mean, True)
+    monkeypatch.delenv("AGRL_IGEMM_WIDE", raising=False)
+    act = ops.conv_bn_act(x, w, b, 1, 0, True, residual=res)
+    torch.cuda.synchronize()
+    a = act.float().cpu()  # (N,16,8,C): pool the bf16 activations exactly as the reference pools its map
+    parts = []
+    for n in splits:
+        for j in range(n):
+            lo, hi = (j * 16) // n, -(-((j + 1) * 16) // n)
+            blk = a[:, lo:hi].reshape(N, -1, Cout)
+            parts.append(blk.mean(1) if mean else blk.sum(1))
+    ref = torch.stack(parts, 1)
+    e = rel_err(pooled, ref)
+    print("fused pool conv", cfg, path, "rel err %.3e" % e)
+    assert e < 1e-5
+    assert rel_err(pooled_lp.float(), ref) < 5e-3
+
+
 WIDE3_CASES = [
     # N, H, W, Cin, Cout, relu -- the two-block 3x3 kernel (conv3x3_wide.hip), forced through AGRL_CONV3X3_WIDE=1
     (3, 16, 8, 128, 128, True),     # odd number of pixel blocks: the last workgroup has one valid block
