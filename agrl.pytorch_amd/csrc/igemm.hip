@@ -842,7 +842,9 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
         if (const char* e = getenv("AGRL_IGEMM_WIDE")) wide = atoi(e);
         if (wide != 0 && lds_epi && igemm_wide_applicable(p)) {
             const int wtiles = cdiv(p.M, 256) * (p.N / 256);
-            if (wide == 1 || (wtiles >= 224 && p.K >= 256)) return launch_igemm_wide(p, stream, who);
+            if (wide >= 1 || (wtiles >= 224 && p.K >= 256)) return launch_igemm_wide(p, stream, who);
+            // N = 256 layers with long K (layer 3's 1024 -> 256): 256 x 128 tiles, one per CU
+            if (p.pool_nparts == 0 && p.N >= 256 && cdiv(p.M, 256) * (p.N / 128) >= 224 && p.K >= 512 && !getenv("AGRL_IGEMM_NO_W128")) return launch_igemm_wide(p, stream, who);
             if (p.pool_nparts > 0 && wide != 0 && wtiles >= 64 && !getenv("AGRL_POOL_PERSIST")) return launch_igemm_wide(p, stream, who);
         }
     }

@@ -23,17 +23,19 @@ namespace {
 
 constexpr int WBM = 256, WBN = 256;
 
-template <int DBG>  // ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
+template <int DBG, int WBN_ = 256>  // WBN_: channels per tile (256, or 128 for N = 256 layers: twice the tiles); DBG: ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
+    static_assert(WBN_ == 256 || (WBN_ == 128 && (DBG & (4096 | 8192 | 16384)) == 0), "the 128-channel tile has the plain schedule + register epilogue only");
     constexpr bool POOL = (DBG & 16384) != 0;   // fused frame pooling epilogue (a tile = two whole 16 x 8 frames)
     constexpr bool REGEPI = (DBG & 8192) == 0;  // bit 8192: the LDS-staged two-half epilogue (kept for A/B)
-    constexpr int BM = WBM, BN = WBN, NW = 8, WM = 4;
+    constexpr int BM = WBM, BN = WBN_, NW = 8, WM = 4;
     constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
     constexpr int FN = BN / 32;         // 8 channel fragments per wave
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF_BYTES = A_BYTES + B_BYTES;  // 64 KB per ring slot
     constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW);                                  // 4 + 4 DMA pieces per wave
     constexpr int DPT = AJ + BJ;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+    constexpr int NS = BN == 128 ? 3 : 2;  // ring slots: the 48 KB k-tiles of the 128-channel tile fit three times
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -80,8 +82,9 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
             // LDS row a*16 + i of a wave column's 128-channel slab holds channel sigma(a, i) = 32 (a>>1) + 8 (i>>2) +
             // 4 (a&1) + (i&3): the MFMA result rows 4 f + r of the 8 fragments of a lane are then 32 channels that the
             // register epilogue reads / writes as 16-byte pieces, 64 contiguous bytes per pixel row and instruction
-            const int rp = row & 127, a = rp >> 4, i = rp & 15;
-            ch = (row & 128) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
+            constexpr int SLAB = BN / 2;  // channels per wave column
+            const int rp = row & (SLAB - 1), a = rp >> 4, i = rp & 15;
+            ch = (row & ~(SLAB - 1)) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
         }
         b_off[j] = (unsigned)(n0 + ch) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
     }
@@ -121,13 +124,18 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     const int nk = p.K >> 6;
     const bool has_res = p.res != nullptr;
 #pragma unroll
-    for (int i = 0; i < DPT; ++i) stage_piece(0, i);
-    kbyte += 128;
+    for (int s = 0; s < NS - 1; ++s) {
+        if (s < nk) {
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) stage_piece(s, i);
+            kbyte += 128;
+        }
+    }
 
     const int frow = lane & 15;
     const int fchunk = lane >> 4;
     int cur = 0;
-    if constexpr ((DBG & 4096) != 0) {
+    if constexpr ((DBG & 4096) != 0 && BN == 256) {
         // ---- ping-pong schedule. The two waves of a SIMD (w and w + 4: wave column 0 / 1) run the same phase
         // sequence {L: fragment reads (+ DMA issue) | barrier | M: 32 MFMAs | barrier}, column 1 ONE BARRIER LATER:
         // while one column's waves are in their matrix section the other column's are reading LDS / issuing DMA, so
@@ -180,11 +188,18 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         if (wn == 0) __builtin_amdgcn_s_barrier();
     } else
     for (int kt = 0; kt < nk; ++kt) {
-        if (!(DBG & 32)) wait_vmcnt<0>();  // k-tile kt has landed (this wave's pieces; the barrier covers everybody else's)
+        // k-tile kt has landed (this wave's pieces; the barrier covers everybody else's). With three slots the NEXT
+        // k-tile stays in flight across the barrier (counted wait): a 48 KB k-tile is 0.56 us of MFMA, less than a
+        // memory round trip, so one tile of look-ahead is latency-bound.
+        if (!(DBG & 32)) {
+            if (NS == 3 && kt + 1 < nk) wait_vmcnt<DPT>();
+            else wait_vmcnt<0>();
+        }
         if (!(DBG & 128)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int fill = cur ^ 1;  // read in iteration kt-1, free now
-        const bool do_stage = kt + 1 < nk && !(DBG & 8);
+        int fill = cur + NS - 1;  // the slot read in iteration kt-1, free now
+        fill = fill >= NS ? fill - NS : fill;
+        const bool do_stage = kt + NS - 1 < nk && !(DBG & 8);
         if (!do_stage && has_res && !REGEPI) stage_residual_half(0, smem + fill * BUF_BYTES);
         const unsigned char* sa = smem + cur * BUF_BYTES;
         const unsigned char* sb = sa + A_BYTES;
@@ -200,26 +215,27 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         };
         auto ldw = [&](int g) {
             if ((DBG & 16) && kt) return make_uint4(kt, g, 1, lane);
-            return *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + (g & 7) * 16 + frow, (g >> 3) * 4 + fchunk));
+            return *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + (g % FN) * 16 + frow, (g / FN) * 4 + fchunk));
         };
+        constexpr int NG = 2 * FN;  // groups of FM MFMAs per k-tile: group g = (k-step g / FN, channel fragment g % FN)
         wfr[0] = ldw(0);
 #pragma unroll
         for (int b = 0; b < FM; ++b) xfr[0][b] = ldx(0, b);
         wfr[1] = ldw(1);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            if (g + 2 < 16) wfr[(g + 2) % 3] = ldw(g + 2);
-            if (g >= 2 && g < 2 + FM) xfr[1][g - 2] = ldx(1, g - 2);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 2 < NG) wfr[(g + 2) % 3] = ldw(g + 2);
+            if (g < FM) xfr[1][g] = ldx(1, g);
             if (do_stage && g < DPT) stage_piece(fill, g);
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
-                if (!(DBG & 2)) acc[g & 7][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g >> 3][b], acc[g & 7][b]);
-                else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g >> 3][b].x), "v"(xfr[g >> 3][b].w));
+                if (!(DBG & 2)) acc[g % FN][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g / FN][b], acc[g % FN][b]);
+                else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g / FN][b].x), "v"(xfr[g / FN][b].w));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         kbyte += 128;
-        cur ^= 1;
+        cur = cur + 1 == NS ? 0 : cur + 1;
     }
     if constexpr (REGEPI) {
         // ---- register epilogue: no LDS, no barrier. Lane (f = lane>>4, pixel = lane&15 of fragment b) holds channels
@@ -228,30 +244,31 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         const int cb = n0 + wn * (BN / 2) + 8 * fchunk;
         const bf16_t* __restrict__ resp = reinterpret_cast<const bf16_t*>(p.res);
         bf16_t* __restrict__ outp = reinterpret_cast<bf16_t*>(p.out);
-        uint4 rres[FM][4];
+        constexpr int NJ = FN / 2;  // 16-byte pieces (8 channels) per lane and pixel fragment
+        uint4 rres[FM][NJ];
         if (has_res) {
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 const int gm = min(m0 + wm * (BM / WM) + b * 16 + frow, p.M - 1);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rres[b][j] = *reinterpret_cast<const uint4*>(resp + (size_t)gm * p.ldo + cb + 32 * j);
+                for (int j = 0; j < NJ; ++j) rres[b][j] = *reinterpret_cast<const uint4*>(resp + (size_t)gm * p.ldo + cb + 32 * j);
             }
         }
-        float4 bia[4][2];
+        float4 bia[NJ][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             bia[j][0] = bia[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.colv) {
                 bia[j][0] = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j);
                 bia[j][1] = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j + 4);
             }
         }
-        float psum[POOL ? 2 : 1][4][8];
+        float psum[POOL ? 2 : 1][NJ][8];
         if constexpr (POOL) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) psum[q][j][e] = 0.f;
         }
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         for (int b = 0; b < FM; ++b) {
             const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 float v[8];
                 v[0] = acc[2 * j][b][0] + bia[j][0].x; v[1] = acc[2 * j][b][1] + bia[j][0].y;
                 v[2] = acc[2 * j][b][2] + bia[j][0].z; v[3] = acc[2 * j][b][3] + bia[j][0].w;
@@ -334,6 +351,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         }
         return;
     }
+    if constexpr (!REGEPI) {
     // cur = slot F (free since the last iteration: holds residual half 0), cur ^ 1 = slot L (the last k-tile)
     unsigned char* soF = smem + cur * BUF_BYTES;
     unsigned char* soL = smem + (cur ^ 1) * BUF_BYTES;
@@ -393,6 +411,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     combine_half(1, soL);
     wg_barrier();
     drain_half(1, soL);
+    }
 }
 
 }  // namespace
@@ -406,24 +425,36 @@ bool igemm_wide_applicable(const IgemmParams& p) {
             if ((p.pool_start[i] & 3) || (p.pool_end[i] & 3)) return false;
     }
     if (p.alpha != 1.f || p.rowc != 0.f) return false;
-    if (p.N % WBN || p.K % 64 || p.ldo % 8) return false;
+    if (p.N % 128 || p.K % 64 || p.ldo % 8) return false;
+    if (p.N % WBN && p.pool_nparts > 0) return false;
     if ((size_t)p.M * p.K * 2 >= (1ull << 32) || (size_t)p.N * p.K * 2 >= (1ull << 32)) return false;
     const uintptr_t al = (uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.colv;
     return (al & 15) == 0;
 }
 
 int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who) {
+    // 128-channel tiles where 256-channel ones would leave CUs idle (N = 256 layers) or do not divide N
+    bool half_n = (p.N % WBN) != 0 || (p.pool_nparts == 0 && p.dbg == 0 && cdiv(p.M, WBM) * (p.N / WBN) < 224);
+    if (const char* e = getenv("AGRL_IGEMM_WIDE")) {  // 2 / 3 force the 256- / 128-channel tile (tests, A/B)
+        if (atoi(e) == 2 && (p.N % WBN) == 0) half_n = false;
+        if (atoi(e) == 3 && p.pool_nparts == 0) half_n = true;
+    }
+    if (half_n) {
+        hipLaunchKernelGGL((igemm_wide_kernel<0, 128>), dim3(cdiv(p.M, WBM) * (p.N / 128)), dim3(512), 0, stream, p);
+        AGRL_CHECK_LAUNCH(who);
+        return 0;
+    }
     const int grid = cdiv(p.M, WBM) * (p.N / WBN);
     if (p.pool_nparts > 0) {
-        hipLaunchKernelGGL(igemm_wide_kernel<16384>, dim3(grid), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((igemm_wide_kernel<16384, 256>), dim3(grid), dim3(512), 0, stream, p);
         AGRL_CHECK_LAUNCH(who);
         return 0;
     }
     switch (p.dbg) {
-#define WIDE_CASE(D) case D: hipLaunchKernelGGL(igemm_wide_kernel<D>, dim3(grid), dim3(512), 0, stream, p); break
+#define WIDE_CASE(D) case D: hipLaunchKernelGGL((igemm_wide_kernel<D, 256>), dim3(grid), dim3(512), 0, stream, p); break
         WIDE_CASE(16384); WIDE_CASE(4096); WIDE_CASE(8192); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
 #undef WIDE_CASE
-        default: hipLaunchKernelGGL(igemm_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p);
+        default: hipLaunchKernelGGL((igemm_wide_kernel<0, 256>), dim3(grid), dim3(512), 0, stream, p);
     }
     AGRL_CHECK_LAUNCH(who);
     return 0;

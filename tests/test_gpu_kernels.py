@@ -79,8 +79,9 @@ WIDE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", WIDE_CASES)
-def test_conv_wide_tile(case, monkeypatch):
+@pytest.mark.parametrize("tile", ["2", "3"])  # AGRL_IGEMM_WIDE: 2 = 256 x 256 tile, 3 = 256 x 128 tile
+@pytest.mark.parametrize("case", WIDE_CASES + [(3, 16, 8, 1024, 384, True, True)])
+def test_conv_wide_tile(case, tile, monkeypatch):
     from torchreid import hip_ops as ops
     N, H, W, Cin, Cout, use_res, relu = case
     g = torch.Generator().manual_seed(sum(case[:5]))
@@ -96,7 +97,9 @@ def test_conv_wide_tile(case, monkeypatch):
         ref = F.relu(ref)
     args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 1, 0, relu)
     kw = dict(residual=None if res is None else nhwc(res, torch.bfloat16))
-    monkeypatch.setenv("AGRL_IGEMM_WIDE", "1")
+    if tile == "2" and Cout % 256:
+        pytest.skip("256-channel tiles need Cout % 256 == 0")
+    monkeypatch.setenv("AGRL_IGEMM_WIDE", tile)
     wide = ops.conv_bn_act(*args, **kw)
     monkeypatch.setenv("AGRL_IGEMM_WIDE", "0")
     narrow = ops.conv_bn_act(*args, **kw)
