@@ -72,7 +72,14 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         const int row = wave * (BM / NW) + j * 8 + lrow;
         const int gm = m0 + row;
         if (gm < p.M) a_okmask |= 1u << j;
-        a_off[j] = (unsigned)(gm < p.M ? gm : 0) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
+        int pix = gm < p.M ? gm : 0;
+        if (p.stride > 1) {  // strided 1x1 (the downsample convs): output pixel -> the input pixel it reads
+            const int ohw = p.OH * p.OW;
+            const int n = pix / ohw, rem = pix - n * ohw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            pix = (n * p.H + oy * p.stride) * p.W + ox * p.stride;
+        }
+        a_off[j] = (unsigned)pix * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
@@ -417,8 +424,9 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 }  // namespace
 
 bool igemm_wide_applicable(const IgemmParams& p) {
-    const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+    const bool pointwise = p.R == 1 && p.S == 1 && p.stride >= 1 && p.pad == 0;  // stride > 1: rows are gathered
     if (!pointwise || p.rowv || p.ksplit > 1) return false;
+    if (p.stride > 1 && (p.pool_nparts > 0 || (size_t)(p.M / (p.OH * p.OW)) * p.H * p.W * p.K * 2 >= (1ull << 32))) return false;
     if (p.pool_nparts > 0) {  // fused pooling: 16 x 8 frames, two per tile, bins made of whole 4-row quarters
         if (p.OH != 16 || p.OW != 8 || p.pool_w != 8) return false;
         for (int i = 0; i < p.pool_nparts; ++i)

@@ -151,6 +151,27 @@ def test_bottleneck_tail(shape):
     assert e1 < 1e-2 and e2 < 1e-2
 
 
+@pytest.mark.parametrize("tile", ["2", "3"])
+@pytest.mark.parametrize("case", [(3, 16, 8, 256, 512), (2, 32, 16, 512, 256), (1, 10, 6, 128, 256)])
+def test_conv_wide_tile_strided(case, tile, monkeypatch):
+    """1x1 stride-2 downsample convs through the wide igemm (gathered pixel rows) against the generic kernel."""
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, Cin, H, W), generator=g).bfloat16().float()
+    w = (torch.randn((Cout, Cin, 1, 1), generator=g) / np.sqrt(Cin)).bfloat16().float()
+    b = torch.randn((Cout,), generator=g)
+    ref = F.conv2d(x, w, bias=b, stride=2)
+    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 2, 0, False)
+    monkeypatch.setenv("AGRL_IGEMM_WIDE", tile)
+    wide = ops.conv_bn_act(*args)
+    monkeypatch.setenv("AGRL_IGEMM_WIDE", "0")
+    narrow = ops.conv_bn_act(*args)
+    torch.cuda.synchronize()
+    assert rel_err(wide.float().permute(0, 3, 1, 2), ref) < 1e-2
+    assert torch.equal(wide, narrow)
+
+
 @pytest.mark.parametrize("path", ["wide", "persistent"])
 @pytest.mark.parametrize("cfg", [(6, 512, 512, [4, 2, 1], True), (5, 256, 768, [1], False), (4, 2048, 256, [4, 2, 1], True)])
 def test_conv1x1_pool_fused(cfg, path, monkeypatch):
