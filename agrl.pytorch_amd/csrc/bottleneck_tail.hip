@@ -214,6 +214,177 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layer transition form: the next block's conv1 has 128 output channels (layer1 -> layer2, 256 -> 128). Its 64 KB of
+// weights leave room for ONE out tile only, so the residual tile is fetched at the top of its own tile (under the
+// first GEMM's MFMAs) instead of one tile ahead; the y2 tile is still prefetched. z (64 px x 128 ch) is staged over the
+// out tile once every wave has finished reading it.
+__global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParams p, int ntiles) {
+    constexpr int CN = 128;
+    constexpr int W3_BYTES = TN1 * 128, W1_KT = CN * 128, W1_BYTES = (TK2 / 64) * W1_KT;  // 32 KB, 64 KB
+    constexpr int A_BYTES = TBM * 128, R_BYTES = TBM * TN1 * 2;                            // 8 KB, 32 KB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W3_BYTES + W1_BYTES + 2 * A_BYTES + R_BYTES];
+    unsigned char* s_w3 = smem;
+    unsigned char* s_w1 = s_w3 + W3_BYTES;
+    unsigned char* s_a = s_w1 + W1_BYTES;
+    unsigned char* sr = s_a + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm2 = wave & 1, wn4 = wave >> 1;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const int G = gridDim.x;
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+    const unsigned char* y2g = reinterpret_cast<const unsigned char*>(p.y2);
+    const unsigned char* resg = reinterpret_cast<const unsigned char*>(p.res);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = wave * 32 + j * 8 + lrow;
+        dma16(reinterpret_cast<const unsigned char*>(p.w3) + (size_t)row * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4),
+              s_w3 + (wave * 32 + j * 8) * 128);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = (wave + 8 * h) * 8 + lrow;
+            dma16(reinterpret_cast<const unsigned char*>(p.w1n) + (size_t)row * (TK2 * 2) + kt * 128 + ((lchk ^ ((row >> 1) & 7)) << 4),
+                  s_w1 + kt * W1_KT + (wave + 8 * h) * 8 * 128);
+        }
+    auto stage_y2 = [&](int T, int slot) {
+        const int row = wave * 8 + lrow;
+        const int gm = T * TBM + row;
+        dma16(gm < p.M ? y2g + (size_t)gm * (TK1 * 2) + ((lchk ^ ((row >> 1) & 7)) << 4) : zsrc, s_a + slot * A_BYTES + wave * 1024);
+    };
+    auto stage_res = [&](int T) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = wave * 4 + j;
+            const int row = piece * 2 + (lane >> 5);
+            const int gm = T * TBM + row;
+            const int gch = (lane & 31) ^ (row & 31);
+            dma16(gm < p.M ? resg + ((size_t)gm * TN1 + gch * 8) * 2 : zsrc, sr + piece * 1024);
+        }
+    };
+    float4 b3v[4], b1v[2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) b3v[a] = *reinterpret_cast<const float4*>(p.b3 + wn4 * 64 + a * 16 + fchunk * 4);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) b1v[a] = *reinterpret_cast<const float4*>(p.b1n + wn4 * 32 + a * 16 + fchunk * 4);
+
+    int T = blockIdx.x;
+    if (T < ntiles) stage_y2(T, 0);
+    wait_vmcnt<0>();
+    wg_barrier();
+    int slot = 0;
+    for (; T < ntiles; T += G, slot ^= 1) {
+        const int m0 = T * TBM;
+        const bool has_next = T + G < ntiles;
+        stage_res(T);                               // 4 pieces, oldest in this iteration's queue
+        if (has_next) stage_y2(T + G, slot ^ 1);    // 1 piece
+        const unsigned char* sa = s_a + slot * A_BYTES;
+        f32x4_t acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 xf[2], wf[4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(sa + lds_off(wm2 * 32 + b * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const uint4*>(s_w3 + lds_off(wn4 * 64 + a * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+        }
+        if (has_next) wait_vmcnt<1>();  // the residual pieces are older than the y2 prefetch
+        else wait_vmcnt<0>();
+        wg_barrier();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int px = wm2 * 32 + b * 16 + frow;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int c = wn4 * 64 + a * 16 + fchunk * 4;
+                unsigned char* cell = sr + px * 512 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
+                float rr[4];
+                load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
+                float v[4];
+                v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
+                v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
+                v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
+                v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
+                store4<bf16_t>(reinterpret_cast<bf16_t*>(cell), v);
+            }
+        }
+        wg_barrier();  // out tile complete
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 5) + 16 * i;
+            const int pch = tid & 31;
+            const int gm = m0 + row;
+            if (gm < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sr + row * 512 + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * TN1 + (pch ^ (row & 31)) * 8) * 2) = v;
+            }
+        }
+        // GEMM 2: 64 px x 128 ch, K = 256. Wave tile 32 px x 32 ch.
+        f32x4_t acc2[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc2[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < TK2 / 32; ++ks) {
+            uint4 wf[2], xf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                wf[a] = *reinterpret_cast<const uint4*>(s_w1 + (ks >> 1) * W1_KT + lds_off(wn4 * 32 + a * 16 + frow, (ks & 1) * 4 + fchunk));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int px = wm2 * 32 + b * 16 + frow;
+                xf[b] = *reinterpret_cast<const uint4*>(sr + px * 512 + (((ks * 4 + fchunk) ^ (px & 31)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc2[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc2[a][b]);
+        }
+        wg_barrier();  // every read of the out tile (drain + GEMM 2) is done: stage z over it, 256-byte rows
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int px = wm2 * 32 + b * 16 + frow;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int c = wn4 * 32 + a * 16 + fchunk * 4;
+                float v[4];
+                v[0] = fmaxf(acc2[a][b][0] + b1v[a].x, 0.f);
+                v[1] = fmaxf(acc2[a][b][1] + b1v[a].y, 0.f);
+                v[2] = fmaxf(acc2[a][b][2] + b1v[a].z, 0.f);
+                v[3] = fmaxf(acc2[a][b][3] + b1v[a].w, 0.f);
+                store4<bf16_t>(reinterpret_cast<bf16_t*>(sr + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
+            }
+        }
+        wg_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = tid >> 3, pch = (tid & 7) * 2 + i;
+            const int gm = m0 + row;
+            if (gm < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sr + row * 256 + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.z) + ((size_t)gm * CN + (pch ^ (row & 15)) * 8) * 2) = v;
+            }
+        }
+        wait_vmcnt<6>();  // the y2 prefetch is older than this tile's 6 stores
+        wg_barrier();     // ... and nobody still reads the z tile when the next residual lands on it
+    }
+}
+
 }  // namespace
 
 extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual,
@@ -225,9 +396,9 @@ extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float*
                    "agrl_bottleneck_tail: pass either the residual map or the downsample conv's input, not both");
     AGRL_CHECK_ARG(!x_short || (w_short && b_short), "agrl_bottleneck_tail: the downsample form needs its weights and bias");
     AGRL_CHECK_ARG(M > 0, "agrl_bottleneck_tail: empty problem");
-    AGRL_CHECK_ARG(Cmid == TK1 && Cout == TN1 && Cnext == TN2 && (!x_short || Cshort == TK1),
-                   "agrl_bottleneck_tail: built for Cmid=64, Cout=256, Cnext=64, Cshort=64 (layer 1), got %d/%d/%d/%d", Cmid,
-                   Cout, Cnext, Cshort);
+    AGRL_CHECK_ARG(Cmid == TK1 && Cout == TN1 && (Cnext == TN2 || (Cnext == 128 && !x_short)) && (!x_short || Cshort == TK1),
+                   "agrl_bottleneck_tail: built for Cmid=64, Cout=256, Cnext=64 (128 without downsample), Cshort=64 "
+                   "(layer 1), got %d/%d/%d/%d", Cmid, Cout, Cnext, Cshort);
     const uintptr_t al = (uintptr_t)y2 | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)residual | (uintptr_t)out |
                          (uintptr_t)w1_next | (uintptr_t)b1_next | (uintptr_t)z | (uintptr_t)x_short | (uintptr_t)w_short |
                          (uintptr_t)b_short;
@@ -237,7 +408,8 @@ extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float*
     p.xs = x_short; p.ws = w_short; p.bs = b_short;
     const int ntiles = cdiv(M, TBM);
     const int grid = ntiles < 256 ? ntiles : 256;
-    if (x_short) hipLaunchKernelGGL(bottleneck_tail_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
+    if (Cnext == 128) hipLaunchKernelGGL(bottleneck_tail128_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
+    else if (x_short) hipLaunchKernelGGL(bottleneck_tail_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
     else hipLaunchKernelGGL(bottleneck_tail_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
     AGRL_CHECK_LAUNCH("agrl_bottleneck_tail");
     return 0;

@@ -101,16 +101,17 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
 def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
     """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 shapes in bf16. ``shortcut_conv`` =
     (weight, stride) of the block's downsample conv when the residual is to be computed in the same pass."""
-    ok = y2.dtype == torch.bfloat16 and tuple(w3.shape) == (256, 1, 1, 64) and tuple(w1_next.shape) == (64, 1, 1, 256)
+    ok = (y2.dtype == torch.bfloat16 and tuple(w3.shape) == (256, 1, 1, 64)
+          and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)))
     if shortcut_conv is not None:
-        ok = ok and tuple(shortcut_conv[0].shape) == (256, 1, 1, 64) and shortcut_conv[1] == 1
+        ok = ok and tuple(shortcut_conv[0].shape) == (256, 1, 1, 64) and shortcut_conv[1] == 1 and w1_next.shape[0] == 64
     return ok
 
 
 def bottleneck_tail(y2, w3, b3, residual, w1_next, b1_next, shortcut=None):
     """out = relu(conv3(y2) + R), z = relu(conv1_next(out)) in one pass (out never re-read from HBM); R = ``residual``
     or, with ``shortcut`` = (x, w_ds, b_ds), the block's 1x1 stride-1 downsample conv of x computed in the same pass.
-    vmgn.py:57-64 (block i) + :48-50 (block i+1). -> out (N,H,W,256), z (N,H,W,64) bf16 NHWC."""
+    vmgn.py:57-64 (block i) + :48-50 (block i+1). -> out (N,H,W,256), z (N,H,W,64 | 128) bf16 NHWC."""
     N, H, W, Cmid = y2.shape
     Cout, Cnext = w3.shape[0], w1_next.shape[0]
     assert y2.dtype == torch.bfloat16 and (residual is None) != (shortcut is None)
