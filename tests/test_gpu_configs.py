@@ -1,0 +1,88 @@
+"""BASELINE.json parity-test configurations at their full sizes (the ones that are not bench lines):
+config 5 -- MARS full eval, 1980 x 12180 x 4096 distance matrix + top-50 ranking -- through size-independent properties
+plus sampled rows against the CPU oracle; config 4 -- a Duke-shaped (seq_len 16, V = 112) xent + htri train step with
+on-GPU batch-hard mining -- against the same step computed on the CPU by the same module tree."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vmgn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_full_mars_distmat_and_rank(precision):
+    from torchreid import hip_ops as ops
+    from torchreid.metrics.distance import hip_distmat_device
+    m, n, D, k = 1980, 12180, 4096, 50
+    g = torch.Generator().manual_seed(55)
+    centers = torch.randn((625, D), generator=g)
+    g_pid = torch.randint(0, 625, (n,), generator=g)
+    q_pid = torch.randint(0, 625, (m,), generator=g)
+    gal = centers[g_pid] + 0.7 * torch.randn((n, D), generator=g)
+    qry = centers[q_pid] + 0.7 * torch.randn((m, D), generator=g)
+    qd, gd = qry.to(DEV), gal.to(DEV)
+    for metric, fn in (("cosine", O.cosine), ("euclidean", O.euclidean_squared)):
+        dist = hip_distmat_device(qd, gd, metric, precision)
+        assert dist.shape == (m, n) and torch.isfinite(dist).all()
+        rows = torch.randperm(m, generator=g)[:48]
+        ref = fn(qry[rows].double(), gal.double())
+        err = ((dist[rows.to(DEV)].double().cpu() - ref).abs().max() / ref.abs().max()).item()
+        assert err < (1e-5 if precision == "fp32" else 1e-2), (metric, err)
+        # ranking of the device matrix: exact top-k, ascending, ties towards the lower index, idempotent
+        idx, val = ops.rank_topk(dist, k)
+        tv, ti = torch.topk(dist, k, dim=1, largest=False, sorted=True)
+        assert torch.equal(val, tv)
+        assert bool((val[:, 1:] >= val[:, :-1]).all())
+        assert torch.equal(torch.gather(dist, 1, idx.long()), val)
+        distinct = (tv[:, 1:] != tv[:, :-1]).all(dim=1)            # rows without exact ties: indices must be identical
+        assert torch.equal(idx.long()[distinct], ti[distinct])
+        idx2, val2 = ops.rank_topk(val.contiguous(), k)
+        assert torch.equal(val2, val) and torch.equal(idx2.long(), torch.arange(k, device=DEV).expand(m, k))
+        # a query's own identity dominates its top ranks (sanity of the whole match)
+        hit = (g_pid.to(DEV)[idx[:, 0].long()] == q_pid.to(DEV)).float().mean().item()
+        assert hit > 0.9, hit
+        # column-sharded computation (what each rank of an 8-GPU run holds) equals the full matrix
+        lo, hi = 3 * (n // 8), 4 * (n // 8)
+        shard = hip_distmat_device(qd, gd[lo:hi].contiguous(), metric, precision)
+        tol = 0 if precision == "fp32" else 2e-2
+        assert (shard - dist[:, lo:hi]).abs().max().item() <= tol * dist.abs().max().item() + (1e-5 if precision == "fp32" else 0)
+
+
+def test_config4_train_step_seq16_matches_cpu_step():
+    """One xent + htri step at seq_len 16 (V = 112, consistent loss on): GPU (native mining) vs the CPU module tree."""
+    from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+    from torchreid import losses, models
+    S, P, K, ncls = 16, 2, 2, 5
+    kw = dict(num_classes=ncls, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1, pyramid_part=True,
+              use_pose=True, learn_graph=True, consistent_loss=True)
+    ref = models.init_model("vmgn", **kw)
+    sd = recipe_state_dict(ref.state_dict(), seed=3)
+    ref.load_state_dict(sd)
+    dev = models.init_model("vmgn", **kw)
+    dev.load_state_dict(sd)
+    dev = dev.to(DEV)
+    pids = torch.arange(P).repeat_interleave(K)
+    x = synthetic_clips(P * K, S, H=128, W=64, seed=9, identities=pids.tolist())  # half-size frames: CPU time
+    adj = synthetic_adj(P * K, S, seed=9)
+    xent = losses.CrossEntropyLabelSmooth(num_classes=ncls, use_gpu=False)
+    xent_d = losses.CrossEntropyLabelSmooth(num_classes=ncls, use_gpu=True)
+    htri = losses.TripletLoss(margin=0.3, soft=True)
+
+    def step(model, x_, adj_, y_, ce):
+        model.train()
+        torch.manual_seed(1234)  # the consistent loss draws its frame subsets with torch.randperm on the host
+        outs, feats = model(x_, adj_)
+        loss = losses.DeepSupervision(ce, outs, y_) + losses.DeepSupervision(htri, feats, y_)
+        loss.backward()
+        gn = torch.sqrt(sum((p.grad.detach().double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+        return loss.item(), gn.item(), len(outs), len(feats)
+
+    l_ref, g_ref, no, nf = step(ref, x, adj, pids, xent)
+    l_dev, g_dev, no2, nf2 = step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), xent_d)
+    assert (no, nf) == (no2, nf2) == (5, 5)
+    print("train step S=16: loss cpu %.6f gpu %.6f | grad norm cpu %.4e gpu %.4e" % (l_ref, l_dev, g_ref, g_dev))
+    assert abs(l_ref - l_dev) < 2e-3 * abs(l_ref)
+    assert abs(g_ref - g_dev) < 2e-2 * g_ref
