@@ -229,6 +229,140 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1, 64 -> 64 channels (layer 1, 64 x 32 maps): HBM-bound (67 MB in, 67 MB out per 256 frames
+// against 39 GFLOP), and with one 64-channel slab the whole filter bank is 72 KB. Persistent workgroups keep ALL NINE
+// taps' weights resident in LDS and walk 16 x 8 pixel blocks: per block only the 23 KB halo patch comes in (LDS-DMA,
+// prefetched one block ahead) and 16 KB goes out; no weight traffic, no barrier inside the 9-tap sweep (72 MFMAs per
+// wave between barriers instead of 8). (Weights in registers -- 144 VGPRs of A fragments -- was tried: with the 36
+// shifted patch addresses hipcc runs out of registers and spills, 60 us against 51 us for this form.)
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, int nblocks) {
+    constexpr int NW = 8, WM = 4, BM = 128, BN = 64;
+    constexpr int FM = BM / (16 * WM), FN = BN / 32;  // 2 x 2 fragments per wave
+    constexpr int PW = 10, PPIX = 18 * PW, PPIECES = (PPIX + 7) / 8, PATCH_BYTES = PPIECES * 1024;
+    constexpr int PJ = (PPIECES + NW - 1) / NW;       // 3 DMA pieces per wave per block (one of the 24 is a dummy)
+    constexpr int W_TAP = BN * 128, W_BYTES = 9 * W_TAP;  // 72 KB
+    constexpr int O_BYTES = BM * BN * 2;                   // 16 KB out tile, 128-byte rows
+    __shared__ __attribute__((aligned(16))) unsigned char smem[W_BYTES + 2 * PATCH_BYTES + O_BYTES + 1024];
+    unsigned char* s_w = smem;
+    unsigned char* s_p = s_w + W_BYTES;
+    unsigned char* s_o = s_p + 2 * PATCH_BYTES;
+    unsigned char* s_dummy = s_o + O_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int G = gridDim.x;
+    const int tw = p.W >> 3, th = p.H >> 4;
+    const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+
+    // resident weights: tap t, rows 8 wave .. +7 (64 output channels); K order of the OHWI weight = (tap, cin)
+    {
+        const int row = wave * 8 + lrow;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            dma16(reinterpret_cast<const unsigned char*>(p.w) + ((size_t)row * p.K + t * 64) * 2 + ((lchk ^ ((row >> 1) & 7)) << 4),
+                  s_w + t * W_TAP + wave * 8 * 128);
+    }
+    auto stage_patch = [&](int blk, int buf) {
+        const int img = blk / (tw * th);
+        const int trem = blk - img * (tw * th);
+        const int oy0 = (trem / tw) << 4, ox0 = (trem % tw) << 3;
+#pragma unroll
+        for (int i = 0; i < PJ; ++i) {
+            const int piece = wave + NW * i;
+            const int row = piece * 8 + lrow;
+            const int py = row / PW, px = row - py * PW;
+            const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+            const bool ok = piece < PPIECES && row < PPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            dma16(ok ? xg + (((size_t)img * p.H + iy) * p.W + ix) * 128 + ((lchk ^ ((row >> 1) & 7)) << 4) : zsrc,
+                  piece < PPIECES ? s_p + buf * PATCH_BYTES + piece * 1024 : s_dummy);
+        }
+    };
+    float4 cv[FN];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        cv[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.colv) cv[a] = *reinterpret_cast<const float4*>(p.colv + wn * 32 + a * 16 + fchunk * 4);
+    }
+    int pr0[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = wm * 32 + b * 16 + frow;
+        pr0[b] = (m >> 3) * PW + (m & 7);
+    }
+
+    int blk = blockIdx.x;
+    if (blk < nblocks) stage_patch(blk, 0);
+    int buf = 0;
+    bool first = true;
+    for (; blk < nblocks; blk += G, buf ^= 1) {
+        // this block's patch (and, the first time, the weights) are the oldest entries of the queue: the previous
+        // block's 2 output stores may stay in flight
+        if (first) wait_vmcnt<0>();
+        else wait_vmcnt<2>();
+        first = false;
+        wg_barrier();
+        if (blk + G < nblocks) stage_patch(blk + G, buf ^ 1);
+        const unsigned char* sp = s_p + buf * PATCH_BYTES;
+        f32x4_t acc[FN][FM];
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3) * PW + (t % 3);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                uint4 xf[FM], wf[FN];
+#pragma unroll
+                for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(sp + lds_off(pr0[b] + shift, kk * 4 + fchunk));
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+                    wf[a] = *reinterpret_cast<const uint4*>(s_w + t * W_TAP + lds_off(wn * 32 + a * 16 + frow, kk * 4 + fchunk));
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+            }
+        }
+        // bias + ReLU -> bf16 out tile (128-byte rows, chunk c at c ^ (row & 7)); the previous block's stores read it
+        // before the barrier at the top of this iteration
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int prow = wm * 32 + b * 16 + frow;
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int c = wn * 32 + a * 16 + fchunk * 4;
+                float v[4] = {acc[a][b][0] + cv[a].x, acc[a][b][1] + cv[a].y, acc[a][b][2] + cv[a].z, acc[a][b][3] + cv[a].w};
+                if (p.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                store4<bf16_t>(reinterpret_cast<bf16_t*>(s_o + prow * 128 + (((c >> 3) ^ (prow & 7)) << 4) + ((c & 4) << 1)), v);
+            }
+        }
+        wg_barrier();
+        {
+            const int img = blk / (tw * th);
+            const int trem = blk - img * (tw * th);
+            const int oy0 = (trem / tw) << 4, ox0 = (trem % tw) << 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (tid >> 3) + 64 * i, pch = tid & 7;
+                const size_t gm = ((size_t)img * p.H + oy0 + (row >> 3)) * p.W + ox0 + (row & 7);
+                const uint4 v = *reinterpret_cast<const uint4*>(s_o + row * 128 + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (gm * p.ldo + (pch ^ (row & 7)) * 8) * 2) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream) {
@@ -236,5 +370,13 @@ int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream) {
     const int grid = cdiv(nblocks, 2) * cdiv(p.N, 128);
     hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(grid), dim3(512), 0, stream, p, nblocks);
     AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 wide)");
+    return 0;
+}
+
+int launch_conv3x3_c64(const IgemmParams& p, hipStream_t stream) {
+    const int nblocks = (p.M / p.OH / p.OW) * (p.H / 16) * (p.W / 8);
+    const int grid = nblocks < 256 ? nblocks : 256;
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(512), 0, stream, p, nblocks);
+    AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 c64)");
     return 0;
 }

@@ -924,6 +924,12 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
             p.ksplit = 1;
             return launch_conv3x3_wide(p, (hipStream_t)stream);
         }
+        int c64 = -1;
+        if (const char* e = getenv("AGRL_CONV3X3_C64")) c64 = atoi(e);
+        if (Cin == 64 && Cout == 64 && p.ldo == 64 && c64 != 0 && (c64 == 1 || tiles >= 256)) {
+            p.ksplit = 1;
+            return launch_conv3x3_c64(p, (hipStream_t)stream);  // layer 1: weights resident, persistent over pixel blocks
+        }
         if (Cout <= 64)
             hipLaunchKernelGGL(conv3x3_patch_kernel<64>, dim3(tiles * cdiv(Cout, 64)), dim3(512), 0, (hipStream_t)stream, p);
         else

@@ -125,3 +125,4 @@ int launch_distmat_stream(const IgemmParams& p, int dtype, hipStream_t stream);
 
 // two-block 3x3 kernel (conv3x3_wide.hip)
 int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream);
+int launch_conv3x3_c64(const IgemmParams& p, hipStream_t stream);

@@ -208,6 +208,28 @@ def test_conv1x1_pool_fused(cfg, path, monkeypatch):
     assert rel_err(pooled_lp.float(), ref) < 5e-3
 
 
+@pytest.mark.parametrize("case", [(2, 32, 16, True), (3, 16, 8, False), (1, 64, 32, True), (5, 16, 24, True)])
+def test_conv3x3_c64_resident_weights(case, monkeypatch):
+    """Layer-1 3x3 (64 -> 64) persistent kernel with all nine taps' weights resident in LDS vs the one-block kernel."""
+    from torchreid import hip_ops as ops
+    N, H, W, relu = case
+    g = torch.Generator().manual_seed(N * H + W)
+    x = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
+    w = (torch.randn((64, 64, 3, 3), generator=g) / 24).bfloat16().float()
+    b = torch.randn((64,), generator=g)
+    ref = F.conv2d(x, w, bias=b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 1, 1, relu)
+    monkeypatch.setenv("AGRL_CONV3X3_C64", "1")
+    fast = ops.conv_bn_act(*args)
+    monkeypatch.setenv("AGRL_CONV3X3_C64", "0")
+    base = ops.conv_bn_act(*args)
+    torch.cuda.synchronize()
+    assert rel_err(fast.float().permute(0, 3, 1, 2), ref) < 1e-2
+    assert torch.equal(fast, base)
+
+
 WIDE3_CASES = [
     # N, H, W, Cin, Cout, relu -- the two-block 3x3 kernel (conv3x3_wide.hip), forced through AGRL_CONV3X3_WIDE=1
     (3, 16, 8, 128, 128, True),     # odd number of pixel blocks: the last workgroup has one valid block
