@@ -229,6 +229,81 @@ __global__ __launch_bounds__(256) void triplet_mine_kernel(const float* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// market1501 protocol (torchreid/metrics/rank.py:95-150; Cython twin rank_cylib/rank_cy.pyx:154-241) WITHOUT sorting
+// the row. The reference argsorts all n distances of a query and walks the ranking; but AP and CMC only depend on the
+// RANKS OF THE CORRECT MATCHES among the kept entries, and
+//     rank(r) = 1 + #{ kept j : (d_j, j) < (d_r, r) }           (stable order: ties -> lower gallery index)
+// is a counting pass. One workgroup per query: collect the (few) correct matches, count each one's rank with one sweep
+// of the row per match (a wavefront per match, wave_sum), sort the <= MAXREL ranks, then
+//     AP = sum_k k / rank_(k) / n_rel   (fp64, ascending k)      CMC[t] = 1 for t >= rank_(1) - 1.
+// "kept" = not (same identity AND same camera as the query); a query without any kept match is invalid (valid = 0).
+constexpr int MK_MAXREL = 4096;
+
+__global__ __launch_bounds__(256) void rank_market1501_kernel(const float* __restrict__ dist, int n, int ldd,
+                                                              const int32_t* __restrict__ q_pids, const int32_t* __restrict__ q_camids,
+                                                              const int32_t* __restrict__ g_pids, const int32_t* __restrict__ g_camids,
+                                                              int max_rank, double* __restrict__ ap, float* __restrict__ cmc,
+                                                              int32_t* __restrict__ valid) {
+    __shared__ int s_rel[MK_MAXREL];   // gallery indices of the correct matches, then their 1-based ranks
+    __shared__ int s_nrel;
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = dist + (size_t)q * ldd;
+    const int qp = q_pids[q], qc = q_camids[q];
+    if (tid == 0) s_nrel = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+        if (g_pids[j] == qp && g_camids[j] != qc) {
+            const int slot = atomicAdd(&s_nrel, 1);
+            if (slot < MK_MAXREL) s_rel[slot] = j;
+        }
+    }
+    __syncthreads();
+    const int nrel = s_nrel;
+    float* crow = cmc + (size_t)q * max_rank;
+    if (nrel == 0 || nrel > MK_MAXREL) {  // identity absent from the kept gallery (or more matches than the kernel holds)
+        for (int t = tid; t < max_rank; t += 256) crow[t] = 0.f;
+        if (tid == 0) {
+            ap[q] = nan("");
+            valid[q] = nrel == 0 ? 0 : -1;
+        }
+        return;
+    }
+    // rank of every correct match: a wavefront per match
+    __shared__ int s_rank[MK_MAXREL];
+    for (int r = wave; r < nrel; r += 4) {
+        const int jr = s_rel[r];
+        const float dr = row[jr];
+        int cnt = 0;
+        for (int j = lane; j < n; j += 64) {
+            const bool kept = !(g_pids[j] == qp && g_camids[j] == qc);
+            const float dj = row[j];
+            cnt += (kept && (dj < dr || (dj == dr && j < jr))) ? 1 : 0;
+        }
+        cnt = wave_sum_i(cnt);
+        if (lane == 0) s_rank[r] = cnt + 1;
+    }
+    __syncthreads();
+    // sort the ranks ascending: rank order statistics by counting (nrel is small; ranks are distinct)
+    for (int r = tid; r < nrel; r += 256) {
+        const int mine = s_rank[r];
+        int pos = 0;
+        for (int o = 0; o < nrel; ++o) pos += s_rank[o] < mine ? 1 : 0;
+        s_rel[pos] = mine;
+    }
+    __syncthreads();
+    const int first = s_rel[0];
+    for (int t = tid; t < max_rank; t += 256) crow[t] = t >= first - 1 ? 1.f : 0.f;
+    if (tid == 0) {
+        double acc = 0.0;
+        for (int k = 0; k < nrel; ++k) acc += (double)(k + 1) / (double)s_rel[k];
+        ap[q] = acc / (double)nrel;
+        valid[q] = 1;
+    }
+}
+
 }  // namespace
 
 extern "C" int agrl_rank_topk(const float* dist, int m, int n, int ldd, int k, int idx_offset, int32_t* idx, float* val,
@@ -262,5 +337,17 @@ extern "C" int agrl_triplet_hard_mine(const float* x, const int32_t* pids, int n
     hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, pids, n, d, dist_ap, dist_an,
                        idx_ap, idx_an);
     AGRL_CHECK_LAUNCH("agrl_triplet_hard_mine");
+    return 0;
+}
+
+extern "C" int agrl_rank_market1501(const float* dist, int m, int n, int ldd, const int32_t* q_pids, const int32_t* q_camids,
+                                    const int32_t* g_pids, const int32_t* g_camids, int max_rank, double* ap, float* cmc,
+                                    int32_t* valid, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(dist && q_pids && q_camids && g_pids && g_camids && ap && cmc && valid, "agrl_rank_market1501: null pointer");
+    AGRL_CHECK_ARG(m > 0 && n > 0 && ldd >= n && max_rank > 0 && max_rank <= n, "agrl_rank_market1501: bad shape m=%d n=%d ldd=%d max_rank=%d",
+                   m, n, ldd, max_rank);
+    hipLaunchKernelGGL(rank_market1501_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, dist, n, ldd, q_pids, q_camids, g_pids,
+                       g_camids, max_rank, ap, cmc, valid);
+    AGRL_CHECK_LAUNCH("agrl_rank_market1501");
     return 0;
 }

@@ -56,6 +56,7 @@ SIGNATURES = {
     "agrl_distmat": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p],
     "agrl_rank_topk": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
+    "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
 }
 

@@ -284,6 +284,21 @@ def rank_mars(topk_idx, q_pids, q_camids, g_pids, g_camids):
     return ap, cmc
 
 
+def rank_market1501(dist, q_pids, q_camids, g_pids, g_camids, max_rank):
+    """-> ap fp64 (m) (NaN when invalid), cmc fp32 (m,max_rank), valid int32 (m). rank.py:95-150."""
+    m, n = dist.shape
+    assert dist.dtype == torch.float32 and dist.stride(1) == 1
+    for t in (q_pids, q_camids, g_pids, g_camids):
+        assert t.dtype == torch.int32
+    ap = torch.empty((m,), dtype=torch.float64, device=dist.device)
+    cmc = torch.empty((m, max_rank), dtype=torch.float32, device=dist.device)
+    valid = torch.empty((m,), dtype=torch.int32, device=dist.device)
+    with _dev(dist):
+        _hip.call("agrl_rank_market1501", dist.data_ptr(), m, n, dist.stride(0), ptr(q_pids), ptr(q_camids), ptr(g_pids),
+                  ptr(g_camids), max_rank, ptr(ap), ptr(cmc), ptr(valid), _stream(dist))
+    return ap, cmc, valid
+
+
 def triplet_hard_mine(x, pids):
     """x (n,d) fp32, pids int32 (n) -> dist_ap, dist_an fp32 (n), idx_ap, idx_an int32 (n)."""
     n, d = x.shape

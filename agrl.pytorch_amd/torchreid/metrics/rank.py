@@ -6,8 +6,10 @@ Only the branch the reference's driver uses is on the hot path: ``use_metric_mar
 ``agrl_rank_mars`` (the AP / CMC walk in fp64, operation order of the reference). Without any GPU the
 same semantics are evaluated by the numpy host code below.
 
-The market1501 / cuhk03 protocols (reference rank.py:22-150 and its Cython twin) are SURVEY.md section 8(f)
-"next" rows and are not built yet: asking for them raises NotImplementedError rather than returning
+The market1501 protocol (reference rank.py:95-150 and its Cython twin rank_cylib/rank_cy.pyx:154-241, SURVEY.md
+section 8(f) row 1) runs on the device too: ``agrl_rank_market1501`` counts the rank of every correct match directly
+from the distance row (no full argsort). The cuhk03 protocol (rank.py:22-92: 100 random single-gallery-shot trials
+drawn from numpy's global RNG) is not built: asking for it raises NotImplementedError rather than returning
 something else.
 """
 from __future__ import absolute_import
@@ -108,13 +110,65 @@ def evaluate_mars(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
     return np.mean(cmc.cpu().numpy().astype(np.float64), axis=0), np.mean(ap)
 
 
+def _evaluate_market1501_host(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
+    """numpy evaluation with the reference's semantics (rank.py:95-150), stable ranking."""
+    num_q, num_g = distmat.shape
+    all_cmc, all_ap = [], []
+    for k in range(num_q):
+        order = np.argsort(distmat[k], kind='stable')
+        keep = ~((g_pids[order] == q_pids[k]) & (g_camids[order] == q_camids[k]))
+        raw = (g_pids[order] == q_pids[k])[keep].astype(np.int64)
+        if not raw.any():
+            continue
+        all_cmc.append(np.minimum(raw.cumsum(), 1)[:max_rank])
+        all_ap.append(((raw.cumsum() / (np.arange(raw.size) + 1.0)) * raw).sum() / raw.sum())
+    assert len(all_ap) > 0, 'Error: all query identities do not appear in gallery'
+    return np.asarray(all_cmc).astype(np.float32).sum(0) / float(len(all_ap)), np.mean(all_ap)
+
+
+def evaluate_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
+    """(CMC float32 (max_rank,), mAP) over the VALID queries (reference rank.py:95-150)."""
+    q_pids, g_pids = np.asarray(q_pids), np.asarray(g_pids)
+    q_camids, g_camids = np.asarray(q_camids), np.asarray(g_camids)
+    on_device = isinstance(distmat, torch.Tensor) and distmat.is_cuda
+    num_g = distmat.shape[1]
+    if num_g < max_rank:
+        max_rank = num_g
+        print('Note: number of gallery samples is quite small, got {}'.format(num_g))
+    if not (on_device or torch.cuda.is_available()):
+        d = distmat.numpy() if isinstance(distmat, torch.Tensor) else np.asarray(distmat)
+        return _evaluate_market1501_host(d, q_pids, g_pids, q_camids, g_camids, max_rank)
+    from torchreid import _hip, hip_ops as ops
+    _hip.lib()
+    dev = distmat.device if on_device else torch.device('cuda', torch.cuda.current_device())
+    d = distmat if on_device else torch.as_tensor(np.ascontiguousarray(distmat, dtype=np.float32))
+    d = d.to(device=dev, dtype=torch.float32)
+    if d.stride(-1) != 1:
+        d = d.contiguous()
+
+    def i32(a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+    ap, cmc, valid = ops.rank_market1501(d, i32(q_pids), i32(q_camids), i32(g_pids), i32(g_camids), max_rank)
+    valid = valid.cpu().numpy()
+    if (valid < 0).any():
+        raise RuntimeError('query {} has more correct matches than agrl_rank_market1501 holds'.format(int((valid < 0).argmax())))
+    ok = valid == 1
+    assert ok.any(), 'Error: all query identities do not appear in gallery'
+    num_valid = float(ok.sum())
+    all_cmc = cmc.cpu().numpy()[ok].astype(np.float32).sum(0) / num_valid
+    return all_cmc, np.mean(ap.cpu().numpy()[ok])
+
+
 def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, use_metric_cuhk03=False,
                   use_metric_market1501=False, use_metric_mars=False, use_cython=True):
     """Evaluate CMC and mAP; same signature and dispatch order as reference rank.py:215-238
     (returns None when no metric flag is set)."""
-    if use_metric_market1501 or use_metric_cuhk03:
+    if use_metric_cuhk03:
         raise NotImplementedError(
-            'market1501 / cuhk03 protocols are outside the vmgn hot path of this build (the reference driver '
-            'only uses use_metric_mars=True, train_vidreid_xent_htri.py:531)')
+            'the cuhk03 protocol (reference rank.py:22-92) is not built (the reference driver only uses '
+            'use_metric_mars=True, train_vidreid_xent_htri.py:531)')
+    if use_metric_market1501:  # ``use_cython`` selects between two implementations of the same protocol upstream
+        return evaluate_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)
     elif use_metric_mars:
         return evaluate_mars(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)

@@ -191,6 +191,17 @@ int agrl_rank_mars(const int32_t* topk_idx, const int32_t* q_pids, const int32_t
                    const int32_t* g_pids, const int32_t* g_camids, int m, int n, int k, double* ap,
                    float* cmc, agrl_stream_t stream);
 
+/* market1501 protocol for every query: eval_market1501, torchreid/metrics/rank.py:95-150 (Cython twin
+ * rank_cylib/rank_cy.pyx:154-241), from the distance matrix itself (no sorted ranking needed: the ranks of the correct
+ * matches among the kept entries are counted; stable order, ties towards the lower gallery index).
+ *   dist fp32 (m,n) row stride ldd; q_pids,q_camids int32 (m); g_pids,g_camids int32 (n); max_rank <= n
+ *   ap fp64 (m) (NaN for an invalid query); cmc fp32 (m,max_rank) (0/1); valid int32 (m): 1 valid, 0 the query identity
+ *   has no kept match in the gallery (the reference skips it), -1 more than 4096 matches (not evaluated).
+ * The caller averages ap / cmc over the valid queries (rank.py:144-148). */
+int agrl_rank_market1501(const float* dist, int m, int n, int ldd, const int32_t* q_pids,
+                         const int32_t* q_camids, const int32_t* g_pids, const int32_t* g_camids,
+                         int max_rank, double* ap, float* cmc, int32_t* valid, agrl_stream_t stream);
+
 /* ---- batch-hard triplet mining (train step, BASELINE config 4) ----------------------------------- */
 
 /* dist = sqrt(clamp(||x_i||^2+||x_j||^2-2x_i.x_j, 1e-12)); per anchor hardest positive (max over

@@ -208,6 +208,38 @@ def evaluate_mars(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, retu
     return cmc.mean(axis=0), ap.mean()
 
 
+def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, return_all=False):
+    """eval_market1501, rank.py:95-150 (and its Cython twin rank_cylib/rank_cy.pyx:154-241): per query the gallery
+    samples of the same identity AND camera are discarded; CMC = first correct match; AP over the FULL ranking
+    (sum of precision at every correct match / number of correct matches); queries whose identity is absent from the
+    (kept) gallery are skipped; both averages run over the valid queries only. The ranking is made deterministic
+    (stable sort: ties -> lower gallery index). -> (cmc float32 (max_rank,), mAP) [, ap (m,) with NaN for invalid
+    queries, first_hit (m,) 0-based rank of the first match or -1]."""
+    distmat = np.asarray(distmat)
+    q_pids, g_pids, q_camids, g_camids = map(np.asarray, (q_pids, g_pids, q_camids, g_camids))
+    m, n = distmat.shape
+    max_rank = min(max_rank, n)
+    all_cmc, ap = [], np.full(m, np.nan)
+    first_hit = np.full(m, -1, dtype=np.int64)
+    for k in range(m):
+        order = np.argsort(distmat[k], kind="stable")
+        keep = ~((g_pids[order] == q_pids[k]) & (g_camids[order] == q_camids[k]))
+        raw = (g_pids[order] == q_pids[k])[keep].astype(np.int64)
+        if not raw.any():
+            continue
+        cmc = np.minimum(raw.cumsum(), 1)
+        all_cmc.append(cmc[:max_rank])
+        first_hit[k] = int(np.argmax(raw))
+        prec = raw.cumsum() / (np.arange(raw.size) + 1.0)
+        ap[k] = (prec * raw).sum() / raw.sum()
+    assert all_cmc, "Error: all query identities do not appear in gallery"
+    cmc = np.asarray(all_cmc).astype(np.float32).sum(0) / float(len(all_cmc))
+    mAP = float(np.nanmean(ap))
+    if return_all:
+        return cmc, mAP, ap, first_hit
+    return cmc, mAP
+
+
 def triplet_hard(x, pids, margin=0.3, soft=True):
     """TripletLoss.forward, hard_mine_triplet_loss.py:24-50. Returns (loss, dist_ap, dist_an, idx_ap, idx_an)."""
     n = x.shape[0]

@@ -155,6 +155,17 @@ def main():
     save("rank_mars", dist=dist, q_pids=q_pids, g_pids=g_pids, q_camids=q_cam, g_camids=g_cam, cmc=cmc, mAP=np.float64(mAP),
          ap=np.array(aps, dtype=np.float64))
 
+    # ---- F9: market1501 protocol, python evaluator (rank.py:95-150; reached through evaluate_rank, :232-236) ----
+    rng = np.random.RandomState(91)
+    m, n = 40, 500
+    dist = rng.rand(m, n).astype(np.float32)
+    q_pids, g_pids = rng.randint(0, 14, m), rng.randint(0, 12, n)   # identities 12, 13 never appear in the gallery
+    q_cam, g_cam = rng.randint(0, 6, m), rng.randint(0, 6, n)
+    cmc, mAP = ref_rank.evaluate_rank(dist, q_pids, g_pids, q_cam, g_cam, max_rank=50, use_metric_market1501=True,
+                                      use_cython=False)
+    save("rank_market1501", dist=dist, q_pids=q_pids, g_pids=g_pids, q_camids=q_cam, g_camids=g_cam, cmc=cmc,
+         mAP=np.float64(mAP))
+
     # ---- F6: batch-hard triplet loss (hard_mine_triplet_loss.py:24-50) ----------------------------------
     g = torch.Generator().manual_seed(61)
     feats = torch.randn((16, 2048), generator=g)

@@ -3,6 +3,8 @@
 fp32 (exact-fp32 MFMA) must agree with the oracle to ~1e-5 relative; the north-star bar is 1e-3.
 bf16 is the throughput mode: operands rounded to bf16, fp32 accumulation -> tolerance 2e-2 of the output scale.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -471,6 +473,36 @@ def test_rank_mars_bit_exact():
     q_bad[0] = 999  # no match in the gallery
     with pytest.raises(ZeroDivisionError):
         metrics.evaluate_rank(d, q_bad, g_pids, q_cam, g_cam, use_metric_mars=True)
+
+
+@pytest.mark.parametrize("shape", [(40, 500), (7, 64), (64, 12180)])
+def test_rank_market1501_device(shape):
+    """agrl_rank_market1501 (rank counting, no argsort) vs the oracle restatement of eval_market1501: CMC and validity
+    exact, AP to fp64 rounding; plus the golden fixture produced by the reference's python evaluator."""
+    from torchreid import hip_ops as ops, metrics
+    m, n = shape
+    rng = np.random.RandomState(m + n)
+    d = rng.rand(m, n).astype(np.float32)
+    d[:, 5] = d[:, 3]                                           # exact ties: stable order decides
+    npid = max(4, n // 40)
+    q_pids, g_pids = rng.randint(0, npid + 2, m), rng.randint(0, npid, n)   # two identities absent from the gallery
+    q_cam, g_cam = rng.randint(0, 6, m), rng.randint(0, 6, n)
+    cmc_o, mAP_o, ap_o, first_o = O.eval_market1501(d, q_pids, g_pids, q_cam, g_cam, 50, return_all=True)
+    i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(DEV)
+    ap, cmc, valid = ops.rank_market1501(torch.from_numpy(d).to(DEV), i32(q_pids), i32(q_cam), i32(g_pids), i32(g_cam), min(50, n))
+    torch.cuda.synchronize()
+    ap, cmc, valid = ap.cpu().numpy(), cmc.cpu().numpy(), valid.cpu().numpy()
+    assert np.array_equal(valid == 1, ~np.isnan(ap_o))
+    assert np.array_equal(np.isnan(ap), np.isnan(ap_o))
+    ok = valid == 1
+    assert np.abs(ap[ok] - ap_o[ok]).max() < 1e-14
+    first = np.where(cmc[ok].max(1) > 0, cmc[ok].argmax(1), -1)
+    assert np.array_equal(first, np.where(first_o[ok] < min(50, n), first_o[ok], -1))
+    cmc2, mAP2 = metrics.evaluate_rank(d, q_pids, g_pids, q_cam, g_cam, max_rank=50, use_metric_market1501=True)
+    assert np.array_equal(cmc2, cmc_o) and abs(mAP2 - mAP_o) < 1e-14
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rank_market1501.npz"))
+    cmc3, mAP3 = metrics.evaluate_rank(z["dist"], z["q_pids"], z["g_pids"], z["q_camids"], z["g_camids"], use_metric_market1501=True)
+    assert np.array_equal(cmc3, z["cmc"]) and abs(mAP3 - float(z["mAP"])) < 1e-14
 
 
 def test_triplet_mining_and_loss():

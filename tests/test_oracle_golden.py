@@ -129,6 +129,28 @@ def test_rank_mars_bit_exact():
         assert mAP2 == float(z["mAP"]) and np.array_equal(cmc2, z["cmc"])
 
 
+def test_rank_market1501_matches_reference_python_and_cython():
+    """oracle.eval_market1501 against the reference's python evaluator (golden fixture, rank.py:95-150) and, when it has
+    been built from /root/reference (oracle/build_ref.py -> oracle/_ref/), against the reference's Cython evaluator."""
+    z = gold("rank_market1501")
+    args = (z["dist"], z["q_pids"], z["g_pids"], z["q_camids"], z["g_camids"])
+    cmc, mAP, ap, first = O.eval_market1501(*args, 50, return_all=True)
+    assert np.array_equal(cmc, z["cmc"])                      # CMC: integer counts / num_valid -> exact
+    assert abs(mAP - float(z["mAP"])) < 1e-14                 # fp64 sums in a different association order
+    assert np.isnan(ap).sum() == int(np.isin(z["q_pids"], [12, 13]).sum()) > 0   # identities absent from the gallery
+    if not torch.cuda.is_available():
+        from torchreid import metrics
+        cmc2, mAP2 = metrics.evaluate_rank(*args, use_metric_market1501=True)
+        assert np.array_equal(cmc2, z["cmc"]) and abs(mAP2 - float(z["mAP"])) < 1e-14
+    from oracle import build_ref
+    cy = build_ref.load()
+    if cy is None:
+        pytest.skip("oracle/_ref/rank_cy not built (needs /root/reference + Cython): python oracle/build_ref.py")
+    i64 = [np.ascontiguousarray(a, dtype=np.int64) for a in args[1:]]
+    cmc_cy, mAP_cy = cy.eval_market1501_cy(np.ascontiguousarray(z["dist"], dtype=np.float32), i64[0], i64[1], i64[2], i64[3], 50)
+    assert np.allclose(cmc_cy, cmc, atol=1e-6) and abs(mAP_cy - mAP) < 1e-6   # the Cython twin accumulates in fp32
+
+
 def test_triplet():
     z = gold("triplet")
     n, d, seed = [int(v) for v in z["meta"]]
