@@ -514,6 +514,71 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Pose adjacency on the device: generate_graph + adj_graph(method 'same'), torchreid/dataset_loader.py:218-388.
+// One workgroup per tracklet. Per frame and body part (head / body / leg keypoint groups) the confident keypoints'
+// y coordinates are bucketed into horizontal stripes (bisect_right on the stripe borders, clamped), the stripes
+// of a part are made contiguous, every stripe also marks its coarser pyramid ancestors -> one node bitmask per
+// (frame, part). adj[i][j] = 1 iff i != j and some part marks both nodes. Borders are evaluated in fp64 exactly as
+// numpy's arange(0, height + 1, height / num_split) does.
+__global__ __launch_bounds__(256) void pose_adjacency_kernel(const float* __restrict__ poses, const unsigned char* __restrict__ detected,
+                                                             float* __restrict__ adj, int S, int num_split, int levels,
+                                                             int pyramid, int P, double height, float threshold) {
+    __shared__ unsigned s_mask[3 * 64];  // [frame][part] node bitmask (P <= 31), S <= 64
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int V = S * P;
+    if (tid < 3 * S) {
+        const int t = tid / 3, part = tid - 3 * t;
+        unsigned mask = 0;
+        if (detected[(size_t)b * S + t]) {
+            // keypoint groups of the reference: head {0,1,14,15,16,17}, body {2..7}, leg {8..13}
+            const int ids[3][6] = {{0, 1, 14, 15, 16, 17}, {2, 3, 4, 5, 6, 7}, {8, 9, 10, 11, 12, 13}};
+            const float* kp = poses + ((size_t)b * S + t) * 18 * 3;
+            const double step = height / (double)num_split;
+            int lo = 1 << 30, hi = -1;
+            for (int i = 0; i < 6; ++i) {
+                const float* q = kp + ids[part][i] * 3;
+                if (q[2] > threshold) {
+                    // bisect_right(borders, y): number of borders <= y; borders = 0, step, 2 step, .. (< height + 1)
+                    int cnt = 0;
+                    for (int e = 0;; ++e) {
+                        const double border = (double)e * step;
+                        if (!(border < height + 1.0)) break;
+                        if (border <= (double)q[1]) ++cnt;
+                    }
+                    const int sid = min(num_split, max(1, cnt));
+                    lo = min(lo, sid);
+                    hi = max(hi, sid);
+                }
+            }
+            for (int sid = lo; sid <= hi; ++sid) {   // contiguous stripes (empty when no confident keypoint)
+                mask |= 1u << (sid - 1);
+                if (pyramid) {
+                    for (int i = 1; i <= levels; ++i) {
+                        const int anc = (sid + (1 << i) - 1) >> i;                                  // ceil(sid / 2^i)
+                        mask |= 1u << (anc + (1 << (levels + 1)) - (1 << (levels + 1 - i)) - 1);
+                    }
+                }
+            }
+        }
+        s_mask[tid] = mask;
+    }
+    __syncthreads();
+    float* ab = adj + (size_t)b * V * V;
+    for (int e = tid; e < V * V; e += 256) {
+        const int i = e / V, j = e - i * V;
+        const int ti = i / P, pi = i - ti * P, tj = j / P, pj = j - tj * P;
+        bool on = false;
+        if (i != j) {
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                on = on || (((s_mask[ti * 3 + part] >> pi) & 1u) && ((s_mask[tj * 3 + part] >> pj) & 1u));
+        }
+        ab[e] = on ? 1.f : 0.f;
+    }
+}
+
 }  // namespace
 
 extern "C" int agrl_graph_gram(const float* f, float* gram_part, int B, int V, int C, int cslice,
@@ -619,5 +684,20 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     LAUNCH_PROP(0);
 #undef LAUNCH_PROP
     AGRL_CHECK_LAUNCH("agrl_graph_propagate");
+    return 0;
+}
+
+extern "C" int agrl_pose_adjacency(const float* poses, const unsigned char* detected, float* adj, int B, int S, int num_split,
+                                   int pyramid_part, float height, float threshold, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(poses && detected && adj, "agrl_pose_adjacency: null pointer");
+    AGRL_CHECK_ARG(B > 0 && S > 0 && S <= 64, "agrl_pose_adjacency: 1 <= S <= 64 frames (got %d)", S);
+    AGRL_CHECK_ARG(num_split >= 1 && num_split <= 16 && (num_split & (num_split - 1)) == 0,
+                   "agrl_pose_adjacency: num_split must be a power of two <= 16 (got %d)", num_split);
+    int levels = 0;
+    while ((1 << levels) < num_split) ++levels;
+    const int P = pyramid_part ? 2 * num_split - 1 : num_split;
+    hipLaunchKernelGGL(pose_adjacency_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, poses, detected, adj, S, num_split, levels,
+                       pyramid_part ? 1 : 0, P, (double)height, threshold);
+    AGRL_CHECK_LAUNCH("agrl_pose_adjacency");
     return 0;
 }

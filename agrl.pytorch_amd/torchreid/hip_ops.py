@@ -284,6 +284,21 @@ def rank_mars(topk_idx, q_pids, q_camids, g_pids, g_camids):
     return ap, cmc
 
 
+def pose_adjacency(poses, detected, height, num_split=4, pyramid_part=True, threshold=0.1):
+    """AlphaPose keypoints (B,S,18,3) fp32 + per-frame detection flags (B,S) -> adjacency (B,V,V) fp32 on the device.
+    dataset_loader.py:218-388 (generate_graph + adj_graph)."""
+    B, S = poses.shape[:2]
+    assert poses.dtype == torch.float32 and tuple(poses.shape[2:]) == (18, 3)
+    det = detected.to(torch.uint8).contiguous()
+    assert tuple(det.shape) == (B, S)
+    P = 2 * num_split - 1 if pyramid_part else num_split
+    adj = torch.empty((B, S * P, S * P), dtype=torch.float32, device=poses.device)
+    with _dev(poses):
+        call("agrl_pose_adjacency", ptr(poses.contiguous()), ptr(det), ptr(adj), B, S, int(num_split), 1 if pyramid_part else 0,
+             float(height), float(threshold), _stream(poses))
+    return adj
+
+
 def rank_market1501(dist, q_pids, q_camids, g_pids, g_camids, max_rank):
     """-> ap fp64 (m) (NaN when invalid), cmc fp32 (m,max_rank), valid int32 (m). rank.py:95-150."""
     m, n = dist.shape

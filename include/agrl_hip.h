@@ -95,6 +95,16 @@ int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const 
 int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
                        int in_dtype, agrl_stream_t stream);
 
+/* ---- pose adjacency (the model's second input, built on the device) ------------------------------ */
+
+/* generate_graph + adj_graph(method 'same') of torchreid/dataset_loader.py:218-388 for a batch of tracklets:
+ *   poses fp32 (B,S,18,3) AlphaPose keypoints (x, y, confidence); detected uint8 (B,S) -- 0 where the frame has no
+ *   pose entry (its P x P blocks stay zero); height = frame height in pixels; threshold = 0.1 in the reference;
+ *   num_split a power of two; pyramid_part != 0 adds the coarser stripe levels (P = 2 num_split - 1 nodes per frame).
+ *   adj fp32 (B, S*P, S*P), values {0,1}, symmetric, zero diagonal: the layout GSTA.forward consumes (vmgn.py:292). */
+int agrl_pose_adjacency(const float* poses, const unsigned char* detected, float* adj, int B, int S,
+                        int num_split, int pyramid_part, float height, float threshold, agrl_stream_t stream);
+
 /* ---- pooling ------------------------------------------------------------------------------- */
 
 /* Part pooling + per-frame global pooling, one pass over the two layer4 maps.

@@ -505,6 +505,24 @@ def test_rank_market1501_device(shape):
     assert np.array_equal(cmc3, z["cmc"]) and abs(mAP3 - float(z["mAP"])) < 1e-14
 
 
+def test_pose_adjacency_device():
+    """agrl_pose_adjacency vs the reference's generate_graph (golden fixture) and vs the oracle on random poses,
+    incl. undetected frames, low-confidence keypoints, num_split 8 and the non-pyramid layout."""
+    from torchreid import hip_ops as ops
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_adjacency.npz"))
+    S, width, height, num_split = [int(v) for v in z["meta"]]
+    adj = ops.pose_adjacency(torch.from_numpy(z["poses"][None]).to(DEV), torch.from_numpy(z["detected"][None]).to(DEV), height, num_split)
+    assert np.array_equal(adj[0].cpu().numpy(), z["adj"])
+    rng = np.random.RandomState(17)
+    for (B, S, H, ns, pyr) in ((5, 8, 256, 4, True), (3, 16, 256, 4, True), (2, 4, 250, 8, True), (4, 8, 256, 4, False), (2, 6, 100, 2, True)):
+        poses = np.stack([rng.rand(B, S, 18) * 128, rng.rand(B, S, 18) * (H + 8) - 4, rng.rand(B, S, 18) * 0.5], axis=-1).astype(np.float32)
+        det = rng.rand(B, S) > 0.15
+        got = ops.pose_adjacency(torch.from_numpy(poses).to(DEV), torch.from_numpy(det).to(DEV), H, ns, pyr).cpu().numpy()
+        for b in range(B):
+            sets = [O.pose_part_sets(poses[b, t] if det[b, t] else None, H, ns) for t in range(S)]
+            assert np.array_equal(got[b], O.pose_adjacency(sets, ns, pyr)), (B, S, H, ns, pyr, b)
+
+
 def test_triplet_mining_and_loss():
     from torchreid import losses, hip_ops as ops
     g = torch.Generator().manual_seed(1)
