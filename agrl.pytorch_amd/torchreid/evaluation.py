@@ -32,13 +32,53 @@ def pool_clips(features, num_clips, pool="avg"):
     return f.mean(dim=1) if pool == "avg" else f.max(dim=1)[0]
 
 
+def device_prefetch(batches, device):
+    """Upload batch i+1 on a copy stream while batch i is being processed (the reference's test() uploads inside the
+    loop, train_vidreid_xent_htri.py:460, and its loaders hand over pinned tensors, :222-247 ``pin_memory``): with pinned
+    sources the 100 MB of fp32 frames per 256-frame batch cross PCIe under the previous batch's forward. Yields the same
+    tuples with imgs / adj on ``device``; tensors already there pass through."""
+    if device.type != "cuda":
+        for item in batches:
+            yield item
+        return
+    copy_stream = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+
+    def upload(item):
+        imgs, pid, camid, adj = item
+        with torch.cuda.stream(copy_stream):
+            imgs_d, adj_d = imgs.to(device, non_blocking=True), adj.to(device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        return imgs_d, pid, camid, adj_d, done
+
+    pending = None
+    for item in batches:
+        nxt = upload(item)
+        if pending is not None:
+            yield _claim(pending, main)
+        pending = nxt
+    if pending is not None:
+        yield _claim(pending, main)
+
+
+def _claim(pending, main):
+    imgs_d, pid, camid, adj_d, done = pending
+    main.wait_event(done)
+    imgs_d.record_stream(main)
+    adj_d.record_stream(main)
+    return imgs_d, pid, camid, adj_d
+
+
 @torch.no_grad()
-def extract_features(model, batches, pool="avg"):
+def extract_features(model, batches, pool="avg", prefetch=True):
     """``batches`` yields (imgs, pids, camids, adj) like the reference's loaders; imgs is (b,S,3,H,W) or, for the
     dense samplers, (b,n,S,3,H,W) with adj (b,n,V,V). Returns (features (N,D) on the model's device, pids, camids)."""
     device = next(model.parameters()).device
     model.eval()
     feats, pids, camids = [], [], []
+    if prefetch:
+        batches = device_prefetch(batches, device)
     for imgs, pid, camid, adj in batches:
         imgs, adj = imgs.to(device, non_blocking=True), adj.to(device, non_blocking=True)
         clips = 1
