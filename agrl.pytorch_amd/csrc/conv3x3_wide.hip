@@ -20,6 +20,7 @@
 
 namespace {
 
+template <int DBG>  // ablation bits (profiling only): 1 no weight DMA after the prologue, 2 no MFMA, 4 no fragment reads, 8 no waits / barriers
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, int nblocks) {
     constexpr int BN = 128, NW = 8, WM = 4, BM = 256;
     constexpr int FM = BM / (16 * WM), FN = BN / 32;  // 4 x 4 fragments per wave
@@ -150,14 +151,15 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
                 const bool more = step + 1 < nsteps;
                 const int ptap = tap - 1;  // the tap of step-1 (same slab unless tap == 0)
                 const bool patch_younger = (tap >= 1) && (ptap < PJ) && next_slab;
-                if (!more) wait_vmcnt<0>();
+                if (DBG & 8) {
+                } else if (!more) wait_vmcnt<0>();
                 else if (patch_younger) wait_vmcnt<BJ + 1>();
                 else wait_vmcnt<BJ>();
             }
-            wg_barrier();
+            if (!(DBG & 8)) wg_barrier();
             // refill: next slab's patch piece, then the weights two steps ahead (into the slot read at step-1)
-            if (tap < PJ && next_slab) stage_patch_piece(slab + 1, tap);
-            if (step + 2 < nsteps) {
+            if (tap < PJ && next_slab && !(DBG & 1)) stage_patch_piece(slab + 1, tap);
+            if (step + 2 < nsteps && !(DBG & 1)) {
                 int t2 = tap + 2, s2 = slab;
                 if (t2 >= 9) { t2 -= 9; ++s2; }
                 int slot2 = wslot + 2;
@@ -169,8 +171,12 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
             const unsigned char* sb = s_b + wslot * B_BYTES;
             // 8 groups of 4 MFMAs: group g = (k-step g >> 2, channel fragment g & 3)
             uint4 xfr[2][FM], wfr[3];
-            auto ldx = [&](int kk, int b) { return *reinterpret_cast<const uint4*>(sp + lds_off(pr0[b] + shift, kk * 4 + fchunk)); };
+            auto ldx = [&](int kk, int b) {
+                if ((DBG & 4) && step) return make_uint4(step, kk, b, lane);
+                return *reinterpret_cast<const uint4*>(sp + lds_off(pr0[b] + shift, kk * 4 + fchunk));
+            };
             auto ldw = [&](int g) {
+                if ((DBG & 4) && step) return make_uint4(step, g, 7, lane);
                 return *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + (g & 3) * 16 + frow, (g >> 2) * 4 + fchunk));
             };
             wfr[0] = ldw(0);
@@ -182,7 +188,10 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
                 if (g + 2 < 8) wfr[(g + 2) % 3] = ldw(g + 2);
                 if (g < FM) xfr[1][g] = ldx(1, g);
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[g & 3][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g >> 2][b], acc[g & 3][b]);
+                for (int b = 0; b < FM; ++b) {
+                    if (!(DBG & 2)) acc[g & 3][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g >> 2][b], acc[g & 3][b]);
+                    else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g >> 2][b].x), "v"(xfr[g >> 2][b].w));
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             wslot = wslot + 1 == WSLOTS ? 0 : wslot + 1;
@@ -368,7 +377,14 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
 int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream) {
     const int nblocks = (p.M / p.OH / p.OW) * (p.H / 16) * (p.W / 8);
     const int grid = cdiv(nblocks, 2) * cdiv(p.N, 128);
-    hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(grid), dim3(512), 0, stream, p, nblocks);
+    int dbg = 0;
+    if (const char* e = getenv("AGRL_CONV3X3_DBG")) dbg = atoi(e);
+    switch (dbg) {
+#define C3_CASE(D) case D: hipLaunchKernelGGL(conv3x3_wide_kernel<D>, dim3(grid), dim3(512), 0, stream, p, nblocks); break
+        C3_CASE(1); C3_CASE(2); C3_CASE(4); C3_CASE(8); C3_CASE(5); C3_CASE(13); C3_CASE(6); C3_CASE(9);
+#undef C3_CASE
+        default: hipLaunchKernelGGL(conv3x3_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p, nblocks);
+    }
     AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 wide)");
     return 0;
 }

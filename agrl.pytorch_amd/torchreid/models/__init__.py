@@ -1,7 +1,8 @@
 """Model registry (reference: torchreid/models/__init__.py:17-41).
 
-Only ``vmgn`` -- the model BASELINE.json's north_star names -- is provided by this build; the reference's
-sibling architectures are out of the hot path.
+``vmgn`` -- the model BASELINE.json's north_star names -- and its single-branch predecessor ``gsta`` (same GraphLayer,
+same kernels) are provided by this build; the reference's other sibling architectures are
+out of the hot path.
 """
 from __future__ import absolute_import
 
@@ -10,9 +11,11 @@ import os
 import shutil
 
 from .vmgn import *
+from .gsta import *
 
 __model_factory = {
     'vmgn': vmgn,
+    'gsta': gsta,
 }
 
 

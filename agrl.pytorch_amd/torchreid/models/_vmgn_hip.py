@@ -77,12 +77,17 @@ def pack_weights(model, device, precision):
             'stem': (stem_w, stem_b),
             'stem_lp': ops.pack_stem_weights_bf16(stem_w) if dtype == torch.bfloat16 else None,
             'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype),
-            'l4_1': _pack_stage(model.layer4_1, dtype),
-            'l4_2': _pack_stage(model.layer4_2, dtype),
             'graph': [],
-            'g_bn': _fold_bn1d(model.global_bottleneck),
-            'a_bn': _fold_bn1d(model.att_bottleneck),
         }
+        if hasattr(model, 'layer4_1'):   # vmgn: two layer4 branches, two BNNecks
+            pack['l4_1'] = _pack_stage(model.layer4_1, dtype)
+            pack['l4_2'] = _pack_stage(model.layer4_2, dtype)
+            pack['g_bn'] = _fold_bn1d(model.global_bottleneck)
+            pack['a_bn'] = _fold_bn1d(model.att_bottleneck)
+        else:                            # gsta: one branch, one BNNeck (the unused global half gets an identity)
+            pack['l4'] = _pack_stage(model.layer4, dtype)
+            pack['a_bn'] = _fold_bn1d(model.bottleneck)
+            pack['g_bn'] = (torch.ones_like(pack['a_bn'][0]), torch.zeros_like(pack['a_bn'][1]))
         for layer in model.graph_layers:
             scale, shift = _fold_bn1d(layer.bn)
             pack['graph'].append({
@@ -248,3 +253,44 @@ def hip_forward(model, x, adj, return_feats=False):
         sqn = ops.row_sqnorm(nodes.view(B * V, C))
         return ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
                                     pack['a_bn'][1], B, S, P, hw, want_feats=return_feats)
+
+
+def hip_forward_gsta(model, x, adj):
+    """Eval forward of the single-branch ``gsta`` on the GPU: (B,S,3,H,W) fp32, (B,V,V) fp32 -> (B,2048) fp32.
+    reference gsta.py:273-298. Same kernels as vmgn; the attention tail kernel writes cat(BN(global), BN(attention)) and
+    only its second half exists for this model (the global half is fed zeros)."""
+    _hip.lib()
+    if x.dtype != torch.float32:
+        raise TypeError('frames must be float32, got {}'.format(x.dtype))
+    B, S, Cc, H, W = x.shape
+    P = model.total_split
+    V = S * P
+    if tuple(adj.shape) != (B, V, V):
+        raise ValueError('adj must be {} for S={} and {} parts, got {}'.format((B, V, V), S, P, tuple(adj.shape)))
+    pack = pack_weights(model, x.device, model.hip_precision)
+    lp = pack['dtype'] == torch.bfloat16
+    splits = list(model.total_split_list)
+    with torch.no_grad():
+        frames = x.reshape(B * S, Cc, H, W)
+        a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+        a = _run_trunk(a, pack['trunk'], model.hip_fuse_tail)
+        hw = (a.shape[1] // pack['l4'][0]['stride']) * (a.shape[2] // pack['l4'][0]['stride'])
+        if lp and model.hip_fuse_pool and a.shape[1] * a.shape[2] == 128 and pack['l4'][0]['stride'] == 1:
+            for blk in pack['l4'][:-1]:
+                a = _run_block(a, blk)
+            nodes, nodes_lp = _run_block(a, pack['l4'][-1], pool=(splits, True, True))
+            hw = 128
+        else:
+            for blk in pack['l4']:
+                a = _run_block(a, blk)
+            hw = a.shape[1] * a.shape[2]
+            _, nodes, nodes_lp = ops.part_pool(a, a, splits, want_lp=lp)
+        C = nodes.shape[-1]
+        nodes = nodes.view(B, V, C)
+        if nodes_lp is not None:
+            nodes_lp = nodes_lp.view(B, V, C)
+        nodes = hip_graph_layers(nodes, nodes_lp, adj.detach().to(torch.float32).contiguous(), pack)
+        sqn = ops.row_sqnorm(nodes.view(B * V, C))
+        gsum = torch.zeros((B * S, C), dtype=torch.float32, device=x.device)
+        out = ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0], pack['a_bn'][1], B, S, P, hw)
+        return out[:, C:].contiguous()

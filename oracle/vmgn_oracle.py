@@ -143,6 +143,22 @@ def vmgn_eval(x, adj, sd, num_split=4, pyramid_part=True, num_gb=2, use_pose=Tru
     return tail(x4_1, x4_2, adj, sd, B, S, splits, num_gb, use_pose, learn_graph)
 
 
+def gsta_eval(x, adj, sd, num_split=4, pyramid_part=True, num_gb=2, use_pose=True, learn_graph=True):
+    """Single-branch sibling (torchreid/models/gsta.py:273-298, eval): ResNet50 with one layer4 (last stride 1,
+    gsta.py:194) -> part pooling -> the same GraphLayer x num_gb -> attention pooling -> BN ``bottleneck`` -> (B,2048)."""
+    B, S = x.shape[:2]
+    splits = calc_splits(num_split) if pyramid_part else [num_split]
+    f = stem(x.reshape((B * S,) + tuple(x.shape[2:])), sd)
+    for name, blocks, stride in RESNET50_STAGES:
+        f = stage(f, sd, name, blocks, stride)
+    f = stage(f, sd, "layer4", 3, 1)
+    nodes = part_nodes(f, B, S, splits)
+    for i in range(num_gb):
+        nodes = graph_layer(nodes, adj, sd, "graph_layers.%d" % i, use_pose, learn_graph)
+    att_f = attention_pool(nodes.reshape(B, S, sum(splits), nodes.shape[-1]))
+    return _bn(att_f, sd, "bottleneck")
+
+
 # ---- match side ------------------------------------------------------------------------------------------
 
 def euclidean_squared(q, g):

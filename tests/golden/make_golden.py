@@ -122,6 +122,25 @@ def main():
         save("vmgn_eval_" + tag, out=y, x4_1_mean=x4_1.mean(dim=(2, 3)), x4_2_mean=x4_2.mean(dim=(2, 3)),
              meta=np.array([B, S, seed, 0]))
 
+    # ---- F10: sibling model gsta (gsta.py:173-336): eval forward + state-dict keys + train outputs --------------
+    ref_gsta = load("ref_gsta", "torchreid/models/gsta.py")
+    ref_gsta.init_pretrained_weights = lambda *a, **k: None
+    gm = ref_gsta.gsta(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                       pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)
+    gsd = recipe_state_dict(gm.state_dict(), seed=0)
+    gm.load_state_dict(gsd)
+    gm.eval()
+    x, adj = synthetic_clips(2, 4, seed=4), synthetic_adj(2, 4, seed=4)
+    with torch.no_grad():
+        gy = gm(x, adj)
+    gm.train()
+    xt, adjt = synthetic_clips(2, 8, seed=8), synthetic_adj(2, 8, seed=8)
+    np.random.seed(123)
+    outs, feats = gm(xt, adjt)
+    save("gsta_b2s4", out=gy, keys=np.array(sorted(gsd.keys())), shapes=np.array([str(tuple(gsd[k].shape)) for k in sorted(gsd.keys())]),
+         train_logits=torch.stack([o.detach() for o in outs]), train_feats=torch.stack([f.detach() for f in feats]),
+         meta=np.array([2, 4, 4, 0]))
+
     # ---- F8: train-mode outputs with the consistent loss (vmgn.py:323-357) ---------------------------------
     model_t = ref_vmgn.vmgn(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
                             pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)

@@ -65,6 +65,29 @@ def test_vmgn_eval_bf16_close_and_ranking_preserved():
     assert d_ref[0].argmin().item() == 1 and d_got[0].argmin().item() == 1
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+def test_gsta_sibling_eval_matches_oracle(precision, tol):
+    """``gsta`` (single layer4 branch, one BNNeck) through the same HIP kernels vs oracle.gsta_eval (pinned on the
+    reference's gsta.py by tests/golden/gsta_b2s4.npz)."""
+    from torchreid import models
+    m = models.init_model("gsta", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    m.load_state_dict(sd)
+    m.eval()
+    m.hip_precision = precision
+    for B, S in ((2, 4), (3, 8)):
+        x, adj = synthetic_clips(B, S, seed=B + S), synthetic_adj(B, S, seed=B + S)
+        with torch.no_grad():
+            ref = O.gsta_eval(x, adj, sd)
+        got = m.to(DEV)(x.to(DEV), adj.to(DEV))
+        torch.cuda.synchronize()
+        assert got.shape == (B, 2048)
+        err = ((got.cpu().double() - ref.double()).abs().max() / ref.double().abs().max()).item()
+        print("gsta", precision, (B, S), "rel err %.3e" % err)
+        assert err < tol
+
+
 def test_weight_cache_tracks_parameter_updates():
     m, sd = build()
     m = m.to(DEV)

@@ -104,6 +104,32 @@ def test_vmgn_train_outputs_match_reference():
         close(feats[i].detach(), z["feat%d" % i], 1e-4)
 
 
+def test_gsta_sibling_model_matches_reference():
+    """The single-branch sibling ``gsta``: oracle.gsta_eval and this build's module tree against the
+    reference's gsta.py -- eval output, state-dict keys/shapes, and train-mode outputs with the consistent loss (whose
+    dropped frames come from numpy's global RNG)."""
+    from torchreid import models
+    z = gold("gsta_b2s4")
+    m = models.init_model("gsta", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)
+    own = m.state_dict()
+    assert sorted(own.keys()) == list(z["keys"])
+    assert [str(tuple(own[k].shape)) for k in sorted(own.keys())] == list(z["shapes"])
+    assert not m.bottleneck.bias.requires_grad
+    sd = recipe_state_dict(own, seed=0)
+    m.load_state_dict(sd)
+    x, adj = synthetic_clips(2, 4, seed=4), synthetic_adj(2, 4, seed=4)
+    with torch.no_grad():
+        close(O.gsta_eval(x, adj, sd), z["out"], 1e-5)
+        m.eval()
+        close(m(x, adj), z["out"], 1e-5)
+    m.train()
+    np.random.seed(123)
+    outs, feats = m(synthetic_clips(2, 8, seed=8), synthetic_adj(2, 8, seed=8))
+    close(torch.stack([o.detach() for o in outs]), z["train_logits"], 1e-4)
+    close(torch.stack([f.detach() for f in feats]), z["train_feats"], 1e-4)
+
+
 def test_distmat():
     z = gold("distmat")
     m, n, D, seed = [int(v) for v in z["meta"]]
