@@ -1,0 +1,88 @@
+"""Race screen for the hand-synchronised kernels: repeat the full-size layer shapes many times on random data and demand
+bitwise-identical outputs against the first run and against the simpler kernel of the same contraction where one exists
+(the LDS rings, counted waits and in-place epilogues either work every time or show up here as rare differing tiles)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
+    sys.path.insert(0, p)
+import torch
+from torchreid import hip_ops as ops
+dev = "cuda:0"
+torch.manual_seed(0)
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+
+def conv_case(N, H, W, Cin, Cout, R, stride, res, env_alt):
+    x = torch.randn((N, H, W, Cin), device=dev).bfloat16()
+    w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).bfloat16()
+    b = torch.randn((Cout,), device=dev)
+    OH, OW = (H + 2 * (R // 2) - R) // stride + 1, (W + 2 * (R // 2) - R) // stride + 1
+    r = torch.randn((N, OH, OW, Cout), device=dev).bfloat16() if res else None
+    for k in env_alt:
+        os.environ[k] = env_alt[k]
+    ref = ops.conv_bn_act(x, w, b, stride, R // 2, True, r).clone()
+    for k in env_alt:
+        os.environ.pop(k)
+    bad = 0
+    for _ in range(REPS):
+        out = ops.conv_bn_act(x, w, b, stride, R // 2, True, r)
+        bad += int(not torch.equal(out, ref))
+    return bad
+
+cases = [("wide 1x1 2048->512", (256, 16, 8, 2048, 512, 1, 1, False, {"AGRL_IGEMM_WIDE": "0"})),
+         ("wide 1x1 512->2048 +res", (256, 16, 8, 512, 2048, 1, 1, True, {"AGRL_IGEMM_WIDE": "0"})),
+         ("wide128 1x1 1024->256", (256, 16, 8, 1024, 256, 1, 1, False, {"AGRL_IGEMM_WIDE": "0"})),
+         ("wide strided 256->512 s2", (256, 64, 32, 256, 512, 1, 2, False, {"AGRL_IGEMM_WIDE": "0"})),
+         ("3x3 two-block 512->512", (256, 16, 8, 512, 512, 3, 1, False, {"AGRL_CONV3X3_WIDE": "0"})),
+         ("3x3 c64 64->64", (256, 64, 32, 64, 64, 3, 1, False, {"AGRL_CONV3X3_C64": "0"}))]
+total = 0
+for name, c in cases:
+    bad = conv_case(*c)
+    total += bad
+    print("%-28s %d / %d runs differ from the baseline kernel" % (name, bad, REPS))
+
+# fused tails vs the split convs
+N, H, W = 256, 64, 32
+y2 = torch.randn((N, H, W, 64), device=dev).bfloat16()
+res = torch.randn((N, H, W, 256), device=dev).bfloat16()
+w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+b3 = torch.randn(256, device=dev)
+for cn in (64, 128):
+    w1 = (torch.randn((cn, 1, 1, 256), device=dev) / 16).bfloat16()
+    b1 = torch.randn(cn, device=dev)
+    o_ref = ops.conv_bn_act(y2, w3, b3, 1, 0, True, residual=res)
+    z_ref = ops.conv_bn_act(o_ref, w1, b1, 1, 0, True)
+    bad = 0
+    for _ in range(REPS):
+        o, z = ops.bottleneck_tail(y2, w3, b3, res, w1, b1)
+        bad += int(not (torch.equal(o, o_ref) and torch.equal(z, z_ref)))
+    total += bad
+    print("%-28s %d / %d runs differ from the split convs" % ("bottleneck tail cnext=%d" % cn, bad, REPS))
+x0 = torch.randn((N, H, W, 64), device=dev).bfloat16()
+ws = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+bs = torch.randn(256, device=dev)
+w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).bfloat16()
+b1 = torch.randn(64, device=dev)
+o0, z0 = ops.bottleneck_tail(y2, w3, b3, None, w1, b1, shortcut=(x0, ws, bs))
+o0, z0 = o0.clone(), z0.clone()
+bad = 0
+for _ in range(REPS):
+    o, z = ops.bottleneck_tail(y2, w3, b3, None, w1, b1, shortcut=(x0, ws, bs))
+    bad += int(not (torch.equal(o, o0) and torch.equal(z, z0)))
+total += bad
+print("%-28s %d / %d runs differ from the first run" % ("bottleneck tail + downsample", bad, REPS))
+# streaming kernels: run-to-run determinism
+f = torch.randn((32, 56, 2048), device=dev); h = torch.randn((32, 56, 2048), device=dev); G = torch.rand((32, 56, 56), device=dev)
+sc, sh = torch.rand(2048, device=dev) + 0.5, torch.randn(2048, device=dev)
+p0 = ops.graph_propagate(f, h, G, sc, sh, 0.1, 0.1, want_lp=True)
+q = torch.randn((32, 4096), device=dev).bfloat16(); g = torch.randn((12180, 4096), device=dev).bfloat16()
+d0 = ops.distmat(q, g, "cosine").clone()
+bad = 0
+for _ in range(REPS):
+    p1 = ops.graph_propagate(f, h, G, sc, sh, 0.1, 0.1, want_lp=True)
+    bad += int(not (torch.equal(p1[0], p0[0]) and torch.equal(p1[1], p0[1])))
+    bad += int(not torch.equal(ops.distmat(q, g, "cosine"), d0))
+total += bad
+print("%-28s %d / %d runs differ from the first run" % ("propagate + distmat", bad, 2 * REPS))
+torch.cuda.synchronize()
+print("RACE SCREEN", "CLEAN" if total == 0 else "FAILED (%d)" % total)
+sys.exit(1 if total else 0)
