@@ -250,7 +250,9 @@ def distmat(q, g, metric, qn=None, gn=None, out=None):
     if _hip.PROFILE is not None:  # (m+n)*D*e + m*n*4
         _hip.PROFILE_TAG = {"flops": 2.0 * m * n * D, "bytes": q.element_size() * (m + n) * D + 4.0 * m * n}
     ws = None
-    if m * 64 <= n:  # streaming form: hand the kernel scratch for its split-K partials
+    # few output tiles (one eval batch against a long gallery, or the gathered queries of an 8-GPU step against a gallery
+    # shard): hand the kernel scratch for split-K partials; the m <= 64 streaming kernels ignore it
+    if (-(-m // 64)) * (-(-n // 128)) < 256:
         ws = torch.empty((8 * m * n,), dtype=torch.float32, device=q.device)
     with _dev(q):
         _hip.call("agrl_distmat", ptr(q), ptr(g), ptr(qn), ptr(gn), out.data_ptr(), m, n, D, out.stride(0), code,

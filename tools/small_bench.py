@@ -56,3 +56,13 @@ for label, fn, nbytes in CASES:
                     times[nm].append(s.elapsed_time(e) * 1000 / reps)
         print("%-52s %-5s " % (label, "cold" if cold else "warm") + "  ".join(
             "%s %6.1fus %5.2fTB/s" % (nm, statistics.median(times[nm]), nbytes / statistics.median(times[nm]) / 1e6) for nm, _ in variants))
+
+# the N = 8 match stage of bench.py: 256 gathered queries against a 1523-row gallery shard
+q8 = torch.randn((256, D), device=dev).bfloat16(); g8 = torch.randn((1523, D), device=dev).bfloat16()
+for _ in range(3): ops.distmat(q8, g8, "cosine")
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(20): ops.distmat(q8, g8, "cosine")
+e.record(); torch.cuda.synchronize()
+print("distmat bf16 256 x 1523 x 4096 (8-GPU shard): %.1f us" % (s.elapsed_time(e) * 50))
