@@ -101,3 +101,72 @@ def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn):
     cand_val = all_gather_rows(val.view(1, m, k)).permute(1, 0, 2).reshape(m, world * k).contiguous()
     pos, best = topk_fn(cand_val, k)
     return torch.gather(cand_idx, 1, pos.to(torch.int64)), best
+
+
+# ---- train step (BASELINE config 4): one process per GPU instead of the reference's nn.DataParallel -----------------
+class _GatherRows(torch.autograd.Function):
+    """All-gather of equally sized row blocks that autograd can see. Every rank goes on to compute the SAME global loss
+    from the gathered tensor, so the gradient of that loss w.r.t. this rank's rows is simply its slice of the incoming
+    gradient (nn.DataParallel's gather-to-GPU-0 / scatter-back, train_vidreid_xent_htri.py:318, :399-411, without GPU 0)."""
+
+    @staticmethod
+    def forward(ctx, local):
+        ctx.rows = local.size(0)
+        return all_gather_rows(local)
+
+    @staticmethod
+    def backward(ctx, grad):
+        r = dist.get_rank() if world_size() > 1 else 0
+        return grad[r * ctx.rows:(r + 1) * ctx.rows].contiguous()
+
+
+def gather_rows_with_grad(local):
+    return _GatherRows.apply(local) if world_size() > 1 else local
+
+
+def allreduce_gradients(parameters, bucket_bytes=64 << 20):
+    """SUM the parameter gradients over the ranks (DataParallel's reduce-add of replica gradients) in flat buckets: a few
+    large RCCL all-reduces over xGMI instead of one per tensor (the 188 MB of fp32 gradients of vmgn go in 3 buckets)."""
+    if world_size() == 1:
+        return
+    grads = [p.grad for p in parameters if p.grad is not None]
+    bucket, size = [], 0
+
+    def flush():
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    for g in grads:
+        bucket.append(g)
+        size += g.numel() * g.element_size()
+        if size >= bucket_bytes:
+            flush()
+            bucket, size = [], 0
+    flush()
+
+
+def train_step(model, imgs, adj, pids, criterion_xent, criterion_htri, optimizer, htri_only=False):
+    """One xent + htri step of the reference's train() (train_vidreid_xent_htri.py:397-413) on THIS rank's shard of the
+    batch: local forward (BatchNorm statistics per replica, as under DataParallel), logits / features / labels gathered
+    over the ranks, losses and the batch-hard mining (native kernel) on the GLOBAL batch, backward, gradient all-reduce,
+    optimizer step. Returns the (global) loss values. With one rank it is exactly the reference's step."""
+    from torchreid.losses import DeepSupervision
+    model.train()
+    outputs, features = model(imgs, adj)
+    outputs = [gather_rows_with_grad(o) for o in (outputs if isinstance(outputs, (list, tuple)) else [outputs])]
+    features = [gather_rows_with_grad(f) for f in (features if isinstance(features, (list, tuple)) else [features])]
+    pids_all = all_gather_rows(pids.view(-1, 1)).view(-1)
+    xent = DeepSupervision(criterion_xent, outputs, pids_all)
+    htri = DeepSupervision(criterion_htri, features, pids_all)
+    loss = htri if htri_only else xent + htri
+    optimizer.zero_grad()
+    loss.backward()
+    allreduce_gradients(list(model.parameters()))
+    optimizer.step()
+    return float(loss.detach()), float(xent.detach()), float(htri.detach())

@@ -79,3 +79,71 @@ def test_sharded_match_equals_single_process(tmp_path):
         idx, val = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert torch.equal(idx, ref_idx)
         assert torch.allclose(val, ref_val, atol=1e-6)
+
+
+def _train_worker(rank, world, port, tmp):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "agrl.pytorch_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+    from torchreid import losses, models, parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    torch.set_num_threads(2)
+    m, x, adj, pids = _train_problem(models, recipe_state_dict, synthetic_clips, synthetic_adj)
+    lo, hi = parallel.shard_bounds(x.size(0), rank, world)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    loss = parallel.train_step(m, x[lo:hi], adj[lo:hi], pids[lo:hi], losses.CrossEntropyLabelSmooth(5, use_gpu=False),
+                               losses.TripletLoss(margin=0.3, soft=True), opt)
+    grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    torch.save((loss, grads), os.path.join(tmp, "t%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _train_problem(models, recipe_state_dict, synthetic_clips, synthetic_adj):
+    torch.manual_seed(0)
+    m = models.init_model("vmgn", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=1, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=False)
+    m.load_state_dict(recipe_state_dict(m.state_dict(), seed=1))
+    pids = torch.tensor([0, 0, 1, 1])
+    x = synthetic_clips(4, 2, H=64, W=32, seed=3, identities=pids.tolist())
+    adj = synthetic_adj(4, 2, seed=3)
+    return m, x, adj, pids
+
+
+@pytest.mark.timeout(600)
+def test_sharded_train_step_equals_replicated_global_step(tmp_path):
+    """BASELINE config 4's data-parallel train step: 2 ranks x 2 tracklets (per-replica BatchNorm statistics, global
+    xent + batch-hard triplet, gradient all-reduce) == one process that runs the two replicas' forwards itself, gathers
+    and backpropagates -- nn.DataParallel's arithmetic (train_vidreid_xent_htri.py:318, :399-411)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "agrl.pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+    from torchreid import losses, models
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    m, x, adj, pids = _train_problem(models, recipe_state_dict, synthetic_clips, synthetic_adj)
+    m.train()
+    outs, feats = [], []
+    for r in range(world):  # the replicas' forwards: BatchNorm batch statistics are per replica
+        o, f = m(x[2 * r:2 * r + 2], adj[2 * r:2 * r + 2])
+        outs.append(o)
+        feats.append(f)
+    outs = [torch.cat([outs[0][i], outs[1][i]]) for i in range(len(outs[0]))]
+    feats = [torch.cat([feats[0][i], feats[1][i]]) for i in range(len(feats[0]))]
+    loss = losses.DeepSupervision(losses.CrossEntropyLabelSmooth(5, use_gpu=False), outs, pids) + \
+        losses.DeepSupervision(losses.TripletLoss(margin=0.3, soft=True), feats, pids)
+    loss.backward()
+    ref = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    for r in range(world):
+        (l, lx, lh), grads = torch.load(os.path.join(str(tmp_path), "t%d.pt" % r))
+        assert abs(l - loss.item()) < 1e-5 * abs(loss.item())
+        assert set(grads) == set(ref)
+        worst = max(((grads[k] - ref[k]).abs().max() / ref[k].abs().max().clamp(min=1e-12)).item() for k in ref)
+        assert worst < 1e-3, worst
