@@ -55,6 +55,8 @@ SIGNATURES = {
     "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_distmat": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p],
     "agrl_pose_adjacency": [_p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _p],
+    "agrl_re_ranking_workspace": [_i, _i, _i],   # returns size_t (restype patched after loading)
+    "agrl_re_ranking": [_p, _p, _p, _i, _i, _i, _i, C.c_double, _p, _i, _p, C.c_size_t, _p],
     "agrl_rank_topk": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
@@ -89,6 +91,7 @@ def lib():
                 raise HipLibraryError("%s does not export %s" % (LIB_PATH, name))
             fn.argtypes = argtypes
             fn.restype = _i
+        h.agrl_re_ranking_workspace.restype = C.c_size_t
         h.agrl_version.restype = _i
         h.agrl_last_error.restype = C.c_char_p
         _lib = h

@@ -316,6 +316,21 @@ def rank_market1501(dist, q_pids, q_camids, g_pids, g_camids, max_rank):
     return ap, cmc, valid
 
 
+def re_ranking(q_g, q_q, g_g, k1=20, k2=6, lambda_value=0.3):
+    """k-reciprocal re-ranking on the device: fp32 CUDA (m,n), (m,m), (n,n) -> fp32 (m,n). utils/re_ranking.py:30-95."""
+    m, n = q_g.shape
+    for t, shp in ((q_g, (m, n)), (q_q, (m, m)), (g_g, (n, n))):
+        assert t.dtype == torch.float32 and tuple(t.shape) == shp
+    q_g, q_q, g_g = q_g.contiguous(), q_q.contiguous(), g_g.contiguous()
+    out = torch.empty((m, n), dtype=torch.float32, device=q_g.device)
+    nbytes = int(_hip.lib().agrl_re_ranking_workspace(m, n, int(k1)))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=q_g.device)
+    with _dev(q_g):
+        call("agrl_re_ranking", ptr(q_g), ptr(q_q), ptr(g_g), m, n, int(k1), int(k2), float(lambda_value), ptr(out), n,
+             ptr(ws), nbytes, _stream(q_g))
+    return out
+
+
 def triplet_hard_mine(x, pids):
     """x (n,d) fp32, pids int32 (n) -> dist_ap, dist_an fp32 (n), idx_ap, idx_an int32 (n)."""
     n, d = x.shape

@@ -212,6 +212,16 @@ int agrl_rank_market1501(const float* dist, int m, int n, int ldd, const int32_t
                          const int32_t* q_camids, const int32_t* g_pids, const int32_t* g_camids,
                          int max_rank, double* ap, float* cmc, int32_t* valid, agrl_stream_t stream);
 
+/* k-reciprocal re-ranking of a query x gallery distance matrix: re_ranking, torchreid/utils/re_ranking.py:30-95 (the
+ * --re-rank post-process of test(), train_vidreid_xent_htri.py:523-527).
+ *   q_g (m,n), q_q (m,m), g_g (n,n) fp32 contiguous distance matrices; 1 <= k1 <= 30, 1 <= k2 <= k1 + 1,
+ *   m + n <= 16384; final_dist fp32 (m,n) row stride ldf; workspace >= agrl_re_ranking_workspace(m, n, k1) bytes of
+ *   device memory (four (m+n)^2 fp32 matrices and the index lists). Rankings are stable (ties -> lower index). */
+size_t agrl_re_ranking_workspace(int m, int n, int k1);
+int agrl_re_ranking(const float* q_g, const float* q_q, const float* g_g, int m, int n, int k1, int k2,
+                    double lambda_value, float* final_dist, int ldf, void* workspace, size_t workspace_bytes,
+                    agrl_stream_t stream);
+
 /* ---- batch-hard triplet mining (train step, BASELINE config 4) ----------------------------------- */
 
 /* dist = sqrt(clamp(||x_i||^2+||x_j||^2-2x_i.x_j, 1e-12)); per anchor hardest positive (max over

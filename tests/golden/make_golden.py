@@ -185,6 +185,22 @@ def main():
     save("rank_market1501", dist=dist, q_pids=q_pids, g_pids=g_pids, q_camids=q_cam, g_camids=g_cam, cmc=cmc,
          mAP=np.float64(mAP))
 
+    # ---- F11: k-reciprocal re-ranking (utils/re_ranking.py:30-95) on the three distance matrices ----------------
+    ref_rr = load("ref_re_ranking", "torchreid/utils/re_ranking.py")
+    g = torch.Generator().manual_seed(111)
+    cent = torch.randn((9, 48), generator=g)
+    qf = cent[torch.randint(0, 9, (14,), generator=g)] + 0.6 * torch.randn((14, 48), generator=g)
+    gf = cent[torch.randint(0, 9, (60,), generator=g)] + 0.6 * torch.randn((60, 48), generator=g)
+    mats = {}
+    for metric in ("euclidean", "cosine"):
+        qg = ref_dist.compute_distance_matrix(qf, gf, metric).numpy()
+        qq = ref_dist.compute_distance_matrix(qf, qf, metric).numpy()
+        gg = ref_dist.compute_distance_matrix(gf, gf, metric).numpy()
+        mats[metric + "_default"] = ref_rr.re_ranking(qg, qq, gg)
+        mats[metric + "_k8_3"] = ref_rr.re_ranking(qg, qq, gg, k1=8, k2=3, lambda_value=0.2)
+        mats[metric + "_k6_1"] = ref_rr.re_ranking(qg, qq, gg, k1=6, k2=1, lambda_value=0.5)
+    save("re_ranking", qf=qf, gf=gf, **mats)
+
     # ---- F6: batch-hard triplet loss (hard_mine_triplet_loss.py:24-50) ----------------------------------
     g = torch.Generator().manual_seed(61)
     feats = torch.randn((16, 2048), generator=g)

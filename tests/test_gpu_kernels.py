@@ -523,6 +523,31 @@ def test_pose_adjacency_device():
             assert np.array_equal(got[b], O.pose_adjacency(sets, ns, pyr)), (B, S, H, ns, pyr, b)
 
 
+def test_re_ranking_device():
+    """agrl_re_ranking vs the reference (golden fixture) and vs the oracle on a larger random problem; the ranking it
+    induces (what evaluate_rank consumes) must be identical."""
+    from torchreid import hip_ops as ops
+    from torchreid.utils.re_ranking import re_ranking
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "re_ranking.npz"))
+    qf, gf = torch.from_numpy(z["qf"]), torch.from_numpy(z["gf"])
+    for metric, fn in (("euclidean", O.euclidean_squared), ("cosine", O.cosine)):
+        qg, qq, gg = fn(qf, gf).numpy(), fn(qf, qf).numpy(), fn(gf, gf).numpy()
+        for tag, kw in (("default", {}), ("k8_3", dict(k1=8, k2=3, lambda_value=0.2)), ("k6_1", dict(k1=6, k2=1, lambda_value=0.5))):
+            got = re_ranking(qg, qq, gg, **kw)
+            assert got.shape == qg.shape and got.dtype == np.float32
+            assert np.abs(got - z[metric + "_" + tag]).max() < 2e-6, (metric, tag)
+    g = torch.Generator().manual_seed(9)
+    cent = torch.randn((40, 64), generator=g)
+    qf = cent[torch.randint(0, 40, (70,), generator=g)] + 0.5 * torch.randn((70, 64), generator=g)
+    gf = cent[torch.randint(0, 40, (600,), generator=g)] + 0.5 * torch.randn((600, 64), generator=g)
+    qg, qq, gg = (O.euclidean_squared(a, b) for a, b in ((qf, gf), (qf, qf), (gf, gf)))
+    ref = O.re_ranking(qg.numpy(), qq.numpy(), gg.numpy())
+    got = ops.re_ranking(qg.to(DEV), qq.to(DEV), gg.to(DEV)).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-6
+    same = (np.argsort(got, axis=1, kind="stable")[:, :20] == np.argsort(ref, axis=1, kind="stable")[:, :20]).mean()
+    assert same > 0.999, same
+
+
 def test_triplet_mining_and_loss():
     from torchreid import losses, hip_ops as ops
     g = torch.Generator().manual_seed(1)

@@ -177,6 +177,21 @@ def test_rank_market1501_matches_reference_python_and_cython():
     assert np.allclose(cmc_cy, cmc, atol=1e-6) and abs(mAP_cy - mAP) < 1e-6   # the Cython twin accumulates in fp32
 
 
+def test_re_ranking_matches_reference():
+    """oracle.re_ranking (and, on a host without GPU, this build's torchreid.utils.re_ranking) against the reference's
+    utils/re_ranking.py on both metrics and three (k1, k2, lambda) settings."""
+    z = gold("re_ranking")
+    qf, gf = torch.from_numpy(z["qf"]), torch.from_numpy(z["gf"])
+    for metric, fn in (("euclidean", O.euclidean_squared), ("cosine", O.cosine)):
+        qg, qq, gg = fn(qf, gf).numpy(), fn(qf, qf).numpy(), fn(gf, gf).numpy()
+        for tag, kw in (("default", {}), ("k8_3", dict(k1=8, k2=3, lambda_value=0.2)), ("k6_1", dict(k1=6, k2=1, lambda_value=0.5))):
+            ref = z[metric + "_" + tag]
+            assert np.abs(O.re_ranking(qg, qq, gg, **kw) - ref).max() < 1e-6
+            if not torch.cuda.is_available():
+                from torchreid.utils.re_ranking import re_ranking
+                assert np.abs(re_ranking(qg, qq, gg, **kw) - ref).max() < 1e-6
+
+
 def test_triplet():
     z = gold("triplet")
     n, d, seed = [int(v) for v in z["meta"]]
