@@ -98,7 +98,7 @@ def _i32(a, device):
 
 @torch.no_grad()
 def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosine", max_rank=50,
-                   precision="fp32", return_topk=False):
+                   precision="fp32", return_topk=False, re_rank=False):
     """Distance matrix + MARS ranking on the device. ``qf``: ALL query embeddings (m,D); ``gf``: this rank's gallery
     rows when a process group is active (rows ``shard_bounds(n, rank, world)`` of the gallery), else the whole
     gallery. ``g_pids``/``g_camids`` always describe the WHOLE gallery. Returns (cmc ndarray (max_rank,), mAP float)."""
@@ -115,7 +115,17 @@ def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosi
     def topk_fn(d, k):
         return ops.rank_topk(d, k)
 
-    idx, val = parallel.sharded_topk(qf.float().contiguous(), gf.float().contiguous(), lo, max_rank, dist_fn, topk_fn)
+    if re_rank:
+        # the reference's --re-rank branch (train_vidreid_xent_htri.py:523-527): three distance matrices, k-reciprocal
+        # re-ranking, then the ranking of the re-ranked matrix. Needs the whole gallery on one device.
+        if world > 1:
+            raise NotImplementedError("re-ranking works on the full (m+n)^2 matrix: gather the gallery embeddings first")
+        q32, g32 = qf.float().contiguous(), gf.float().contiguous()
+        dist = ops.re_ranking(dist_fn(q32, g32), dist_fn(q32, q32), dist_fn(g32, g32))
+        idx, val = topk_fn(dist, max_rank)
+        idx = idx.to(torch.int64)
+    else:
+        idx, val = parallel.sharded_topk(qf.float().contiguous(), gf.float().contiguous(), lo, max_rank, dist_fn, topk_fn)
     ap, cmc = ops.rank_mars(idx.to(torch.int32).contiguous(), _i32(q_pids, device), _i32(q_camids, device),
                             _i32(g_pids, device), _i32(g_camids, device))
     ap = ap.cpu().numpy()
@@ -129,13 +139,13 @@ def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosi
 
 @torch.no_grad()
 def evaluate(model, query_batches, gallery_batches, dist_metric="cosine", pool="avg", max_rank=50,
-             ranks=(1, 5, 10, 20), verbose=False):
+             ranks=(1, 5, 10, 20), verbose=False, re_rank=False):
     """Single-process form of the reference's ``test()``: returns (rank1, mAP) and, like the reference, can print the
     CMC table. For the sharded form run ``extract_features`` on each rank's slice and call ``match_and_rank``."""
     qf, q_pids, q_camids = extract_features(model, query_batches, pool)
     gf, g_pids, g_camids = extract_features(model, gallery_batches, pool)
     cmc, mAP = match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric, max_rank,
-                              getattr(model, "hip_precision", "fp32"))
+                              getattr(model, "hip_precision", "fp32"), re_rank=re_rank)
     if verbose:
         print("Results ----------")
         print("mAP: {:.2%}".format(mAP))

@@ -130,3 +130,15 @@ def test_dense_clip_pooling_path(world):
     assert torch.allclose(dense, flat.view(2, 3, -1).mean(1), atol=1e-6)
     dmax, _, _ = evaluation.extract_features(m, [(x.view(2, 3, S, 3, 256, 128), np.arange(2), np.zeros(2), adj.view(2, 3, 28, 28))], pool="max")
     assert torch.allclose(dmax, flat.view(2, 3, -1).max(1)[0], atol=1e-6)
+
+
+def test_re_rank_branch_matches_oracle_pipeline(world):
+    """test() with --re-rank: distance matrices -> k-reciprocal re-ranking -> MARS ranking, device vs oracle."""
+    from torchreid import evaluation
+    q_pids, q_cams, g_pids, g_cams = world["split"]
+    qf, gf = world["qf"], world["gf"]
+    d = O.re_ranking(O.cosine(qf, gf).numpy(), O.cosine(qf, qf).numpy(), O.cosine(gf, gf).numpy())
+    cmc_ref, map_ref = O.evaluate_mars(d, q_pids, g_pids, q_cams, g_cams, 50)
+    cmc, mAP = evaluation.match_and_rank(qf.to(DEV), q_pids, q_cams, gf.to(DEV), g_pids, g_cams, "cosine", 50, "fp32", re_rank=True)
+    assert abs(mAP - map_ref) < 1e-3 and np.abs(cmc - cmc_ref).max() < 0.1  # near-ties of the Jaccard term may swap
+    print("re-rank branch: mAP %.6f (oracle %.6f) rank-1 %.4f (oracle %.4f)" % (mAP, map_ref, cmc[0], cmc_ref[0]))
