@@ -46,6 +46,27 @@ def test_vmgn_eval_fp32_matches_oracle(cfg):
     assert e < 1e-3  # north-star bar; measured ~1e-5
 
 
+@pytest.mark.parametrize("cfg", [(3, 5, 128, 64, 4, True), (2, 16, 256, 128, 4, True), (1, 1, 256, 128, 4, True),
+                                 (2, 4, 256, 128, 2, True), (2, 4, 256, 128, 4, False), (5, 3, 192, 96, 4, True)])
+@pytest.mark.parametrize("precision,tol", [("bf16", 5e-2), ("fp32", 1e-3)])
+def test_vmgn_eval_shape_variants(cfg, precision, tol):
+    """Frame sizes / clip lengths / split counts off the bench configuration: every dispatch (fused pooling or not, wide
+    or narrow tiles, streaming or LDS message pass, fused layer-1 tails) must agree with the oracle."""
+    B, S, H, W, num_split, pyramid = cfg
+    m, sd = build(num_split=num_split, pyramid_part=pyramid)
+    x = synthetic_clips(B, S, H=H, W=W, seed=B + S)
+    adj = synthetic_adj(B, S, seed=B + S, num_split=num_split, pyramid_part=pyramid)
+    with torch.no_grad():
+        ref = O.vmgn_eval(x, adj, sd, num_split=num_split, pyramid_part=pyramid)
+    m = m.to(DEV)
+    m.hip_precision = precision
+    got = m(x.to(DEV), adj.to(DEV))
+    torch.cuda.synchronize()
+    e = rel(got, ref)
+    print("vmgn", precision, cfg, "max rel err %.3e" % e)
+    assert got.shape == (B, 4096) and e < tol
+
+
 def test_vmgn_eval_bf16_close_and_ranking_preserved():
     B, S = 4, 4
     m, sd = build()
