@@ -8,9 +8,11 @@ same semantics are evaluated by the numpy host code below.
 
 The market1501 protocol (reference rank.py:95-150 and its Cython twin rank_cylib/rank_cy.pyx:154-241, SURVEY.md
 section 8(f) row 1) runs on the device too: ``agrl_rank_market1501`` counts the rank of every correct match directly
-from the distance row (no full argsort). The cuhk03 protocol (rank.py:22-92: 100 random single-gallery-shot trials
-drawn from numpy's global RNG) is not built: asking for it raises NotImplementedError rather than returning
-something else.
+from the distance row (no full argsort). The cuhk03 protocol (rank.py:22-92: random single-gallery-shot trials drawn
+from numpy's GLOBAL RNG) is defined by that host RNG stream, so its trials are evaluated on the host -- with every
+draw of the evaluation made by ONE vectorised ``np.random.randint`` call that consumes the stream exactly like the
+reference's per-identity ``np.random.choice`` calls (same values, same final state) -- while the ranking (stable sort)
+and the AP (``agrl_rank_market1501``) come from the device.
 """
 from __future__ import absolute_import
 from __future__ import print_function
@@ -160,14 +162,97 @@ def evaluate_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank):
     return all_cmc, np.mean(ap.cpu().numpy()[ok])
 
 
+def _cuhk03_trials(order, q_pids, g_pids, q_camids, g_camids, max_rank, num_repeats):
+    """The trial part of the cuhk03 protocol (reference rank.py:39-72) given every query's ranking ``order`` (m, n):
+    -> (per-query mean trial CMC (n_valid, L) float32, valid mask (m,)). All draws of the evaluation are made by one
+    ``np.random.randint(0, sizes)`` call: per valid query, per trial, one draw per gallery identity in order of first
+    appearance in the kept ranking -- value for value what ``np.random.choice(idxs)`` (rank.py:65) draws."""
+    m, n = order.shape
+    plans, sizes = [], []
+    valid = np.zeros(m, dtype=bool)
+    for k in range(m):
+        pid_sorted = g_pids[order[k]]
+        keep = ~((pid_sorted == q_pids[k]) & (g_camids[order[k]] == q_camids[k]))
+        kept = pid_sorted[keep]
+        if not (kept == q_pids[k]).any():
+            continue
+        valid[k] = True
+        uniq, first, inv, counts = np.unique(kept, return_index=True, return_inverse=True, return_counts=True)
+        by_group = np.argsort(inv, kind='stable')           # kept positions, grouped by identity, ascending inside
+        start = np.cumsum(counts) - counts
+        visit = np.argsort(first, kind='stable')            # identities in order of first appearance (dict order)
+        plans.append((by_group, start[visit], int(np.nonzero(uniq[visit] == q_pids[k])[0][0])))
+        sizes.append(np.tile(counts[visit], num_repeats))
+    if not plans:
+        return None, valid
+    draws = np.random.randint(0, np.concatenate(sizes))
+    cmcs, at = [], 0
+    for (by_group, start, gq), sz in zip(plans, sizes):
+        G = start.size
+        pick = by_group[start[None, :] + draws[at:at + sz.size].reshape(num_repeats, G)]   # chosen position per identity
+        at += sz.size
+        hit = (pick < pick[:, gq:gq + 1]).sum(axis=1)       # trial rank of the one correct match
+        L = min(G, max_rank)
+        trial = (np.arange(L)[None, :] >= hit[:, None]).astype(np.float32)
+        cmc = np.float32(0.0)
+        for r in range(num_repeats):                        # the reference accumulates trial by trial in fp32
+            cmc = cmc + trial[r]
+        cmcs.append(cmc / num_repeats)
+    return cmcs, valid
+
+
+def evaluate_cuhk03(distmat, q_pids, g_pids, q_camids, g_camids, max_rank, num_repeats=10):
+    """(CMC float32, mAP) with the single-gallery-shot protocol, reference rank.py:22-92. Ranking and AP on the device
+    when there is one; the random trials follow numpy's global RNG like the reference (seed ``np.random`` to reproduce)."""
+    q_pids, g_pids = np.asarray(q_pids), np.asarray(g_pids)
+    q_camids, g_camids = np.asarray(q_camids), np.asarray(g_camids)
+    on_device = isinstance(distmat, torch.Tensor) and distmat.is_cuda
+    num_g = distmat.shape[1]
+    if num_g < max_rank:
+        max_rank = num_g
+        print('Note: number of gallery samples is quite small, got {}'.format(num_g))
+    if not (on_device or torch.cuda.is_available()):
+        d = distmat.numpy() if isinstance(distmat, torch.Tensor) else np.asarray(distmat)
+        order = np.argsort(d, axis=1, kind='stable')
+        cmcs, valid = _cuhk03_trials(order, q_pids, g_pids, q_camids, g_camids, max_rank, num_repeats)
+        assert cmcs is not None, 'Error: all query identities do not appear in gallery'
+        aps = []
+        for k in np.nonzero(valid)[0]:
+            keep = ~((g_pids[order[k]] == q_pids[k]) & (g_camids[order[k]] == q_camids[k]))
+            raw = (g_pids[order[k]] == q_pids[k])[keep].astype(np.int64)
+            aps.append(((raw.cumsum() / (np.arange(raw.size) + 1.0)) * raw).sum() / raw.sum())
+    else:
+        from torchreid import _hip, hip_ops as ops
+        _hip.lib()
+        dev = distmat.device if on_device else torch.device('cuda', torch.cuda.current_device())
+        d = distmat if on_device else torch.as_tensor(np.ascontiguousarray(distmat, dtype=np.float32))
+        d = d.to(device=dev, dtype=torch.float32)
+        if d.stride(-1) != 1:
+            d = d.contiguous()
+
+        def i32(a):
+            return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+        ap, _, dvalid = ops.rank_market1501(d, i32(q_pids), i32(q_camids), i32(g_pids), i32(g_camids), min(max_rank, num_g))
+        order = torch.sort(d, dim=1, stable=True)[1].cpu().numpy()
+        cmcs, valid = _cuhk03_trials(order, q_pids, g_pids, q_camids, g_camids, max_rank, num_repeats)
+        assert cmcs is not None, 'Error: all query identities do not appear in gallery'
+        dvalid = dvalid.cpu().numpy()
+        if (dvalid < 0).any():
+            raise RuntimeError('query {} has more correct matches than agrl_rank_market1501 holds'.format(int((dvalid < 0).argmax())))
+        assert np.array_equal(dvalid == 1, valid)
+        aps = ap.cpu().numpy()[valid]
+    num_valid = float(valid.sum())
+    all_cmc = np.asarray(cmcs).astype(np.float32).sum(0) / num_valid
+    return all_cmc, np.mean(aps)
+
+
 def evaluate_rank(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, use_metric_cuhk03=False,
                   use_metric_market1501=False, use_metric_mars=False, use_cython=True):
     """Evaluate CMC and mAP; same signature and dispatch order as reference rank.py:215-238
     (returns None when no metric flag is set)."""
     if use_metric_cuhk03:
-        raise NotImplementedError(
-            'the cuhk03 protocol (reference rank.py:22-92) is not built (the reference driver only uses '
-            'use_metric_mars=True, train_vidreid_xent_htri.py:531)')
+        return evaluate_cuhk03(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)
     if use_metric_market1501:  # ``use_cython`` selects between two implementations of the same protocol upstream
         return evaluate_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank)
     elif use_metric_mars:

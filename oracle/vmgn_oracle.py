@@ -256,6 +256,43 @@ def eval_market1501(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, re
     return cmc, mAP
 
 
+def eval_cuhk03(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50, num_repeats=10, rng=None):
+    """eval_cuhk03, rank.py:22-92 (single-gallery-shot protocol): per valid query the gallery samples of the same identity
+    AND camera are discarded; ``num_repeats`` trials each keep ONE randomly chosen sample per gallery identity
+    (``np.random.choice`` over the identity's positions in the kept ranking, identities visited in order of first
+    appearance, :60-66) and the CMC of the trials is averaged (:67-72); AP as in market1501 over the full kept ranking
+    (:74-80). Draws come from numpy's GLOBAL legacy RNG (or ``rng``), one per identity per trial per valid query, in
+    exactly that order -- seeding ``np.random`` reproduces the reference's result. Stable ranking."""
+    rng = np.random if rng is None else rng
+    distmat = np.asarray(distmat)
+    q_pids, g_pids, q_camids, g_camids = map(np.asarray, (q_pids, g_pids, q_camids, g_camids))
+    m, n = distmat.shape
+    max_rank = min(max_rank, n)
+    all_cmc, all_ap = [], []
+    for k in range(m):
+        order = np.argsort(distmat[k], kind="stable")
+        keep = ~((g_pids[order] == q_pids[k]) & (g_camids[order] == q_camids[k]))
+        raw = (g_pids[order] == q_pids[k])[keep].astype(np.int64)
+        if not raw.any():
+            continue
+        groups = {}
+        for pos, pid in enumerate(g_pids[order][keep]):
+            groups.setdefault(int(pid), []).append(pos)
+        cmc = 0.0
+        for _ in range(num_repeats):
+            mask = np.zeros(raw.size, dtype=bool)
+            for idxs in groups.values():
+                mask[rng.choice(idxs)] = True
+            trial = np.minimum(raw[mask].cumsum(), 1)
+            cmc = cmc + trial[:max_rank].astype(np.float32)
+        all_cmc.append(cmc / num_repeats)
+        prec = raw.cumsum() / (np.arange(raw.size) + 1.0)
+        all_ap.append((prec * raw).sum() / raw.sum())
+    assert all_cmc, "Error: all query identities do not appear in gallery"
+    cmc = np.asarray(all_cmc).astype(np.float32).sum(0) / float(len(all_cmc))
+    return cmc, float(np.mean(all_ap))
+
+
 def re_ranking(q_g_dist, q_q_dist, g_g_dist, k1=20, k2=6, lambda_value=0.3):
     """k-reciprocal re-ranking, torchreid/utils/re_ranking.py:30-95 (Zhong et al., CVPR 2017), restated step by step:
     joint squared distance matrix of all N = m + n samples, each row scaled by its maximum (:37-38); k-reciprocal

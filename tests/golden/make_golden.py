@@ -55,6 +55,8 @@ def install_shims():
 
 
 def save(name, **arrays):
+    if len(sys.argv) > 1 and name not in sys.argv[1:]:   # python make_golden.py NAME...: rewrite only those fixtures
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
     print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
@@ -184,6 +186,21 @@ def main():
                                       use_cython=False)
     save("rank_market1501", dist=dist, q_pids=q_pids, g_pids=g_pids, q_camids=q_cam, g_camids=g_cam, cmc=cmc,
          mAP=np.float64(mAP))
+
+    # ---- F12: cuhk03 protocol (rank.py:22-92), numpy's global RNG seeded right before the call -------------------
+    rng = np.random.RandomState(121)
+    m, n = 36, 420
+    dist = rng.rand(m, n).astype(np.float32)
+    q_pids, g_pids = rng.randint(0, 64, m), rng.randint(0, 60, n)   # identities 60..63 never appear in the gallery
+    q_cam, g_cam = rng.randint(0, 2, m), rng.randint(0, 2, n)
+    out = {}
+    for max_rank in (50, 20):
+        np.random.seed(1203)
+        cmc, mAP = ref_rank.evaluate_rank(dist, q_pids, g_pids, q_cam, g_cam, max_rank=max_rank, use_metric_cuhk03=True,
+                                          use_cython=False)
+        out["cmc_%d" % max_rank], out["mAP_%d" % max_rank] = cmc, np.float64(mAP)
+        out["next_draw_%d" % max_rank] = np.random.randint(0, 1 << 30)  # the global stream must end in the same place
+    save("rank_cuhk03", dist=dist, q_pids=q_pids, g_pids=g_pids, q_camids=q_cam, g_camids=g_cam, seed=np.array(1203), **out)
 
     # ---- F11: k-reciprocal re-ranking (utils/re_ranking.py:30-95) on the three distance matrices ----------------
     ref_rr = load("ref_re_ranking", "torchreid/utils/re_ranking.py")

@@ -95,7 +95,7 @@ def test_metrics_contract_without_gpu():
         metrics.compute_distance_matrix(q.numpy(), g)
     with pytest.raises(AssertionError):
         metrics.compute_distance_matrix(q[0], g)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError):   # every gallery sample shares identity AND camera with the query (rank.py:83)
         metrics.evaluate_rank(np.zeros((4, 60)), np.zeros(4), np.zeros(60), np.zeros(4), np.zeros(60), use_metric_cuhk03=True)
     acc = metrics.accuracy([torch.eye(4), torch.eye(4).flip(0)], torch.arange(4), topk=(1, 2))
     assert acc.shape == (2, 2) and acc[0, 0] == 1.0 and acc[1, 0] == 0.0

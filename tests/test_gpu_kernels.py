@@ -505,6 +505,32 @@ def test_rank_market1501_device(shape):
     assert np.array_equal(cmc3, z["cmc"]) and abs(mAP3 - float(z["mAP"])) < 1e-14
 
 
+def test_rank_cuhk03_device():
+    """evaluate_rank(use_metric_cuhk03=True) with the ranking and the AP from the device: equal to the reference's python
+    evaluator (golden, seeded np.random) and to the oracle on a case with exact distance ties; a device-resident
+    distance matrix gives the same answer as a host one."""
+    from torchreid import metrics
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rank_cuhk03.npz"))
+    args = (z["q_pids"], z["g_pids"], z["q_camids"], z["g_camids"])
+    for max_rank in (50, 20):
+        for dist in (z["dist"], torch.from_numpy(z["dist"]).to(DEV)):
+            np.random.seed(int(z["seed"]))
+            cmc, mAP = metrics.evaluate_rank(dist, *args, max_rank=max_rank, use_metric_cuhk03=True)
+            assert np.random.randint(0, 1 << 30) == int(z["next_draw_%d" % max_rank])
+            assert np.array_equal(cmc, z["cmc_%d" % max_rank]) and abs(mAP - float(z["mAP_%d" % max_rank])) < 1e-14
+    rng = np.random.RandomState(77)
+    m, n = 50, 900
+    d = rng.rand(m, n).astype(np.float32)
+    d[:, 7] = d[:, 2]
+    q_pids, g_pids = rng.randint(0, 72, m), rng.randint(0, 70, n)
+    q_cam, g_cam = rng.randint(0, 3, m), rng.randint(0, 3, n)
+    np.random.seed(5)
+    cmc_o, mAP_o = O.eval_cuhk03(d, q_pids, g_pids, q_cam, g_cam, 50)
+    np.random.seed(5)
+    cmc, mAP = metrics.evaluate_rank(d, q_pids, g_pids, q_cam, g_cam, max_rank=50, use_metric_cuhk03=True)
+    assert np.array_equal(cmc, cmc_o) and abs(mAP - mAP_o) < 1e-14
+
+
 def test_pose_adjacency_device():
     """agrl_pose_adjacency vs the reference's generate_graph (golden fixture) and vs the oracle on random poses,
     incl. undetected frames, low-confidence keypoints, num_split 8 and the non-pyramid layout."""

@@ -177,6 +177,26 @@ def test_rank_market1501_matches_reference_python_and_cython():
     assert np.allclose(cmc_cy, cmc, atol=1e-6) and abs(mAP_cy - mAP) < 1e-6   # the Cython twin accumulates in fp32
 
 
+def test_rank_cuhk03_matches_reference_and_rng_stream():
+    """oracle.eval_cuhk03 (and, on a host without GPU, this build's evaluate_rank(use_metric_cuhk03=True)) against the
+    reference's python evaluator (rank.py:22-92) under the same np.random seed: CMC bit-exact, mAP to fp64 rounding, and
+    numpy's global RNG left in the same state (the next draw agrees)."""
+    z = gold("rank_cuhk03")
+    args = (z["dist"], z["q_pids"], z["g_pids"], z["q_camids"], z["g_camids"])
+    assert int(np.isin(z["q_pids"], [60, 61, 62, 63]).sum()) > 0          # invalid queries are part of the case
+    for max_rank in (50, 20):
+        np.random.seed(int(z["seed"]))
+        cmc, mAP = O.eval_cuhk03(*args, max_rank=max_rank)
+        assert np.random.randint(0, 1 << 30) == int(z["next_draw_%d" % max_rank])
+        assert np.array_equal(cmc, z["cmc_%d" % max_rank]) and abs(mAP - float(z["mAP_%d" % max_rank])) < 1e-14
+        if not torch.cuda.is_available():
+            from torchreid import metrics
+            np.random.seed(int(z["seed"]))
+            cmc2, mAP2 = metrics.evaluate_rank(*args, max_rank=max_rank, use_metric_cuhk03=True)
+            assert np.random.randint(0, 1 << 30) == int(z["next_draw_%d" % max_rank])
+            assert np.array_equal(cmc2, z["cmc_%d" % max_rank]) and abs(mAP2 - float(z["mAP_%d" % max_rank])) < 1e-14
+
+
 def test_re_ranking_matches_reference():
     """oracle.re_ranking (and, on a host without GPU, this build's torchreid.utils.re_ranking) against the reference's
     utils/re_ranking.py on both metrics and three (k1, k2, lambda) settings."""
