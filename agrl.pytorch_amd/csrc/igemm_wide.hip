@@ -23,7 +23,7 @@ namespace {
 
 constexpr int WBM = 256, WBN = 256;
 
-template <int DBG, int WBN_ = 256>  // WBN_: channels per tile (256, or 128 for N = 256 layers: twice the tiles); DBG: ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
+template <int DBG, int WBN_ = 256, bool RES = false>  // RES: + residual (its 64 staging registers leave no room for the persistent form's carried state); WBN_: channels per tile (256, or 128 for N = 256 layers: twice the tiles); DBG: ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     static_assert(WBN_ == 256 || (WBN_ == 128 && (DBG & (4096 | 8192 | 16384)) == 0), "the 128-channel tile has the plain schedule + register epilogue only");
     constexpr bool POOL = (DBG & 16384) != 0;   // fused frame pooling epilogue (a tile = two whole 16 x 8 frames)
@@ -43,19 +43,21 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     const int wm = wave % WM;
     const int wn = wave / WM;
 
-    // XCD-aware block -> tile map (blocks b, b+8, .. share an XCD): N-tiles of one M-tile are neighbours in one L2
+    // XCD-aware block -> tile map (blocks b, b+8, .. share an XCD): every XCD owns a contiguous range of tiles, so the
+    // N-tiles of one M-tile are neighbours in one L2. PERSISTENT when the grid is smaller than the tile count: a
+    // workgroup walks its XCD's range with the stride of the workgroups on that XCD; the first k-tile of its next tile
+    // is requested BEFORE the epilogue's stores are issued, so the stores drain under the next tile's matrix work
+    // (a workgroup that ends instead holds its LDS until its last store is acknowledged, and its successor on the CU
+    // starts with a cold pipeline).
     const int nNt = p.N / BN;
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, within = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
-    }
-    const int mt = bid / nNt;
-    const int nt = bid - mt * nNt;
-    const int m0 = mt * BM;
-    const int n0 = nt * BN;
+    const int ntiles = ((p.M + BM - 1) / BM) * nNt;
+    const int xcd = blockIdx.x & 7;
+    int tl = blockIdx.x >> 3;                                                  // tile index inside the XCD's range
+    const int xq = ntiles >> 3, xr = ntiles & 7;
+    const int xbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int xcnt = xq + (xcd < xr ? 1 : 0);
+    const int wstep = (int)(gridDim.x >> 3) + (xcd < (int)(gridDim.x & 7) ? 1 : 0);  // workgroups on this XCD
+    if (tl >= xcnt) return;
 
     const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
     const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
@@ -67,34 +69,43 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     const unsigned row_bytes = (unsigned)p.K * 2u;
     unsigned a_off[AJ], b_off[BJ];
     unsigned a_okmask = 0;
+    int m0 = 0, n0 = 0;
+    auto setup_tile = [&](int tile) {
+        const int mt = tile / nNt;
+        const int nt = tile - mt * nNt;
+        m0 = mt * BM;
+        n0 = nt * BN;
+        a_okmask = 0;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-        const int row = wave * (BM / NW) + j * 8 + lrow;
-        const int gm = m0 + row;
-        if (gm < p.M) a_okmask |= 1u << j;
-        int pix = gm < p.M ? gm : 0;
-        if (p.stride > 1) {  // strided 1x1 (the downsample convs): output pixel -> the input pixel it reads
-            const int ohw = p.OH * p.OW;
-            const int n = pix / ohw, rem = pix - n * ohw;
-            const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            pix = (n * p.H + oy * p.stride) * p.W + ox * p.stride;
+        for (int j = 0; j < AJ; ++j) {
+            const int row = wave * (BM / NW) + j * 8 + lrow;
+            const int gm = m0 + row;
+            if (gm < p.M) a_okmask |= 1u << j;
+            int pix = gm < p.M ? gm : 0;
+            if (p.stride > 1) {  // strided 1x1 (the downsample convs): output pixel -> the input pixel it reads
+                const int ohw = p.OH * p.OW;
+                const int n = pix / ohw, rem = pix - n * ohw;
+                const int oy = rem / p.OW, ox = rem - oy * p.OW;
+                pix = (n * p.H + oy * p.stride) * p.W + ox * p.stride;
+            }
+            a_off[j] = (unsigned)pix * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
         }
-        a_off[j] = (unsigned)pix * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
-    }
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-        const int row = wave * (BN / NW) + j * 8 + lrow;
-        int ch = row;
-        if constexpr (REGEPI) {
-            // LDS row a*16 + i of a wave column's 128-channel slab holds channel sigma(a, i) = 32 (a>>1) + 8 (i>>2) +
-            // 4 (a&1) + (i&3): the MFMA result rows 4 f + r of the 8 fragments of a lane are then 32 channels that the
-            // register epilogue reads / writes as 16-byte pieces, 64 contiguous bytes per pixel row and instruction
-            constexpr int SLAB = BN / 2;  // channels per wave column
-            const int rp = row & (SLAB - 1), a = rp >> 4, i = rp & 15;
-            ch = (row & ~(SLAB - 1)) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
+        for (int j = 0; j < BJ; ++j) {
+            const int row = wave * (BN / NW) + j * 8 + lrow;
+            int ch = row;
+            if constexpr (REGEPI) {
+                // LDS row a*16 + i of a wave column's 128-channel slab holds channel sigma(a, i) = 32 (a>>1) + 8 (i>>2) +
+                // 4 (a&1) + (i&3): the MFMA result rows 4 f + r of the 8 fragments of a lane are then 32 channels that the
+                // register epilogue reads / writes as 16-byte pieces, 64 contiguous bytes per pixel row and instruction
+                constexpr int SLAB = BN / 2;  // channels per wave column
+                const int rp = row & (SLAB - 1), a = rp >> 4, i = rp & 15;
+                ch = (row & ~(SLAB - 1)) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
+            }
+            b_off[j] = (unsigned)(n0 + ch) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
         }
-        b_off[j] = (unsigned)(n0 + ch) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
-    }
+    };
+    setup_tile(xbase + tl);
     unsigned kbyte = 0;  // byte offset of the k-tile being STAGED inside a row
     auto stage_piece = [&](int buf, int idx) {
         if (idx < AJ) {
@@ -122,26 +133,43 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         }
     };
 
+    const int nk = p.K >> 6;
+    constexpr bool has_res = RES;
+    int frow = lane & 15;
+    int fchunk = lane >> 4;
+    int cur = 0;
+    // the first NS-1 k-tiles of the CURRENT tile (a_off / b_off) into the ring slots cur, cur+1, ..
+    auto stage_head = [&]() {
+        kbyte = 0;
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) {
+            if (s < nk) {
+                int slot = cur + s;
+                slot = slot >= NS ? slot - NS : slot;
+#pragma unroll
+                for (int i = 0; i < DPT; ++i) stage_piece(slot, i);
+                kbyte += 128;
+            }
+        }
+    };
+    stage_head();
+    constexpr int EPI_STORES = FM * (FN / 2);  // 16-byte stores per lane in the register epilogue
+    bool carried_any = false;  // not the workgroup's first tile
+    bool carried = false;  // this tile's head was requested in front of the previous tile's stores (still in flight)
+    for (;;) {
+    // per-tile recomputation instead of registers held across the epilogue: the lane's fragment addresses (derived from
+    // frow / fchunk) and, for a carried tile, its DMA offsets
+    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's accumulator initialisation out of this tile's epilogue
+    asm volatile("" : "+v"(frow), "+v"(fchunk));
+    if (carried_any) {
+        asm volatile("" : "+s"(tl));
+        setup_tile(xbase + tl);
+    }
     f32x4_t acc[FN][FM];
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K >> 6;
-    const bool has_res = p.res != nullptr;
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) {
-        if (s < nk) {
-#pragma unroll
-            for (int i = 0; i < DPT; ++i) stage_piece(s, i);
-            kbyte += 128;
-        }
-    }
-
-    const int frow = lane & 15;
-    const int fchunk = lane >> 4;
-    int cur = 0;
     if constexpr ((DBG & 4096) != 0 && BN == 256) {
         // ---- ping-pong schedule. The two waves of a SIMD (w and w + 4: wave column 0 / 1) run the same phase
         // sequence {L: fragment reads (+ DMA issue) | barrier | M: 32 MFMAs | barrier}, column 1 ONE BARRIER LATER:
@@ -199,7 +227,10 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         // k-tile stays in flight across the barrier (counted wait): a 48 KB k-tile is 0.56 us of MFMA, less than a
         // memory round trip, so one tile of look-ahead is latency-bound.
         if (!(DBG & 32)) {
-            if (NS == 3 && kt + 1 < nk) wait_vmcnt<DPT>();
+            if (kt == 0 && carried) {  // the previous tile's stores are younger than this k-tile: leave them in flight
+                if (NS == 3 && nk > 1) wait_vmcnt<DPT + EPI_STORES>();
+                else wait_vmcnt<EPI_STORES>();
+            } else if (NS == 3 && kt + 1 < nk) wait_vmcnt<DPT>();
             else wait_vmcnt<0>();
         }
         if (!(DBG & 128)) __builtin_amdgcn_s_barrier();
@@ -245,29 +276,47 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         cur = cur + 1 == NS ? 0 : cur + 1;
     }
     if constexpr (REGEPI) {
+        const int em0 = m0, en0 = n0;  // the tile whose results are in the accumulators
+        bool has_next = false;
+        if constexpr (!POOL && !RES) {
+            tl += wstep;
+            has_next = tl < xcnt;
+            if (has_next) {  // the ring is free (every wave is past the barrier of the last k-tile's predecessor)
+                setup_tile(xbase + tl);
+                stage_head();
+            }
+        }
+        // counted wait at the next tile's first k-tile: valid only if every one of the EPI_STORES stores is issued
+        carried = has_next && em0 + BM <= p.M && (DBG & 1) == 0;
+        carried_any = has_next;
         // ---- register epilogue: no LDS, no barrier. Lane (f = lane>>4, pixel = lane&15 of fragment b) holds channels
         // cb + 32 j + {0..7} (cb = n0 + 128 wn + 8 f) in acc[2j][b], acc[2j+1][b]: residual in / result out as one
         // 16-byte access per (b, j); the four lanes of a pixel cover 64 contiguous bytes per instruction.
-        const int cb = n0 + wn * (BN / 2) + 8 * fchunk;
+        const int cb = en0 + wn * (BN / 2) + 8 * fchunk;
         const bf16_t* __restrict__ resp = reinterpret_cast<const bf16_t*>(p.res);
         bf16_t* __restrict__ outp = reinterpret_cast<bf16_t*>(p.out);
         constexpr int NJ = FN / 2;  // 16-byte pieces (8 channels) per lane and pixel fragment
+        // every residual piece is requested before the first store: loads and stores retire in order on one counter, so a
+        // load behind a store would wait for that store's acknowledgement
         uint4 rres[FM][NJ];
         if (has_res) {
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
-                const int gm = min(m0 + wm * (BM / WM) + b * 16 + frow, p.M - 1);
+                const int gm = min(em0 + wm * (BM / WM) + b * 16 + frow, p.M - 1);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) rres[b][j] = *reinterpret_cast<const uint4*>(resp + (size_t)gm * p.ldo + cb + 32 * j);
             }
         }
-        float4 bia[NJ][2];
+        if (p.colv) {  // bias first, eight values in registers at a time (same order of operations: acc + bias, then + residual)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            bia[j][0] = bia[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.colv) {
-                bia[j][0] = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j);
-                bia[j][1] = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j + 4);
+            for (int j = 0; j < NJ; ++j) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j);
+                const float4 b1 = *reinterpret_cast<const float4*>(p.colv + cb + 32 * j + 4);
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    acc[2 * j][b][0] += b0.x; acc[2 * j][b][1] += b0.y; acc[2 * j][b][2] += b0.z; acc[2 * j][b][3] += b0.w;
+                    acc[2 * j + 1][b][0] += b1.x; acc[2 * j + 1][b][1] += b1.y; acc[2 * j + 1][b][2] += b1.z; acc[2 * j + 1][b][3] += b1.w;
+                }
             }
         }
         float psum[POOL ? 2 : 1][NJ][8];
@@ -281,14 +330,12 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         }
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
-            const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
+            const int gm = em0 + wm * (BM / WM) + b * 16 + frow;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 float v[8];
-                v[0] = acc[2 * j][b][0] + bia[j][0].x; v[1] = acc[2 * j][b][1] + bia[j][0].y;
-                v[2] = acc[2 * j][b][2] + bia[j][0].z; v[3] = acc[2 * j][b][3] + bia[j][0].w;
-                v[4] = acc[2 * j + 1][b][0] + bia[j][1].x; v[5] = acc[2 * j + 1][b][1] + bia[j][1].y;
-                v[6] = acc[2 * j + 1][b][2] + bia[j][1].z; v[7] = acc[2 * j + 1][b][3] + bia[j][1].w;
+                v[0] = acc[2 * j][b][0]; v[1] = acc[2 * j][b][1]; v[2] = acc[2 * j][b][2]; v[3] = acc[2 * j][b][3];
+                v[4] = acc[2 * j + 1][b][0]; v[5] = acc[2 * j + 1][b][1]; v[6] = acc[2 * j + 1][b][2]; v[7] = acc[2 * j + 1][b][3];
                 if (has_res) {
                     const uint32_t w4[4] = {rres[b][j].x, rres[b][j].y, rres[b][j].z, rres[b][j].w};
 #pragma unroll
@@ -302,7 +349,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
                 const uint4 pk = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-                if (gm < p.M && (!POOL || p.pool_store_out)) *reinterpret_cast<uint4*>(outp + (size_t)gm * p.ldo + cb + 32 * j) = pk;
+                if (gm < p.M && (!POOL || p.pool_store_out) && (!(DBG & 1) || p.relu == 12345)) *reinterpret_cast<uint4*>(outp + (size_t)gm * p.ldo + cb + 32 * j) = pk;
                 if constexpr (POOL) {  // pool the bf16-rounded activations (what a separate pooling pass would read)
                     const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
                     const float live = gm < p.M ? 1.f : 0.f;
@@ -345,18 +392,18 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
             const int P = p.pool_nparts;
             for (int o = tid; o < 2 * P * BN; o += 512) {
                 const int c = o % BN, fp = o / BN, part = fp % P, fr = fp / P;
-                const int frame = (m0 >> 7) + fr;
+                const int frame = (em0 >> 7) + fr;
                 if (frame * 128 >= p.M) continue;
                 const int q0 = p.pool_start[part] >> 2, q1 = p.pool_end[part] >> 2;  // bins are whole quarters (host-checked)
                 float t = 0.f;
                 for (int q = q0; q < q1; ++q) t += s_q[(fr * 4 + q) * BN + c];
                 if (p.pool_mean) t *= 1.f / (float)((q1 - q0) * 32);
-                const size_t oi = ((size_t)frame * P + part) * p.N + n0 + c;
+                const size_t oi = ((size_t)frame * P + part) * p.N + en0 + c;
                 p.pool_out[oi] = t;
                 if (p.pool_out_lp) reinterpret_cast<bf16_t*>(p.pool_out_lp)[oi] = f32_to_bf16(t);
             }
         }
-        return;
+        if (!has_next) return;
     }
     if constexpr (!REGEPI) {
     // cur = slot F (free since the last iteration: holds residual half 0), cur ^ 1 = slot L (the last k-tile)
@@ -418,7 +465,9 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     combine_half(1, soL);
     wg_barrier();
     drain_half(1, soL);
+    return;
     }
+    }  // tile loop
 }
 
 }  // namespace
@@ -447,20 +496,39 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
         if (atoi(e) == 2 && (p.N % WBN) == 0) half_n = false;
         if (atoi(e) == 3 && p.pool_nparts == 0) half_n = true;
     }
+    // persistent form: one workgroup per CU walks its share of the tiles (AGRL_IGEMM_WIDE_PERSIST=0: one per tile)
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const char* pe = getenv("AGRL_IGEMM_WIDE_PERSIST");
+    const bool persist = !(pe && atoi(pe) == 0);
+    const bool res = p.res != nullptr;
     if (half_n) {
-        hipLaunchKernelGGL((igemm_wide_kernel<0, 128>), dim3(cdiv(p.M, WBM) * (p.N / 128)), dim3(512), 0, stream, p);
+        const int tiles = cdiv(p.M, WBM) * (p.N / 128);
+        if (res) hipLaunchKernelGGL((igemm_wide_kernel<0, 128, true>), dim3(tiles), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((igemm_wide_kernel<0, 128, false>), dim3(persist ? min(tiles, n_cu) : tiles), dim3(512), 0, stream, p);
         AGRL_CHECK_LAUNCH(who);
         return 0;
     }
-    const int grid = cdiv(p.M, WBM) * (p.N / WBN);
+    const int tiles256 = cdiv(p.M, WBM) * (p.N / WBN);
+    const int grid = persist && !res && p.pool_nparts == 0 && (p.dbg & (4096 | 8192)) == 0 ? min(tiles256, n_cu) : tiles256;
     if (p.pool_nparts > 0) {
-        hipLaunchKernelGGL((igemm_wide_kernel<16384, 256>), dim3(grid), dim3(512), 0, stream, p);
+        if (res) hipLaunchKernelGGL((igemm_wide_kernel<16384, 256, true>), dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((igemm_wide_kernel<16384, 256, false>), dim3(grid), dim3(512), 0, stream, p);
+        AGRL_CHECK_LAUNCH(who);
+        return 0;
+    }
+    if (res) {
+        if (p.dbg == 8192) hipLaunchKernelGGL((igemm_wide_kernel<8192, 256, true>), dim3(grid), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((igemm_wide_kernel<0, 256, true>), dim3(grid), dim3(512), 0, stream, p);
         AGRL_CHECK_LAUNCH(who);
         return 0;
     }
     switch (p.dbg) {
 #define WIDE_CASE(D) case D: hipLaunchKernelGGL((igemm_wide_kernel<D, 256>), dim3(grid), dim3(512), 0, stream, p); break
-        WIDE_CASE(16384); WIDE_CASE(4096); WIDE_CASE(8192); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
+        WIDE_CASE(1); WIDE_CASE(16384); WIDE_CASE(4096); WIDE_CASE(8192); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
 #undef WIDE_CASE
         default: hipLaunchKernelGGL((igemm_wide_kernel<0, 256>), dim3(grid), dim3(512), 0, stream, p);
     }

@@ -82,7 +82,10 @@ WIDE_CASES = [
 
 
 @pytest.mark.parametrize("tile", ["2", "3"])  # AGRL_IGEMM_WIDE: 2 = 256 x 256 tile, 3 = 256 x 128 tile
-@pytest.mark.parametrize("case", WIDE_CASES + [(3, 16, 8, 1024, 384, True, True)])
+@pytest.mark.parametrize("case", WIDE_CASES + [(3, 16, 8, 1024, 384, True, True),
+                                  # more tiles than CUs: the persistent form (a workgroup walks several tiles, the next
+                                  # tile's first k-tile is requested in front of the stores); ragged last M tile; 1 / 3 k-tiles
+                                  (81, 16, 8, 64, 2048, False, True), (90, 16, 8, 192, 1024, False, False)])
 def test_conv_wide_tile(case, tile, monkeypatch):
     from torchreid import hip_ops as ops
     N, H, W, Cin, Cout, use_res, relu = case

@@ -30,6 +30,7 @@ def conv_case(N, H, W, Cin, Cout, R, stride, res, env_alt):
 
 cases = [("wide 1x1 2048->512", (256, 16, 8, 2048, 512, 1, 1, False, {"AGRL_IGEMM_WIDE": "0"})),
          ("wide 1x1 512->2048 +res", (256, 16, 8, 512, 2048, 1, 1, True, {"AGRL_IGEMM_WIDE": "0"})),
+         ("wide persistent 1024->2048", (256, 16, 8, 1024, 2048, 1, 1, False, {"AGRL_IGEMM_WIDE": "0"})),
          ("wide128 1x1 1024->256", (256, 16, 8, 1024, 256, 1, 1, False, {"AGRL_IGEMM_WIDE": "0"})),
          ("wide strided 256->512 s2", (256, 64, 32, 256, 512, 1, 2, False, {"AGRL_IGEMM_WIDE": "0"})),
          ("3x3 two-block 512->512", (256, 16, 8, 512, 512, 3, 1, False, {"AGRL_CONV3X3_WIDE": "0"})),
