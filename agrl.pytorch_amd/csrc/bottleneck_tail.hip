@@ -385,6 +385,207 @@ __global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParam
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Layer-2 form: conv3 128 -> 512 + residual + ReLU, then the next block's conv1 512 -> 128 (32 x 16 maps, 131 072
+// pixels per 256-frame step). The two weight matrices are 128 KB each -- they do not fit the LDS beside the tiles --
+// but a wave only ever needs ITS output channels of them: with the eight waves splitting the channels (64 of conv3,
+// 16 of the next conv1) each lane keeps its 16 + 16 MFMA weight fragments in 128 VGPRs for the whole kernel, and the
+// LDS holds nothing but tiles: y2 (16 KB) and the residual / out tile (64 KB), both double-buffered = 160 KB.
+// Per 64-pixel tile the kernel moves 160 KB of HBM traffic (y2, residual in; out, z out) for 2 x 64 MFMAs per wave:
+// HBM-bound, like the layer-1 form.
+constexpr int L2K1 = 128, L2N1 = 512, L2K2 = 512, L2N2 = 128;
+
+__global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParams p, int ntiles) {
+    constexpr int A_BYTES = 2 * TBM * 128;      // 16 KB: two 64-channel k-tiles of [64 rows][128 B]
+    constexpr int R_BYTES = TBM * L2N1 * 2;     // 64 KB: 1024-byte rows, chunk c at c ^ (row & 31)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_BYTES + 2 * R_BYTES];
+    unsigned char* s_a = smem;
+    unsigned char* s_r = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const int G = gridDim.x;
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+    const unsigned char* y2g = reinterpret_cast<const unsigned char*>(p.y2);
+    const unsigned char* resg = reinterpret_cast<const unsigned char*>(p.res);
+
+    // ---- this wave's weight fragments, resident in registers: conv3 channels 64 wave + 16 a + frow, k = 32 kk + 8 fchunk;
+    // next conv1 channel 16 wave + frow, k = 32 ks + 8 fchunk (the MFMA A operand: row = lane & 15, k-chunk = lane >> 4)
+    uint4 w3f[4][4], w1f[16];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            w3f[a][kk] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.w3) +
+                                                         ((size_t)(wave * 64 + a * 16 + frow) * L2K1 + kk * 32 + fchunk * 8) * 2);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+        w1f[ks] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p.w1n) +
+                                                  ((size_t)(wave * 16 + frow) * L2K2 + ks * 32 + fchunk * 8) * 2);
+    // biases: one value per lane (lane L: conv3 channel 64 wave + L, next conv1 channel 16 wave + (L & 15)), fetched
+    // through the cross-lane network where they are used -- 2 registers instead of 20
+    float b3l = p.b3[wave * 64 + lane];
+    float b1l = p.b1n[wave * 16 + (lane & 15)];
+    asm volatile("" : "+v"(b3l), "+v"(b1l));
+    auto lane_bias = [&](float held, int src_lane) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(held)));
+    };
+    // opaque from here on: the compiler must keep them in registers rather than re-load them inside the tile loop (its
+    // own loads come with vmcnt waits that would drain the DMA queue)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            asm volatile("" : "+v"(w3f[a][kk].x), "+v"(w3f[a][kk].y), "+v"(w3f[a][kk].z), "+v"(w3f[a][kk].w));
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(w1f[ks].x), "+v"(w1f[ks].y), "+v"(w1f[ks].z), "+v"(w1f[ks].w));
+
+    // ---- per-tile DMA: 2 y2 pieces (rows 8 wave .. +7 of both k-tiles) + 8 residual pieces (whole rows 8 wave + j)
+    auto stage_tile = [&](int T, int slot) {
+        const int m0 = T * TBM;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));  // addresses are recomputed per tile: hoisted out of the loop they end up in scratch
+        {
+            const int row = wave * 8 + (ln >> 3);
+            const int gm = m0 + row;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+                dma16(gm < p.M ? y2g + (size_t)gm * (L2K1 * 2) + kt * 128 + (((ln & 7) ^ ((row >> 1) & 7)) << 4) : zsrc,
+                      s_a + slot * A_BYTES + kt * (TBM * 128) + wave * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = wave * 8 + j;
+            const int gm = m0 + row;
+            dma16(gm < p.M ? resg + (size_t)gm * (L2N1 * 2) + ((ln ^ (row & 31)) << 4) : zsrc, s_r + slot * R_BYTES + row * 1024);
+        }
+    };
+
+    int T = blockIdx.x;
+    if (T < ntiles) stage_tile(T, 0);
+    wait_vmcnt<0>();
+    wg_barrier();
+    int slot = 0;
+    for (; T < ntiles; T += G, slot ^= 1) {
+        const int m0 = T * TBM;
+        if (T + G < ntiles) stage_tile(T + G, slot ^ 1);  // 10 DMA pieces at the head of this iteration's queue
+        const unsigned char* sa = s_a + slot * A_BYTES;
+        unsigned char* sr = s_r + slot * R_BYTES;
+        // ---- GEMM 1: 64 px x 512 ch, K = 128. Wave tile 64 px x 64 ch, weights from registers; two passes of 32
+        // channels (32 accumulator registers at a time beside the 128 weight registers), each followed by its
+        // bias + residual (in place) + ReLU -> bf16 out tile
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah) {
+            f32x4_t acc[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            uint4 xp[2][4];
+            auto ld1 = [&](int kk, int b) {
+                return *reinterpret_cast<const uint4*>(sa + (kk >> 1) * (TBM * 128) + lds_off(b * 16 + frow, (kk & 1) * 4 + fchunk));
+            };
+#pragma unroll
+            for (int b = 0; b < 4; ++b) xp[0][b] = ld1(0, b);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) xp[(kk + 1) & 1][b] = ld1(kk + 1, b);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = Frag<bf16_t>::mma(w3f[2 * ah + a][kk], xp[kk & 1][b], acc[a][b]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float bv[2][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[a][r] = lane_bias(b3l, (2 * ah + a) * 16 + fchunk * 4 + r);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int px = b * 16 + frow;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int c = wave * 64 + (2 * ah + a) * 16 + fchunk * 4;
+                    unsigned char* cell = sr + px * 1024 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
+                    float rr[4];
+                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[a][b][r] + bv[a][r] + rr[r], 0.f);
+                    store4<bf16_t>(reinterpret_cast<bf16_t*>(cell), v);
+                }
+            }
+        }
+        wg_barrier();  // out tile complete; every read of the y2 tile done
+        // drain the out tile: 4096 16-byte chunks, 8 per thread, one whole 1024-byte row per wave instruction
+        int ld = lane, td = tid;
+        asm volatile("" : "+v"(ld), "+v"(td));  // store addresses recomputed per tile (see stage_tile)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = wave + 8 * i;
+            const int gm = m0 + row;
+            if (gm < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sr + row * 1024 + (ld << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * L2N1 + (ld ^ (row & 31)) * 8) * 2) = v;
+            }
+        }
+        // ---- GEMM 2: 64 px x 128 ch, K = 512, B operand straight from the out tile. Wave tile 64 px x 16 ch.
+        f32x4_t acc2[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc2[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // fragment reads one k-step ahead of the MFMAs; sched_barrier keeps the compiler from hoisting all 64 reads
+        uint4 xq[2][4];
+        auto ld2 = [&](int ks, int b) {
+            const int px = b * 16 + frow;
+            return *reinterpret_cast<const uint4*>(sr + px * 1024 + (((ks * 4 + fchunk) ^ (px & 31)) << 4));
+        };
+#pragma unroll
+        for (int b = 0; b < 4; ++b) xq[0][b] = ld2(0, b);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 1 < 16) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) xq[(ks + 1) & 1][b] = ld2(ks + 1, b);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc2[b] = Frag<bf16_t>::mma(w1f[ks], xq[ks & 1][b], acc2[b]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // z tile (64 px x 128 ch, 256-byte rows, chunk c at c ^ (row & 15)) over this tile's y2 slot
+        unsigned char* sz = s_a + slot * A_BYTES;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int px = b * 16 + frow;
+            const int c = wave * 16 + fchunk * 4;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc2[b][r] + lane_bias(b1l, fchunk * 4 + r), 0.f);
+            store4<bf16_t>(reinterpret_cast<bf16_t*>(sz + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
+        }
+        wg_barrier();  // z tile complete; every read of the out tile done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (td >> 4) + 32 * i, pch = td & 15;
+            const int gm = m0 + row;
+            if (gm < p.M) {
+                const uint4 v = *reinterpret_cast<const uint4*>(sz + row * 256 + (pch << 4));
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.z) + ((size_t)gm * L2N2 + (pch ^ (row & 15)) * 8) * 2) = v;
+            }
+        }
+        // the next tile's DMA (issued first) has landed once at most the 10 stores above are still outstanding (a ragged
+        // tile issues fewer, but it is the last tile of its workgroup: nothing is in flight then)
+        wait_vmcnt<10>();
+        wg_barrier();
+    }
+}
+
 }  // namespace
 
 extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual,
@@ -396,9 +597,10 @@ extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float*
                    "agrl_bottleneck_tail: pass either the residual map or the downsample conv's input, not both");
     AGRL_CHECK_ARG(!x_short || (w_short && b_short), "agrl_bottleneck_tail: the downsample form needs its weights and bias");
     AGRL_CHECK_ARG(M > 0, "agrl_bottleneck_tail: empty problem");
-    AGRL_CHECK_ARG(Cmid == TK1 && Cout == TN1 && (Cnext == TN2 || (Cnext == 128 && !x_short)) && (!x_short || Cshort == TK1),
+    const bool layer2 = Cmid == L2K1 && Cout == L2N1 && Cnext == L2N2 && !x_short;
+    AGRL_CHECK_ARG(layer2 || (Cmid == TK1 && Cout == TN1 && (Cnext == TN2 || (Cnext == 128 && !x_short)) && (!x_short || Cshort == TK1)),
                    "agrl_bottleneck_tail: built for Cmid=64, Cout=256, Cnext=64 (128 without downsample), Cshort=64 "
-                   "(layer 1), got %d/%d/%d/%d", Cmid, Cout, Cnext, Cshort);
+                   "(layer 1) and Cmid=128, Cout=512, Cnext=128 without downsample (layer 2), got %d/%d/%d/%d", Cmid, Cout, Cnext, Cshort);
     const uintptr_t al = (uintptr_t)y2 | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)residual | (uintptr_t)out |
                          (uintptr_t)w1_next | (uintptr_t)b1_next | (uintptr_t)z | (uintptr_t)x_short | (uintptr_t)w_short |
                          (uintptr_t)b_short;
@@ -408,7 +610,8 @@ extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float*
     p.xs = x_short; p.ws = w_short; p.bs = b_short;
     const int ntiles = cdiv(M, TBM);
     const int grid = ntiles < 256 ? ntiles : 256;
-    if (Cnext == 128) hipLaunchKernelGGL(bottleneck_tail128_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
+    if (layer2) hipLaunchKernelGGL(bottleneck_tail_l2_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
+    else if (Cnext == 128) hipLaunchKernelGGL(bottleneck_tail128_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
     else if (x_short) hipLaunchKernelGGL(bottleneck_tail_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
     else hipLaunchKernelGGL(bottleneck_tail_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p, ntiles);
     AGRL_CHECK_LAUNCH("agrl_bottleneck_tail");

@@ -6,6 +6,7 @@ input's device, and launches on the calling thread's current HIP stream. No arit
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -99,8 +100,11 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
 
 
 def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
-    """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 shapes in bf16. ``shortcut_conv`` =
+    """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 and layer-2 shapes in bf16. ``shortcut_conv`` =
     (weight, stride) of the block's downsample conv when the residual is to be computed in the same pass."""
+    if (y2.dtype == torch.bfloat16 and tuple(w3.shape) == (512, 1, 1, 128) and tuple(w1_next.shape) == (128, 1, 1, 512)
+            and shortcut_conv is None and os.environ.get('AGRL_HIP_FUSE_TAIL_L2', '1') != '0'):
+        return True  # layer-2 form (weights resident in registers)
     ok = (y2.dtype == torch.bfloat16 and tuple(w3.shape) == (256, 1, 1, 64)
           and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)))
     if shortcut_conv is not None:

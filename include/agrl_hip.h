@@ -83,8 +83,8 @@ int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const float* bias, co
  * (vmgn.py:60-61), computed in the same pass (the shortcut map is then neither written nor read; it is added in fp32
  * without the intermediate bf16 rounding of a separate conv). out is written once and never read back from HBM.
  * Built for Cmid = Cshort = 64, Cout = 256, Cnext = 64 (layer 1; Cnext = 128, the layer1 -> layer2 transition, with the
- * identity-shortcut form only); other shapes are rejected (the caller then runs the
- * convs separately through agrl_conv2d_bn_act). */
+ * identity-shortcut form only) and for Cmid = 128, Cout = 512, Cnext = 128 (layer 2, identity-shortcut form); other
+ * shapes are rejected (the caller then runs the convs separately through agrl_conv2d_bn_act). */
 int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const void* residual,
                          const void* x_short, const void* w_short, const float* b_short, void* out,
                          const void* w1_next, const float* b1_next, void* z, int M, int Cmid, int Cout,

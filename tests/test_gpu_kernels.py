@@ -159,6 +159,35 @@ def test_bottleneck_tail(shape, cnext):
     assert e1 < 1e-2 and e2 < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 16), (1, 16, 8), (3, 10, 7), (40, 32, 16)])
+def test_bottleneck_tail_layer2(shape):
+    """Layer-2 form of the fused tail (conv3 128 -> 512 + residual + relu, next conv1 512 -> 128; weights resident in
+    registers) against the two separate igemm launches (bitwise) and the fp32 reference; (40, 32, 16) = 320 tiles, more
+    than one per workgroup (prefetch ring, counted waits), (3, 10, 7) a ragged last tile."""
+    from torchreid import hip_ops as ops
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * H + 7)
+    y2 = torch.randn((N, 128, H, W), generator=g).bfloat16().float()
+    res = torch.randn((N, 512, H, W), generator=g).bfloat16().float()
+    w3 = (torch.randn((512, 128, 1, 1), generator=g) / 11).bfloat16().float()
+    w1 = (torch.randn((128, 512, 1, 1), generator=g) / 22).bfloat16().float()
+    b3, b1 = torch.randn(512, generator=g), torch.randn(128, generator=g)
+    out_ref = F.relu(F.conv2d(y2, w3, bias=b3) + res)
+    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
+    dy2, dres = nhwc(y2, torch.bfloat16), nhwc(res, torch.bfloat16)
+    dw3 = w3.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    dw1 = w1.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    assert ops.bottleneck_tail_supported(dy2, dw3, dw1)
+    out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
+    out2 = ops.conv_bn_act(dy2, dw3, b3.to(DEV), 1, 0, True, residual=dres)
+    z2 = ops.conv_bn_act(out2, dw1, b1.to(DEV), 1, 0, True)
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(z.float().permute(0, 3, 1, 2), z_ref)
+    print("bottleneck tail layer 2", shape, "out %.3e z %.3e" % (e1, e2))
+    assert e1 < 1e-2 and e2 < 1e-2
+    assert torch.equal(out, out2) and torch.equal(z, z2)
+
+
 @pytest.mark.parametrize("tile", ["2", "3"])
 @pytest.mark.parametrize("case", [(3, 16, 8, 256, 512), (2, 32, 16, 512, 256), (1, 10, 6, 128, 256)])
 def test_conv_wide_tile_strided(case, tile, monkeypatch):

@@ -27,3 +27,22 @@ for name, fn in (("fused", fused), ("split", split)):
     us = statistics.median(ts)
     gb = 2.0 * (y2.numel() + 2 * res.numel() + N * H * W * 64) / 1e9
     print("%s %7.1f us  (fused traffic %.0f MB -> %.2f TB/s)" % (name, us, gb * 1e3, gb / us * 1e-3 * 1e3 if False else gb / (us * 1e-6) / 1e3))
+
+# layer-2 form: conv3 128 -> 512 + residual, next conv1 512 -> 128 at 32 x 16
+H, W = 32, 16
+y2 = torch.randn((N, H, W, 128), device=dev).bfloat16()
+res = torch.randn((N, H, W, 512), device=dev).bfloat16()
+w3 = (torch.randn((512, 1, 1, 128), device=dev) / 11).bfloat16()
+w1 = (torch.randn((128, 1, 1, 512), device=dev) / 22).bfloat16()
+b3, b1 = torch.randn(512, device=dev), torch.randn(128, device=dev)
+for name, fn in (("layer2 fused", fused), ("layer2 split", split)):
+    ts = []
+    for r in range(8):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10): fn()
+        e.record(); torch.cuda.synchronize()
+        if r >= 2: ts.append(s.elapsed_time(e) * 100)
+    us = statistics.median(ts)
+    gb = 2.0 * (y2.numel() + 2 * res.numel() + N * H * W * 128) / 1e9
+    print("%s %7.1f us  (fused traffic %.0f MB -> %.2f TB/s)" % (name, us, gb * 1e3, gb / (us * 1e-6) / 1e3))
