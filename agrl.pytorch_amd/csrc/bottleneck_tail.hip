@@ -406,7 +406,6 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fchunk = lane >> 4;
-    const int lrow = lane >> 3, lchk = lane & 7;
     const int G = gridDim.x;
     const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
     const unsigned char* y2g = reinterpret_cast<const unsigned char*>(p.y2);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
         const bool real = pi < 2 * PPIECES;
         pok[i] = real && row < PPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W &&
                  (bsel == 0 || second_valid);
-        poff[i] = (unsigned)((((size_t)img * p.H + iy) * p.W + ix) * p.Cin * 2 + ((lchk ^ ((row >> 1) & 7)) << 4));
+        poff[i] = (unsigned)((((size_t)img * p.H + iy) * p.W + ix) * p.Cin * 2 + ((lchk ^ patch_g(py, px)) << 4));
         pdst[i] = real ? bsel * PATCH_BYTES + piece * 1024 : -1;
     }
     unsigned boff[BJ];
@@ -117,11 +117,12 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
     const int frow = lane & 15, fchunk = lane >> 4;
     // this wave's 64 pixels lie in block wm >> 1 (pixels (wm & 1) * 64 .. + 63 of it)
     const int pbase = (wm >> 1) * PATCH_BYTES;
-    int pr0[FM];  // patch pixel of this lane's output pixel at tap (0,0)
+    int py0[FM], px0[FM];  // patch pixel of this lane's output pixel at tap (0,0)
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-        const int m = (wm & 1) * 64 + b * 16 + frow;
-        pr0[b] = (m >> 3) * PW + (m & 7);
+        const int m = (wm & 1) * 64 + b * 16 + frag_px(frow);
+        py0[b] = m >> 3;
+        px0[b] = m & 7;
     }
 
     const int nslab = p.Cin >> 6;
@@ -167,13 +168,12 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
                 stage_b(s2, t2, slot2);
             }
             const int tr = tap / 3, ts = tap - tr * 3;
-            const int shift = tr * PW + ts;
             const unsigned char* sb = s_b + wslot * B_BYTES;
             // 8 groups of 4 MFMAs: group g = (k-step g >> 2, channel fragment g & 3)
             uint4 xfr[2][FM], wfr[3];
             auto ldx = [&](int kk, int b) {
                 if ((DBG & 4) && step) return make_uint4(step, kk, b, lane);
-                return *reinterpret_cast<const uint4*>(sp + lds_off(pr0[b] + shift, kk * 4 + fchunk));
+                return *reinterpret_cast<const uint4*>(sp + patch_off<PW>(py0[b] + tr, px0[b] + ts, kk * 4 + fchunk));
             };
             auto ldw = [&](int g) {
                 if ((DBG & 4) && step) return make_uint4(step, g, 7, lane);
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
         if (p.colv && n0 + c < p.N) cv = *reinterpret_cast<const float4*>(p.colv + n0 + c);
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
-            const int prow = wm * (BM / WM) + b * 16 + frow;
+            const int prow = wm * (BM / WM) + b * 16 + frag_px(frow);
             float v[4] = {acc[a][b][0] + cv.x, acc[a][b][1] + cv.y, acc[a][b][2] + cv.z, acc[a][b][3] + cv.w};
             if (p.relu) {
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
             const int py = row / PW, px = row - py * PW;
             const int iy = oy0 + py - 1, ix = ox0 + px - 1;
             const bool ok = piece < PPIECES && row < PPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            dma16(ok ? xg + (((size_t)img * p.H + iy) * p.W + ix) * 128 + ((lchk ^ ((row >> 1) & 7)) << 4) : zsrc,
+            dma16(ok ? xg + (((size_t)img * p.H + iy) * p.W + ix) * 128 + ((lchk ^ patch_g(py, px)) << 4) : zsrc,
                   piece < PPIECES ? s_p + buf * PATCH_BYTES + piece * 1024 : s_dummy);
         }
     };
@@ -298,11 +298,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
         cv[a] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.colv) cv[a] = *reinterpret_cast<const float4*>(p.colv + wn * 32 + a * 16 + fchunk * 4);
     }
-    int pr0[FM];
+    int py0[FM], px0[FM];
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-        const int m = wm * 32 + b * 16 + frow;
-        pr0[b] = (m >> 3) * PW + (m & 7);
+        const int m = wm * 32 + b * 16 + frag_px(frow);
+        py0[b] = m >> 3;
+        px0[b] = m & 7;
     }
 
     int blk = blockIdx.x;
@@ -325,12 +326,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
             for (int b = 0; b < FM; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int shift = (t / 3) * PW + (t % 3);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 uint4 xf[FM], wf[FN];
 #pragma unroll
-                for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(sp + lds_off(pr0[b] + shift, kk * 4 + fchunk));
+                for (int b = 0; b < FM; ++b) xf[b] = *reinterpret_cast<const uint4*>(sp + patch_off<PW>(py0[b] + t / 3, px0[b] + t % 3, kk * 4 + fchunk));
 #pragma unroll
                 for (int a = 0; a < FN; ++a)
                     wf[a] = *reinterpret_cast<const uint4*>(s_w + t * W_TAP + lds_off(wn * 32 + a * 16 + frow, kk * 4 + fchunk));
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
         // before the barrier at the top of this iteration
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
-            const int prow = wm * 32 + b * 16 + frow;
+            const int prow = wm * 32 + b * 16 + frag_px(frow);
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
                 const int c = wn * 32 + a * 16 + fchunk * 4;

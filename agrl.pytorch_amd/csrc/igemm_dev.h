@@ -115,6 +115,20 @@ __device__ inline void wg_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// Conflict-free shifted patch reads. A ds_read_b128 is served in groups of 16 lanes -- MFMA columns (lane & 15) 0-3 and
+// 12-15 of one k-chunk together with columns 4-11 of the neighbouring k-chunk -- and 16 lanes are conflict-free when
+// they hit 16 different 16-byte slots of the 256-byte bank window (= two 128-byte patch pixels, even / odd x). The
+// pixel <-> MFMA column assignment is free, so columns 0-3, 12-15 take the eight pixels of one block row and columns
+// 4-11 the eight of the next one; with the k-chunk of patch pixel (py, px) stored at chunk ^ g(py, px),
+// g = ((px >> 1) & 3) ^ 4 (py & 1), the four same-parity pixels of a row land in four different slots for ANY tap shift
+// (x >> 1 runs over four consecutive values), the neighbouring row differs in bit 2, and the k-chunk pair c, c ^ 1 of a
+// group stays inside the row's own four-slot class. (With consecutive pixels on consecutive columns no swizzle of a
+// 10-wide patch is conflict-free: exhaustive search.)
+__device__ inline int frag_px(int col) { return col < 4 ? col : (col < 12 ? col + 4 : col - 8); }  // 8 * row + x inside the fragment
+__device__ inline int patch_g(int py, int px) { return ((px >> 1) & 3) ^ ((py & 1) << 2); }
+template <int PW_>
+__device__ inline int patch_off(int py, int px, int chunk) { return (py * PW_ + px) * 128 + ((chunk ^ patch_g(py, px)) << 4); }
+
 // 256 x 256 tile kernel for the MFMA-bound pointwise layers (igemm_wide.hip)
 bool igemm_wide_applicable(const IgemmParams& p);
 int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who);
