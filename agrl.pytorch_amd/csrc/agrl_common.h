@@ -96,6 +96,15 @@ struct DT<float> {
     __device__ static inline float ld(const float* p) { return *p; }
     __device__ static inline void st(float* p, float v) { *p = v; }
 };
+// fp32 storage, split-bf16 arithmetic (AGRL_F32X3): same layout as float, different MFMA recipe (Frag<f32s_t>)
+struct f32s_t {
+    float v;
+};
+template <>
+struct DT<f32s_t> {
+    static constexpr int code = AGRL_F32X3;
+    static constexpr int epc = 4;
+};
 template <>
 struct DT<bf16_t> {
     static constexpr int code = AGRL_BF16;

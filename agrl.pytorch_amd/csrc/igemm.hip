@@ -898,7 +898,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     AGRL_CHECK_ARG(x && w && out, "agrl_conv2d_bn_act: null pointer");
     AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "agrl_conv2d_bn_act: bad shape");
     AGRL_CHECK_ARG(R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_conv2d_bn_act: bad filter geometry");
-    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_conv2d_bn_act: bad dtype %d", dtype);
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16 || dtype == AGRL_F32X3, "agrl_conv2d_bn_act: bad dtype %d", dtype);
     IgemmParams p;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
@@ -909,6 +909,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     p.Cin = Cin; p.H = H; p.W = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.ldo = Cout;
     if (dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
+    if (dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
     const bool patch_ok = R == 3 && S == 3 && stride == 1 && pad == 1 && !residual && (H % 16) == 0 && (W % 8) == 0 &&
                           (Cin % 64) == 0 && (Cout % 8) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0 &&
                           (!bias || (((uintptr_t)bias) & 15) == 0) && (size_t)N * H * W * Cin * 2 < (1ull << 32) &&
@@ -973,7 +974,7 @@ extern "C" int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const floa
 extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
                                   int in_dtype, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && w && y, "agrl_linear_nobias: null pointer");
-    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16, "agrl_linear_nobias: bad dtype %d", in_dtype);
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_linear_nobias: bad dtype %d", in_dtype);
     IgemmParams p;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
@@ -981,6 +982,7 @@ extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M,
     p.Cin = K; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.ldo = Nout;
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
+    if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
     return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
 }
 

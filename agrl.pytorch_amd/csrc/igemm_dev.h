@@ -55,6 +55,33 @@ struct Frag<float> {
     }
 };
 
+template <>
+struct Frag<f32s_t> {
+    // Same operand layout as Frag<float> (a 16-byte chunk = 4 fp32 = the four hardware-k values of this lane's k-group in
+    // v_mfma_f32_16x16x16_bf16). x = xh + xl with xh = x truncated to bf16 (exact difference) and xl rounded to bf16:
+    // x w = xh wh + xh wl + xl wh + O(2^-16 |x w|), three bf16 MFMAs (3 x 16 cycles) instead of four fp32 ones (4 x 32).
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    __device__ static inline void split(const uint4& v, s16x4_t& hi, s16x4_t& lo) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = __uint_as_float(w[i]) - __uint_as_float(w[i] & 0xffff0000u);
+        const uint32_t h0 = (w[0] >> 16) | (w[1] & 0xffff0000u), h1 = (w[2] >> 16) | (w[3] & 0xffff0000u);
+        const uint32_t l0 = pack_bf16x2(d[0], d[1]), l1 = pack_bf16x2(d[2], d[3]);
+        hi = __builtin_bit_cast(s16x4_t, make_uint2(h0, h1));
+        lo = __builtin_bit_cast(s16x4_t, make_uint2(l0, l1));
+    }
+    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+        s16x4_t ah, al, bh, bl;
+        split(a, ah, al);
+        split(b, bh, bl);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, c, 0, 0, 0);
+        return c;
+    }
+};
+
 __device__ inline int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <typename TOUT>

@@ -17,6 +17,7 @@ import torch
 
 F32 = 0
 BF16 = 1
+F32X3 = 2  # fp32 tensors, split-bf16 MFMA arithmetic (include/agrl_hip.h)
 METRIC_EUCLIDEAN = 0
 METRIC_COSINE = 1
 

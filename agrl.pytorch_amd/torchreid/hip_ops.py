@@ -14,6 +14,30 @@ from . import _hip
 from ._hip import BF16, F32, METRIC_COSINE, METRIC_EUCLIDEAN, call, dtype_code, ptr
 
 
+import contextlib
+import threading
+
+_MODE = threading.local()
+
+
+@contextlib.contextmanager
+def f32_split(on=True):
+    """Inside this block fp32 convs / Linears use the split-bf16 recipe (dtype code AGRL_F32X3: every product as three
+    bf16 MFMAs on the high / low halves of the operands, ~1e-5 relative, 2-3 x the exact-fp32 rate). Per thread."""
+    prev = getattr(_MODE, 'split', False)
+    _MODE.split = bool(on)
+    try:
+        yield
+    finally:
+        _MODE.split = prev
+
+
+def _gemm_code(dt):
+    if dt == torch.float32 and getattr(_MODE, 'split', False):
+        return _hip.F32X3
+    return dtype_code(dt)
+
+
 def _stream(t):
     return _hip.stream_ptr(t.device)
 
@@ -76,7 +100,7 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
                             "bytes": e * (x.numel() + w_ohwi.numel() + out.numel() * (2 if residual is not None else 1))}
     with _dev(x):
         call("agrl_conv2d_bn_act", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
-             stride, pad, 1 if relu else 0, dtype_code(x.dtype), _stream(x))
+             stride, pad, 1 if relu else 0, _gemm_code(x.dtype), _stream(x))
     return out
 
 
@@ -149,7 +173,7 @@ def linear_nobias(x, w):
     if _hip.PROFILE is not None:
         _hip.PROFILE_TAG = {"flops": 2.0 * M * K * Nout, "bytes": x.element_size() * (x.numel() + w.numel()) + 4 * y.numel()}
     with _dev(x):
-        call("agrl_linear_nobias", ptr(x), ptr(w), ptr(y), M, K, Nout, dtype_code(x.dtype), _stream(x))
+        call("agrl_linear_nobias", ptr(x), ptr(w), ptr(y), M, K, Nout, _gemm_code(x.dtype), _stream(x))
     return y
 
 

@@ -19,7 +19,8 @@ import torch
 from torchreid import hip_ops as ops
 from torchreid import _hip
 
-_PRECISIONS = {'fp32': torch.float32, 'bf16': torch.bfloat16}
+# 'bf16x3': fp32 tensors and layouts of the parity mode, conv / Linear products as three bf16 MFMAs (hip_ops.f32_split)
+_PRECISIONS = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'bf16x3': torch.float32}
 
 
 def _fold_conv_bn(conv, bn, dtype):
@@ -61,7 +62,7 @@ def _fingerprint(model):
 def pack_weights(model, device, precision):
     """BN-fold + re-layout every weight of the eval forward for ``device``; cached on the model."""
     if precision not in _PRECISIONS:
-        raise ValueError("hip_precision must be 'fp32' or 'bf16', got {!r}".format(precision))
+        raise ValueError("hip_precision must be 'fp32', 'bf16' or 'bf16x3', got {!r}".format(precision))
     key = (device.index if device.index is not None else torch.cuda.current_device(), precision)
     cached = model._hip_packs.get(key)
     if cached is not None and (model.hip_static_weights or cached['fingerprint'] == _fingerprint(model)):
@@ -233,7 +234,7 @@ def hip_forward(model, x, adj, return_feats=False):
         raise ValueError('adj must be {} for S={} and {} parts, got {}'.format((B, V, V), S, P, tuple(adj.shape)))
     pack = pack_weights(model, x.device, model.hip_precision)
     lp = pack['dtype'] == torch.bfloat16
-    with torch.no_grad():
+    with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
         fused = hip_features_pooled(model, frames, pack, model.total_split_list) if model.hip_fuse_pool else None
         if fused is not None:
@@ -270,7 +271,7 @@ def hip_forward_gsta(model, x, adj):
     pack = pack_weights(model, x.device, model.hip_precision)
     lp = pack['dtype'] == torch.bfloat16
     splits = list(model.total_split_list)
-    with torch.no_grad():
+    with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
         a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
         a = _run_trunk(a, pack['trunk'], model.hip_fuse_tail)

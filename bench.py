@@ -30,7 +30,7 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd"), os.path.join(ROOT, "test
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}  # dense MFMA peaks, MI355X_MICROARCH.md (split mode: 3 bf16 MFMAs per product)
 PEAK_HBM_GBS = 8000.0
 GALLERY_ROWS = 12180  # MARS gallery of the reference tree
 FEATURE_DIM = 4096
@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="tracklets per GPU per step")
     ap.add_argument("--seq-len", type=int, default=8)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--metric", default="cosine", choices=["cosine", "euclidean"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="lower bound of CPU-baseline work")

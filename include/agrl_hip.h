@@ -11,7 +11,10 @@
  *   - activations are NHWC ("pixel-major"): x[n][h][w][c]; conv weights are OHWI:
  *     w[cout][r][s][cin] with eval-mode BatchNorm already folded in (scale into w, shift into bias)
  *   - dtype codes: AGRL_F32 = 0 (exact-fp32 MFMA, the parity mode), AGRL_BF16 = 1 (bf16 MFMA with
- *     fp32 accumulation, the throughput mode)
+ *     fp32 accumulation, the throughput mode), AGRL_F32X3 = 2 (fp32 tensors, each product formed as three bf16 MFMAs
+ *     on the high / low halves of the operands: x = xh + xl, x w ~ xh wh + xh wl + xl wh, fp32 accumulation; ~1e-5
+ *     relative instead of bit-exact fp32, 2-3 x the exact mode's rate; accepted by agrl_conv2d_bn_act and
+ *     agrl_linear_nobias)
  *
  * Each entry point cites the reference call site it replaces (paths relative to the reference
  * tree weleen/AGRL.pytorch).
@@ -28,6 +31,7 @@ extern "C" {
 
 #define AGRL_F32 0
 #define AGRL_BF16 1
+#define AGRL_F32X3 2
 
 #define AGRL_METRIC_EUCLIDEAN 0 /* squared euclidean, torchreid/metrics/distance.py:59-73 */
 #define AGRL_METRIC_COSINE 1    /* 1 - cos,          torchreid/metrics/distance.py:76-89 */

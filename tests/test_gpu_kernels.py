@@ -563,6 +563,38 @@ def test_rank_cuhk03_device():
     assert np.array_equal(cmc, cmc_o) and abs(mAP - mAP_o) < 1e-14
 
 
+def test_conv_and_linear_split_bf16_mode():
+    """AGRL_F32X3: fp32 tensors, products as three bf16 MFMAs on high / low operand halves. Against the fp32 reference:
+    ~1e-5 relative (the exact-fp32 kernel: ~1e-7), for a 1x1, a 3x3 strided conv with residual and the Linear."""
+    from torchreid import hip_ops as ops
+    g = torch.Generator().manual_seed(33)
+    for (N, H, W, Cin, Cout, R, stride, use_res) in [(2, 16, 8, 256, 128, 1, 1, False), (2, 16, 8, 64, 96, 3, 2, True)]:
+        x = torch.randn((N, Cin, H, W), generator=g)
+        w = torch.randn((Cout, Cin, R, R), generator=g) / np.sqrt(Cin * R * R)
+        b = torch.randn((Cout,), generator=g)
+        ref = F.conv2d(x.double(), w.double(), bias=b.double(), stride=stride, padding=R // 2)
+        res = torch.randn(ref.shape, generator=g) if use_res else None
+        if use_res:
+            ref = ref + res.double()
+        ref = F.relu(ref)
+        args = (nhwc(x, torch.float32), w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV), stride, R // 2, True)
+        kw = dict(residual=None if res is None else nhwc(res, torch.float32))
+        exact = ops.conv_bn_act(*args, **kw)
+        with ops.f32_split():
+            split = ops.conv_bn_act(*args, **kw)
+        torch.cuda.synchronize()
+        e0 = rel_err(exact.double().permute(0, 3, 1, 2), ref)
+        e3 = rel_err(split.double().permute(0, 3, 1, 2), ref)
+        print("split conv", (Cin, Cout, R, stride), "exact %.2e split %.2e" % (e0, e3))
+        assert e0 < 2e-6 and e3 < 5e-5 and not torch.equal(exact, split)
+    xm = torch.randn((300, 512), generator=g)
+    wm = torch.randn((256, 512), generator=g) * 0.05
+    ref = xm.double() @ wm.double().t()
+    with ops.f32_split():
+        y = ops.linear_nobias(xm.to(DEV), wm.to(DEV))
+    assert rel_err(y.double(), ref) < 5e-5
+
+
 def test_pose_adjacency_device():
     """agrl_pose_adjacency vs the reference's generate_graph (golden fixture) and vs the oracle on random poses,
     incl. undetected frames, low-confidence keypoints, num_split 8 and the non-pyramid layout."""

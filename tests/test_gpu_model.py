@@ -44,6 +44,13 @@ def test_vmgn_eval_fp32_matches_oracle(cfg):
     print("vmgn fp32", cfg, "max rel err %.3e  (|ref|max %.3f, tracklet spread %.3e)" % (
         e, ref.abs().max().item(), (ref[0] - ref[-1]).abs().max().item()))
     assert e < 1e-3  # north-star bar; measured ~1e-5
+    # split-bf16 mode (fp32 tensors, every conv / Linear product as three bf16 MFMAs): same bar, 2-3 x the rate
+    m.hip_precision = "bf16x3"
+    got3 = m(x.to(DEV), adj.to(DEV))
+    torch.cuda.synchronize()
+    e3 = rel(got3, ref)
+    print("vmgn bf16x3", cfg, "max rel err %.3e" % e3)
+    assert got3.dtype == torch.float32 and e3 < 1e-3 and not torch.equal(got3, got)
 
 
 @pytest.mark.parametrize("cfg", [(3, 5, 128, 64, 4, True), (2, 16, 256, 128, 4, True), (1, 1, 256, 128, 4, True),
