@@ -506,6 +506,18 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bv[a][r] = lane_bias(b3l, (2 * ah + a) * 16 + fchunk * 4 + r);
+            // all eight residual cells are read before the first is written back (a read behind a write to the same array is
+            // not hoisted by the compiler: eight LDS round trips in a row otherwise)
+            uint2 rcell[4][2];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int px = b * 16 + frow;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int c = wave * 64 + (2 * ah + a) * 16 + fchunk * 4;
+                    rcell[b][a] = *reinterpret_cast<const uint2*>(sr + px * 1024 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1));
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int px = b * 16 + frow;
@@ -513,8 +525,8 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
                 for (int a = 0; a < 2; ++a) {
                     const int c = wave * 64 + (2 * ah + a) * 16 + fchunk * 4;
                     unsigned char* cell = sr + px * 1024 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
-                    float rr[4];
-                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
+                    const float rr[4] = {__uint_as_float(rcell[b][a].x << 16), __uint_as_float(rcell[b][a].x & 0xffff0000u),
+                                         __uint_as_float(rcell[b][a].y << 16), __uint_as_float(rcell[b][a].y & 0xffff0000u)};
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[a][b][r] + bv[a][r] + rr[r], 0.f);

@@ -45,6 +45,7 @@ SIGNATURES = {
     "agrl_stem_conv_bn_relu_maxpool_bf16": [_p, _p, _p, _p, _i, _i, _i, _p],
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "agrl_bottleneck_block": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "agrl_conv1x1_bn_act_pool": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_linear_nobias": [_p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_part_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],

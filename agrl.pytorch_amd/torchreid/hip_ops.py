@@ -164,6 +164,44 @@ def bottleneck_tail(y2, w3, b3, residual, w1_next, b1_next, shortcut=None):
     return out, z
 
 
+def bottleneck_block_supported(z, w2, stride, w3, w1_next, shortcut_conv=None):
+    """The fused 3x3 -> conv3(+shortcut) -> next conv1 kernel exists for the layer-1 shapes in bf16 (stride-1 3x3,
+    8 x 8-divisible maps). ``shortcut_conv`` as in bottleneck_tail_supported."""
+    if os.environ.get('AGRL_HIP_FUSE_BLOCK', '1') == '0':
+        return False
+    ok = (z.dtype == torch.bfloat16 and stride == 1 and tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64)
+          and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)) and z.shape[1] % 8 == 0 and z.shape[2] % 8 == 0)
+    if shortcut_conv is not None:
+        ok = ok and tuple(shortcut_conv[0].shape) == (256, 1, 1, 64) and shortcut_conv[1] == 1 and w1_next.shape[0] == 64
+    return ok
+
+
+def bottleneck_block(z, w2, b2, w3, b3, residual, w1_next, b1_next, shortcut=None):
+    """y2 = relu(conv3x3(z)), out = relu(conv3(y2) + R), z_next = relu(conv1_next(out)) in one pass: y2 never leaves the
+    CU, out is written once. R = ``residual`` or, with ``shortcut`` = (x, w_ds, b_ds), the block's 1x1 stride-1
+    downsample conv. vmgn.py:52-64 (block i) + :48-50 (block i+1). -> out (N,H,W,256), z_next (N,H,W,64 | 128)."""
+    N, H, W, Cmid = z.shape
+    Cout, Cnext = w3.shape[0], w1_next.shape[0]
+    assert z.dtype == torch.bfloat16 and (residual is None) != (shortcut is None)
+    xs = ws = bs = None
+    if shortcut is not None:
+        xs, ws, bs = shortcut
+        assert tuple(xs.shape) == (N, H, W, 64) and xs.dtype == z.dtype
+    else:
+        assert tuple(residual.shape) == (N, H, W, Cout) and residual.dtype == z.dtype
+    out = torch.empty((N, H, W, Cout), dtype=z.dtype, device=z.device)
+    zn = torch.empty((N, H, W, Cnext), dtype=z.dtype, device=z.device)
+    M = N * H * W
+    if _hip.PROFILE is not None:
+        rd = residual.numel() if residual is not None else xs.numel() + ws.numel()
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * (9 * Cmid * Cmid + (Cmid + (64 if shortcut is not None else 0)) * Cout + Cout * Cnext),
+                            "bytes": 2.0 * (z.numel() + rd + out.numel() + zn.numel() + w2.numel() + w3.numel() + w1_next.numel())}
+    with _dev(z):
+        call("agrl_bottleneck_block", ptr(z), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(residual), ptr(xs), ptr(ws), ptr(bs),
+             ptr(out), ptr(w1_next), ptr(b1_next), ptr(zn), N, H, W, Cmid, Cout, Cnext, _stream(z))
+    return out, zn
+
+
 def linear_nobias(x, w):
     """(M,K) @ (N,K)^T -> fp32 (M,N). vmgn.py:148."""
     M, K = x.shape

@@ -109,6 +109,18 @@ def _run_trunk(a, blocks, fuse_tail=True):
     for i, blk in enumerate(blocks):
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
         y = z if z is not None else ops.conv_bn_act(a, blk['c1'][0], blk['c1'][1], 1, 0, True)
+        if fuse_tail and nxt is not None:
+            # layer 1: 3x3 + conv3 (+ shortcut) + next conv1 in ONE pass over 8 x 8 pixel tiles (ops.bottleneck_block)
+            ds = None if blk['ds'] is None else (blk['ds'][0], blk['ds_stride'])
+            if ops.bottleneck_block_supported(y, blk['c2'][0], blk['stride'], blk['c3'][0], nxt['c1'][0], ds) and (
+                    ds is None or a.shape[3] == 64):
+                if ds is None:
+                    a, z = ops.bottleneck_block(y, blk['c2'][0], blk['c2'][1], blk['c3'][0], blk['c3'][1], a,
+                                                nxt['c1'][0], nxt['c1'][1])
+                else:
+                    a, z = ops.bottleneck_block(y, blk['c2'][0], blk['c2'][1], blk['c3'][0], blk['c3'][1], None,
+                                                nxt['c1'][0], nxt['c1'][1], shortcut=(a, blk['ds'][0], blk['ds'][1]))
+                continue
         y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
         fusable = fuse_tail and nxt is not None and ops.bottleneck_tail_supported(y, blk['c3'][0], nxt['c1'][0])
         if fusable and blk['ds'] is not None and ops.bottleneck_tail_supported(

@@ -94,6 +94,19 @@ int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const 
                          const void* w1_next, const float* b1_next, void* z, int M, int Cmid, int Cout,
                          int Cnext, int Cshort, agrl_stream_t stream);
 
+/* Whole body of a layer-1 Bottleneck behind its first conv, fused with the head of the next block (bf16 only;
+ * torchreid/models/vmgn.py:45-65: conv2/bn2/relu :52-54, conv3/bn3/+residual/relu :56-64 of block i, conv1/bn1/relu
+ * :48-50 of block i+1):
+ *   y2    (F,H,W,64)    = relu(conv3x3(z (F,H,W,64), w2 (64,3,3,64) OHWI, stride 1, pad 1) + b2)    never written
+ *   out   (F,H,W,Cout)  = relu(y2 @ w3 (Cout,64)^T + b3 + R)
+ *   z_next(F,H,W,Cnext) = relu(out @ w1_next (Cnext,Cout)^T + b1_next)
+ * R = residual (F,H,W,Cout), or -- first block, residual == NULL -- x_short (F,H,W,64) @ w_short (Cout,64)^T + b_short.
+ * Built for Cmid = 64, Cout = 256, Cnext = 64 (128 with the identity shortcut only), H and W multiples of 8. */
+int agrl_bottleneck_block(const void* z, const void* w2, const float* b2, const void* w3, const float* b3,
+                          const void* residual, const void* x_short, const void* w_short, const float* b_short,
+                          void* out, const void* w1_next, const float* b1_next, void* z_next, int F, int H, int W,
+                          int Cmid, int Cout, int Cnext, agrl_stream_t stream);
+
 /* y = x @ w^T (no bias): x (M,K) in_dtype, w (Nout,K) in_dtype, y (M,Nout) fp32.
  * Replaces GraphLayer's nn.Linear(2048,2048,bias=False), torchreid/models/vmgn.py:148. */
 int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,

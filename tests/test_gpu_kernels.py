@@ -159,6 +159,54 @@ def test_bottleneck_tail(shape, cnext):
     assert e1 < 1e-2 and e2 < 1e-2
 
 
+@pytest.mark.parametrize("cnext", [64, 128])
+@pytest.mark.parametrize("shape", [(2, 64, 32), (1, 16, 8), (3, 8, 24), (9, 64, 32)])
+def test_bottleneck_block(shape, cnext, monkeypatch):
+    """3x3 conv + conv3 + residual + relu of a layer-1 block fused with the next block's conv1 (bottleneck_block.hip)
+    against the three separate launches (bitwise: same fp32 accumulation order, same roundings) and the fp32 reference;
+    (9, 64, 32) = 288 tiles, more than one per workgroup; also the first-block form with the downsample conv."""
+    from torchreid import hip_ops as ops
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * H + cnext)
+    z = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
+    res = torch.randn((N, 256, H, W), generator=g).bfloat16().float()
+    w2 = (torch.randn((64, 64, 3, 3), generator=g) / 24).bfloat16().float()
+    w3 = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
+    w1 = (torch.randn((cnext, 256, 1, 1), generator=g) / 16).bfloat16().float()
+    b2, b3, b1 = torch.randn(64, generator=g), torch.randn(256, generator=g), torch.randn(cnext, generator=g)
+    y2_ref = F.relu(F.conv2d(z, w2, bias=b2, padding=1)).bfloat16().float()
+    out_ref = F.relu(F.conv2d(y2_ref, w3, bias=b3) + res)
+    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
+    dz, dres = nhwc(z, torch.bfloat16), nhwc(res, torch.bfloat16)
+    ohwi = lambda w: w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    dw2, dw3, dw1 = ohwi(w2), ohwi(w3), ohwi(w1)
+    assert ops.bottleneck_block_supported(dz, dw2, 1, dw3, dw1)
+    out, zn = ops.bottleneck_block(dz, dw2, b2.to(DEV), dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
+    y2s = ops.conv_bn_act(dz, dw2, b2.to(DEV), 1, 1, True)
+    out2 = ops.conv_bn_act(y2s, dw3, b3.to(DEV), 1, 0, True, residual=dres)
+    z2 = ops.conv_bn_act(out2, dw1, b1.to(DEV), 1, 0, True)
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(zn.float().permute(0, 3, 1, 2), z_ref)
+    print("bottleneck block", shape, cnext, "out %.3e z %.3e" % (e1, e2))
+    assert e1 < 1e-2 and e2 < 1e-2
+    assert torch.equal(out, out2) and torch.equal(zn, z2)
+    if cnext != 64:
+        return
+    x0 = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
+    ws = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
+    bs = torch.randn(256, generator=g)
+    out_ref = F.relu(F.conv2d(y2_ref, w3, bias=b3) + F.conv2d(x0, ws, bias=bs))
+    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
+    out, zn = ops.bottleneck_block(dz, dw2, b2.to(DEV), dw3, b3.to(DEV), None, dw1, b1.to(DEV),
+                                   shortcut=(nhwc(x0, torch.bfloat16), ohwi(ws), bs.to(DEV)))
+    out3, z3 = ops.bottleneck_tail(y2s, dw3, b3.to(DEV), None, dw1, b1.to(DEV), shortcut=(nhwc(x0, torch.bfloat16), ohwi(ws), bs.to(DEV)))
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(zn.float().permute(0, 3, 1, 2), z_ref)
+    print("bottleneck block + downsample", shape, "out %.3e z %.3e" % (e1, e2))
+    assert e1 < 1e-2 and e2 < 1e-2
+    assert torch.equal(out, out3) and torch.equal(zn, z3)
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 16), (1, 16, 8), (3, 10, 7), (40, 32, 16)])
 def test_bottleneck_tail_layer2(shape):
     """Layer-2 form of the fused tail (conv3 128 -> 512 + residual + relu, next conv1 512 -> 128; weights resident in

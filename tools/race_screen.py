@@ -41,6 +41,40 @@ for name, c in cases:
     total += bad
     print("%-28s %d / %d runs differ from the baseline kernel" % (name, bad, REPS))
 
+# fused layer-1 block (3x3 + conv3 + residual + next conv1) vs the split launches
+Nb, Hb, Wb = 256, 64, 32
+zin = torch.randn((Nb, Hb, Wb, 64), device=dev).bfloat16()
+resb = torch.randn((Nb, Hb, Wb, 256), device=dev).bfloat16()
+w2b = (torch.randn((64, 3, 3, 64), device=dev) / 24).bfloat16()
+w3b = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+b2b, b3b = torch.randn(64, device=dev), torch.randn(256, device=dev)
+for cn in (64, 128):
+    w1b = (torch.randn((cn, 1, 1, 256), device=dev) / 16).bfloat16()
+    b1b = torch.randn(cn, device=dev)
+    yb = ops.conv_bn_act(zin, w2b, b2b, 1, 1, True)
+    ob = ops.conv_bn_act(yb, w3b, b3b, 1, 0, True, residual=resb)
+    zb = ops.conv_bn_act(ob, w1b, b1b, 1, 0, True)
+    bad = 0
+    for _ in range(REPS):
+        o, zz = ops.bottleneck_block(zin, w2b, b2b, w3b, b3b, resb, w1b, b1b)
+        bad += int(not (torch.equal(o, ob) and torch.equal(zz, zb)))
+    total += bad
+    print("bottleneck block cnext=%-3d     %d / %d runs differ from the split convs" % (cn, bad, REPS))
+xsb = torch.randn((Nb, Hb, Wb, 64), device=dev).bfloat16()
+wsb = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+bsb = torch.randn(256, device=dev)
+w1b = (torch.randn((64, 1, 1, 256), device=dev) / 16).bfloat16()
+b1b = torch.randn(64, device=dev)
+o0, z0 = ops.bottleneck_block(zin, w2b, b2b, w3b, b3b, None, w1b, b1b, shortcut=(xsb, wsb, bsb))
+o0, z0 = o0.clone(), z0.clone()
+bad = 0
+for _ in range(REPS):
+    o, zz = ops.bottleneck_block(zin, w2b, b2b, w3b, b3b, None, w1b, b1b, shortcut=(xsb, wsb, bsb))
+    bad += int(not (torch.equal(o, o0) and torch.equal(zz, z0)))
+total += bad
+print("bottleneck block + downsample %d / %d runs differ from the first run" % (bad, REPS))
+del zin, resb, xsb
+
 # fused tails vs the split convs
 N, H, W = 256, 64, 32
 y2 = torch.randn((N, H, W, 64), device=dev).bfloat16()

@@ -46,3 +46,29 @@ for name, fn in (("layer2 fused", fused), ("layer2 split", split)):
     us = statistics.median(ts)
     gb = 2.0 * (y2.numel() + 2 * res.numel() + N * H * W * 128) / 1e9
     print("%s %7.1f us  (fused traffic %.0f MB -> %.2f TB/s)" % (name, us, gb * 1e3, gb / (us * 1e-6) / 1e3))
+
+# whole layer-1 block: 3x3 64 -> 64, conv3 64 -> 256 + residual, next conv1 256 -> 64 at 64 x 32
+H, W = 64, 32
+zin = torch.randn((N, H, W, 64), device=dev).bfloat16()
+res = torch.randn((N, H, W, 256), device=dev).bfloat16()
+w2 = (torch.randn((64, 3, 3, 64), device=dev) / 24).bfloat16()
+w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+b2, b3 = torch.randn(64, device=dev), torch.randn(256, device=dev)
+for cn in (64, 128):
+    w1 = (torch.randn((cn, 1, 1, 256), device=dev) / 16).bfloat16()
+    b1 = torch.randn(cn, device=dev)
+    def fusedb(): return ops.bottleneck_block(zin, w2, b2, w3, b3, res, w1, b1)
+    def splitb():
+        y = ops.conv_bn_act(zin, w2, b2, 1, 1, True)
+        return ops.bottleneck_tail(y, w3, b3, res, w1, b1)
+    for name, fn in (("block fused cn=%d" % cn, fusedb), ("block 3x3 + tail cn=%d" % cn, splitb)):
+        ts = []
+        for r in range(8):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10): fn()
+            e.record(); torch.cuda.synchronize()
+            if r >= 2: ts.append(s.elapsed_time(e) * 100)
+        us = statistics.median(ts)
+        gb = 2.0 * (zin.numel() + 2 * res.numel() + N * H * W * cn) / 1e9
+        print("%s %7.1f us  (fused traffic %.0f MB -> %.2f TB/s)" % (name, us, gb * 1e3, gb / (us * 1e-6) / 1e3))
