@@ -7,9 +7,11 @@
 // straight out of the patch. 1.5x redundant MFMA work buys zero gather instructions.
 //
 // One 512-thread workgroup -> an 8x8 tile of POOLED pixels x 64 channels of one frame:
-//   patch 39x40x4 bf16 (12.5 KB) + packed weights 64 x 232 bf16 (29 KB, LDS-DMA)      -> LDS
+//   patch 39x40x4 bf16 (12.5 KB) + packed weights 64 x 240 bf16 (30 KB, LDS-DMA)      -> LDS
 //   conv tile 17x17 = 289 positions x 64 ch: 19 position fragments over 8 waves, 7 k-steps, +bias, ReLU
 //   -> bf16 conv tile in LDS (overlaying patch+weights) -> 3x3/2 max -> NHWC store (128 B per pooled pixel)
+#include <stdlib.h>
+
 #include "agrl_common.h"
 
 namespace {
@@ -23,65 +25,66 @@ constexpr int FPW = (NFRAG + NWV - 1) / NWV;  // position fragments per wave: 3
 constexpr int IT = 2 * (CT - 1) + 7;  // input patch edge 39
 constexpr int PWP = 40;               // padded patch width (pixels)
 constexpr int PATCH_BYTES = IT * PWP * 8;      // 12480
-constexpr int WROW_BYTES = 464;                // 7*32 bf16 = 448 + 16 pad (odd number of 16-B slots: conflict-free)
-constexpr int W_BYTES = 64 * WROW_BYTES;       // 29696 = 29 KiB
-constexpr int LDS_BYTES = PATCH_BYTES + W_BYTES;  // 42176 >= the 289 x 128 B conv tile that later overlays it
-static_assert(NPOS * 128 <= LDS_BYTES, "conv tile must fit");
+// 7*32 bf16 = 448 + 32 pad = 30 sixteen-byte slots per row. A ds_read_b128 is served in groups of 16 lanes: rows
+// (lane & 15) 0-3, 12-15 at k-chunk g with rows 4-11 at k-chunk g + 1; 30 r mod 16 sends the first set to the even slots and
+// the second (+1) to the odd ones: conflict-free (29 slots, the "odd stride" choice, collides on five of sixteen)
+constexpr int WROW_BYTES = 480;
+constexpr int W_BYTES = 64 * WROW_BYTES;       // 30720 = 30 KiB
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
-__global__ __launch_bounds__(NTH) void stem_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
+// Persistent form: a workgroup keeps the packed weights in LDS and walks tiles; the NEXT tile's input pixels are requested
+// (12 floats per thread, in registers) right after the current patch has been written to LDS, so the HBM round trip runs
+// under the MFMA sweep, the conv-tile epilogue and the pooling of the current tile. The one-tile-per-workgroup form spent
+// most of a workgroup's life waiting: for its weights (30 KB per 8 x 8 pooled pixels), its pixels, its three barriers.
+// LDS: weights 30 KB + one region that holds the patch, then the conv tile (37 KB) = 67 KB: two workgroups per CU.
+constexpr int CT_BYTES = (NPOS + 3) * 128;
+constexpr int REGION_BYTES = CT_BYTES > PATCH_BYTES ? CT_BYTES : PATCH_BYTES;
+
+__global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
-                                                        int W, int CH, int CW, int PH, int PW, int tiles_w, int tiles_hw) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+                                                        int W, int CH, int CW, int PH, int PW, int tiles_w, int tiles_hw,
+                                                        int ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[REGION_BYTES + W_BYTES];
     unsigned char* s_patch = smem;
-    unsigned char* s_w = smem + PATCH_BYTES;
+    unsigned char* s_ct = smem;
+    unsigned char* s_w = smem + REGION_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = blockIdx.x / tiles_hw;
-    const int trem = blockIdx.x - n * tiles_hw;
-    const int ph0 = (trem / tiles_w) * PT;
-    const int pw0 = (trem % tiles_w) * PT;
-    const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1;
-    const int iy0 = 2 * cr0 - 3, ix0 = 2 * cc0 - 3;
+    const int G = gridDim.x;
 
-    // weights: 29 one-KiB DMA pieces, contiguous
+    // weights: 30 one-KiB DMA pieces, contiguous, once per workgroup
     for (int piece = wave; piece < W_BYTES / 1024; piece += NWV)
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(wpk + piece * 1024 + lane * 16), (lds_void_t*)(s_w + piece * 1024), 16, 0, 0);
-    // patch: one pixel (3 channels -> 4 bf16) per thread per pass; all loads of all passes are issued before the
-    // first one is consumed (a load->convert->store loop would serialise 7 HBM round trips)
-    const float* xn = x + (size_t)n * 3 * H * W;
+
+    // patch: one pixel (3 channels -> 4 bf16) per thread per pass; all loads of all passes are issued together
     constexpr int NPASS = (IT * PWP + NTH - 1) / NTH;  // 4
     float pv[NPASS][3];
+    auto load_patch = [&](int T) {
+        const int n = T / tiles_hw;
+        const int trem = T - n * tiles_hw;
+        const int ph0 = (trem / tiles_w) * PT, pw0 = (trem % tiles_w) * PT;
+        const int iy0 = 2 * (2 * ph0 - 1) - 3, ix0 = 2 * (2 * pw0 - 1) - 3;
+        const float* xn = x + (size_t)n * 3 * H * W;
+        int td = tid;
+        asm volatile("" : "+v"(td));  // per-tile address arithmetic (hoisted out of the tile loop it costs 100 registers)
 #pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int e = tid + NTH * i;
-        const int py = e / PWP, px = e - py * PWP;
-        const int iy = iy0 + py, ix = ix0 + px;
-        pv[i][0] = pv[i][1] = pv[i][2] = 0.f;
-        if (e < IT * PWP && px < IT && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-            const size_t o = (size_t)iy * W + ix;
-            pv[i][0] = xn[o];
-            pv[i][1] = xn[(size_t)H * W + o];
-            pv[i][2] = xn[2 * (size_t)H * W + o];
+        for (int i = 0; i < NPASS; ++i) {
+            const int e = td + NTH * i;
+            const int py = e / PWP, px = e - py * PWP;
+            const int iy = iy0 + py, ix = ix0 + px;
+            pv[i][0] = pv[i][1] = pv[i][2] = 0.f;
+            if (e < IT * PWP && px < IT && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const size_t o = (size_t)iy * W + ix;
+                pv[i][0] = xn[o];
+                pv[i][1] = xn[(size_t)H * W + o];
+                pv[i][2] = xn[2 * (size_t)H * W + o];
+            }
         }
-    }
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int e = tid + NTH * i;
-        if (e < IT * PWP) {
-            uint2 u;
-            u.x = pack_bf16x2(pv[i][0], pv[i][1]);
-            u.y = (uint32_t)f32_to_bf16(pv[i][2]);
-            *reinterpret_cast<uint2*>(s_patch + e * 8) = u;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+    };
     const int frow = lane & 15, g = lane >> 4;
     int a_off[FPW];  // byte offset of this lane's patch slice at filter row 0
 #pragma unroll
@@ -91,78 +94,107 @@ __global__ __launch_bounds__(NTH) void stem_mfma_kernel(const float* __restrict_
         const int cy = pos / CT, cx = pos - cy * CT;
         a_off[i] = ((2 * cy) * PWP + 2 * cx + 2 * g) * 8;
     }
-    f32x4_t acc[FPW][4];
+    auto ct_row = [](int pos) { return (pos & ~3) | ((pos & 1) << 1) | ((pos >> 1) & 1); };
+
+    int T = blockIdx.x;
+    if (T < ntiles) load_patch(T);
+    for (; T < ntiles; T += G) {
+        const int n = T / tiles_hw;
+        const int trem = T - n * tiles_hw;
+        const int ph0 = (trem / tiles_w) * PT, pw0 = (trem % tiles_w) * PT;
+        const int cr0 = 2 * ph0 - 1, cc0 = 2 * pw0 - 1;
+        // ---- this tile's pixels (requested one tile ago) -> bf16 patch in LDS
 #pragma unroll
-    for (int i = 0; i < FPW; ++i)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) acc[i][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        uint4 wf[4], xf[FPW];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-            wf[a] = *reinterpret_cast<const uint4*>(s_w + (a * 16 + frow) * WROW_BYTES + r * 64 + g * 16);
-#pragma unroll
-        for (int i = 0; i < FPW; ++i) xf[i] = *reinterpret_cast<const uint4*>(s_patch + a_off[i] + r * (PWP * 8));
+        for (int i = 0; i < NPASS; ++i) {
+            const int e = tid + NTH * i;
+            if (e < IT * PWP) {
+                uint2 u;
+                u.x = pack_bf16x2(pv[i][0], pv[i][1]);
+                u.y = (uint32_t)f32_to_bf16(pv[i][2]);
+                *reinterpret_cast<uint2*>(s_patch + e * 8) = u;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tile: the weight DMA (invisible to the compiler) has landed
+        __syncthreads();
+        if (T + G < ntiles) load_patch(T + G);  // in flight until the top of the next iteration
+
+        f32x4_t acc[FPW][4];
 #pragma unroll
         for (int i = 0; i < FPW; ++i)
 #pragma unroll
+            for (int a = 0; a < 4; ++a) acc[i][a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            uint4 wf[4], xf[FPW];
+#pragma unroll
             for (int a = 0; a < 4; ++a)
-                acc[i][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[a]),
-                                                                    __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][a], 0, 0, 0);
-    }
-    __syncthreads();  // every wave is done with patch + weights: the conv tile may overlay them
+                wf[a] = *reinterpret_cast<const uint4*>(s_w + (a * 16 + frow) * WROW_BYTES + r * 64 + g * 16);
+#pragma unroll
+            for (int i = 0; i < FPW; ++i) xf[i] = *reinterpret_cast<const uint4*>(s_patch + a_off[i] + r * (PWP * 8));
+#pragma unroll
+            for (int i = 0; i < FPW; ++i)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    acc[i][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[a]),
+                                                                        __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][a], 0, 0, 0);
+        }
+        __syncthreads();  // every wave is done with the patch: the conv tile may overlay it
+        int fr = frow, gg = g, tq = tid;
+        asm volatile("" : "+v"(fr), "+v"(gg), "+v"(tq));  // epilogue / pooling addresses are recomputed per tile
 
-    // conv tile [pos][64 ch] bf16, 8-byte slot s of row p stored at slot s ^ (p & 15)
-    unsigned char* s_ct = smem;
+        // conv tile [pos][64 ch] bf16, 8-byte slot s of row p stored at slot s ^ (p & 15); row p lives at row index ct_row(p)
+        // = p with bits 0 and 1 swapped: a 32-lane group of the pooling reads below covers two pooled pixels = rows p and
+        // p + 2, which would share every bank (rows alternate between the halves of the 256-byte bank window by bit 0)
 #pragma unroll
-    for (int i = 0; i < FPW; ++i) {
-        const int pos = (wave + NWV * i) * 16 + frow;
-        if (pos < NPOS) {
-            const int cy = pos / CT, cx = pos - cy * CT;
-            const bool in = (unsigned)(cr0 + cy) < (unsigned)CH && (unsigned)(cc0 + cx) < (unsigned)CW;
+        for (int i = 0; i < FPW; ++i) {
+            const int pos = (wave + NWV * i) * 16 + fr;
+            if (pos < NPOS) {
+                const int cy = pos / CT, cx = pos - cy * CT;
+                const bool in = (unsigned)(cr0 + cy) < (unsigned)CH && (unsigned)(cc0 + cx) < (unsigned)CW;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int ch = a * 16 + g * 4;
-                const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-                const float v0 = in ? fmaxf(acc[i][a][0] + bv.x, 0.f) : 0.f;
-                const float v1 = in ? fmaxf(acc[i][a][1] + bv.y, 0.f) : 0.f;
-                const float v2 = in ? fmaxf(acc[i][a][2] + bv.z, 0.f) : 0.f;
-                const float v3 = in ? fmaxf(acc[i][a][3] + bv.w, 0.f) : 0.f;
-                uint2 u;
-                u.x = pack_bf16x2(v0, v1);
-                u.y = pack_bf16x2(v2, v3);
-                *reinterpret_cast<uint2*>(s_ct + pos * 128 + (((ch >> 2) ^ (pos & 15)) << 3)) = u;
+                for (int a = 0; a < 4; ++a) {
+                    const int ch = a * 16 + gg * 4;
+                    const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
+                    const float v0 = in ? fmaxf(acc[i][a][0] + bv.x, 0.f) : 0.f;
+                    const float v1 = in ? fmaxf(acc[i][a][1] + bv.y, 0.f) : 0.f;
+                    const float v2 = in ? fmaxf(acc[i][a][2] + bv.z, 0.f) : 0.f;
+                    const float v3 = in ? fmaxf(acc[i][a][3] + bv.w, 0.f) : 0.f;
+                    uint2 u;
+                    u.x = pack_bf16x2(v0, v1);
+                    u.y = pack_bf16x2(v2, v3);
+                    *reinterpret_cast<uint2*>(s_ct + ct_row(pos) * 128 + (((ch >> 2) ^ (pos & 15)) << 3)) = u;
+                }
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // 3x3/2 max pool: thread -> 4 channels (one 8-byte slot) of pooled pixels (tid>>4) + 16 i
-    const int cq = tid & 15;
+        // 3x3/2 max pool: thread -> 4 channels (one 8-byte slot) of pooled pixels (tid>>4) + 32 i
+        const int cq = tq & 15;
 #pragma unroll
-    for (int i = 0; i < (PT * PT * 16) / NTH; ++i) {
-        const int pp = (tid >> 4) + (NTH / 16) * i;
-        const int py = pp / PT, px = pp - py * PT;
-        const int ph = ph0 + py, pw = pw0 + px;
-        if (ph < PH && pw < PW) {
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;  // post-ReLU values are >= 0
+        for (int i = 0; i < (PT * PT * 16) / NTH; ++i) {
+            const int pp = (tq >> 4) + (NTH / 16) * i;
+            const int py = pp / PT, px = pp - py * PT;
+            const int ph = ph0 + py, pw = pw0 + px;
+            if (ph < PH && pw < PW) {
+                float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;  // post-ReLU values are >= 0
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int pos = (2 * py + dy) * CT + 2 * px + dx;
-                    const uint2 u = *reinterpret_cast<const uint2*>(s_ct + pos * 128 + ((cq ^ (pos & 15)) << 3));
-                    m0 = fmaxf(m0, __uint_as_float(u.x << 16));
-                    m1 = fmaxf(m1, __uint_as_float(u.x & 0xffff0000u));
-                    m2 = fmaxf(m2, __uint_as_float(u.y << 16));
-                    m3 = fmaxf(m3, __uint_as_float(u.y & 0xffff0000u));
-                }
-            uint2 o;  // already bf16-representable: plain truncation is exact
-            o.x = (__float_as_uint(m0) >> 16) | (__float_as_uint(m1) & 0xffff0000u);
-            o.y = (__float_as_uint(m2) >> 16) | (__float_as_uint(m3) & 0xffff0000u);
-            *reinterpret_cast<uint2*>(out + (((size_t)n * PH + ph) * PW + pw) * 64 + cq * 4) = o;
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int pos = (2 * py + dy) * CT + 2 * px + dx;
+                        const uint2 u = *reinterpret_cast<const uint2*>(s_ct + ct_row(pos) * 128 + ((cq ^ (pos & 15)) << 3));
+                        m0 = fmaxf(m0, __uint_as_float(u.x << 16));
+                        m1 = fmaxf(m1, __uint_as_float(u.x & 0xffff0000u));
+                        m2 = fmaxf(m2, __uint_as_float(u.y << 16));
+                        m3 = fmaxf(m3, __uint_as_float(u.y & 0xffff0000u));
+                    }
+                uint2 o;  // already bf16-representable: plain truncation is exact
+                o.x = (__float_as_uint(m0) >> 16) | (__float_as_uint(m1) & 0xffff0000u);
+                o.y = (__float_as_uint(m2) >> 16) | (__float_as_uint(m3) & 0xffff0000u);
+                *reinterpret_cast<uint2*>(out + (((size_t)n * PH + ph) * PW + pw) * 64 + cq * 4) = o;
+            }
         }
+        __syncthreads();  // the conv tile is consumed: the next patch may overwrite it
     }
 }
 }  // namespace
@@ -178,8 +210,12 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w
     const int tiles_h = cdiv(PH, PT), tiles_w = cdiv(PW, PT);
     const long long grid = (long long)N * tiles_h * tiles_w;
     AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_bf16: grid too large");
-    hipLaunchKernelGGL(stem_mfma_kernel, dim3((unsigned)grid), dim3(NTH), 0, (hipStream_t)stream, x,
-                       (const unsigned char*)w_packed, bias, (bf16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w);
+    int wgs = 512;  // two persistent workgroups per CU (67 KB of LDS each)
+    if (const char* e = getenv("AGRL_STEM_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+    const unsigned launch = (unsigned)(grid < wgs ? grid : wgs);
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3(launch), dim3(NTH), 0, (hipStream_t)stream, x,
+                       (const unsigned char*)w_packed, bias, (bf16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w,
+                       (int)grid);
     AGRL_CHECK_LAUNCH("agrl_stem_bf16");
     return 0;
 }

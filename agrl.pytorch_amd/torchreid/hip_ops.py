@@ -61,11 +61,12 @@ def stem(x_nchw, w_ohwi, bias, out_dtype):
 
 
 def pack_stem_weights_bf16(w_ohwi):
-    """(64,7,7,3) fp32 OHWI (BN folded) -> (64,232) bf16: per filter row 8 taps x 4 channels, zero padded."""
+    """(64,7,7,3) fp32 OHWI (BN folded) -> (64,240) bf16: per filter row 8 taps x 4 channels, zero padded; 480-byte rows
+    (30 sixteen-byte slots: the stride that makes the kernel's weight-fragment reads bank-conflict free)."""
     assert tuple(w_ohwi.shape) == (64, 7, 7, 3)
     w = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=w_ohwi.device)
     w[:, :, :7, :3] = w_ohwi.float()
-    packed = torch.zeros((64, 232), dtype=torch.bfloat16, device=w_ohwi.device)
+    packed = torch.zeros((64, 240), dtype=torch.bfloat16, device=w_ohwi.device)
     packed[:, :224] = w.view(64, 224).to(torch.bfloat16)
     return packed.contiguous()
 
@@ -73,7 +74,7 @@ def pack_stem_weights_bf16(w_ohwi):
 def stem_bf16(x_nchw, w_packed, bias):
     """bf16-MFMA stem: (N,3,H,W) fp32 NCHW -> (N,PH,PW,64) bf16 NHWC. vmgn.py:281-284."""
     assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.size(1) == 3
-    assert w_packed.dtype == torch.bfloat16 and tuple(w_packed.shape) == (64, 232)
+    assert w_packed.dtype == torch.bfloat16 and tuple(w_packed.shape) == (64, 240)
     x_nchw = x_nchw.contiguous()
     N, _, H, W = x_nchw.shape
     CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1

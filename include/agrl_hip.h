@@ -53,8 +53,9 @@ int agrl_stem_conv_bn_relu_maxpool(const float* x, const float* w, const float* 
                                    int N, int H, int W, int out_dtype, agrl_stream_t stream);
 
 /* bf16-MFMA form of the same stem (throughput mode). Same input; weights pre-packed by the host as
- * bf16 (64, 232): row o = [r=0..6][s=0..7][c=0..3] (i.e. 7 x 32 values, zero where s == 7 or c == 3,
- * value w[o][r][s][c] * bn_scale[o] elsewhere) followed by 8 zeros; out is bf16 NHWC (N, PH, PW, 64). */
+ * bf16 (64, 240): row o = [r=0..6][s=0..7][c=0..3] (i.e. 7 x 32 values, zero where s == 7 or c == 3,
+ * value w[o][r][s][c] * bn_scale[o] elsewhere) followed by 16 zeros (480-byte rows: the stride that keeps the kernel's
+ * LDS weight reads bank-conflict free); out is bf16 NHWC (N, PH, PW, 64). */
 int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w_packed, const float* bias,
                                         void* out, int N, int H, int W, agrl_stream_t stream);
 
