@@ -162,36 +162,36 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
                     uint2 u;
                     u.x = pack_bf16x2(v0, v1);
                     u.y = pack_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2*>(s_ct + ct_row(pos) * 128 + (((ch >> 2) ^ (pos & 15)) << 3)) = u;
+                    *reinterpret_cast<uint2*>(s_ct + ct_row(pos) * 128 + (((ch >> 3) ^ (pos & 7)) << 4) + ((ch & 4) << 1)) = u;
                 }
             }
         }
         __syncthreads();
 
-        // 3x3/2 max pool: thread -> 4 channels (one 8-byte slot) of pooled pixels (tid>>4) + 32 i
-        const int cq = tq & 15;
-#pragma unroll
-        for (int i = 0; i < (PT * PT * 16) / NTH; ++i) {
-            const int pp = (tq >> 4) + (NTH / 16) * i;
+        // 3x3/2 max pool: thread -> 8 channels (one 16-byte slot) of ONE pooled pixel. The activations are post-ReLU bf16,
+        // i.e. non-negative: their bit patterns order like unsigned 16-bit integers, so the maximum is two v_pk_max_u16 per
+        // dword pair instead of unpack + fmax per channel (the kernel is VALU-bound)
+        {
+            typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+            const int cq = tq & 7;
+            const int pp = tq >> 3;
             const int py = pp / PT, px = pp - py * PT;
             const int ph = ph0 + py, pw = pw0 + px;
             if (ph < PH && pw < PW) {
-                float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;  // post-ReLU values are >= 0
+                u16x2_t m[4] = {u16x2_t{0, 0}, u16x2_t{0, 0}, u16x2_t{0, 0}, u16x2_t{0, 0}};
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
                         const int pos = (2 * py + dy) * CT + 2 * px + dx;
-                        const uint2 u = *reinterpret_cast<const uint2*>(s_ct + ct_row(pos) * 128 + ((cq ^ (pos & 15)) << 3));
-                        m0 = fmaxf(m0, __uint_as_float(u.x << 16));
-                        m1 = fmaxf(m1, __uint_as_float(u.x & 0xffff0000u));
-                        m2 = fmaxf(m2, __uint_as_float(u.y << 16));
-                        m3 = fmaxf(m3, __uint_as_float(u.y & 0xffff0000u));
+                        const uint4 u = *reinterpret_cast<const uint4*>(s_ct + ct_row(pos) * 128 + ((cq ^ (pos & 7)) << 4));
+                        const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) m[e] = __builtin_elementwise_max(m[e], __builtin_bit_cast(u16x2_t, w4[e]));
                     }
-                uint2 o;  // already bf16-representable: plain truncation is exact
-                o.x = (__float_as_uint(m0) >> 16) | (__float_as_uint(m1) & 0xffff0000u);
-                o.y = (__float_as_uint(m2) >> 16) | (__float_as_uint(m3) & 0xffff0000u);
-                *reinterpret_cast<uint2*>(out + (((size_t)n * PH + ph) * PW + pw) * 64 + cq * 4) = o;
+                const uint4 o = make_uint4(__builtin_bit_cast(uint32_t, m[0]), __builtin_bit_cast(uint32_t, m[1]),
+                                           __builtin_bit_cast(uint32_t, m[2]), __builtin_bit_cast(uint32_t, m[3]));
+                *reinterpret_cast<uint4*>(out + (((size_t)n * PH + ph) * PW + pw) * 64 + cq * 8) = o;
             }
         }
         __syncthreads();  // the conv tile is consumed: the next patch may overwrite it
@@ -203,7 +203,7 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w
                                                    int N, int H, int W, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && w_packed && bias && out, "agrl_stem_bf16: null pointer");
     AGRL_CHECK_ARG(N > 0 && H >= 7 && W >= 7, "agrl_stem_bf16: bad shape N=%d H=%d W=%d", N, H, W);
-    AGRL_CHECK_ARG((((uintptr_t)w_packed) & 15) == 0 && (((uintptr_t)bias) & 15) == 0 && (((uintptr_t)out) & 7) == 0,
+    AGRL_CHECK_ARG((((uintptr_t)w_packed) & 15) == 0 && (((uintptr_t)bias) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
                    "agrl_stem_bf16: misaligned pointer");
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
