@@ -98,7 +98,8 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
     if _hip.PROFILE is not None:
         e = x.element_size()
         _hip.PROFILE_TAG = {"flops": 2.0 * N * OH * OW * Cout * R * S * Cin,
-                            "bytes": e * (x.numel() + w_ohwi.numel() + out.numel() * (2 if residual is not None else 1))}
+                            "bytes": e * (x.numel() + w_ohwi.numel() + out.numel() * (2 if residual is not None else 1)),
+                            "conv": (R, stride, Cin, Cout, OH, OW)}
     with _dev(x):
         call("agrl_conv2d_bn_act", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
              stride, pad, 1 if relu else 0, _gemm_code(x.dtype), _stream(x))

@@ -215,13 +215,22 @@ def main():
     if rank == 0:
         prof, _hip.PROFILE = _hip.PROFILE, None
         agg = {}
+        dom = {"ms": 0.0, "launches": 0, "flops": 0.0}  # the dominant kernel: conv3x3_wide_kernel (see below)
         for name, s_ev, e_ev, tag in prof:
             a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
-            a["ms"] += s_ev.elapsed_time(e_ev)
+            ms = s_ev.elapsed_time(e_ev)
+            a["ms"] += ms
             a["launches"] += 1
             if tag:
                 a["flops"] += tag["flops"]
                 a["bytes"] += tag["bytes"]
+                c = tag.get("conv")
+                # dispatch rule of agrl_conv2d_bn_act (csrc/igemm.hip): bf16 3x3 stride-1 convs with >= 256 input channels
+                # on 16 x 8 maps go to conv3x3_wide_kernel -- the 3x3 convs of layers 3 and 4
+                if lp and c and c[0] == 3 and c[1] == 1 and c[2] >= 256:
+                    dom["ms"] += ms
+                    dom["launches"] += 1
+                    dom["flops"] += tag["flops"]
         kernels = {}
         for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
             sec = a["ms"] * 1e-3
@@ -231,26 +240,43 @@ def main():
             if a["flops"]:
                 kernels[name]["tflops"] = round(a["flops"] / sec / 1e12, 2)
                 kernels[name]["gbs"] = round(a["bytes"] / sec / 1e9, 1)
-        # the dominant kernel family: every conv launch (generic / persistent / wide implicit GEMM, 3x3 patch kernels,
-        # the fused layer-1 bottleneck tail, the pool-fused last conv)
+        # the conv family: every conv launch (generic / persistent / wide implicit GEMM, 3x3 patch kernels, the fused
+        # layer-1 block and layer-2 tail, the pool-fused last conv)
         a = {"ms": 0.0, "launches": 0, "flops": 0.0}
-        for dom in ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail"):
-            if dom in agg:
+        for fam in ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block"):
+            if fam in agg:
                 for key in a:
-                    a[key] += agg[dom][key]
+                    a[key] += agg[fam][key]
         achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        traffic = None
+        traffic = fam_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.precision, {}).get("igemm_bytes_per_launch")
+                tj = json.load(open(tpath)).get(args.precision, {})
+                fam_traffic = tj.get("igemm_bytes_per_launch")
+                k3 = tj.get("other_kernels", {}).get("conv3x3_wide_kernel")
+                if k3:
+                    traffic = k3["fetch_bytes_per_launch"] + (k3["write_bytes_per_launch"] or 0.0)
             except Exception:
-                traffic = None
-        result["roofline"] = {"bound": "mfma", "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv1x1_bn_act_pool + agrl_bottleneck_tail)", "achieved": round(achieved, 2),
-                              "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                              "flops_per_launch": round(a["flops"] / a["launches"], 1),
-                              "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2)}
+                traffic = fam_traffic = None
+        family = {"bound": "mfma (layers 3-4) / hbm (layers 1-2)",
+                  "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv1x1_bn_act_pool + agrl_bottleneck_tail + agrl_bottleneck_block)",
+                  "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                  "traffic": fam_traffic, "flops_per_launch": round(a["flops"] / a["launches"], 1),
+                  "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2), "ms_per_step": round(a["ms"] / max(1, args.profile_steps), 4)}
+        if dom["launches"]:
+            # THE dominant kernel by time (profiles/r01_bench_kernel_stats.csv): conv3x3_wide_kernel<0>
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_wide_kernel<0> (3x3 stride-1 convs of layers 3-4, csrc/conv3x3_wide.hip)",
+                                  "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                                  "traffic": traffic, "flops_per_launch": round(dom["flops"] / dom["launches"], 1),
+                                  "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
+                                  "launches_per_step": dom["launches"] // max(1, args.profile_steps),
+                                  "ms_per_step": round(dom["ms"] / max(1, args.profile_steps), 4)}
+            result["roofline_conv_family"] = family
+        else:  # fp32 / split modes: one generic kernel serves every conv
+            result["roofline"] = family
         for name, label in (("agrl_graph_propagate", "gcn_message_pass"), ("agrl_distmat", "distmat")):
             if name in agg and agg[name]["bytes"]:
                 gbs = agg[name]["bytes"] / (agg[name]["ms"] * 1e-3) / 1e9

@@ -11,7 +11,10 @@ def load(path, counter):
         if row["Counter_Name"] != counter:
             continue
         name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "bottleneck_tail")) else name.split("(")[0][-40:]
+        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "bottleneck_")) else name.split("(")[0][-40:]
+        if "conv3x3_wide_kernel" in name:   # the dominant kernel is also reported on its own
+            per["conv3x3_wide_kernel"][0] += float(row["Counter_Value"])
+            per["conv3x3_wide_kernel"][1] += 1
         per[key][0] += float(row["Counter_Value"])
         per[key][1] += 1
     return per
@@ -21,9 +24,9 @@ launches = fi[1]
 fetch_b = fi[0] * 1024 * 2.0   # gfx950 correction for wide coalesced reads
 write_b = wi[0] * 1024
 extra = {}
-for k in ("graph_propagate_stream_kernel", "distmat_regq_kernel"):
+for k in ("graph_propagate_stream_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel"):
     for kk in f:
-        if k in kk:
+        if k in kk and not (k == "conv3x3_wide_kernel" and kk != k):
             extra[k] = {"fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
                         "write_bytes_per_launch": (w[kk][0] * 1024 / max(w[kk][1], 1)) if kk in w else None}
 out = {prec: {"igemm_launches": launches, "steps": steps, "other_kernels": extra,
