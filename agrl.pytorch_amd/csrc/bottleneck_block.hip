@@ -168,6 +168,23 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
         }
     };
 
+    // LDS byte offsets of the 3x3 sweep, computed ONCE: the swizzles make them 18 + 4 different per-lane values, and
+    // recomputing them per tile (as the other phases do to stay out of scratch) was a quarter of the kernel's VALU work
+    int xoff[18], woff[2][2];
+    {
+        const int q = frag_px(frow);
+        const int py0 = 2 * wm + (q >> 3), px0 = q & 7;
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            const int t = st >> 1, kk = st & 1;
+            xoff[st] = patch_off<PW>(py0 + t / 3, px0 + t % 3, kk * 4 + fchunk);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) woff[kk][a] = lds_off(wn * 32 + a * 16 + frow, kk * 4 + fchunk);
+    }
+
     int T = blockIdx.x;
     if (T < ntiles) stage_patch(T, 0);
     int buf = 0;
@@ -191,17 +208,15 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
         {
             const unsigned char* sp = s_p + buf * PATCH_BYTES;
             const int q = frag_px(fr);
-            const int py0 = 2 * wm + (q >> 3), px0 = q & 7;
             f32x4_t acc0[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
             // fragments of step st + 2 (st = 2 tap + k-step) are requested before the MFMAs of step st: the sweep is a chain of
             // LDS round trips otherwise (hipcc issues one read, waits, issues one MFMA)
             uint4 xq[3], wq[3][2];
             auto ld0 = [&](int st, int slot) {
                 const int t = st >> 1, kk = st & 1;
-                xq[slot] = *reinterpret_cast<const uint4*>(sp + patch_off<PW>(py0 + t / 3, px0 + t % 3, kk * 4 + fc));
+                xq[slot] = *reinterpret_cast<const uint4*>(sp + xoff[st]);
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    wq[slot][a] = *reinterpret_cast<const uint4*>(s_w2 + t * W_TAP + lds_off(wn * 32 + a * 16 + fr, kk * 4 + fc));
+                for (int a = 0; a < 2; ++a) wq[slot][a] = *reinterpret_cast<const uint4*>(s_w2 + t * W_TAP + woff[kk][a]);
             };
             ld0(0, 0);
             ld0(1, 1);
