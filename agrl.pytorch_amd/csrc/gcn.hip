@@ -29,10 +29,20 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, 
     const int nf = Vp >> 4;
     // stage: thread -> float4 (tid&31) of row (tid>>5) + 8*i
     const float* src = f + (size_t)b * V * C + (size_t)z * GRAM_CS;
-    for (int r = tid >> 5; r < Vp; r += 8) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < V) v = *reinterpret_cast<const float4*>(src + (size_t)r * C + (tid & 31) * 4);
-        *reinterpret_cast<float4*>(s_f + r * GRAM_ROWB + (tid & 31) * 16) = v;
+    // all of a thread's loads are issued before the first LDS store (a load -> store loop is a chain of HBM round trips)
+    for (int r0 = tid >> 5; r0 < Vp; r0 += 64) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = r0 + 8 * i;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < V) v[i] = *reinterpret_cast<const float4*>(src + (size_t)r * C + (tid & 31) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = r0 + 8 * i;
+            if (r < Vp) *reinterpret_cast<float4*>(s_f + r * GRAM_ROWB + (tid & 31) * 16) = v[i];
+        }
     }
     __syncthreads();
     const int frow = lane & 15, fch = lane >> 4;
@@ -42,14 +52,20 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, 
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const unsigned char* pa = s_f + (fi * 16 + frow) * GRAM_ROWB + fch * 16;
         const unsigned char* pb = s_f + (fj * 16 + frow) * GRAM_ROWB + fch * 16;
+        // all sixteen operand reads of the fragment pair first, then the 32 MFMAs (one read -> wait -> MFMA per k-step is
+        // a chain of LDS round trips)
+        float4 av[GRAM_CS / 16], bv[GRAM_CS / 16];
 #pragma unroll
         for (int ks = 0; ks < GRAM_CS / 16; ++ks) {
-            const float4 a = *reinterpret_cast<const float4*>(pa + ks * 64);
-            const float4 bb = *reinterpret_cast<const float4*>(pb + ks * 64);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, acc, 0, 0, 0);
+            av[ks] = *reinterpret_cast<const float4*>(pa + ks * 64);
+            bv[ks] = *reinterpret_cast<const float4*>(pb + ks * 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GRAM_CS / 16; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].x, bv[ks].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].y, bv[ks].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].z, bv[ks].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks].w, bv[ks].w, acc, 0, 0, 0);
         }
         // D[row = 4*(lane>>4) + r][col = lane&15]
         const int j = fj * 16 + frow;
@@ -59,6 +75,21 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, 
             if (i < V && j < V) dst[(size_t)i * V + j] = acc[r];
         }
     }
+}
+
+// sum of the nz Gram partials of one element, z ascending (fixed order); sixteen loads in flight at a time instead of a
+// load -> add chain (nz = 16 for C = 2048: one batch)
+__device__ inline float zsum(const float* p, int nz, int zstride) {
+    float s = 0.f;
+    for (int z0 = 0; z0 < nz; z0 += 16) {
+        float part[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[i] = z0 + i < nz ? p[(size_t)(z0 + i) * zstride] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (z0 + i < nz) s += part[i];
+    }
+    return s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -73,11 +104,7 @@ __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* gp = gram_part + (size_t)b * nz * V * V;
     if (learn_graph) {
-        for (int j = tid; j < V; j += 256) {
-            float s = 0.f;
-            for (int z = 0; z < nz; ++z) s += gp[(size_t)z * V * V + (size_t)j * V + j];
-            s_n[j] = s;
-        }
+        for (int j = tid; j < V; j += 256) s_n[j] = zsum(gp + (size_t)j * V + j, nz, V * V);
         __syncthreads();
     }
     const int i = blockIdx.y * 4 + wave;
@@ -92,8 +119,7 @@ __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __rest
         av[q] = 0.f;
         if (j < V) {
             if (learn_graph) {
-                float g = 0.f;
-                for (int z = 0; z < nz; ++z) g += gp[(size_t)z * V * V + (size_t)i * V + j];
+                const float g = zsum(gp + (size_t)i * V + j, nz, V * V);
                 // similarity: 2 / (exp(sqrt(clamp(n_j + n_i - 2 g_ij, 1e-12))) + 1)
                 float d2 = (s_n[j] + s_n[i]) - 2.f * g;
                 d2 = fmaxf(d2, 1e-12f);

@@ -172,26 +172,46 @@ __global__ __launch_bounds__(256) void attn_pool_bnneck_kernel(
     const int b = blockIdx.x;
     const int V = S * P;
     // a[s,p] = ||f[s,p]|| / max(sum_s ||f[s,p]||, 1e-12)   (F.normalize p=1 over the frame axis)
+    // every node's norm by its own thread (one round trip), then P threads normalise over the frame axis out of LDS -- the
+    // same sums in the same order as a per-part loop over global memory, without its chain of 2 S dependent loads
+    for (int t = threadIdx.x; t < V; t += blockDim.x) s_att[t] = sqrtf(sqn[(size_t)b * V + t]);
+    __syncthreads();
     for (int q = threadIdx.x; q < P; q += blockDim.x) {
         float tot = 0.f;
-        for (int s = 0; s < S; ++s) tot += sqrtf(sqn[(size_t)b * V + s * P + q]);
+        for (int s = 0; s < S; ++s) tot += s_att[s * P + q];
         const float den = fmaxf(tot, 1e-12f);
-        for (int s = 0; s < S; ++s) s_att[s * P + q] = sqrtf(sqn[(size_t)b * V + s * P + q]) / den;
+        for (int s = 0; s < S; ++s) s_att[s * P + q] = s_att[s * P + q] / den;
     }
     __syncthreads();
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     if (c >= C) return;
     // attention branch: mean over parts of the attention-weighted sum over frames
     float att = 0.f;
+    // eight loads in flight per part instead of a load -> fma chain over the S x P nodes (the kernel was a string of HBM
+    // round trips); the arithmetic keeps its order: fuse over s ascending, then over the parts
     for (int q = 0; q < P; ++q) {
         float fuse = 0.f;
-        for (int s = 0; s < S; ++s) fuse = fmaf(s_att[s * P + q], nodes[((size_t)b * V + s * P + q) * C + c], fuse);
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float nv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nv[i] = s0 + i < S ? nodes[((size_t)b * V + (s0 + i) * P + q) * C + c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (s0 + i < S) fuse = fmaf(s_att[(s0 + i) * P + q], nv[i], fuse);
+        }
         att += fuse;
     }
     att /= (float)P;
     // global branch: mean over (S, h, w)
     float g = 0.f;
-    for (int s = 0; s < S; ++s) g += gsum[((size_t)b * S + s) * C + c];
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        float gv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gv[i] = s0 + i < S ? gsum[((size_t)b * S + s0 + i) * C + c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (s0 + i < S) g += gv[i];
+    }
     g *= inv_ghw;
     if (g_f) g_f[(size_t)b * C + c] = g;
     if (att_f) att_f[(size_t)b * C + c] = att;
