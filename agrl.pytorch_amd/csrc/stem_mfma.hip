@@ -46,10 +46,12 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
                                                         const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
                                                         int W, int CH, int CW, int PH, int PW, int tiles_w, int tiles_hw,
                                                         int ntiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[REGION_BYTES + W_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[REGION_BYTES + W_BYTES + 256];
     unsigned char* s_patch = smem;
     unsigned char* s_ct = smem;
     unsigned char* s_w = smem + REGION_BYTES;
+    float* s_bias = reinterpret_cast<float*>(smem + REGION_BYTES + W_BYTES);  // 64 biases: LDS reads in the epilogue instead
+                                                                             // of global loads whose waits also cover the prefetch
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
     for (int piece = wave; piece < W_BYTES / 1024; piece += NWV)
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(wpk + piece * 1024 + lane * 16), (lds_void_t*)(s_w + piece * 1024), 16, 0, 0);
 
+    if (tid < 64) s_bias[tid] = bias[tid];
     // patch: one pixel (3 channels -> 4 bf16) per thread per pass; all loads of all passes are issued together
     constexpr int NPASS = (IT * PWP + NTH - 1) / NTH;  // 4
     float pv[NPASS][3];
@@ -145,24 +148,33 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
         // conv tile [pos][64 ch] bf16, 8-byte slot s of row p stored at slot s ^ (p & 15); row p lives at row index ct_row(p)
         // = p with bits 0 and 1 swapped: a 32-lane group of the pooling reads below covers two pooled pixels = rows p and
         // p + 2, which would share every bank (rows alternate between the halves of the 256-byte bank window by bit 0)
+        // conv positions outside the conv map (only tiles on the top / left image border have any) count as 0 in the pool
+        const bool interior = cr0 >= 0 && cc0 >= 0 && cr0 + CT <= CH && cc0 + CT <= CW;
+        int rowo[FPW], swz[FPW];
+        bool live[FPW], in[FPW];
 #pragma unroll
         for (int i = 0; i < FPW; ++i) {
             const int pos = (wave + NWV * i) * 16 + fr;
-            if (pos < NPOS) {
-                const int cy = pos / CT, cx = pos - cy * CT;
-                const bool in = (unsigned)(cr0 + cy) < (unsigned)CH && (unsigned)(cc0 + cx) < (unsigned)CW;
+            const int cy = pos / CT, cx = pos - cy * CT;
+            live[i] = pos < NPOS;
+            in[i] = interior || ((unsigned)(cr0 + cy) < (unsigned)CH && (unsigned)(cc0 + cx) < (unsigned)CW);
+            rowo[i] = ct_row(pos) * 128;
+            swz[i] = pos & 7;
+        }
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const int ch = a * 16 + gg * 4;
-                    const float4 bv = *reinterpret_cast<const float4*>(bias + ch);
-                    const float v0 = in ? fmaxf(acc[i][a][0] + bv.x, 0.f) : 0.f;
-                    const float v1 = in ? fmaxf(acc[i][a][1] + bv.y, 0.f) : 0.f;
-                    const float v2 = in ? fmaxf(acc[i][a][2] + bv.z, 0.f) : 0.f;
-                    const float v3 = in ? fmaxf(acc[i][a][3] + bv.w, 0.f) : 0.f;
+        for (int a = 0; a < 4; ++a) {
+            const int ch = a * 16 + gg * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(s_bias + ch);
+#pragma unroll
+            for (int i = 0; i < FPW; ++i) {
+                if (live[i]) {
+                    const float v0 = fmaxf(acc[i][a][0] + bv.x, 0.f), v1 = fmaxf(acc[i][a][1] + bv.y, 0.f);
+                    const float v2 = fmaxf(acc[i][a][2] + bv.z, 0.f), v3 = fmaxf(acc[i][a][3] + bv.w, 0.f);
                     uint2 u;
                     u.x = pack_bf16x2(v0, v1);
                     u.y = pack_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2*>(s_ct + ct_row(pos) * 128 + (((ch >> 3) ^ (pos & 7)) << 4) + ((ch & 4) << 1)) = u;
+                    if (!in[i]) u = make_uint2(0u, 0u);
+                    *reinterpret_cast<uint2*>(s_ct + rowo[i] + (((ch >> 3) ^ swz[i]) << 4) + ((ch & 4) << 1)) = u;
                 }
             }
         }
