@@ -230,7 +230,34 @@ __global__ __launch_bounds__(256) void attn_pool_bnneck_kernel(
     out[(size_t)b * 2 * C + C + c] = fmaf(att, a_scale[c], a_shift[c]);
 }
 
+// out[t][c] = mean / max over i < n of feats[t*n + i][c]; thread -> one channel of one tracklet, clips in ascending order
+__global__ __launch_bounds__(256) void clip_pool_kernel(const float* __restrict__ feats, float* __restrict__ out, int n, int D,
+                                                        int mode) {
+    const int t = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= D) return;
+    const float* src = feats + (size_t)t * n * D + c;
+    float acc = src[0];
+    for (int i0 = 1; i0 < n; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = i0 + i < n ? src[(size_t)(i0 + i) * D] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i0 + i < n) acc = mode ? fmaxf(acc, v[i]) : acc + v[i];
+    }
+    out[(size_t)t * D + c] = mode ? acc : acc / (float)n;
+}
+
 }  // namespace
+
+extern "C" int agrl_clip_pool(const float* feats, float* out, int T, int n, int D, int mode, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(feats && out && T > 0 && n > 0 && D > 0, "agrl_clip_pool: bad arguments");
+    AGRL_CHECK_ARG(mode == 0 || mode == 1, "agrl_clip_pool: mode must be 0 (mean) or 1 (max), got %d", mode);
+    hipLaunchKernelGGL(clip_pool_kernel, dim3(T, cdiv(D, 256)), dim3(256), 0, (hipStream_t)stream, feats, out, n, D, mode);
+    AGRL_CHECK_LAUNCH("agrl_clip_pool");
+    return 0;
+}
 
 extern "C" int agrl_part_pool(const void* x4_1, const void* x4_2, float* gsum, float* nodes, void* nodes_lp, int F,
                               int h, int w, int C, const int* splits, int n_splits, int dtype,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "agrl_conv1x1_bn_act_pool": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_linear_nobias": [_p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_part_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
+    "agrl_clip_pool": [_p, _p, _i, _i, _i, _i, _p],
     "agrl_graph_gram": [_p, _p, _i, _i, _i, _i, _p],
     "agrl_graph_finalize": [_p, _i, _p, _p, _i, _i, _i, _i, _p],
     "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _p],

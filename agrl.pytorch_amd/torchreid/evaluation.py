@@ -28,6 +28,8 @@ def pool_clips(features, num_clips, pool="avg"):
     (reference: features.view(n, 1, -1) then mean/max over dim 0, train_vidreid_xent_htri.py:471-476)."""
     if num_clips == 1:
         return features
+    if features.is_cuda:
+        return ops.clip_pool(features, num_clips, "avg" if pool == "avg" else "max")
     f = features.view(-1, num_clips, features.size(-1))
     return f.mean(dim=1) if pool == "avg" else f.max(dim=1)[0]
 

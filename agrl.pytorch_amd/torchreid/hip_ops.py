@@ -267,6 +267,17 @@ def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp):
     return out, out_lp
 
 
+def clip_pool(feats, num_clips, mode="avg"):
+    """(T*num_clips, D) fp32 -> (T, D): mean / max over each tracklet's clips. train_vidreid_xent_htri.py:471-476."""
+    assert feats.dtype == torch.float32 and feats.dim() == 2 and feats.size(0) % num_clips == 0 and mode in ("avg", "max")
+    feats = feats.contiguous()
+    T, D = feats.size(0) // num_clips, feats.size(1)
+    out = torch.empty((T, D), dtype=torch.float32, device=feats.device)
+    with _dev(feats):
+        call("agrl_clip_pool", ptr(feats), ptr(out), T, num_clips, D, 0 if mode == "avg" else 1, _stream(feats))
+    return out
+
+
 def row_sqnorm(x):
     R, Cc = x.shape
     out = torch.empty((R,), dtype=torch.float32, device=x.device)

@@ -180,6 +180,12 @@ int agrl_attn_pool_bnneck(const float* nodes, const float* sqn, const float* gsu
                           const float* a_shift, float* out, float* g_f, float* att_f, int B, int S,
                           int P, int C, int hw, agrl_stream_t stream);
 
+/* Clip pooling of the dense / skipdense test samplers: every tracklet is evaluated as n clips and its embedding is the
+ * mean (mode 0) or maximum (mode 1) over them (train_vidreid_xent_htri.py:471-476: features.view(n, 1, -1) ->
+ * torch.mean / torch.max over dim 0).  feats fp32 (T*n, D), clip index fastest -> out fp32 (T, D). The mean adds the clips
+ * in ascending order and divides once. */
+int agrl_clip_pool(const float* feats, float* out, int T, int n, int D, int mode, agrl_stream_t stream);
+
 /* ---- distance matrix + ranking ------------------------------------------------------------------ */
 
 /* y[r,:C] = x[r,:] / max(||x[r,:]||_2, 1e-12)  (F.normalize p=2), x fp32 (R,C) -> y out_dtype with row

@@ -643,6 +643,22 @@ def test_conv_and_linear_split_bf16_mode():
     assert rel_err(y.double(), ref) < 5e-5
 
 
+def test_clip_pool_device():
+    """agrl_clip_pool (dense / skipdense test samplers: mean or max over a tracklet's clips) against torch, as the reference
+    computes it (train_vidreid_xent_htri.py:471-476); ragged channel count and clip counts 1..11."""
+    from torchreid import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    for T, n, D in ((3, 1, 4096), (5, 4, 4096), (2, 11, 2048), (7, 3, 1000)):
+        f = torch.randn((T * n, D), generator=g)
+        for mode in ("avg", "max"):
+            got = ops.clip_pool(f.to(DEV), n, mode).cpu()
+            ref = torch.stack([(torch.mean(f[t * n:(t + 1) * n], 0) if mode == "avg" else torch.max(f[t * n:(t + 1) * n], 0)[0]) for t in range(T)])
+            if mode == "max":
+                assert torch.equal(got, ref)
+            else:
+                assert (got - ref).abs().max().item() < 1e-6
+
+
 def test_pose_adjacency_device():
     """agrl_pose_adjacency vs the reference's generate_graph (golden fixture) and vs the oracle on random poses,
     incl. undetected frames, low-confidence keypoints, num_split 8 and the non-pyramid layout."""
