@@ -125,6 +125,17 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
 #pragma unroll
     for (int a = 0; a < NA2; ++a) asm volatile("" : "+v"(b1v[a].x), "+v"(b1v[a].y), "+v"(b1v[a].z), "+v"(b1v[a].w));
 
+    // per-lane parts of the residual-tile and out-tile global offsets (pixel (row >> 3, row & 7) of the tile and the
+    // swizzled chunk), computed ONCE; per tile only the tile's base pixel (uniform) is added
+    unsigned res_lane[4], out_lane[CN == 64 ? 4 : 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rrow = (wave * 4 + j) * 2 + (lane >> 5);
+        res_lane[j] = (unsigned)(((rrow >> 3) * p.W + (rrow & 7)) * 512 + (((lane & 31) ^ (rrow & 31)) << 4));
+        const int orow = (tid >> 5) + 16 * j;
+        if constexpr (CN == 64) out_lane[j] = (unsigned)(((orow >> 3) * p.W + (orow & 7)) * 512 + (((tid & 31) ^ (orow & 31)) << 4));
+    }
+
     auto tile_origin = [&](int T, int& img, int& oy0, int& ox0) {
         img = T / (tw * th);
         const int trem = T - img * (tw * th);
@@ -159,12 +170,9 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
             const int row = wave * 8 + (ln >> 3);
             dma16(xsg + gpix(img, oy0, ox0, row) * 128 + (((ln & 7) ^ ((row >> 1) & 7)) << 4), s_x + wave * 1024);
         } else {
+            const unsigned char* tbase = resg + gpix(img, oy0, ox0, 0) * 512;  // uniform
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int piece = wave * 4 + j;
-                const int row = piece * 2 + (ln >> 5);
-                dma16(resg + (gpix(img, oy0, ox0, row) * 256 + (((ln & 31) ^ (row & 31)) * 8)) * 2, s_r + piece * 1024);
-            }
+            for (int j = 0; j < 4; ++j) dma16(tbase + res_lane[j], s_r + (wave * 4 + j) * 1024);
         }
     };
 
@@ -310,12 +318,16 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
         }
         wg_barrier();  // out tile complete
         // drain the out tile: 2048 16-byte chunks, 4 per thread, whole 512-byte rows per 32 lanes
+        {
+            unsigned char* obase = reinterpret_cast<unsigned char*>(p.out) + gpix(img, oy0, ox0, 0) * 512;  // uniform
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (td >> 5) + 16 * i;
-            const int pch = td & 31;
-            const uint4 v = *reinterpret_cast<const uint4*>(s_r + row * 512 + (pch << 4));
-            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (gpix(img, oy0, ox0, row) * 256 + (pch ^ (row & 31)) * 8) * 2) = v;
+            for (int i = 0; i < 4; ++i) {
+                const int row = (td >> 5) + 16 * i;
+                const int pch = td & 31;
+                const uint4 v = *reinterpret_cast<const uint4*>(s_r + row * 512 + (pch << 4));
+                if constexpr (CN == 64) *reinterpret_cast<uint4*>(obase + out_lane[i]) = v;  // (CN 128: no registers to spare)
+                else *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + (gpix(img, oy0, ox0, row) * 256 + (pch ^ (row & 31)) * 8) * 2) = v;
+            }
         }
         // ---- GEMM 2: 64 px x CN ch, K = 256, B operand straight from the out tile. Wave tile 32 px x CN/4 ch.
         f32x4_t acc2[NA2][2];
