@@ -193,14 +193,21 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
             for (int a = 0; a < 2; ++a) woff[kk][a] = lds_off(wn * 32 + a * 16 + frow, kk * 4 + fchunk);
     }
 
-    int T = blockIdx.x;
-    if (T < ntiles) stage_patch(T, 0);
+    // XCD-aware tile walk (workgroups b, b + 8, .. share an XCD and its L2): an XCD owns a contiguous range of tiles, so the
+    // tiles in flight on it at any time are neighbours and their overlapping halo rows / columns are L2 hits
+    const int xcd = blockIdx.x & 7;
+    const int xq = ntiles >> 3, xr = ntiles & 7;
+    const int xbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int tend = xbase + xq + (xcd < xr ? 1 : 0);                         // end of this XCD's range
+    const int tstep = (G >> 3) + (xcd < (G & 7) ? 1 : 0);                     // workgroups on this XCD
+    int T = xbase + (int)(blockIdx.x >> 3);
+    if (T < tend) stage_patch(T, 0);
     int buf = 0;
     bool first = true;
-    for (; T < ntiles; T += G, buf ^= 1) {
+    for (; T < tend; T += tstep, buf ^= 1) {
         int img, oy0, ox0;
         tile_origin(T, img, oy0, ox0);
-        const bool has_next = T + G < ntiles;
+        const bool has_next = T + tstep < tend;
         // this tile's patch (and, the first time, the weights) are the oldest entries of the queue; the previous tile's
         // stores may stay in flight
         if (first) wait_vmcnt<0>();
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
         first = false;
         wg_barrier();
         stage_shortcut(T);
-        if (has_next) stage_patch(T + G, buf ^ 1);
+        if (has_next) stage_patch(T + tstep, buf ^ 1);
         int fr = frow, fc = fchunk, td = tid;
         asm volatile("" : "+v"(fr), "+v"(fc), "+v"(td));  // per-tile address arithmetic, nothing hoisted into scratch
 
