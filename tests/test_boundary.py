@@ -168,3 +168,21 @@ def test_reference_overlay_resolves_out_of_scope_modules():
     out = subprocess.check_output(["python", "-c", code], env=env, cwd="/tmp").decode().split()
     assert "agrl.pytorch_amd" in out[0] and out[1].startswith("/root/reference")
     assert out[2].startswith("/root/reference") and "agrl.pytorch_amd" in out[3]
+
+
+def test_host_side_helpers_without_gpu():
+    """Host logic that needs no device: the per-thread split-precision switch and the clip pooling of the eval harness on
+    CPU tensors (reference train_vidreid_xent_htri.py:471-476)."""
+    from torchreid import hip_ops as ops, _hip
+    from torchreid.evaluation import pool_clips
+    assert ops._gemm_code(torch.float32) == _hip.F32
+    with ops.f32_split():
+        assert ops._gemm_code(torch.float32) == _hip.F32X3 and ops._gemm_code(torch.bfloat16) == _hip.BF16
+        with ops.f32_split(False):
+            assert ops._gemm_code(torch.float32) == _hip.F32
+        assert ops._gemm_code(torch.float32) == _hip.F32X3
+    assert ops._gemm_code(torch.float32) == _hip.F32
+    f = torch.arange(24, dtype=torch.float32).view(6, 4)
+    assert torch.equal(pool_clips(f, 1), f)
+    assert torch.equal(pool_clips(f, 3, "avg"), torch.stack([f[0:3].mean(0), f[3:6].mean(0)]))
+    assert torch.equal(pool_clips(f, 3, "max"), torch.stack([f[0:3].max(0)[0], f[3:6].max(0)[0]]))
