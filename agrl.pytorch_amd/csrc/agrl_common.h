@@ -114,3 +114,27 @@ struct DT<bf16_t> {
 };
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- tuning switches: read from the environment ONCE, when the library is loaded (agrl_reload_options() re-reads them: the
+// A/B tools and the kernel tests flip them inside one process). No entry point calls getenv on the launch path.
+// AGRL_OPT_UNSET = the variable is not set -> the measured-best default applies. Flags are 1 when set to anything but "0".
+#define AGRL_OPT_UNSET (-2147483647 - 1)
+struct AgrlOpts {
+    int igemm_ns, igemm_bm, igemm_nw, igemm_wide, igemm_persist, igemm_wgs, igemm_wide_persist;  // AGRL_IGEMM_*
+    int igemm_no_w128, pool_persist;                                                             // flags
+    int conv3x3_generic, conv3x3_wide, conv3x3_c64;                                              // AGRL_CONV3X3_*
+    int distmat_tiled, distmat_ring;                                                             // flags
+    int gcn_lds, gcn_valu, gcn_nwv, gcn_split;                                                   // AGRL_GCN_*
+    int stem_wgs;
+    int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library
+};
+const AgrlOpts& agrl_opts();
+inline bool agrl_opt_set(int v) { return v != AGRL_OPT_UNSET; }
+
+// Ablation bits (skip stores / DMA / waits / MFMA: wrong results by design, profiling only) exist only in a library built
+// with -DAGRL_ABLATE (make ABLATE=1 -> lib/libagrl_hip_ablate.so); the shipped object has no switch that removes work.
+#ifdef AGRL_ABLATE
+#define AGRL_DBG_BITS(p) ((p).dbg)
+#else
+#define AGRL_DBG_BITS(p) 0
+#endif

@@ -12,3 +12,59 @@ void agrl_set_error(const char* fmt, ...) {
 
 extern "C" int agrl_version(void) { return 100; }
 extern "C" const char* agrl_last_error(void) { return g_err; }
+
+// ---- tuning switches (agrl_common.h) ----------------------------------------------------------------------------------
+#include <stdlib.h>
+
+static int opt_int(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : AGRL_OPT_UNSET;
+}
+static int opt_flag(const char* name) {
+    const char* e = getenv(name);
+    return e && !(e[0] == '0' && e[1] == 0) ? 1 : 0;
+}
+static AgrlOpts load_opts() {
+    AgrlOpts o;
+    o.igemm_ns = opt_int("AGRL_IGEMM_NS");
+    o.igemm_bm = opt_int("AGRL_IGEMM_BM");
+    o.igemm_nw = opt_int("AGRL_IGEMM_NW");
+    o.igemm_wide = opt_int("AGRL_IGEMM_WIDE");
+    o.igemm_persist = opt_int("AGRL_IGEMM_PERSIST");
+    o.igemm_wgs = opt_int("AGRL_IGEMM_WGS");
+    o.igemm_wide_persist = opt_int("AGRL_IGEMM_WIDE_PERSIST");
+    o.igemm_no_w128 = opt_flag("AGRL_IGEMM_NO_W128");
+    o.pool_persist = opt_flag("AGRL_POOL_PERSIST");
+    o.conv3x3_generic = opt_flag("AGRL_CONV3X3_GENERIC");
+    o.conv3x3_wide = opt_int("AGRL_CONV3X3_WIDE");
+    o.conv3x3_c64 = opt_int("AGRL_CONV3X3_C64");
+    o.distmat_tiled = opt_flag("AGRL_DISTMAT_TILED");
+    o.distmat_ring = opt_flag("AGRL_DISTMAT_RING");
+    o.gcn_lds = opt_flag("AGRL_GCN_LDS");
+    o.gcn_valu = opt_flag("AGRL_GCN_VALU");
+    o.gcn_nwv = opt_int("AGRL_GCN_NWV");
+    o.gcn_split = opt_flag("AGRL_GCN_SPLIT");
+    o.stem_wgs = opt_int("AGRL_STEM_WGS");
+#ifdef AGRL_ABLATE
+    o.igemm_dbg = agrl_opt_set(opt_int("AGRL_IGEMM_DBG")) ? opt_int("AGRL_IGEMM_DBG") : 0;
+    o.conv3x3_dbg = agrl_opt_set(opt_int("AGRL_CONV3X3_DBG")) ? opt_int("AGRL_CONV3X3_DBG") : 0;
+#else
+    o.igemm_dbg = 0;
+    o.conv3x3_dbg = 0;
+#endif
+    return o;
+}
+static AgrlOpts g_opts = load_opts();  // at library load
+
+const AgrlOpts& agrl_opts() { return g_opts; }
+extern "C" int agrl_reload_options(void) {
+    g_opts = load_opts();
+    return 0;
+}
+extern "C" int agrl_built_with_ablation(void) {
+#ifdef AGRL_ABLATE
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -377,12 +377,12 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
 int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream) {
     const int nblocks = (p.M / p.OH / p.OW) * (p.H / 16) * (p.W / 8);
     const int grid = cdiv(nblocks, 2) * cdiv(p.N, 128);
-    int dbg = 0;
-    if (const char* e = getenv("AGRL_CONV3X3_DBG")) dbg = atoi(e);
-    switch (dbg) {
+    switch (agrl_opts().conv3x3_dbg) {  // non-zero only in an -DAGRL_ABLATE build
+#ifdef AGRL_ABLATE
 #define C3_CASE(D) case D: hipLaunchKernelGGL(conv3x3_wide_kernel<D>, dim3(grid), dim3(512), 0, stream, p, nblocks); break
         C3_CASE(1); C3_CASE(2); C3_CASE(4); C3_CASE(8); C3_CASE(5); C3_CASE(13); C3_CASE(6); C3_CASE(9);
 #undef C3_CASE
+#endif
         default: hipLaunchKernelGGL(conv3x3_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p, nblocks);
     }
     AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 wide)");

@@ -616,6 +616,10 @@ extern "C" int agrl_graph_gram(const float* f, float* gram_part, int B, int V, i
     const size_t lds = (size_t)Vp * GRAM_ROWB;
     AGRL_CHECK_ARG(lds <= 160 * 1024, "agrl_graph_gram: V=%d too large", V);
     const int nz = C / GRAM_CS;
+    if (lds > 64 * 1024) {  // V >= 125 (e.g. seq_len 20 x 7 parts): above the default dynamic-LDS limit of a launch
+        hipError_t e = hipFuncSetAttribute((const void*)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_gram: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(gram_kernel, dim3(B, nz), dim3(256), lds, (hipStream_t)stream, f, gram_part, V, C, nz);
     AGRL_CHECK_LAUNCH("agrl_graph_gram");
     return 0;
@@ -643,11 +647,11 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     const float omg_m = (float)(1.0 - (double)gamma);
     const bool aligned = ((((uintptr_t)f | (uintptr_t)h | (uintptr_t)out | (uintptr_t)out_lp | (uintptr_t)bn_scale |
                             (uintptr_t)bn_shift) & 15) == 0);
-    if (V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned && (((uintptr_t)G) & 15) == 0 && !getenv("AGRL_GCN_LDS")) {
+    if (V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned && (((uintptr_t)G) & 15) == 0 && !agrl_opts().gcn_lds) {
         const int V4 = (V + 3) & ~3;
         const int nvf = (V + 15) / 16;
         int nwv = (C % 256) == 0 ? 4 : 2;  // 4-wave workgroups: one wave per SIMD of a CU by construction
-        if (const char* e = getenv("AGRL_GCN_NWV")) nwv = atoi(e) == 2 ? 2 : nwv;
+        if (agrl_opts().gcn_nwv == 2) nwv = 2;
         const size_t lds_s = (size_t)16 * nvf * V4 * sizeof(float) + 2048;  // padded fragment rows + DMA piece rounding + spare
 #define LAUNCH_PS(NT_)                                                                                                \
     case NT_:                                                                                                         \
@@ -668,7 +672,7 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
         AGRL_CHECK_LAUNCH("agrl_graph_propagate");
         return 0;
     }
-    if (V <= 128 && (C % 128) == 0 && !getenv("AGRL_GCN_VALU")) {
+    if (V <= 128 && (C % 128) == 0 && !agrl_opts().gcn_valu) {
         const int V4 = (V + 3) & ~3;
         const int hrows = (V4 + 1) & ~1;
         const int nvf = V <= 64 ? 4 : 8;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         // tiles issued after tile kt so far: min(NS-2, nk-1-kt); everything older must have landed
         const int younger = min(NS - 2, nk - 1 - kt);
-        if (p.dbg & 32) {
+        if (AGRL_DBG_BITS(p) & 32) {
         } else if (NS >= 3 && younger == 1) wait_vmcnt<DPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -210,8 +210,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         // The DMA pieces of the next k-tile are interleaved with the MFMA groups (one piece per FM MFMAs): a burst of
         // 8 back-to-back pieces fills the memory pipeline's queue and stalls the wave for ~500 cycles, spread out they
         // ride under the matrix work. sched_barrier pins that order.
-        bool do_stage = kt + NS - 1 < nk && !(p.dbg & 8);
-        if (do_stage && (p.dbg & 64)) {  // A/B switch: burst-issue the whole k-tile up front
+        bool do_stage = kt + NS - 1 < nk && !(AGRL_DBG_BITS(p) & 8);
+        if (do_stage && (AGRL_DBG_BITS(p) & 64)) {  // A/B switch: burst-issue the whole k-tile up front
             stage(fill);
             do_stage = false;
         }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         // phase 1: combine in fp32, round once, park the bf16 tile in the free staging buffer (in place over the
         // residual image: every lane overwrites exactly the 8 bytes it just read)
         unsigned char* so = smem + last_fill * BUF_BYTES;
-        if (!(p.dbg & 4))
+        if (!(AGRL_DBG_BITS(p) & 4))
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
             const int prow = wm * (BM / WM) + b * 16 + frow;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
             const int gch = pch ^ (row & (CPR - 1));
             const int gm = m0 + row;
             const int gn = n0 + gch * 8;
-            if (gm < p.M && gn < p.N && !(p.dbg & 1)) {
+            if (gm < p.M && gn < p.N && !(AGRL_DBG_BITS(p) & 1)) {
                 const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
                 *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * p.ldo + gn) * 2) = v;
             }
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                 for (int a = 0; a < FN; ++a)
 #pragma unroll
                     for (int b = 0; b < FM; ++b)
-                        if (!(p.dbg & 2)) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
+                        if (!(AGRL_DBG_BITS(p) & 2)) acc[a][b] = Frag<TIN>::mma(wf[a], xf[b], acc[a][b]);
             }
             cur ^= 1;
         }
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
         if (loader && has_next) stage(cur ^ 1);  // next tile's first k-tile flies under this tile's epilogue
 
         unsigned char* so = smem + cur * BUF_BYTES;
-        if (!(p.dbg & 4)) {
+        if (!(AGRL_DBG_BITS(p) & 4)) {
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 const int prow = wm * (BM / WM) + b * 16 + frow;
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                 const int gch = pch ^ (row & (CPR - 1));
                 const int gm = cm0 + row;
                 const int gn = cn0 + gch * 8;
-                if (gm < p.M && gn < p.N && !(p.dbg & 1)) {
+                if (gm < p.M && gn < p.N && !(AGRL_DBG_BITS(p) & 1)) {
                     const uint4 v = *reinterpret_cast<const uint4*>(so + row * ROWB + (pch << 4));
                     *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.out) + ((size_t)gm * p.ldo + gn) * 2) = v;
                 }
@@ -800,9 +800,9 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     AGRL_CHECK_ARG(p.K == p.R * p.S * p.Cin, "%s: K mismatch", who);
     AGRL_CHECK_ARG((((uintptr_t)p.x) & 15) == 0 && (((uintptr_t)p.w) & 15) == 0,
                    "%s: operands must be 16-byte aligned", who);
-    p.dbg = 0;
+    const AgrlOpts& opt = agrl_opts();
+    p.dbg = opt.igemm_dbg;
     if (p.ksplit < 1) p.ksplit = 1;
-    if (const char* e = getenv("AGRL_IGEMM_DBG")) p.dbg = atoi(e);
     p.vec_ok = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 && (!p.colv || (((uintptr_t)p.colv) & 15) == 0) &&
                (!p.res || (((uintptr_t)p.res) & 15) == 0);
     // bf16 outputs whose rows are whole 16-byte chunks take the LDS-staged (fully coalesced) epilogue
@@ -811,15 +811,15 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     const bool narrow = p.N <= 64;
     // ring depth 2 at two workgroups per CU beats deeper rings at one (measured: 6.4 vs 9.1 ms per forward)
     int ns = 2;
-    if (const char* e = getenv("AGRL_IGEMM_NS")) ns = atoi(e);
+    if (agrl_opt_set(opt.igemm_ns)) ns = opt.igemm_ns;
     // short K loops (<= 2 k-tiles) are pure load->store latency chains: 64-row tiles halve the LDS footprint so
     // three workgroups fit a CU
     int bm = (p.K / BKE) <= 2 ? 64 : 128;
     if (cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128) < 400) bm = 64;  // too few 128-row tiles to fill 256 CUs twice
-    if (const char* e = getenv("AGRL_IGEMM_BM")) bm = atoi(e);
+    if (agrl_opt_set(opt.igemm_bm)) bm = opt.igemm_bm;
     const int grid = cdiv(p.M, bm) * cdiv(p.N, narrow ? 64 : 128);
     int nw = 8;  // 8-wave workgroups (4 x 2 wave grid) beat 4-wave ones by 3-14 % at equal tile size (A/B measured)
-    if (const char* e = getenv("AGRL_IGEMM_NW")) nw = atoi(e);
+    if (agrl_opt_set(opt.igemm_nw)) nw = opt.igemm_nw;
 #define LAUNCH_IG(BM_, BN_, EPI_, NS_) \
     do {                                                                                                          \
         if (nw == 8)                                                                                              \
@@ -839,29 +839,29 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 2) {
         // MFMA-bound pointwise layers (long K, enough 256 x 256 tiles to cover the chip): the wide-tile kernel
         int wide = -1;
-        if (const char* e = getenv("AGRL_IGEMM_WIDE")) wide = atoi(e);
+        if (agrl_opt_set(opt.igemm_wide)) wide = opt.igemm_wide;
         if (wide != 0 && lds_epi && igemm_wide_applicable(p)) {
             const int wtiles = cdiv(p.M, 256) * (p.N / 256);
             if (wide >= 1 || (wtiles >= 224 && p.K >= 256)) return launch_igemm_wide(p, stream, who);
             // N = 256 layers with long K (layer 3's 1024 -> 256): 256 x 128 tiles, one per CU
-            if (p.pool_nparts == 0 && p.N >= 256 && cdiv(p.M, 256) * (p.N / 128) >= 224 && p.K >= 512 && !getenv("AGRL_IGEMM_NO_W128")) return launch_igemm_wide(p, stream, who);
-            if (p.pool_nparts > 0 && wide != 0 && wtiles >= 64 && !getenv("AGRL_POOL_PERSIST")) return launch_igemm_wide(p, stream, who);
+            if (p.pool_nparts == 0 && p.N >= 256 && cdiv(p.M, 256) * (p.N / 128) >= 224 && p.K >= 512 && !opt.igemm_no_w128) return launch_igemm_wide(p, stream, who);
+            if (p.pool_nparts > 0 && wide != 0 && wtiles >= 64 && !opt.pool_persist) return launch_igemm_wide(p, stream, who);
         }
     }
     if constexpr (sizeof(TOUT) == 2) {
         // persistent tiles pay off where a tile is short (<= 8 k-tiles): its first DMA round trip and its store
         // drain are a large share of the tile; long K loops run better as independent workgroups (A/B measured)
         int persist = (p.K / BKE) <= 8 ? 1 : 0;
-        if (const char* e = getenv("AGRL_IGEMM_PERSIST")) persist = atoi(e);
+        if (agrl_opt_set(opt.igemm_persist)) persist = opt.igemm_persist;
         if (p.pool_nparts > 0) persist = 1;  // the fused pooling epilogue lives in the persistent kernel
         const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
         if (lds_epi && persist && !p.rowv && pointwise) {
             const int ntiles = cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128);
             int wgs = 512;  // two resident workgroups per CU
-            if (const char* e = getenv("AGRL_IGEMM_WGS")) wgs = atoi(e);
+            if (agrl_opt_set(opt.igemm_wgs)) wgs = opt.igemm_wgs;
             const int g = ntiles < wgs ? ntiles : wgs;
             int pnw = 8;
-            if (const char* e = getenv("AGRL_IGEMM_NW")) pnw = atoi(e);
+            if (agrl_opt_set(opt.igemm_nw)) pnw = opt.igemm_nw;
             if (p.pool_nparts > 0) pnw = 8;  // the pooling epilogue exists for the 8-wave 128x128 instantiation only
             if (p.pool_nparts > 0) {
                 AGRL_CHECK_ARG(!narrow, "%s: fused pooling needs more than 64 output channels", who);
@@ -913,12 +913,12 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     const bool patch_ok = R == 3 && S == 3 && stride == 1 && pad == 1 && !residual && (H % 16) == 0 && (W % 8) == 0 &&
                           (Cin % 64) == 0 && (Cout % 8) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0 &&
                           (!bias || (((uintptr_t)bias) & 15) == 0) && (size_t)N * H * W * Cin * 2 < (1ull << 32) &&
-                          !getenv("AGRL_CONV3X3_GENERIC");
+                          !agrl_opts().conv3x3_generic;
     if (patch_ok) {
         p.dbg = 0; p.vec_ok = 1;
         const int tiles = N * (H / 16) * (W / 8);
         int wide3 = -1;
-        if (const char* e = getenv("AGRL_CONV3X3_WIDE")) wide3 = atoi(e);
+        if (agrl_opt_set(agrl_opts().conv3x3_wide)) wide3 = agrl_opts().conv3x3_wide;
         // two pixel blocks per workgroup for the deep layers (3/4: measured +3..4 %; at Cin = 128 the one-block kernel
         // at two workgroups per CU is 5 % faster), where that still leaves >= one workgroup per CU
         if (Cout > 64 && wide3 != 0 && (wide3 == 1 || (Cin >= 256 && cdiv(tiles, 2) * cdiv(Cout, 128) >= 256))) {
@@ -926,7 +926,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
             return launch_conv3x3_wide(p, (hipStream_t)stream);
         }
         int c64 = -1;
-        if (const char* e = getenv("AGRL_CONV3X3_C64")) c64 = atoi(e);
+        if (agrl_opt_set(agrl_opts().conv3x3_c64)) c64 = agrl_opts().conv3x3_c64;
         if (Cin == 64 && Cout == 64 && p.ldo == 64 && c64 != 0 && (c64 == 1 || tiles >= 256)) {
             p.ksplit = 1;
             return launch_conv3x3_c64(p, (hipStream_t)stream);  // layer 1: weights resident, persistent over pixel blocks
@@ -1019,7 +1019,7 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
     p.Cin = D; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
     p.ldo = ldd;
     // streaming form (one eval batch of queries against a long gallery): dedicated single-pass kernel
-    if (!getenv("AGRL_DISTMAT_TILED") && distmat_stream_applicable(p, dtype == AGRL_F32 ? 4 : 2))
+    if (!agrl_opts().distmat_tiled && distmat_stream_applicable(p, dtype == AGRL_F32 ? 4 : 2))
         return launch_distmat_stream(p, dtype, (hipStream_t)stream);
     // otherwise, when there are too few output tiles to fill 256 CUs -> split K over
     // workgroups, fp32 partials in the caller's workspace, deterministic reduce + epilogue afterwards

@@ -492,18 +492,17 @@ bool igemm_wide_applicable(const IgemmParams& p) {
 int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who) {
     // 128-channel tiles where 256-channel ones would leave CUs idle (N = 256 layers) or do not divide N
     bool half_n = (p.N % WBN) != 0 || (p.pool_nparts == 0 && p.dbg == 0 && cdiv(p.M, WBM) * (p.N / WBN) < 224);
-    if (const char* e = getenv("AGRL_IGEMM_WIDE")) {  // 2 / 3 force the 256- / 128-channel tile (tests, A/B)
-        if (atoi(e) == 2 && (p.N % WBN) == 0) half_n = false;
-        if (atoi(e) == 3 && p.pool_nparts == 0) half_n = true;
-    }
+    const AgrlOpts& opt = agrl_opts();
+    // AGRL_IGEMM_WIDE = 2 / 3 force the 256- / 128-channel tile (tests, A/B)
+    if (opt.igemm_wide == 2 && (p.N % WBN) == 0) half_n = false;
+    if (opt.igemm_wide == 3 && p.pool_nparts == 0) half_n = true;
     // persistent form: one workgroup per CU walks its share of the tiles (AGRL_IGEMM_WIDE_PERSIST=0: one per tile)
     static const int n_cu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const char* pe = getenv("AGRL_IGEMM_WIDE_PERSIST");
-    const bool persist = !(pe && atoi(pe) == 0);
+    const bool persist = opt.igemm_wide_persist != 0;
     const bool res = p.res != nullptr;
     if (half_n) {
         const int tiles = cdiv(p.M, WBM) * (p.N / 128);
@@ -521,15 +520,20 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
         return 0;
     }
     if (res) {
+#ifdef AGRL_ABLATE
         if (p.dbg == 8192) hipLaunchKernelGGL((igemm_wide_kernel<8192, 256, true>), dim3(grid), dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((igemm_wide_kernel<0, 256, true>), dim3(grid), dim3(512), 0, stream, p);
+        else
+#endif
+        hipLaunchKernelGGL((igemm_wide_kernel<0, 256, true>), dim3(grid), dim3(512), 0, stream, p);
         AGRL_CHECK_LAUNCH(who);
         return 0;
     }
-    switch (p.dbg) {
+    switch (p.dbg) {  // non-zero only in an -DAGRL_ABLATE build
+#ifdef AGRL_ABLATE
 #define WIDE_CASE(D) case D: hipLaunchKernelGGL((igemm_wide_kernel<D, 256>), dim3(grid), dim3(512), 0, stream, p); break
         WIDE_CASE(1); WIDE_CASE(16384); WIDE_CASE(4096); WIDE_CASE(8192); WIDE_CASE(178); WIDE_CASE(50); WIDE_CASE(146); WIDE_CASE(2); WIDE_CASE(8); WIDE_CASE(16); WIDE_CASE(32); WIDE_CASE(160); WIDE_CASE(184); WIDE_CASE(18);
 #undef WIDE_CASE
+#endif
         default: hipLaunchKernelGGL((igemm_wide_kernel<0, 256>), dim3(grid), dim3(512), 0, stream, p);
     }
     AGRL_CHECK_LAUNCH(who);

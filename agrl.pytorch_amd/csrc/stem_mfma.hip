@@ -223,7 +223,7 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w
     const long long grid = (long long)N * tiles_h * tiles_w;
     AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_bf16: grid too large");
     int wgs = 512;  // two persistent workgroups per CU (67 KB of LDS each)
-    if (const char* e = getenv("AGRL_STEM_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+    if (agrl_opt_set(agrl_opts().stem_wgs) && agrl_opts().stem_wgs > 0) wgs = agrl_opts().stem_wgs;
     const unsigned launch = (unsigned)(grid < wgs ? grid : wgs);
     hipLaunchKernelGGL(stem_mfma_kernel, dim3(launch), dim3(NTH), 0, (hipStream_t)stream, x,
                        (const unsigned char*)w_packed, bias, (bf16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
+    "agrl_diag_read_stream": [_p, C.c_size_t, _p, _i, _p],
 }
 
 _lock = threading.Lock()
@@ -95,10 +96,18 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _i
         h.agrl_re_ranking_workspace.restype = C.c_size_t
+        for name in ("agrl_reload_options", "agrl_built_with_ablation"):
+            getattr(h, name).argtypes = []
+            getattr(h, name).restype = _i
         h.agrl_version.restype = _i
         h.agrl_last_error.restype = C.c_char_p
         _lib = h
     return _lib
+
+
+def reload_options():
+    """Make the library re-read its AGRL_* tuning switches from the environment (they are read once at load time)."""
+    lib().agrl_reload_options()
 
 
 def available() -> bool:

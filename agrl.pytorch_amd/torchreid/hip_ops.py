@@ -421,3 +421,13 @@ def triplet_hard_mine(x, pids):
     with _dev(x):
         call("agrl_triplet_hard_mine", ptr(x), ptr(pids), n, d, ptr(dap), ptr(dan), ptr(iap), ptr(ian), _stream(x))
     return dap, dan, iap, ian
+
+
+def read_stream(buf, nbytes=None, workgroups=2048):
+    """Measurement yardstick (bench.py): one pure read pass over the first ``nbytes`` of ``buf`` on the current stream."""
+    total = buf.numel() * buf.element_size()
+    nbytes = total if nbytes is None else min(int(nbytes), total)
+    sink = torch.empty((1,), dtype=torch.float32, device=buf.device)
+    with _dev(buf):
+        call("agrl_diag_read_stream", ptr(buf), nbytes & ~15, ptr(sink), int(workgroups), _stream(buf))
+    return sink

@@ -36,8 +36,9 @@ class TripletLoss(nn.Module):
             from torchreid import hip_ops as ops
             _, _, idx_ap, idx_an = ops.triplet_hard_mine(inputs.detach().float().contiguous(),
                                                          targets.detach().to(torch.int32).contiguous())
-            if bool((idx_an < 0).any()):
-                raise RuntimeError('an anchor has no negative in the batch')
+            # no host round trip here (the loss is called 2-5 x per step through DeepSupervision): an anchor without any
+            # negative keeps idx_an = -1 and forward() turns its distance -- and with it the loss -- into NaN instead of
+            # raising (the reference's boolean-mask .min() on an empty selection raises, hard_mine_triplet_loss.py:43)
             return idx_ap.long(), idx_an.long()
         with torch.no_grad():
             sq = inputs.pow(2).sum(dim=1, keepdim=True)
@@ -52,7 +53,9 @@ class TripletLoss(nn.Module):
     def forward(self, inputs, targets):
         idx_ap, idx_an = self.mine(inputs, targets)
         dist_ap = _pair_dist(inputs, idx_ap)
-        dist_an = _pair_dist(inputs, idx_an)
+        missing = idx_an < 0
+        dist_an = _pair_dist(inputs, idx_an.clamp(min=0))
+        dist_an = torch.where(missing, torch.full_like(dist_an, float('nan')), dist_an)
         if self.soft:
             return torch.log(1 + torch.exp(dist_ap - dist_an)).mean()
         return self.ranking_loss(dist_an, dist_ap, torch.ones_like(dist_an))

@@ -178,12 +178,19 @@ def _side_stream(device):
 def hip_features_pooled(model, frames, pack, splits):
     """Conv stages with the global / part pooling fused into the last conv of each layer4 branch (bf16, 16x8 maps):
     -> gsum (F,C) per-frame sums, nodes (F,P,C) fp32, nodes_lp bf16, hw. None when the fusion does not apply."""
-    if pack['dtype'] != torch.bfloat16:
+    if pack['dtype'] != torch.bfloat16 or pack['l4_1'][0]['stride'] != 1:
+        return None
+    # applicability is decided from the input size BEFORE anything is launched (a late bail-out would make the caller
+    # recompute stem + trunk): the fused epilogue needs 16 x 8 = 128-pixel layer-4 maps, i.e. frames of 256 x 128
+    H, W = frames.shape[2], frames.shape[3]
+    h4, w4 = H, W
+    for _ in range(4):   # stem conv /2, maxpool /2, layer2 /2, layer3 /2 (kernel 7 pad 3 / kernel 3 pad 1: ceil halving)
+        h4, w4 = (h4 + 1) // 2, (w4 + 1) // 2
+    if (h4, w4) != (16, 8):
         return None
     a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1])
     a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))
-    if a.shape[1] * a.shape[2] != 128 or pack['l4_1'][0]['stride'] != 1:
-        return None
+    assert a.shape[1] == 16 and a.shape[2] == 8
     splits = list(splits)
     if not model.hip_branch_streams:
         x4_1 = a
@@ -220,7 +227,7 @@ def hip_features_pooled(model, frames, pack, splits):
     return gsum.view(gsum.shape[0], gsum.shape[2]), nodes, nodes_lp, 128
 
 
-def hip_graph_layers(nodes, nodes_lp, adj, pack):
+def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None):
     """GraphLayer x num_gb on (B,V,C) fp32 nodes. reference vmgn.py:311-312 -> :142-172."""
     lp = pack['dtype'] == torch.bfloat16
     B, V, C = nodes.shape
@@ -229,13 +236,17 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack):
         operand = nodes_lp if lp else nodes
         h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
         G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+        if stages is not None:
+            stages['G%d' % i] = G
         nodes, nodes_lp = ops.graph_propagate(nodes, h, G, g['scale'], g['shift'], g['gamma'], g['slope'],
                                               want_lp=lp and i + 1 < n_layers)
     return nodes
 
 
-def hip_forward(model, x, adj, return_feats=False):
-    """Eval forward on the GPU: (B,S,3,H,W) fp32, (B,V,V) fp32 -> (B,4096) fp32."""
+def hip_forward(model, x, adj, return_feats=False, stages=None):
+    """Eval forward on the GPU: (B,S,3,H,W) fp32, (B,V,V) fp32 -> (B,4096) fp32. ``stages``: an optional dict that
+    receives the intermediate tensors of the path (per-frame sums of x4_1, part nodes, graphs, graph output, pre-BN
+    features) for the stage-by-stage parity tests."""
     _hip.lib()  # fail loudly before touching anything if the extension is missing
     if x.dtype != torch.float32:
         raise TypeError('frames must be float32, got {}'.format(x.dtype))
@@ -262,10 +273,16 @@ def hip_forward(model, x, adj, return_feats=False):
         if nodes_lp is not None:
             nodes_lp = nodes_lp.view(B, V, C)
         adj32 = adj.detach().to(torch.float32).contiguous()
-        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack)
+        if stages is not None:
+            stages.update(gsum=gsum, hw=hw, nodes=nodes)
+        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages)
         sqn = ops.row_sqnorm(nodes.view(B * V, C))
-        return ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
-                                    pack['a_bn'][1], B, S, P, hw, want_feats=return_feats)
+        res = ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
+                                   pack['a_bn'][1], B, S, P, hw, want_feats=return_feats or stages is not None)
+        if stages is not None:
+            stages.update(nodes_out=nodes, out=res[0], g_f=res[1], att_f=res[2])
+            return res if return_feats else res[0]
+        return res
 
 
 def hip_forward_gsta(model, x, adj):

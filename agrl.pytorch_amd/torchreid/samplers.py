@@ -13,7 +13,15 @@ import random
 
 import numpy as np
 import torch
-from torch.utils.data.sampler import Sampler
+from torch.utils.data.sampler import *  # noqa: F401,F403 -- the driver evals e.g. 'SequentialSampler' by name (:227)
+
+
+class RandomSampler(RandomSampler):  # noqa: F405
+    """``--train-sampler RandomSampler``: the stock sampler behind the constructor every train sampler is called with,
+    ``(data_source, batch_size=..., num_instances=...)`` (train_vidreid_xent_htri.py:227; reference samplers.py:12-15)."""
+
+    def __init__(self, data_source, batch_size, num_instances):
+        super(RandomSampler, self).__init__(data_source)
 
 
 class RandomIdentitySampler(Sampler):
@@ -51,17 +59,16 @@ class RandomIdentitySampler(Sampler):
                 order.extend(chunks[pid].pop(0))
                 if not chunks[pid]:
                     alive.remove(pid)
-        self.length = len(order)
         return iter(order)
 
     def __len__(self):
-        return self.length
+        return self.length  # the constructor-time estimate, as in the reference (an epoch may yield fewer)
 
 
 class RandomIdentitySamplerV1(Sampler):
     """For every identity (random order) draw ``num_instances`` samples (reference samplers.py:79-111)."""
 
-    def __init__(self, data_source, batch_size, num_instances=4):
+    def __init__(self, data_source, num_instances=4, **kwargs):
         self.data_source = data_source
         self.num_instances = num_instances
         self.index_dic = defaultdict(list)

@@ -4,7 +4,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (the Python host side allocates
- *     through torch); the library allocates nothing and keeps no global mutable state
+ *     through torch); the library allocates nothing and keeps no global mutable state besides the tuning switches it
+ *     reads from the environment at load time
  *   - every entry point is re-entrant, takes the HIP stream to launch on (hipStream_t passed as
  *     void*), never synchronises the device, and returns 0 on success / non-zero on error;
  *     agrl_last_error() returns a thread-local message for the last non-zero return
@@ -41,6 +42,13 @@ typedef void* agrl_stream_t; /* hipStream_t */
 /* library version (major*10000 + minor*100 + patch) and last error of the calling thread */
 int agrl_version(void);
 const char* agrl_last_error(void);
+
+/* Tuning switches (AGRL_IGEMM_*, AGRL_CONV3X3_*, AGRL_GCN_*, AGRL_DISTMAT_*) are read from the environment
+ * once, when the library is loaded; agrl_reload_options() re-reads them (the A/B tools and the kernel tests flip them inside
+ * one process; not thread-safe against concurrent launches). agrl_built_with_ablation() is 1 only for the -DAGRL_ABLATE
+ * profiling build: the shipped library has no switch that removes work from a kernel. */
+int agrl_reload_options(void);
+int agrl_built_with_ablation(void);
 
 /* ---- conv stages ------------------------------------------------------------------------- */
 
@@ -255,6 +263,13 @@ int agrl_re_ranking(const float* q_g, const float* q_q, const float* g_g, int m,
  *   (lowest index on ties). */
 int agrl_triplet_hard_mine(const float* x, const int32_t* pids, int n, int d, float* dist_ap,
                            float* dist_an, int32_t* idx_ap, int32_t* idx_an, agrl_stream_t stream);
+
+/* ---- measurement yardstick (bench.py; not on the hot path) ------------------- */
+
+/* Pure read stream over `bytes` of device memory at src (16-byte loads, eight in flight per lane, `workgroups` x 256
+ * threads): the achievable single-pass read rate of this chip at a given size, printed by bench.py beside the HBM-bound
+ * kernels of the path (reference call sites they replace: vmgn.py:142-172, distance.py:59-89). sink: one device float. */
+int agrl_diag_read_stream(const void* src, size_t bytes, float* sink, int workgroups, agrl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -23,3 +23,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _tuning_switches_follow_the_environment():
+    """libagrl_hip.so reads its AGRL_* tuning switches once at load time; tests that flip them through monkeypatch call
+    _hip.reload_options() themselves, and this fixture (set up before monkeypatch, so torn down after its undo) puts the
+    library back on the restored environment afterwards."""
+    yield
+    from torchreid import _hip
+    if _hip._lib is not None:
+        _hip.reload_options()

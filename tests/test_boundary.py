@@ -104,14 +104,24 @@ def test_metrics_contract_without_gpu():
 def test_samplers_star_import_binds_driver_names():
     ns = {}
     exec("from torchreid.samplers import *", ns)
-    for name in ("np", "torch", "random", "copy", "RandomIdentitySampler", "RandomIdentitySamplerV1"):
-        assert name in ns
+    for name in ("np", "torch", "random", "copy", "RandomIdentitySampler", "RandomIdentitySamplerV1", "RandomSampler",
+                 "SequentialSampler", "Sampler", "BatchSampler", "SubsetRandomSampler", "WeightedRandomSampler"):
+        assert name in ns   # reference samplers.py:9 star-imports torch.utils.data.sampler; the driver evals names (:227)
     data = [(None, pid, 0) for pid in range(6) for _ in range(5)]
     s = ns["RandomIdentitySampler"](data, batch_size=8, num_instances=4)
     order = list(iter(s))
     assert len(order) % 8 == 0 and len(order) == len(s)
     for i in range(0, len(order), 4):
         assert len({data[j][1] for j in order[i:i + 4]}) == 1
+    list(iter(s))
+    assert len(s) == 24   # the constructor-time estimate: iterating does not change len(trainloader)
+    # the driver's call shape for every train sampler: eval(name)(data, batch_size=..., num_instances=...)  (:227)
+    for name in ("RandomSampler", "RandomIdentitySampler", "RandomIdentitySamplerV1"):
+        smp = eval(name, ns)(data, batch_size=8, num_instances=4)
+        assert {int(i) for i in iter(smp)} <= set(range(len(data))) and len(smp) > 0
+    assert sorted(iter(ns["RandomSampler"](data, 8, 4))) == list(range(len(data)))
+    v1 = ns["RandomIdentitySamplerV1"](data, 4)   # reference signature (data_source, num_instances=4, **kwargs)
+    assert v1.num_instances == 4 and len(v1) == 24
 
 
 def test_losses_contract():
@@ -138,8 +148,10 @@ def test_cabi_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert set(_hip.SIGNATURES) == declared - {"agrl_version", "agrl_last_error"}
+    assert set(_hip.SIGNATURES) == declared - {"agrl_version", "agrl_last_error", "agrl_reload_options", "agrl_built_with_ablation"}
     assert lib.agrl_version() >= 100
+    assert lib.agrl_built_with_ablation() == 0   # the shipped library has no switch that removes work from a kernel
+    assert lib.agrl_reload_options() == 0
     # argument validation happens before any launch, so it is checkable without a GPU
     assert lib.agrl_distmat(None, None, None, None, None, 1, 1, 64, 1, 0, 0, None, 0, None) != 0
     assert b"null pointer" in lib.agrl_last_error()
@@ -168,6 +180,80 @@ def test_reference_overlay_resolves_out_of_scope_modules():
     out = subprocess.check_output(["python", "-c", code], env=env, cwd="/tmp").decode().split()
     assert "agrl.pytorch_amd" in out[0] and out[1].startswith("/root/reference")
     assert out[2].startswith("/root/reference") and "agrl.pytorch_amd" in out[3]
+
+
+@pytest.mark.skipif(not os.path.isfile("/root/reference/train_vidreid_xent_htri.py"), reason="reference tree only exists in the build container")
+def test_driver_import_block_under_overlay():
+    """INTEGRATION.md route A: the reference driver's own import block (train_vidreid_xent_htri.py:1-29, read from the
+    reference at test time) executes with this package first on PYTHONPATH -- in particular the names it takes from the
+    modules this build shadows (set_wd, cur_time, visualize_ranked_results, calc_splits, re_ranking, the samplers' star
+    names). tensorboardX / torchvision / h5py are absent from this image and stubbed."""
+    code = r'''
+import sys, types
+for name in ("tensorboardX", "torchvision", "torchvision.transforms", "torchvision.transforms.functional", "h5py"):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["tensorboardX"].SummaryWriter = object
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+def _stub_attr(n):
+    if n.startswith("__"):
+        raise AttributeError(n)
+    return type(n, (), {})
+sys.modules["torchvision.transforms"].__getattr__ = _stub_attr
+for cls in ("ToPILImage", "Resize", "RandomHorizontalFlip", "ToTensor", "Normalize", "Compose"):
+    setattr(sys.modules["torchvision.transforms"], cls, type(cls, (), {}))   # what the reference's transforms.py star-imports
+import scipy.misc, sklearn.metrics._base      # APIs the reference's 2019 pins still had (scipy<1.2, scikit-learn<0.24)
+scipy.misc.imsave = lambda *a, **k: None
+sys.modules["sklearn.metrics.base"] = sklearn.metrics._base
+src = open("/root/reference/train_vidreid_xent_htri.py").read().split("parser = argparse.ArgumentParser")[0]
+ns = {}
+exec(compile(src, "driver_imports", "exec"), ns)
+import torchreid.utils.torchtools as tt, torchreid.utils.reidtools as rt, torchreid.samplers as sm
+assert "agrl.pytorch_amd" in tt.__file__ and "agrl.pytorch_amd" in rt.__file__ and "agrl.pytorch_amd" in sm.__file__
+for name in ("set_wd", "cur_time", "visualize_ranked_results", "calc_splits", "re_ranking", "compute_model_complexity",
+             "save_checkpoint", "AverageMeter", "Logger", "init_optim", "np", "torch", "random", "RandomSampler",
+             "RandomIdentitySampler", "TripletLoss", "CrossEntropyLabelSmooth", "DeepSupervision", "models", "metrics"):
+    assert name in ns, name
+print("ok")
+'''
+    env = dict(os.environ, AGRL_REFERENCE_ROOT="/root/reference", PYTHONPATH=os.path.join(ROOT, "agrl.pytorch_amd"))
+    out = subprocess.check_output(["python", "-c", code], env=env, cwd="/tmp").decode()
+    assert out.strip().endswith("ok")
+
+
+def test_shadowed_util_modules_carry_the_reference_names(tmp_path):
+    """torchtools / reidtools shadow the reference's modules of the same name: every public function those define
+    (reference torchtools.py:10-141, reidtools.py:13-80) exists here and behaves."""
+    from torchreid.utils import torchtools as tt, reidtools as rt
+    for name in ("cur_time", "adjust_learning_rate", "set_bn_to_eval", "set_wd", "count_num_param", "flip_tensor",
+                 "weights_init_kaiming", "weights_init_xavier", "weights_init_classifier", "mem_report"):
+        assert callable(getattr(tt, name)), name
+    lin = torch.nn.Linear(4, 3)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1, weight_decay=5e-4)
+    tt.set_wd(opt, 0)
+    assert opt.param_groups[0]["weight_decay"] == 0
+    tt.adjust_learning_rate(opt, 0.1, epoch=45, stepsize=20)
+    assert abs(opt.param_groups[0]["lr"] - 0.001) < 1e-12
+    bn = torch.nn.BatchNorm1d(3).train()
+    bn.apply(tt.set_bn_to_eval)
+    assert not bn.training
+    assert abs(tt.count_num_param(lin) - 15e-6) < 1e-12
+    assert torch.equal(tt.flip_tensor(torch.arange(6).view(2, 3), 1), torch.tensor([[2, 1, 0], [5, 4, 3]]))
+    assert re.match(r"\d{4}-\d\d-\d\d \d\d:\d\d:\d\d$", tt.cur_time())
+    # visualize_ranked_results: tracklets (tuples of frame paths) and single images; same id + same camera skipped
+    def touch(*parts):
+        path = tmp_path.joinpath(*parts)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        path.write_bytes(b"x")
+        return str(path)
+    class DS:
+        query = [((touch("q", "0007", "a.jpg"), touch("q", "0007", "b.jpg")), 7, 0)]
+        gallery = [(touch("g", "x.jpg"), 7, 0), (touch("g", "y.jpg"), 7, 1), (touch("g", "z.jpg"), 3, 0)]
+    out = tmp_path / "ranked"
+    rt.visualize_ranked_results(np.array([[0.1, 0.3, 0.2]]), DS, save_dir=str(out), topk=2)
+    qdir = out / "id0007_cam0"
+    assert sorted(os.listdir(str(qdir))) == ["gallery_top001_name_z.jpg", "gallery_top002_name_y.jpg", "query_top000"]
+    assert sorted(os.listdir(str(qdir / "query_top000"))) == ["a.jpg", "b.jpg"]
 
 
 def test_host_side_helpers_without_gpu():

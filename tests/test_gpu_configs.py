@@ -2,6 +2,8 @@
 config 5 -- MARS full eval, 1980 x 12180 x 4096 distance matrix + top-50 ranking -- through size-independent properties
 plus sampled rows against the CPU oracle; config 4 -- a Duke-shaped (seq_len 16, V = 112) xent + htri train step with
 on-GPU batch-hard mining -- against the same step computed on the CPU by the same module tree."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -86,3 +88,24 @@ def test_config4_train_step_seq16_matches_cpu_step():
     print("train step S=16: loss cpu %.6f gpu %.6f | grad norm cpu %.4e gpu %.4e" % (l_ref, l_dev, g_ref, g_dev))
     assert abs(l_ref - l_dev) < 2e-3 * abs(l_ref)
     assert abs(g_ref - g_dev) < 2e-2 * g_ref
+
+
+def test_bench_self_launches_two_ranks():
+    """BASELINE configs[2]'s launch path on a 1-GPU box: ``python bench.py --gpus 2`` itself starts two fresh rank
+    processes (the parent never touches the GPU), which share the one GPU over gloo here (RCCL needs one GPU per rank), run
+    the all-gather + sharded-gallery step, and rank 0 prints the JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch", "8", "--sustain-seconds", "0", "--profile-steps", "1"], env=env, cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["config"]["ranks"] == 2 and r["config"]["global_batch"] == 16
+    assert r["config"]["gallery_rows_per_gpu"] == 6090 and len(r["config"]["per_rank_ms_per_step"]) == 2
+    assert r["value"] > 0 and "allgather_us" in r["config"] and r["scaling"] == "weak"
+    print("bench --gpus 2 (2 ranks on one GPU, gloo): %.0f frames/s, all-gather %.0f us" % (r["value"], r["config"]["allgather_us"]))

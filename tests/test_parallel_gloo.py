@@ -98,6 +98,21 @@ def _train_worker(rank, world, port, tmp):
     loss = parallel.train_step(m, x[lo:hi], adj[lo:hi], pids[lo:hi], losses.CrossEntropyLabelSmooth(5, use_gpu=False),
                                losses.TripletLoss(margin=0.3, soft=True), opt)
     grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    # the overlapped form: .grad are views into flat buckets, every bucket's all-reduce is issued from a post-accumulate
+    # hook while backward is still running (small buckets here so that several are in flight) -> the same gradients
+    m2, _, _, _ = _train_problem(models, recipe_state_dict, synthetic_clips, synthetic_adj)
+    buckets = parallel.GradientBuckets(m2.parameters(), bucket_bytes=8 << 20)
+    assert len(buckets.buckets) > 3
+    opt2 = torch.optim.SGD(m2.parameters(), lr=0.0)
+    for _ in range(2):   # twice: zero_grad() must keep the views and re-arm the counters
+        loss2 = parallel.train_step(m2, x[lo:hi], adj[lo:hi], pids[lo:hi], losses.CrossEntropyLabelSmooth(5, use_gpu=False),
+                                    losses.TripletLoss(margin=0.3, soft=True), opt2, buckets=buckets)
+    assert abs(loss2[0] - loss[0]) < 1e-6 * abs(loss[0])
+    for k, p in m2.named_parameters():
+        if k in grads:
+            assert p.grad.data_ptr() >= buckets.buckets[buckets._bucket_of[p]][0].data_ptr()
+            assert torch.allclose(p.grad, grads[k], rtol=1e-5, atol=1e-7 * grads[k].abs().max().item() + 1e-12), k
+    buckets.remove()
     torch.save((loss, grads), os.path.join(tmp, "t%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
-from torchreid import hip_ops as ops
+from torchreid import hip_ops as ops, _hip
 dev = "cuda:0"
 variants = []
 for a in sys.argv[1:]:
@@ -30,6 +30,7 @@ for label, fn, flops in CASES:
             for k in keys:
                 os.environ.pop(k, None)
             os.environ.update(env)
+            _hip.reload_options()  # the library reads its switches once; re-read after flipping them
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(10):

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
-from torchreid import hip_ops as ops
+from torchreid import hip_ops as ops, _hip
 dev = "cuda:0"
 torch.manual_seed(0)
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
@@ -19,9 +19,11 @@ def conv_case(N, H, W, Cin, Cout, R, stride, res, env_alt):
     r = torch.randn((N, OH, OW, Cout), device=dev).bfloat16() if res else None
     for k in env_alt:
         os.environ[k] = env_alt[k]
+    _hip.reload_options()
     ref = ops.conv_bn_act(x, w, b, stride, R // 2, True, r).clone()
     for k in env_alt:
         os.environ.pop(k)
+    _hip.reload_options()
     bad = 0
     for _ in range(REPS):
         out = ops.conv_bn_act(x, w, b, stride, R // 2, True, r)

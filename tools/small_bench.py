@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
-from torchreid import hip_ops as ops
+from torchreid import hip_ops as ops, _hip
 dev = "cuda:0"
 variants = []
 for a in sys.argv[1:]:
@@ -43,6 +43,7 @@ for label, fn, nbytes in CASES:
                 for k in keys:
                     os.environ.pop(k, None)
                 os.environ.update(env)
+                _hip.reload_options()  # the library reads its switches once; re-read after flipping them
                 if cold:
                     trash.fill_(rnd & 0xff)
                 reps = 1 if cold else 20  # warm: back-to-back launches (launch latency amortised, operands in L2/MALL)
