@@ -98,7 +98,7 @@ __device__ inline float zsum(const float* p, int nz, int zstride) {
 // rows, was latency-bound at ~70 us).
 __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __restrict__ gram_part, int nz,
                                                              const float* __restrict__ adj, float* __restrict__ G,
-                                                             int V, int use_pose, int learn_graph) {
+                                                             int V, int use_pose, int learn_graph, int mask_diag) {
     extern __shared__ __attribute__((aligned(16))) float s_n[];  // V squared norms (Gram diagonal)
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,10 +124,12 @@ __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __rest
                 float d2 = (s_n[j] + s_n[i]) - 2.f * g;
                 d2 = fmaxf(d2, 1e-12f);
                 sim[q] = 2.f / (expf(sqrtf(d2)) + 1.f);
+                if (mask_diag && j == i) sim[q] = 0.f;  // ganet.py:259-268: self-loops masked out before the normalisation
                 ssum += fabsf(sim[q]);
             }
             if (use_pose) {
                 av[q] = adj[((size_t)b * V + i) * V + j];
+                if (mask_diag && j == i) av[q] = 0.f;
                 asum += fabsf(av[q]);
             }
         }
@@ -626,25 +628,26 @@ extern "C" int agrl_graph_gram(const float* f, float* gram_part, int B, int V, i
 }
 
 extern "C" int agrl_graph_finalize(const float* gram_part, int nz, const float* adj, float* G, int B, int V,
-                                   int use_pose, int learn_graph, agrl_stream_t stream) {
+                                   int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream) {
     AGRL_CHECK_ARG(G && B > 0 && V > 0, "agrl_graph_finalize: bad arguments");
     AGRL_CHECK_ARG(use_pose || learn_graph, "agrl_graph_finalize: use_pose or learn_graph must be set");
     AGRL_CHECK_ARG(!use_pose || adj, "agrl_graph_finalize: use_pose needs adj");
     AGRL_CHECK_ARG(!learn_graph || (gram_part && nz > 0), "agrl_graph_finalize: learn_graph needs the Gram partials");
     AGRL_CHECK_ARG(V <= 256, "agrl_graph_finalize: V=%d > 256 not supported", V);
     hipLaunchKernelGGL(graph_finalize_kernel, dim3(B, cdiv(V, 4)), dim3(256), (size_t)V * sizeof(float),
-                       (hipStream_t)stream, gram_part, nz, adj, G, V, use_pose, learn_graph);
+                       (hipStream_t)stream, gram_part, nz, adj, G, V, use_pose, learn_graph, mask_diag);
     AGRL_CHECK_LAUNCH("agrl_graph_finalize");
     return 0;
 }
 
 extern "C" int agrl_graph_propagate(const float* f, const float* h, const float* G, const float* bn_scale,
-                                    const float* bn_shift, float gamma, float slope, float* out, void* out_lp, int B,
-                                    int V, int C, agrl_stream_t stream) {
+                                    const float* bn_shift, float keep, float gamma, float slope, float* out, void* out_lp,
+                                    int B, int V, int C, agrl_stream_t stream) {
     AGRL_CHECK_ARG(f && h && G && bn_scale && bn_shift && out, "agrl_graph_propagate: null pointer");
     AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0, "agrl_graph_propagate: bad shape");
-    // (1 - gamma) is evaluated in double like the reference's Python float, then rounded once
-    const float omg_m = (float)(1.0 - (double)gamma);
+    // keep = the coefficient of f: (1 - gamma) for vmgn / gsta, evaluated by the host in double like the reference's Python
+    // float and rounded once; 1 for ganet's ``input + gamma * h'``
+    const float omg_m = keep;
     const bool aligned = ((((uintptr_t)f | (uintptr_t)h | (uintptr_t)out | (uintptr_t)out_lp | (uintptr_t)bn_scale |
                             (uintptr_t)bn_shift) & 15) == 0);
     if (V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned && (((uintptr_t)G) & 15) == 0 && !agrl_opts().gcn_lds) {
@@ -697,8 +700,7 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     const bool fixed = false;  // register-resident h (VT > 0) spills: hipcc hoists every LDS graph read; keep h in LDS
     const size_t lds = ((size_t)V * Vp + (fixed ? 0 : (size_t)V * PROP_THREADS)) * sizeof(float);
     AGRL_CHECK_ARG(lds <= 160 * 1024, "agrl_graph_propagate: V=%d too large", V);
-    // (1 - gamma) is evaluated in double like the reference's Python float, then rounded once
-    const float omg = (float)(1.0 - (double)gamma);
+    const float omg = keep;
     const dim3 grid(B, cdiv(C, PROP_THREADS));
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_PROP(VT)                                                                                              \

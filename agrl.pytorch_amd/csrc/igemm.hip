@@ -900,6 +900,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     AGRL_CHECK_ARG(R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_conv2d_bn_act: bad filter geometry");
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16 || dtype == AGRL_F32X3, "agrl_conv2d_bn_act: bad dtype %d", dtype);
     IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
     p.OH = (H + 2 * pad - R) / stride + 1;
@@ -941,6 +942,23 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
 }
 
+extern "C" int agrl_conv1x1_dual_bn_act(const void* x1, const void* x2, const void* w, const float* bias, void* out, int M,
+                                       int K1, int K2, int Cout, int relu, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x1 && x2 && w && out, "agrl_conv1x1_dual_bn_act: null pointer");
+    AGRL_CHECK_ARG(M > 0 && K1 > 0 && K2 > 0 && Cout > 0, "agrl_conv1x1_dual_bn_act: bad shape");
+    IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0;
+    p.x = x1; p.x2 = x2; p.K1 = K1; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = nullptr; p.out = out;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0; p.dbg = 0; p.vec_ok = 1;
+    p.M = M; p.N = Cout; p.K = K1 + K2;
+    p.Cin = p.K; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.ldo = Cout;
+    AGRL_CHECK_ARG(igemm_wide_applicable(p),
+                   "agrl_conv1x1_dual_bn_act: needs K1 == 2 K2, K1 %% 64 == 0, Cout %% 256 == 0 and 16-byte aligned operands "
+                   "(got K1=%d K2=%d Cout=%d)", K1, K2, Cout);
+    return launch_igemm_wide(p, (hipStream_t)stream, "agrl_conv1x1_dual_bn_act");
+}
+
 extern "C" int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const float* bias, const void* residual, void* out,
                                        float* pool_out, void* pool_out_lp, int N, int H, int W, int Cin, int Cout,
                                        int relu, const int* splits, int n_splits, int mean, agrl_stream_t stream) {
@@ -948,6 +966,7 @@ extern "C" int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const floa
     AGRL_CHECK_ARG(H * W == 128, "agrl_conv1x1_bn_act_pool: a frame must be exactly 128 pixels (got %dx%d)", H, W);
     AGRL_CHECK_ARG(Cout > 64 && Cout % 8 == 0 && Cin % 64 == 0, "agrl_conv1x1_bn_act_pool: unsupported channel counts");
     IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1;
     p.OH = H; p.OW = W;
@@ -976,6 +995,7 @@ extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M,
     AGRL_CHECK_ARG(x && w && y, "agrl_linear_nobias: null pointer");
     AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_linear_nobias: bad dtype %d", in_dtype);
     IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     p.M = M; p.N = Nout; p.K = K;
@@ -1005,6 +1025,7 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
     AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && ldd >= n, "agrl_distmat: bad shape m=%d n=%d D=%d ldd=%d", m, n, D, ldd);
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_distmat: bad dtype %d", dtype);
     IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0;
     p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     if (metric == AGRL_METRIC_EUCLIDEAN) {
         AGRL_CHECK_ARG(qn && gn, "agrl_distmat: euclidean needs the squared row norms");

@@ -5,6 +5,8 @@
 
 struct IgemmParams {
     const void* x;
+    const void* x2;  // second pixel-row operand of the two-source pointwise GEMM (igemm_wide DUAL form) or nullptr
+    int K1;          // two-source form: k-columns [0, K1) come from x (row length K1), [K1, K) from x2 (row length K - K1)
     const void* w;
     const float* colv;  // per output channel (bias / gallery sq-norm) or nullptr
     const float* rowv;  // per output pixel (query sq-norm) or nullptr

@@ -27,6 +27,11 @@ template <int DBG, int WBN_ = 256, bool RES = false>  // RES: + residual (its 64
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     static_assert(WBN_ == 256 || (WBN_ == 128 && (DBG & (4096 | 8192 | 16384)) == 0), "the 128-channel tile has the plain schedule + register epilogue only");
     constexpr bool POOL = (DBG & 16384) != 0;   // fused frame pooling epilogue (a tile = two whole 16 x 8 frames)
+    // DUAL (bit 32768): TWO pixel-row operands concatenated along K -- out = [x | x2] [W1 | W2]^T: a Bottleneck's last conv
+    // and its 1x1 downsample conv as ONE GEMM (vmgn.py:56-64: bn3(conv3(y2)) + downsample(x), both BatchNorms folded), so the
+    // shortcut map is neither written nor read back and the sum is formed in fp32. x rows are exactly twice as long as x2
+    // rows (ResNet: inplanes = 2 planes in the first block of layers 2-4), which lets ONE stored offset per piece serve both.
+    constexpr bool DUAL = (DBG & 32768) != 0;
     constexpr bool REGEPI = (DBG & 8192) == 0;  // bit 8192: the LDS-staged two-half epilogue (kept for A/B)
     constexpr int BM = WBM, BN = WBN_, NW = 8, WM = 4;
     constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
@@ -60,6 +65,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     if (tl >= xcnt) return;
 
     const unsigned char* __restrict__ xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* __restrict__ xg2 = reinterpret_cast<const unsigned char*>(p.x2);
     const unsigned char* __restrict__ wg = reinterpret_cast<const unsigned char*>(p.w);
     const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
 
@@ -67,6 +73,10 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     // covers tile rows wave*32 + 8j .. +7, lane L -> row + (L>>3), physical chunk L&7 = global chunk (L&7)^((row>>1)&7)
     const int lrow = lane >> 3, lchk = lane & 7;
     const unsigned row_bytes = (unsigned)p.K * 2u;
+    // DUAL: a_off is kept for the SHORT rows (x2, K - K1 = K1 / 2 elements); the long-row offset of the same pixel and chunk
+    // is 2 a_off - (a_off & 127) (row starts are multiples of 128 bytes, the swizzled chunk sits in the low 7 bits)
+    const unsigned row_bytes_a = DUAL ? (unsigned)(p.K - p.K1) * 2u : row_bytes;
+    const unsigned split_bytes = DUAL ? (unsigned)p.K1 * 2u : 0u;
     unsigned a_off[AJ], b_off[BJ];
     unsigned a_okmask = 0;
     int m0 = 0, n0 = 0;
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 const int oy = rem / p.OW, ox = rem - oy * p.OW;
                 pix = (n * p.H + oy * p.stride) * p.W + ox * p.stride;
             }
-            a_off[j] = (unsigned)pix * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
+            a_off[j] = (unsigned)pix * row_bytes_a + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
         }
 #pragma unroll
         for (int j = 0; j < BJ; ++j) {
@@ -110,6 +120,12 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     auto stage_piece = [&](int buf, int idx) {
         if (idx < AJ) {
             unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / NW) * 128;
+            if constexpr (DUAL) {
+                const bool second = kbyte >= split_bytes;  // wave-uniform
+                const unsigned char* src = second ? xg2 + a_off[idx] + (kbyte - split_bytes)
+                                                  : xg + (2u * a_off[idx] - (a_off[idx] & 127u)) + kbyte;
+                dma16((a_okmask >> idx) & 1u ? src : zsrc, sa + idx * 1024);
+            } else
             dma16((a_okmask >> idx) & 1u ? xg + a_off[idx] + kbyte : zsrc, sa + idx * 1024);
         } else {
             const int j = idx - AJ;
@@ -473,6 +489,9 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 }  // namespace
 
 bool igemm_wide_applicable(const IgemmParams& p) {
+    if (p.x2 && (p.stride != 1 || p.res || p.pool_nparts > 0 || p.K1 <= 0 || p.K1 != 2 * (p.K - p.K1) || (p.K1 % 64) || (p.N % WBN) ||
+                 (((uintptr_t)p.x2) & 15)))
+        return false;
     const bool pointwise = p.R == 1 && p.S == 1 && p.stride >= 1 && p.pad == 0;  // stride > 1: rows are gathered
     if (!pointwise || p.rowv || p.ksplit > 1) return false;
     if (p.stride > 1 && (p.pool_nparts > 0 || (size_t)(p.M / (p.OH * p.OW)) * p.H * p.W * p.K * 2 >= (1ull << 32))) return false;
@@ -491,11 +510,11 @@ bool igemm_wide_applicable(const IgemmParams& p) {
 
 int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who) {
     // 128-channel tiles where 256-channel ones would leave CUs idle (N = 256 layers) or do not divide N
-    bool half_n = (p.N % WBN) != 0 || (p.pool_nparts == 0 && p.dbg == 0 && cdiv(p.M, WBM) * (p.N / WBN) < 224);
+    bool half_n = (p.N % WBN) != 0 || (p.pool_nparts == 0 && p.dbg == 0 && !p.x2 && cdiv(p.M, WBM) * (p.N / WBN) < 224);
     const AgrlOpts& opt = agrl_opts();
     // AGRL_IGEMM_WIDE = 2 / 3 force the 256- / 128-channel tile (tests, A/B)
     if (opt.igemm_wide == 2 && (p.N % WBN) == 0) half_n = false;
-    if (opt.igemm_wide == 3 && p.pool_nparts == 0) half_n = true;
+    if (opt.igemm_wide == 3 && p.pool_nparts == 0 && !p.x2) half_n = true;
     // persistent form: one workgroup per CU walks its share of the tiles (AGRL_IGEMM_WIDE_PERSIST=0: one per tile)
     static const int n_cu = [] {
         int dev = 0, n = 0;
@@ -516,6 +535,11 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
     if (p.pool_nparts > 0) {
         if (res) hipLaunchKernelGGL((igemm_wide_kernel<16384, 256, true>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((igemm_wide_kernel<16384, 256, false>), dim3(grid), dim3(512), 0, stream, p);
+        AGRL_CHECK_LAUNCH(who);
+        return 0;
+    }
+    if (p.x2) {  // two-source form (agrl_conv1x1_dual_bn_act): no residual, no pooling, 256-channel tiles
+        hipLaunchKernelGGL((igemm_wide_kernel<32768, 256, false>), dim3(grid), dim3(512), 0, stream, p);
         AGRL_CHECK_LAUNCH(who);
         return 0;
     }

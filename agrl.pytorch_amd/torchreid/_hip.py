@@ -46,13 +46,16 @@ SIGNATURES = {
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_block": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_conv1x1_dual_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_conv1x1_bn_act_pool": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_linear_nobias": [_p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_part_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_clip_pool": [_p, _p, _i, _i, _i, _i, _p],
     "agrl_graph_gram": [_p, _p, _i, _i, _i, _i, _p],
-    "agrl_graph_finalize": [_p, _i, _p, _p, _i, _i, _i, _i, _p],
-    "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _p, _p, _i, _i, _i, _p],
+    "agrl_graph_finalize": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _i, _p],
+    "agrl_pam_pool": [_p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
+    "agrl_pam_combine": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
     "agrl_row_sqnorm": [_p, _p, _i, _i, _i, _p],
     "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _i, _p],

@@ -106,6 +106,31 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
     return out
 
 
+def conv1x1_dual_supported(x1, x2, w_cat):
+    """The two-source pointwise GEMM exists for bf16, K1 == 2 K2, K1 % 64 == 0, Cout % 256 == 0 (layer-4 first blocks)."""
+    K1, K2 = x1.shape[-1], x2.shape[-1]
+    return (x1.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and K1 == 2 * K2 and K1 % 64 == 0
+            and w_cat.shape[0] % 256 == 0 and x1.shape[:-1] == x2.shape[:-1] and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0')
+
+
+def conv1x1_dual(x1, x2, w_cat, bias, relu=True):
+    """relu([x1 | x2] @ w_cat^T + bias): a first Bottleneck's conv3 + its 1x1 stride-1 downsample conv in one GEMM
+    (vmgn.py:56-64). x1 (N,H,W,K1) block input, x2 (N,H,W,K2) conv2 output, w_cat (Cout, K1+K2) -> (N,H,W,Cout) bf16."""
+    N, H, W, K1 = x1.shape
+    K2 = x2.shape[-1]
+    Cout = w_cat.shape[0]
+    assert tuple(w_cat.shape) == (Cout, K1 + K2) and w_cat.dtype == x1.dtype
+    out = torch.empty((N, H, W, Cout), dtype=x1.dtype, device=x1.device)
+    M = N * H * W
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * Cout * (K1 + K2), "bytes": 2.0 * (x1.numel() + x2.numel() + w_cat.numel() + out.numel()),
+                            "conv": (1, 1, K1 + K2, Cout, H, W)}
+    with _dev(x1):
+        call("agrl_conv1x1_dual_bn_act", ptr(x1), ptr(x2), ptr(w_cat), ptr(bias), ptr(out), M, K1, K2, Cout, 1 if relu else 0,
+             _stream(x1))
+    return out
+
+
 def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=True):
     """Last 1x1 conv of a layer4 branch with the frame pooling fused in (bf16, 128-pixel frames): the 2048-channel map
     is never written. -> pooled fp32 (F, P, Cout) [, bf16 copy]. vmgn.py:45-65 + :298-308."""
@@ -235,8 +260,8 @@ def part_pool(x4_1, x4_2, splits, want_lp):
 GRAM_CSLICE = 128
 
 
-def graph_matrix(f, adj, use_pose, learn_graph):
-    """f (B,V,C) fp32, adj (B,V,V) fp32 -> G (B,V,V). vmgn.py:114-120, :155-166."""
+def graph_matrix(f, adj, use_pose, learn_graph, mask_diag=False):
+    """f (B,V,C) fp32, adj (B,V,V) fp32 -> G (B,V,V). vmgn.py:114-120, :155-166; ``mask_diag``: ganet.py:259-268."""
     B, V, Cc = f.shape
     G = torch.empty((B, V, V), dtype=torch.float32, device=f.device)
     gram = None
@@ -250,21 +275,54 @@ def graph_matrix(f, adj, use_pose, learn_graph):
             assert adj is not None and tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32
             adj = adj.contiguous()
         call("agrl_graph_finalize", ptr(gram), nz, ptr(adj) if use_pose else None, ptr(G), B, V,
-             1 if use_pose else 0, 1 if learn_graph else 0, _stream(f))
+             1 if use_pose else 0, 1 if learn_graph else 0, 1 if mask_diag else 0, _stream(f))
     return G
 
 
-def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp):
-    """out = (1-gamma) f + gamma lrelu(bn(G h)). vmgn.py:168-172."""
+def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp, keep=None):
+    """out = keep f + gamma lrelu(bn(G h)); keep defaults to the reference's Python-float (1 - gamma). vmgn.py:168-172;
+    ganet.py:278-283 passes keep = 1."""
+    if keep is None:
+        keep = 1.0 - float(gamma)
     B, V, Cc = f.shape
     out = torch.empty_like(f)
     out_lp = torch.empty((B, V, Cc), dtype=torch.bfloat16, device=f.device) if want_lp else None
     if _hip.PROFILE is not None:  # SURVEY 8(d): read f + read h + read G(adj-sized) + write out
         _hip.PROFILE_TAG = {"flops": 2.0 * B * V * V * Cc, "bytes": 4.0 * (3 * B * V * Cc + B * V * V)}
     with _dev(f):
-        call("agrl_graph_propagate", ptr(f), ptr(h), ptr(G), ptr(bn_scale), ptr(bn_shift), float(gamma), float(slope),
-             ptr(out), ptr(out_lp), B, V, Cc, _stream(f))
+        call("agrl_graph_propagate", ptr(f), ptr(h), ptr(G), ptr(bn_scale), ptr(bn_shift), float(keep), float(gamma),
+             float(slope), ptr(out), ptr(out_lp), B, V, Cc, _stream(f))
     return out, out_lp
+
+
+def pam_pool(x, qk, splits):
+    """ganet's position-attention part nodes, first half: x (F,h,w,C) NHWC, qk (F,h,w,2*Cq) NHWC stacked query / key conv
+    output (None when the module's gamma is 0) -> xbar (F,P,C) fp32 (None without qk), xmean (F,P,C) fp32. ganet.py:98-136,
+    :384-400."""
+    F_, h, w, Cc = x.shape
+    P = int(sum(splits))
+    xmean = torch.empty((F_, P, Cc), dtype=torch.float32, device=x.device)
+    xbar = None
+    Cq = 0
+    if qk is not None:
+        assert qk.dtype == x.dtype and tuple(qk.shape[:3]) == (F_, h, w) and qk.shape[3] % 2 == 0
+        Cq = qk.shape[3] // 2
+        xbar = torch.empty((F_, P, Cc), dtype=torch.float32, device=x.device)
+    arr = (C.c_int * len(splits))(*[int(s) for s in splits])
+    with _dev(x):
+        call("agrl_pam_pool", ptr(x), ptr(qk), ptr(xbar), ptr(xmean), F_, h, w, Cc, Cq, arr, len(splits), dtype_code(x.dtype),
+             _stream(x))
+    return xbar, xmean
+
+
+def pam_combine(y, bv, xmean, gamma, want_lp):
+    """nodes = gamma (y + bv) + 2 xmean (y = Wv xbar), ganet.py:394-399 -> nodes fp32 like xmean [, bf16 copy]."""
+    nodes = torch.empty_like(xmean)
+    nodes_lp = torch.empty(xmean.shape, dtype=torch.bfloat16, device=xmean.device) if want_lp else None
+    rows, Cc = xmean.numel() // xmean.shape[-1], xmean.shape[-1]
+    with _dev(xmean):
+        call("agrl_pam_combine", ptr(y), ptr(bv), ptr(xmean), float(gamma), ptr(nodes), ptr(nodes_lp), rows, Cc, _stream(xmean))
+    return nodes, nodes_lp
 
 
 def clip_pool(feats, num_clips, mode="avg"):

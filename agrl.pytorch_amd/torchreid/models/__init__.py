@@ -1,7 +1,8 @@
 """Model registry (reference: torchreid/models/__init__.py:17-41).
 
-``vmgn`` -- the model BASELINE.json's north_star names -- and its single-branch predecessor ``gsta`` (same GraphLayer,
-same kernels) are provided by this build; the reference's other sibling architectures are
+``vmgn`` -- the model BASELINE.json's north_star names -- and its two siblings that share the kernels (SURVEY.md section 8f
+row 4): the single-branch predecessor ``gsta`` (same GraphLayer) and ``ganet`` (position-attention part nodes, diagonal-masked
+graph layers) are provided by this build; the reference's other sibling architectures are
 out of the hot path.
 """
 from __future__ import absolute_import
@@ -12,10 +13,12 @@ import shutil
 
 from .vmgn import *
 from .gsta import *
+from .ganet import *
 
 __model_factory = {
     'vmgn': vmgn,
     'gsta': gsta,
+    'ganet': ganet,
 }
 
 

@@ -51,6 +51,11 @@ def _pack_stage(stage, dtype):
         if unit.downsample is not None:
             blk['ds'] = _fold_conv_bn(unit.downsample[0], unit.downsample[1], dtype)
             blk['ds_stride'] = unit.downsample[0].stride[0]
+            if dtype == torch.bfloat16 and blk['ds_stride'] == 1 and blk['stride'] == 1:
+                # conv3 + downsample as ONE GEMM over the concatenated K axis (ops.conv1x1_dual): [w_ds | w3], b_ds + b3
+                cout = blk['c3'][0].shape[0]
+                blk['dual'] = (torch.cat([blk['ds'][0].view(cout, -1), blk['c3'][0].view(cout, -1)], dim=1).contiguous(),
+                               (blk['ds'][1] + blk['c3'][1]).contiguous())
         blocks.append(blk)
     return blocks
 
@@ -143,6 +148,8 @@ def _run_block(x, blk, pool=None):
     return the pooled tensors instead of the activation map (which is then never written to HBM)."""
     y = ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
     y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
+    if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
+        return ops.conv1x1_dual(x, y, blk['dual'][0], blk['dual'][1], True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
     if pool is not None:
         return ops.conv1x1_bn_act_pool(y, blk['c3'][0], blk['c3'][1], shortcut, pool[0], pool[1], pool[2])

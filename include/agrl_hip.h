@@ -77,6 +77,16 @@ int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const vo
                        void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride,
                        int pad, int relu, int dtype, agrl_stream_t stream);
 
+/* Last conv of a Bottleneck and the block's 1x1 stride-1 downsample conv as ONE GEMM over the concatenated K axis (bf16):
+ *   out (M, Cout) = act([x1 (M,K1) | x2 (M,K2)] @ w (Cout, K1+K2)^T + bias)
+ * torchreid/models/vmgn.py:56-64 for the first block of a stage: bn3(conv3(y2)) + downsample(x) with both BatchNorms
+ * folded -- x1 = the block input x, x2 = y2, w = [w_downsample | w_conv3] per output channel, bias = b_downsample + b_conv3.
+ * The shortcut map is neither written nor read back and the two products are summed in fp32 (one rounding instead of two).
+ * Built for the 256 x 256 tile kernel: K1 == 2 K2 (ResNet: inplanes = 2 planes), K1 a multiple of 64, Cout a multiple of
+ * 256; other shapes are rejected (the caller then runs the two convs through agrl_conv2d_bn_act). */
+int agrl_conv1x1_dual_bn_act(const void* x1, const void* x2, const void* w, const float* bias, void* out, int M,
+                             int K1, int K2, int Cout, int relu, agrl_stream_t stream);
+
 /* Last conv of a layer4 branch with the pooling fused into its epilogue (bf16 only): 1x1 conv + folded BN + residual
  * + ReLU on frames of exactly 128 pixels (16x8), and per frame the row-bin pooling of the result is written directly:
  *   mean == 0, splits {1}       -> pool_out (N, 1, Cout) = per-frame sums        (global branch, vmgn.py:298-300)
@@ -158,18 +168,40 @@ int agrl_graph_gram(const float* f, float* gram_part, int B, int V, int C, int c
  * sim = 2/(exp(d)+1), row-L1-normalise sim and adj, G = (adj^ + sim^)/2 (or one of them).
  * torchreid/models/vmgn.py:118-120 and :155-166.
  *   adj fp32 (B,V,V) or NULL when use_pose == 0; gram_part may be NULL when learn_graph == 0
+ *   mask_diag != 0: the sibling model ganet's form -- self-loops (the diagonal of adj and of sim) are zeroed before the row-L1
+ *   normalisation, torchreid/models/ganet.py:259-268
  *   G   fp32 (B,V,V) */
 int agrl_graph_finalize(const float* gram_part, int nz, const float* adj, float* G, int B, int V,
-                        int use_pose, int learn_graph, agrl_stream_t stream);
+                        int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream);
 
 /* Message pass + BatchNorm1d(eval) + LeakyReLU + residual mix:
- *   out[b,v,c] = (1-gamma)*f[b,v,c] + gamma*lrelu(bn_scale[c]*(sum_u G[b,v,u]*h[b,u,c]) + bn_shift[c])
- * torchreid/models/vmgn.py:168-172.
+ *   out[b,v,c] = keep*f[b,v,c] + gamma*lrelu(bn_scale[c]*(sum_u G[b,v,u]*h[b,u,c]) + bn_shift[c])
+ * torchreid/models/vmgn.py:168-172 with keep = (float)(1.0 - gamma) (the reference's Python-float 1 - gamma, rounded once);
+ * torchreid/models/ganet.py:278-283 with keep = 1 (``input + gamma * h'``).
  *   f,h fp32 (B,V,C); G fp32 (B,V,V); out fp32 (B,V,C); out_lp NULL or bf16 copy of out (the A
  *   operand of the next layer's bf16 Linear). Deterministic: no atomics. */
 int agrl_graph_propagate(const float* f, const float* h, const float* G, const float* bn_scale,
-                         const float* bn_shift, float gamma, float slope, float* out, void* out_lp,
+                         const float* bn_shift, float keep, float gamma, float slope, float* out, void* out_lp,
                          int B, int V, int C, agrl_stream_t stream);
+
+/* ---- position-attention part nodes (sibling model ganet) ---------------------------------------------- */
+
+/* Per frame and pyramid slice (h / n rows of the h x w map, n over splits; remainder rows dropped as the reference does):
+ *   attention = softmax over the key axis of query_p . key_q  (PAM_Module, torchreid/models/ganet.py:98-136)
+ *   xbar  (F, P, C) fp32 = sum_q abar[q] x[q],  abar[q] = mean_p attention[p][q]
+ *   xmean (F, P, C) fp32 = mean of the slice
+ * from x (F,h,w,C) NHWC and qk (F,h,w,2*Cq) NHWC = the stacked query / key 1x1 conv outputs (query first), both of dtype.
+ * avgpool(gamma * value . attention^T + 2 slice) (ganet.py:394-399) = gamma * (Wv xbar + bv) + 2 xmean because pooling is
+ * linear and attention rows sum to one: the value conv becomes ONE Linear on xbar (agrl_linear_nobias) + agrl_pam_combine.
+ * qk == NULL && xbar == NULL: only xmean (the module's gamma is 0, its value at construction). A slice may hold at most 128
+ * positions; Cq a multiple of 32. */
+int agrl_pam_pool(const void* x, const void* qk, float* xbar, float* xmean, int F, int h, int w, int C, int Cq,
+                  const int* splits, int n_splits, int dtype, agrl_stream_t stream);
+
+/* nodes[r][c] = gamma * (y[r][c] + bv[c]) + 2 * xmean[r][c]  (y = Wv xbar; y == bv == NULL: nodes = 2 xmean), optional bf16
+ * copy nodes_lp. torchreid/models/ganet.py:394-399. */
+int agrl_pam_combine(const float* y, const float* bv, const float* xmean, float gamma, float* nodes, void* nodes_lp,
+                     int rows, int C, agrl_stream_t stream);
 
 /* ---- attention temporal pooling + BNNeck tail -------------------------------------------------- */
 

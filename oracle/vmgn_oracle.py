@@ -159,6 +159,70 @@ def gsta_eval(x, adj, sd, num_split=4, pyramid_part=True, num_gb=2, use_pose=Tru
     return _bn(att_f, sd, "bottleneck")
 
 
+def pam_module(x, sd, prefix, gamma=None):
+    """PAM_Module.forward (position attention), torchreid/models/ganet.py:98-136: 1x1 query / key / value convs WITH bias,
+    energy = q^T k over the slice's h*w positions, softmax over the key axis, out = value . attention^T,
+    returns gamma * out + x (gamma: the module's scalar parameter, zero at construction)."""
+    n, c, h, w = x.shape
+    q = F.conv2d(x, sd[prefix + ".query_conv.weight"], sd[prefix + ".query_conv.bias"]).reshape(n, -1, h * w).permute(0, 2, 1)
+    k = F.conv2d(x, sd[prefix + ".key_conv.weight"], sd[prefix + ".key_conv.bias"]).reshape(n, -1, h * w)
+    att = torch.softmax(torch.bmm(q, k), dim=-1)
+    v = F.conv2d(x, sd[prefix + ".value_conv.weight"], sd[prefix + ".value_conv.bias"]).reshape(n, -1, h * w)
+    out = torch.bmm(v, att.permute(0, 2, 1)).reshape(n, c, h, w)
+    g = sd[prefix + ".gamma"] if gamma is None else gamma
+    return g * out + x
+
+
+def ganet_graph_layer(f, adj, sd, prefix, use_pose=True, learn_graph=True, gamma=0.0, slope=0.1):
+    """ganet's GraphLayer.forward, torchreid/models/ganet.py:253-283: like vmgn's, but the DIAGONAL of both the pose graph
+    and the learned similarity is masked to zero before the row-L1 normalisation, and the residual form is
+    ``input + gamma * h'`` with the constructor default gamma = 0 (ganet.py:175)."""
+    h = f @ sd[prefix + ".linear.weight"].t()
+    n, v, c = h.shape
+    mask = 1.0 - torch.eye(v, dtype=f.dtype).unsqueeze(0)
+    graph = None
+    if use_pose:
+        graph = l1_rows(mask * adj)
+    if learn_graph:
+        learned = l1_rows(mask * sim_matrix(f))
+        graph = learned if graph is None else (graph + learned) / 2
+    msg = torch.bmm(graph, h)
+    msg = F.leaky_relu(_bn(msg.reshape(n * v, c), sd, prefix + ".bn"), slope).reshape(n, v, c)
+    return f + gamma * msg
+
+
+def ganet_nodes(fmap, sd, B, S, splits):
+    """Part nodes of ganet, ganet.py:384-400: the map is cut into h // n row slices per pyramid level (NOT adaptive bins:
+    remainder rows are dropped), every slice goes through the position attention module, ``pam_f + slice`` is average
+    pooled. -> (B, S*P, c)."""
+    _, c, h, w = fmap.shape
+    cols = []
+    for n in splits:
+        step = h // n
+        for i in range(n):
+            sl = fmap[:, :, step * i: step * (i + 1)]
+            cols.append((pam_module(sl, sd, "pam_layer") + sl).mean(dim=(2, 3)))
+    return torch.stack(cols, dim=1).reshape(B, S * len(cols), c)
+
+
+def ganet_eval(x, adj, sd, num_split=4, pyramid_part=True, num_gb=2, use_pose=True, learn_graph=True, graph_gamma=0.0):
+    """``ganet`` in eval mode, torchreid/models/ganet.py:378-424: single-branch ResNet50 (layer4 stride 1, :307) -> PAM part
+    nodes -> num_gb diagonal-masked graph layers whose outputs are CONCATENATED with their input along the channels (:402-405)
+    -> attention pooling over the (num_gb + 1) * 2048 channels -> BN ``bottleneck`` -> (B, (num_gb + 1) * 2048)."""
+    B, S = x.shape[:2]
+    splits = calc_splits(num_split) if pyramid_part else [num_split]
+    f = stem(x.reshape((B * S,) + tuple(x.shape[2:])), sd)
+    for name, blocks, stride in RESNET50_STAGES:
+        f = stage(f, sd, name, blocks, stride)
+    f = stage(f, sd, "layer4", 3, 1)
+    outs = [ganet_nodes(f, sd, B, S, splits)]
+    for i in range(num_gb):
+        outs.append(ganet_graph_layer(outs[-1], adj, sd, "graph_layers.%d" % i, use_pose, learn_graph, graph_gamma))
+    cat = torch.cat(outs, dim=2)
+    att_f = attention_pool(cat.reshape(B, S, sum(splits), cat.shape[-1]))
+    return _bn(att_f, sd, "bottleneck")
+
+
 # ---- match side ------------------------------------------------------------------------------------------
 
 def euclidean_squared(q, g):

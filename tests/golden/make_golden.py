@@ -143,6 +143,32 @@ def main():
          train_logits=torch.stack([o.detach() for o in outs]), train_feats=torch.stack([f.detach() for f in feats]),
          meta=np.array([2, 4, 4, 0]))
 
+    # ---- F11: sibling model ganet (ganet.py:98-477): PAM part nodes, diagonal-masked graph layers, concatenated outputs --
+    ref_ganet = load("ref_ganet", "torchreid/models/ganet.py")
+    am = ref_ganet.ganet(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1, knn=4,
+                         pyramid_part=True, use_pose=True, learn_graph=True, pretrained=False, consistent_loss=True)
+    asd = recipe_state_dict(am.state_dict(), seed=0)
+    am.load_state_dict(asd)
+    am.eval()
+    x, adj = synthetic_clips(2, 4, seed=6), synthetic_adj(2, 4, seed=6)
+    with torch.no_grad():
+        ay0 = am(x, adj)                       # graph layers with the constructor's gamma = 0 (ganet.py:175)
+        for layer in am.graph_layers:
+            layer.gamma = 0.1
+        ay1 = am(x, adj)                       # the masked-graph arithmetic made visible
+        fm = am.featuremaps(x.view(8, 3, 256, 128))
+        pam_out, _ = am.pam_layer(fm[:, :, 4:8])
+        for layer in am.graph_layers:
+            layer.gamma = 0
+    am.train()
+    xt, adjt = synthetic_clips(2, 6, seed=9), synthetic_adj(2, 6, seed=9)
+    np.random.seed(321)
+    aouts, afeats = am(xt, adjt)
+    save("ganet_b2s4", out_gamma0=ay0, out_gamma01=ay1, pam_slice_mean=pam_out.mean(dim=(2, 3)),
+         keys=np.array(sorted(asd.keys())), shapes=np.array([str(tuple(asd[k].shape)) for k in sorted(asd.keys())]),
+         train_logits=torch.stack([o.detach() for o in aouts]), train_feats=torch.stack([f_.detach() for f_ in afeats]),
+         meta=np.array([2, 4, 6, 0]))
+
     # ---- F8: train-mode outputs with the consistent loss (vmgn.py:323-357) ---------------------------------
     model_t = ref_vmgn.vmgn(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
                             pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)

@@ -27,9 +27,14 @@ def recipe_tensor(key, shape, seed):
         return 0.1 * torch.randn(shape, generator=g)
     if leaf == "running_var":
         return 0.5 + torch.rand(shape, generator=g)
+    if leaf == "gamma":  # ganet's attention-module scalars (zero at construction; a trained model has them non-zero)
+        return torch.full(shape, 0.5)
     if len(shape) == 4:  # conv: kaiming fan_in
         fan_in = shape[1] * shape[2] * shape[3]
-        return torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+        w = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+        if "query_conv" in key or "key_conv" in key:
+            w = w * 0.15  # keeps ganet's position-attention energies O(1): a softmax that is neither uniform nor one-hot
+        return w
     if len(shape) == 2:  # linear
         std = 0.02 if "graph_layers" in key else 0.001
         return torch.randn(shape, generator=g) * std

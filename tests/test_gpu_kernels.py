@@ -262,6 +262,40 @@ def test_conv_wide_tile_strided(case, tile, monkeypatch):
     assert torch.equal(wide, narrow)
 
 
+DUAL_CASES = [(256, 16, 8, 1024, 512, 2048), (3, 16, 8, 1024, 512, 2048), (90, 16, 8, 128, 64, 512), (81, 16, 8, 512, 256, 256)]
+
+
+@pytest.mark.parametrize("case", DUAL_CASES)
+def test_conv1x1_dual_source(case):
+    """agrl_conv1x1_dual_bn_act: a first Bottleneck's conv3 + its 1x1 stride-1 downsample conv as ONE GEMM over the
+    concatenated K axis (vmgn.py:56-64), against the fp32 reference of the sum and against the two separate launches (which
+    round the shortcut map to bf16 first): full-size layer-4 shape (1024 tiles, persistent walk), ragged M, 3 / 6 / 12 k-tiles,
+    the source switch inside the ring."""
+    from torchreid import hip_ops as ops
+    N, H, W, K1, K2, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, K1, H, W), generator=g).bfloat16().float()
+    y2 = torch.randn((N, K2, H, W), generator=g).relu().bfloat16().float()
+    wd = (torch.randn((Cout, K1, 1, 1), generator=g) / np.sqrt(K1)).bfloat16().float()
+    w3 = (torch.randn((Cout, K2, 1, 1), generator=g) / np.sqrt(K2)).bfloat16().float()
+    bd, b3 = torch.randn((Cout,), generator=g), torch.randn((Cout,), generator=g)
+    ref = F.relu(F.conv2d(x, wd, bias=bd) + F.conv2d(y2, w3, bias=b3))
+    xd, yd = nhwc(x, torch.bfloat16), nhwc(y2, torch.bfloat16)
+    wcat = torch.cat([wd.view(Cout, K1), w3.view(Cout, K2)], dim=1).bfloat16().to(DEV).contiguous()
+    assert ops.conv1x1_dual_supported(xd, yd, wcat)
+    out = ops.conv1x1_dual(xd, yd, wcat, (bd + b3).to(DEV), True)
+    sc = ops.conv_bn_act(xd, wd.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), bd.to(DEV), 1, 0, False)
+    sep = ops.conv_bn_act(yd, w3.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b3.to(DEV), 1, 0, True, residual=sc)
+    again = ops.conv1x1_dual(xd, yd, wcat, (bd + b3).to(DEV), True)
+    torch.cuda.synchronize()
+    e, es = rel_err(out.float().permute(0, 3, 1, 2), ref), rel_err(sep.float().permute(0, 3, 1, 2), ref)
+    print("dual conv", case, "rel err %.3e (separate launches: %.3e)" % (e, es))
+    assert e < 6e-3 and e <= es * 1.05 + 1e-6   # one bf16 rounding of the sum instead of two
+    assert torch.equal(out, again)
+    with pytest.raises(Exception):   # K1 != 2 K2 is not built: loud rejection, the caller keeps the two-launch form
+        ops.conv1x1_dual(xd, xd, torch.cat([wcat[:, :K1], wcat[:, :K1]], 1).contiguous(), (bd + b3).to(DEV), True)
+
+
 @pytest.mark.parametrize("path", ["wide", "persistent"])
 @pytest.mark.parametrize("cfg", [(6, 512, 512, [4, 2, 1], True), (5, 256, 768, [1], False), (4, 2048, 256, [4, 2, 1], True)])
 def test_conv1x1_pool_fused(cfg, path, monkeypatch):
@@ -470,6 +504,44 @@ def test_graph_layer(V, mode):
         print("   off-diagonal profile of the learned graph vs the fp32 oracle: %.3e (whole G incl. diagonal: %.3e)" % (ep, eG32))
         assert ep < 1e-3
         assert eG32 < 3e-2   # the diagonal noise of the fp32 reference, not a kernel error (fp64 check above: eG < 5e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(5, 16, 8, 256, 32, [4, 2, 1]), (3, 12, 8, 512, 64, [4, 2, 1]), (2, 16, 8, 128, 32, [2]), (2, 6, 4, 64, 32, [4])])
+def test_pam_pool(shape, dtype):
+    """agrl_pam_pool + the folded value conv (one Linear on the attention-weighted slice mean) + agrl_pam_combine against
+    the oracle's literal PAM_Module (ganet.py:98-136: value conv on every position, attention, pooling), per pyramid slice
+    incl. h // n slices that drop remainder rows (h = 6, n = 4) and the gamma = 0 form."""
+    from torchreid import hip_ops as ops
+    Fr, h, w, C, Cq, splits = shape
+    g = torch.Generator().manual_seed(Fr + h + C)
+    x = torch.randn((Fr, C, h, w), generator=g)
+    sd = {"pam.query_conv.weight": 0.3 * torch.randn((Cq, C, 1, 1), generator=g) / np.sqrt(C) * 4, "pam.query_conv.bias": 0.1 * torch.randn(Cq, generator=g),
+          "pam.key_conv.weight": 0.3 * torch.randn((Cq, C, 1, 1), generator=g) / np.sqrt(C) * 4, "pam.key_conv.bias": 0.1 * torch.randn(Cq, generator=g),
+          "pam.value_conv.weight": torch.randn((C, C, 1, 1), generator=g) / np.sqrt(C), "pam.value_conv.bias": 0.1 * torch.randn(C, generator=g),
+          "pam.gamma": torch.tensor([0.7])}
+    if dtype == torch.bfloat16:   # the same rounded operands on both sides
+        x = x.bfloat16().float()
+        for k in ("pam.query_conv.weight", "pam.key_conv.weight", "pam.value_conv.weight"):
+            sd[k] = sd[k].bfloat16().float()
+    ref = O.ganet_nodes(x, {k.replace("pam.", "pam_layer."): v for k, v in sd.items()}, Fr, 1, splits).view(Fr, sum(splits), C)
+    xd = nhwc(x, dtype)
+    qk_w = torch.cat([sd["pam.query_conv.weight"], sd["pam.key_conv.weight"]], 0).permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+    qk_b = torch.cat([sd["pam.query_conv.bias"], sd["pam.key_conv.bias"]], 0).to(DEV)
+    qk = ops.conv_bn_act(xd, qk_w, qk_b, 1, 0, False)
+    xbar, xmean = ops.pam_pool(xd, qk, splits)
+    y = ops.linear_nobias(xbar.to(dtype).view(-1, C), sd["pam.value_conv.weight"].view(C, C).to(dtype).to(DEV))
+    nodes, nodes_lp = ops.pam_combine(y, sd["pam.value_conv.bias"].to(DEV), xmean, 0.7, want_lp=True)
+    _, xmean0 = ops.pam_pool(xd, None, splits)
+    nodes0, _ = ops.pam_combine(None, None, xmean0, 0.0, want_lp=False)
+    torch.cuda.synchronize()
+    e = rel_err(nodes, ref)
+    sd0 = {k.replace("pam.", "pam_layer."): v for k, v in sd.items()}
+    sd0["pam_layer.gamma"] = torch.zeros(1)
+    e0 = rel_err(nodes0, O.ganet_nodes(x, sd0, Fr, 1, splits).view(Fr, sum(splits), C))
+    print("pam_pool", shape, dtype, "rel err %.3e (gamma = 0 form %.3e)" % (e, e0))
+    assert e < (2e-2 if dtype == torch.bfloat16 else 1e-4) and e0 < 1e-5
+    assert torch.equal(xmean, xmean0) and rel_err(nodes_lp.float(), nodes) < 5e-3
 
 
 def test_attention_tail():

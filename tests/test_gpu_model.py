@@ -116,6 +116,38 @@ def test_gsta_sibling_eval_matches_oracle(precision, tol):
         assert err < tol
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16x3", 1e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("variant", ["default_gammas", "pam_on", "pam_and_graph_on"])
+def test_ganet_sibling_eval_matches_oracle(variant, precision, tol):
+    """``ganet`` (position-attention part nodes, diagonal-masked graph layers, concatenated outputs) through the HIP kernels
+    vs oracle.ganet_eval (pinned on the reference's ganet.py by tests/golden/ganet_b2s4.npz): as constructed (both gammas 0:
+    nodes = 2 x slice means, graph layers pass their input through), with the attention module's gamma set (the value conv
+    folded into one Linear on the attention-weighted slice mean), and with the graph layers' gamma set as well (masked
+    graphs, input + gamma h')."""
+    from torchreid import models
+    m = models.init_model("ganet", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1, knn=4,
+                          pyramid_part=True, use_pose=True, learn_graph=True, pretrained=False)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    if variant == "default_gammas":
+        sd["pam_layer.gamma"] = torch.zeros(1)
+    m.load_state_dict(sd)
+    graph_gamma = 0.1 if variant == "pam_and_graph_on" else 0.0
+    for layer in m.graph_layers:
+        layer.gamma = graph_gamma
+    m.eval()
+    m.hip_precision = precision
+    for B, S in ((2, 4), (3, 8)):
+        x, adj = synthetic_clips(B, S, seed=B + S), synthetic_adj(B, S, seed=B + S)
+        with torch.no_grad():
+            ref = O.ganet_eval(x, adj, sd, graph_gamma=graph_gamma)
+        got = m.to(DEV)(x.to(DEV), adj.to(DEV))
+        torch.cuda.synchronize()
+        assert got.shape == (B, 3 * 2048)
+        err = rel(got, ref)
+        print("ganet", variant, precision, (B, S), "rel err %.3e" % err)
+        assert err < tol
+
+
 @pytest.fixture(scope="module")
 def bench_size_oracle():
     """The CPU oracle at the BENCHMARKED size (BASELINE configs[1]: 32 tracklets x 8 frames of 256 x 128), every stage."""

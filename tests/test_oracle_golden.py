@@ -130,6 +130,50 @@ def test_gsta_sibling_model_matches_reference():
     close(torch.stack([f.detach() for f in feats]), z["train_feats"], 1e-4)
 
 
+def test_ganet_sibling_model_matches_reference():
+    """The sibling ``ganet``: oracle.ganet_eval / oracle.pam_module and this build's module tree against
+    the reference's ganet.py -- eval output with the graph layers' default gamma = 0 AND with gamma = 0.1 (the diagonal-masked
+    graph arithmetic made visible), the position-attention module on one pyramid slice, state-dict keys / shapes, and
+    train-mode outputs with the consistent loss. The factory is constructible through init_model with ``knn`` passed."""
+    from torchreid import models
+    z = gold("ganet_b2s4")
+    assert "ganet" in models.get_names()
+    with pytest.raises(TypeError):   # reference ganet.py:458: knn is a required positional the driver never passes
+        models.init_model("ganet", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True)
+    m = models.init_model("ganet", num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          knn=4, pyramid_part=True, use_pose=True, learn_graph=True, pretrained=False, consistent_loss=True)
+    own = m.state_dict()
+    assert sorted(own.keys()) == list(z["keys"])
+    assert [str(tuple(own[k].shape)) for k in sorted(own.keys())] == list(z["shapes"])
+    assert not m.bottleneck.bias.requires_grad and float(m.pam_layer.gamma.detach()) == 0.0 and m.graph_layers[0].gamma == 0
+    sd = recipe_state_dict(own, seed=0)
+    m.load_state_dict(sd)
+    x, adj = synthetic_clips(2, 4, seed=6), synthetic_adj(2, 4, seed=6)
+    with torch.no_grad():
+        close(O.ganet_eval(x, adj, sd), z["out_gamma0"], 1e-5)
+        close(O.ganet_eval(x, adj, sd, graph_gamma=0.1), z["out_gamma01"], 1e-5)
+        assert np.abs(z["out_gamma0"] - z["out_gamma01"]).max() > 1e-3     # the second fixture does exercise the graph
+        fm = O.stage(O.stem(x.view(8, 3, 256, 128), sd), sd, "layer1", 3, 1)
+        for name, blocks, stride in O.RESNET50_STAGES[1:]:
+            fm = O.stage(fm, sd, name, blocks, stride)
+        fm = O.stage(fm, sd, "layer4", 3, 1)
+        sl = fm[:, :, 4:8]
+        close(O.pam_module(sl, sd, "pam_layer").mean(dim=(2, 3)), z["pam_slice_mean"], 1e-5)   # gamma * attended + slice
+        m.eval()
+        close(m(x, adj), z["out_gamma0"], 1e-5)
+        for layer in m.graph_layers:
+            layer.gamma = 0.1
+        close(m(x, adj), z["out_gamma01"], 1e-5)
+        for layer in m.graph_layers:
+            layer.gamma = 0
+    m.train()
+    np.random.seed(321)
+    outs, feats = m(synthetic_clips(2, 6, seed=9), synthetic_adj(2, 6, seed=9))
+    close(torch.stack([o.detach() for o in outs]), z["train_logits"], 1e-4)
+    close(torch.stack([f.detach() for f in feats]), z["train_feats"], 1e-4)
+
+
 def test_distmat():
     z = gold("distmat")
     m, n, D, seed = [int(v) for v in z["meta"]]
