@@ -486,7 +486,7 @@ def main():
                     which = "dom"
                 elif lp and c and c[0] == 1 and max(c[2], c[3]) >= 2048:   # the pointwise convs of the layer-4 branches
                     which = "pw4"
-                elif lp and name == "agrl_conv1x1_bn_act_pool":
+                elif lp and name in ("agrl_conv1x1_bn_act_pool", "agrl_conv1x1_dual_bn_act"):
                     which = "pw4"
                 if which:
                     cls[which]["ms"] += ms
@@ -504,7 +504,7 @@ def main():
         # layer-1 block and layer-2 tail, the pool-fused last conv)
         a = {"ms": 0.0, "launches": 0, "flops": 0.0}
         for fam in ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block",
-                    "agrl_conv1x1_dual"):
+                    "agrl_conv1x1_dual_bn_act"):
             if fam in agg:
                 for key in a:
                     a[key] += agg[fam][key]
@@ -527,7 +527,7 @@ def main():
                 except Exception:
                     traffic = fam_traffic = None
         family = {"bound": "mfma (layers 3-4) / hbm (layers 1-2)",
-                  "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv1x1_bn_act_pool + agrl_bottleneck_tail + agrl_bottleneck_block)",
+                  "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv1x1_dual_bn_act + agrl_conv1x1_bn_act_pool + agrl_bottleneck_tail + agrl_bottleneck_block)",
                   "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                   "traffic": fam_traffic, "traffic_source": traffic_src, "flops_per_launch": round(a["flops"] / a["launches"], 1),
                   "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2), "ms_per_step": round(a["ms"] / nprof, 4)}
@@ -556,18 +556,20 @@ def main():
         scratch = torch.empty((64 << 20,), dtype=torch.float32, device=device)  # 256 MB: rotate so no pass hits a warm MALL
 
         def yardstick(nbytes):
+            """Best single-pass read rate of this chip at this size: grid sweep, rotating through a 256 MB buffer."""
             best = None
             span = scratch.numel() * 4 - nbytes
-            for rep in range(6):
-                off = ((rep * (48 << 20)) % max(span, 1)) // 16 * 4
-                s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s_ev.record()
-                ops.read_stream(scratch[off:], nbytes)
-                e_ev.record()
-                e_ev.synchronize()
-                ms = s_ev.elapsed_time(e_ev)
-                if rep >= 1 and (best is None or ms < best):
-                    best = ms
+            for wgs in (512, 1024, 2048, 4096):
+                for rep in range(5):
+                    off = ((rep * (48 << 20)) % max(span, 1)) // 16 * 4
+                    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s_ev.record()
+                    ops.read_stream(scratch[off:], nbytes, workgroups=wgs)
+                    e_ev.record()
+                    e_ev.synchronize()
+                    ms = s_ev.elapsed_time(e_ev)
+                    if rep >= 1 and (best is None or ms < best):
+                        best = ms
             return nbytes / (best * 1e-3) / 1e9
 
         V, Cc, n_layers = S * 7, 2048, 2
