@@ -1019,6 +1019,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+extern "C" int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M, int K, int Nout, int in_dtype, void* workspace,
+                                   size_t workspace_bytes, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && w && y, "agrl_gemm_nt_splitk: null pointer");
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_gemm_nt_splitk: bad dtype %d", in_dtype);
+    IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0;
+    p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
+    p.M = M; p.N = Nout; p.K = K;
+    p.Cin = K; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.ldo = Nout;
+    // weight gradients: a handful of output tiles and a K axis of 10^4..10^6 pixels -> K slices over workgroups until the
+    // chip is covered twice, fp32 partials in the caller's workspace, summed in slice order (deterministic)
+    const int bke = in_dtype == AGRL_BF16 ? 64 : 32;
+    AGRL_CHECK_ARG(K % bke == 0, "agrl_gemm_nt_splitk: K=%d must be a multiple of %d", K, bke);
+    const int nk = K / bke;
+    const int tiles = cdiv(M, 64) * cdiv(Nout, Nout <= 64 ? 64 : 128);
+    int ks = 1;
+    while (ks < 256 && tiles * ks < 1024 && nk % (ks * 2) == 0 && nk / (ks * 2) >= 8) ks *= 2;
+    if (ks > 1 && workspace && workspace_bytes >= (size_t)ks * M * Nout * sizeof(float)) {
+        IgemmParams ps = p;
+        ps.out = workspace; ps.ksplit = ks;
+        int rc;
+        if (in_dtype == AGRL_F32) rc = launch_igemm<float, float>(ps, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+        else if (in_dtype == AGRL_F32X3) rc = launch_igemm<f32s_t, float>(ps, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+        else rc = launch_igemm<bf16_t, float>(ps, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+        if (rc) return rc;
+        const size_t total = (size_t)M * Nout;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, ks, y, M, Nout,
+                           Nout, 1.f, (const float*)nullptr, (const float*)nullptr, 0.f);
+        AGRL_CHECK_LAUNCH("agrl_gemm_nt_splitk(reduce)");
+        return 0;
+    }
+    if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+    if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+}
+
 extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist, int m, int n, int D,
                             int ldd, int metric, int dtype, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
     AGRL_CHECK_ARG(q && g && dist, "agrl_distmat: null pointer");

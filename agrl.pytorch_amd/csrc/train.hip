@@ -1,0 +1,306 @@
+// Train-step kernels of the conv trunk (BASELINE config 4; reference train(), train_vidreid_xent_htri.py:397-413, running
+// Bottleneck.forward / backward of torchreid/models/vmgn.py:45-65 under model.train()): everything around the three conv
+// GEMMs (forward, data gradient, weight gradient -- all on the implicit-GEMM kernel of igemm.hip in exact-fp32 MFMA) that
+// torch's autograd would otherwise run as stock kernels.
+//
+//   agrl_bn_stats          batch statistics of a conv output (BatchNorm2d in train mode, vmgn.py:49/53/57)
+//   agrl_bn_apply          y * scale + shift (+ residual) (ReLU)
+//   agrl_bn_backward       ReLU mask + BatchNorm backward: dgamma / dbeta reductions, then dy (and the masked gradient that
+//                          flows on to the residual branch)
+//   agrl_im2col_t          channel-major, tap-expanded transpose of an NHWC tensor: the K-contiguous operand of the weight-
+//                          gradient GEMM dW[co][tap,ci] = sum_pixels dy[pixel][co] x[pixel + tap][ci]
+//   agrl_gemm_nt_splitk    y = x w^T with K split over workgroups (weight gradients: K = pixels, few output tiles)
+//   agrl_maxpool3x3s2      forward with the arg-max tap, and its backward (gather form, deterministic)
+//
+// All HBM-bound, deterministic (no atomics: fixed-order two-stage reductions with double partials).
+#include "agrl_common.h"
+#include "igemm_dev.h"
+
+namespace {
+
+// ---- per-channel reductions over the rows of an (M, C) fp32 matrix ---------------------------------------------------------
+// MODE 0: s1 = sum y,  s2 = sum y^2                      (batch statistics)
+// MODE 1: s1 = sum dz, s2 = sum dz * xhat                (BatchNorm backward), dz = relu ? (out > 0 ? dout : 0) : dout,
+//                                                         xhat = (y - mean) * invstd
+// grid = (ceil(C/64), chunks), 256 threads = 4 row lanes x 64 channels; partial[chunk][2][C] in double.
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                        const float* __restrict__ out, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, int relu, int M, int C,
+                                                        int rows_per_chunk, double* __restrict__ partial) {
+    __shared__ float s_a[4][64], s_b[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(M, r0 + rows_per_chunk);
+    float a = 0.f, b = 0.f;
+    if (c < C) {
+        float mu = 0.f, is = 0.f;
+        if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t i = (size_t)r * C + c;
+            if (MODE == 0) {
+                const float v = y[i];
+                a += v;
+                b = fmaf(v, v, b);
+            } else {
+                float dz = dout[i];
+                if (relu && !(out[i] > 0.f)) dz = 0.f;
+                a += dz;
+                b = fmaf(dz, (y[i] - mu) * is, b);
+            }
+        }
+    }
+    s_a[rl][threadIdx.x & 63] = a;
+    s_b[rl][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const int t = threadIdx.x;
+        const double sa = ((double)s_a[0][t] + (double)s_a[1][t]) + ((double)s_a[2][t] + (double)s_a[3][t]);
+        const double sb = ((double)s_b[0][t] + (double)s_b[1][t]) + ((double)s_b[2][t] + (double)s_b[3][t]);
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = sa;
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = sb;
+    }
+}
+
+// MODE 0 -> mean, biased variance; MODE 1 -> the two sums themselves (dbeta, dgamma)
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partial, int chunks, int C, int M,
+                                                              float* __restrict__ o1, float* __restrict__ o2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double sa = 0.0, sb = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        sa += partial[((size_t)k * 2 + 0) * C + c];
+        sb += partial[((size_t)k * 2 + 1) * C + c];
+    }
+    if (MODE == 0) {
+        const double mu = sa / (double)M;
+        o1[c] = (float)mu;
+        o2[c] = (float)fmax(sb / (double)M - mu * mu, 0.0);
+    } else {
+        o1[c] = (float)sa;
+        o2[c] = (float)sb;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ res,
+                                                       float* __restrict__ out, int relu, size_t total4, int C4) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(e % C4);
+        const float4 v = reinterpret_cast<const float4*>(y)[e];
+        const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
+        const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
+        float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+        if (res) {
+            const float4 r = reinterpret_cast<const float4*>(res)[e];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(out)[e] = o;
+    }
+}
+
+// dy = k1[c] * (dz - k2[c] - xhat * k3[c]),  k1 = gamma * invstd, k2 = sum dz / M, k3 = sum(dz xhat) / M; dz optionally stored
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                           const float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ s1, const float* __restrict__ s2, int relu,
+                                                           float inv_m, float* __restrict__ dy, float* __restrict__ dz_out,
+                                                           size_t total, int C) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        float dz = dout[e];
+        if (relu && !(out[e] > 0.f)) dz = 0.f;
+        const float is = invstd[c];
+        const float xhat = (y[e] - mean[c]) * is;
+        dy[e] = gamma[c] * is * (dz - s1[c] * inv_m - xhat * (s2[c] * inv_m));
+        if (dz_out) dz_out[e] = dz;
+    }
+}
+
+// ---- channel-major tap-expanded transpose ------------------------------------------------------------------------------------
+// T[(tap * C + c)][m] = x[f][oh * stride - pad + r][ow * stride - pad + s][c] (0 outside the frame), m = (f, oh, ow),
+// tap = r * S + s. grid = (ceil(Mout/32), ceil(C/32), R*S), 256 threads: a 32 x 32 tile through LDS (both sides coalesced).
+__global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__ x, float* __restrict__ T, int H, int W, int C,
+                                                       int OH, int OW, int R, int S, int stride, int pad, int Mout, int ldT) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tap = blockIdx.z;
+    const int r = tap / S, s = tap - r * S;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // ty 0..7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ml = ty + 8 * i;
+        const int m = m0 + ml;
+        float v = 0.f;
+        if (m < Mout && c0 + tx < C) {
+            const int f = m / (OH * OW), rem = m - f * OH * OW;
+            const int oh = rem / OW, ow = rem - oh * OW;
+            const int ih = oh * stride - pad + r, iw = ow * stride - pad + s;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) v = x[(((size_t)f * H + ih) * W + iw) * C + c0 + tx];
+        }
+        tile[ml][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cl = ty + 8 * i;
+        if (c0 + cl < C && m0 + tx < ldT) T[((size_t)tap * C + c0 + cl) * ldT + m0 + tx] = tile[tx][cl];  // columns >= Mout: zeros
+    }
+}
+
+// ---- 3x3 / stride 2 / pad 1 max pooling (nn.MaxPool2d of the stem, vmgn.py:284) ------------------------------------------------
+// forward: first maximum in window scan order wins (strict >), its tap index 0..8 is kept for the backward pass
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          unsigned char* __restrict__ idx, int H, int W, int C, int OH, int OW,
+                                                          size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        size_t p = e / C;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int f = (int)(p / OH);
+        float best = -INFINITY;
+        int bi = 0;
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ih = 2 * oh - 1 + r, iw = 2 * ow - 1 + s;
+                if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+                const float v = x[(((size_t)f * H + ih) * W + iw) * C + c];
+                if (!any || v > best) { best = v; bi = r * 3 + s; any = true; }
+            }
+        out[e] = best;
+        idx[e] = (unsigned char)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout, const unsigned char* __restrict__ idx,
+                                                          float* __restrict__ dx, int H, int W, int C, int OH, int OW, size_t total) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        size_t p = e / C;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int f = (int)(p / H);
+        float g = 0.f;
+        // windows (oh, ow) that contain (ih, iw): 2 oh - 1 <= ih <= 2 oh + 1
+        for (int oh = (ih >> 1); oh <= ((ih + 1) >> 1); ++oh) {
+            if (oh < 0 || oh >= OH) continue;
+            const int r = ih - (2 * oh - 1);
+            if (r < 0 || r > 2) continue;
+            for (int ow = (iw >> 1); ow <= ((iw + 1) >> 1); ++ow) {
+                if (ow < 0 || ow >= OW) continue;
+                const int s = iw - (2 * ow - 1);
+                if (s < 0 || s > 2) continue;
+                const size_t o = (((size_t)f * OH + oh) * OW + ow) * C + c;
+                if (idx[o] == (unsigned char)(r * 3 + s)) g += dout[o];
+            }
+        }
+        dx[e] = g;
+    }
+}
+
+static int reduce_chunks(int M, int C, int* rows_per_chunk) {
+    const int cg = cdiv(C, 64);
+    int chunks = 1024 / cg;
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    int rpc = cdiv(M, chunks);
+    rpc = (rpc + 3) & ~3;
+    if (rpc < 4) rpc = 4;
+    *rows_per_chunk = rpc;
+    return cdiv(M, rpc);
+}
+
+}  // namespace
+
+extern "C" size_t agrl_bn_workspace(int M, int C) {
+    int rpc;
+    const int chunks = reduce_chunks(M, C, &rpc);
+    return (size_t)chunks * 2 * C * sizeof(double);
+}
+
+extern "C" int agrl_bn_stats(const float* y, float* mean, float* var, int M, int C, void* workspace, size_t workspace_bytes,
+                             agrl_stream_t stream) {
+    AGRL_CHECK_ARG(y && mean && var && workspace && M > 0 && C > 0, "agrl_bn_stats: bad arguments");
+    AGRL_CHECK_ARG(workspace_bytes >= agrl_bn_workspace(M, C) && (((uintptr_t)workspace) & 7) == 0, "agrl_bn_stats: workspace too small");
+    int rpc;
+    const int chunks = reduce_chunks(M, C, &rpc);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0, M, C,
+                       rpc, (double*)workspace);
+    hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, mean, var);
+    AGRL_CHECK_LAUNCH("agrl_bn_stats");
+    return 0;
+}
+
+extern "C" int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, int M,
+                             int C, int relu, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(y && scale && shift && out && M > 0 && C > 0 && (C % 4) == 0, "agrl_bn_apply: bad arguments (C %% 4 == 0)");
+    const uintptr_t al = (uintptr_t)y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)residual | (uintptr_t)out;
+    AGRL_CHECK_ARG((al & 15) == 0, "agrl_bn_apply: operands must be 16-byte aligned");
+    const size_t total4 = (size_t)M * C / 4;
+    const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual, out, relu, total4, C / 4);
+    AGRL_CHECK_LAUNCH("agrl_bn_apply");
+    return 0;
+}
+
+extern "C" int agrl_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
+                                const float* gamma, int relu, float* dy, float* dz, float* dgamma, float* dbeta, int M, int C,
+                                void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace, "agrl_bn_backward: null pointer");
+    AGRL_CHECK_ARG(!relu || out, "agrl_bn_backward: the ReLU mask needs the forward output");
+    AGRL_CHECK_ARG(M > 0 && C > 0, "agrl_bn_backward: bad shape");
+    AGRL_CHECK_ARG(workspace_bytes >= agrl_bn_workspace(M, C) && (((uintptr_t)workspace) & 7) == 0, "agrl_bn_backward: workspace too small");
+    int rpc;
+    const int chunks = reduce_chunks(M, C, &rpc);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, M, C, rpc,
+                       (double*)workspace);
+    hipLaunchKernelGGL(colreduce_final_kernel<1>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, dbeta, dgamma);
+    const size_t total = (size_t)M * C;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, mean, invstd, gamma, dbeta, dgamma, relu,
+                       1.f / (float)M, dy, dz, total, C);
+    AGRL_CHECK_LAUNCH("agrl_bn_backward");
+    return 0;
+}
+
+extern "C" int agrl_im2col_t(const float* x, float* T, int ldT, int F, int H, int W, int C, int R, int S, int stride, int pad,
+                             agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && T && F > 0 && H > 0 && W > 0 && C > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_im2col_t: bad arguments");
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    AGRL_CHECK_ARG(OH > 0 && OW > 0 && R * S <= 65535, "agrl_im2col_t: empty output");
+    const int Mout = F * OH * OW;
+    AGRL_CHECK_ARG(ldT >= Mout, "agrl_im2col_t: ldT=%d < %d output pixels", ldT, Mout);
+    hipLaunchKernelGGL(im2col_t_kernel, dim3(cdiv(ldT, 32), cdiv(C, 32), R * S), dim3(256), 0, (hipStream_t)stream, x, T, H, W, C, OH,
+                       OW, R, S, stride, pad, Mout, ldT);
+    AGRL_CHECK_LAUNCH("agrl_im2col_t");
+    return 0;
+}
+
+extern "C" int agrl_maxpool3x3s2(const float* x, float* out, unsigned char* idx, int F, int H, int W, int C, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && out && idx && F > 0 && H > 0 && W > 0 && C > 0, "agrl_maxpool3x3s2: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)F * OH * OW * C;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, idx, H, W, C, OH, OW, total);
+    AGRL_CHECK_LAUNCH("agrl_maxpool3x3s2");
+    return 0;
+}
+
+extern "C" int agrl_maxpool3x3s2_backward(const float* dout, const unsigned char* idx, float* dx, int F, int H, int W, int C,
+                                          agrl_stream_t stream) {
+    AGRL_CHECK_ARG(dout && idx && dx && F > 0 && H > 0 && W > 0 && C > 0, "agrl_maxpool3x3s2_backward: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)F * H * W * C;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, idx, dx, H, W, C, OH, OW, total);
+    AGRL_CHECK_LAUNCH("agrl_maxpool3x3s2_backward");
+    return 0;
+}

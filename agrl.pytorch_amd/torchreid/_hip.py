@@ -67,6 +67,14 @@ SIGNATURES = {
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
+    "agrl_bn_workspace": [_i, _i],   # returns size_t
+    "agrl_bn_stats": [_p, _p, _p, _i, _i, _p, C.c_size_t, _p],
+    "agrl_bn_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "agrl_bn_backward": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, C.c_size_t, _p],
+    "agrl_im2col_t": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_gemm_nt_splitk": [_p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p],
+    "agrl_maxpool3x3s2": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "agrl_maxpool3x3s2_backward": [_p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_diag_read_stream": [_p, C.c_size_t, _p, _i, _p],
 }
 
@@ -99,6 +107,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _i
         h.agrl_re_ranking_workspace.restype = C.c_size_t
+        h.agrl_bn_workspace.restype = C.c_size_t
         for name in ("agrl_reload_options", "agrl_built_with_ablation"):
             getattr(h, name).argtypes = []
             getattr(h, name).restype = _i

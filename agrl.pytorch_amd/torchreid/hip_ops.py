@@ -489,3 +489,90 @@ def read_stream(buf, nbytes=None, workgroups=2048):
     with _dev(buf):
         call("agrl_diag_read_stream", ptr(buf), nbytes & ~15, ptr(sink), int(workgroups), _stream(buf))
     return sink
+
+
+# ---- train step of the conv trunk (include/agrl_hip.h, "train step" section) ----------------------------------------------
+def _bn_ws(M, Cc, device):
+    nbytes = int(_hip.lib().agrl_bn_workspace(int(M), int(Cc)))
+    return torch.empty((nbytes // 8,), dtype=torch.float64, device=device), nbytes
+
+
+def bn_stats(y2d):
+    """(M,C) fp32 -> mean (C), biased var (C): BatchNorm2d batch statistics. vmgn.py:49-61 under model.train()."""
+    M, Cc = y2d.shape
+    assert y2d.dtype == torch.float32 and y2d.is_contiguous()
+    mean = torch.empty((Cc,), dtype=torch.float32, device=y2d.device)
+    var = torch.empty((Cc,), dtype=torch.float32, device=y2d.device)
+    ws, nbytes = _bn_ws(M, Cc, y2d.device)
+    with _dev(y2d):
+        call("agrl_bn_stats", ptr(y2d), ptr(mean), ptr(var), M, Cc, ptr(ws), nbytes, _stream(y2d))
+    return mean, var
+
+
+def bn_apply(y2d, scale, shift, residual, relu):
+    M, Cc = y2d.shape
+    out = torch.empty_like(y2d)
+    with _dev(y2d):
+        call("agrl_bn_apply", ptr(y2d), ptr(scale), ptr(shift), ptr(residual), ptr(out), M, Cc, 1 if relu else 0, _stream(y2d))
+    return out
+
+
+def bn_backward(dout, out, y2d, mean, invstd, gamma, relu, want_dz):
+    """-> dy (M,C), dz (M,C) or None, dgamma (C), dbeta (C)."""
+    M, Cc = y2d.shape
+    dy = torch.empty_like(y2d)
+    dz = torch.empty_like(y2d) if want_dz else None
+    dgamma = torch.empty((Cc,), dtype=torch.float32, device=y2d.device)
+    dbeta = torch.empty((Cc,), dtype=torch.float32, device=y2d.device)
+    ws, nbytes = _bn_ws(M, Cc, y2d.device)
+    with _dev(y2d):
+        call("agrl_bn_backward", ptr(dout), ptr(out) if relu else None, ptr(y2d), ptr(mean), ptr(invstd), ptr(gamma), 1 if relu else 0,
+             ptr(dy), ptr(dz), ptr(dgamma), ptr(dbeta), M, Cc, ptr(ws), nbytes, _stream(y2d))
+    return dy, dz, dgamma, dbeta
+
+
+def im2col_t(x, R, S, stride, pad):
+    """x (F,H,W,C) fp32 NHWC -> (R*S*C, Mpad) fp32, Mpad = F*OH*OW rounded up to the GEMM's k-tile (zero columns):
+    tap-expanded channel-major transpose (weight-gradient operand)."""
+    F_, H, W, Cc = x.shape
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    ld = -(-(F_ * OH * OW) // 32) * 32
+    T = torch.empty((R * S * Cc, ld), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        call("agrl_im2col_t", ptr(x), ptr(T), ld, F_, H, W, Cc, R, S, stride, pad, _stream(x))
+    return T
+
+
+def gemm_nt_splitk(x, w):
+    """(M,K) @ (N,K)^T -> fp32 (M,N), K split over workgroups (weight gradients)."""
+    M, K = x.shape
+    Nout, K2 = w.shape
+    assert K == K2 and x.dtype == w.dtype
+    y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
+    # enough for the split the entry point will choose: it stops at >= 1024 workgroups, i.e. at most 1024 / tiles slices
+    tiles = (-(-M // 64)) * (-(-Nout // (64 if Nout <= 64 else 128)))
+    ks_cap = 1
+    while ks_cap < 256 and tiles * ks_cap < 1024:
+        ks_cap *= 2
+    ws = torch.empty((ks_cap * M * Nout,), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        call("agrl_gemm_nt_splitk", ptr(x), ptr(w), ptr(y), M, K, Nout, _gemm_code(x.dtype), ptr(ws), ws.numel() * 4, _stream(x))
+    return y
+
+
+def maxpool3x3s2(x):
+    F_, H, W, Cc = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((F_, OH, OW, Cc), dtype=torch.float32, device=x.device)
+    idx = torch.empty((F_, OH, OW, Cc), dtype=torch.uint8, device=x.device)
+    with _dev(x):
+        call("agrl_maxpool3x3s2", ptr(x), ptr(out), ptr(idx), F_, H, W, Cc, _stream(x))
+    return out, idx
+
+
+def maxpool3x3s2_backward(dout, idx, H, W):
+    F_, OH, OW, Cc = dout.shape
+    dx = torch.empty((F_, H, W, Cc), dtype=torch.float32, device=dout.device)
+    with _dev(dout):
+        call("agrl_maxpool3x3s2_backward", ptr(dout), ptr(idx), ptr(dx), F_, H, W, Cc, _stream(dout))
+    return dx

@@ -9,9 +9,12 @@ Two execution paths, chosen by where the input lives:
 * CUDA tensors, ``model.eval()``  -> the MI355X path: ``_vmgn_hip.hip_forward`` drives the gfx950 kernels of
   libagrl_hip.so (stem, implicit-GEMM convs, part pooling, graph layers, attention tail). There is no
   fallback: a missing library raises.
+* CUDA tensors, ``model.train()`` -> the conv trunk (99 % of the step's arithmetic), forward with batch-statistics
+  BatchNorm and the whole backward, runs on the gfx950 kernels through ``_train_hip`` (autograd Functions whose forward
+  and backward are C-ABI calls); the small tail stays on the module tree below.
 * CPU tensors (the reference's own CPU-runnable configuration, also what ``compute_model_complexity`` runs
-  at start-up) and train mode -> the module tree below, evaluated by stock ``torch.nn`` leaf modules so
-  forward hooks, autograd and ``nn.DataParallel`` replication behave exactly as they do for the reference.
+  at start-up) -> the module tree below, evaluated by stock ``torch.nn`` leaf modules so forward hooks, autograd
+  and ``nn.DataParallel`` replication behave exactly as they do for the reference.
 """
 from __future__ import absolute_import
 from __future__ import division
@@ -175,6 +178,7 @@ class GSTA(nn.Module):
         self.hip_fuse_pool = os.environ.get('AGRL_HIP_FUSE_POOL', '1') != '0'
         self.hip_branch_streams = os.environ.get('AGRL_HIP_BRANCH_STREAMS', '0') != '0'
         self.hip_fuse_tail = os.environ.get('AGRL_HIP_FUSE_TAIL', '1') != '0'
+        self.hip_train = os.environ.get('AGRL_HIP_TRAIN', '1') != '0'   # train-mode conv trunk (fwd + bwd) on the HIP kernels
         self._hip_packs = {}
 
     # ------------------------------------------------------------------ stock-torch path (CPU / train)
@@ -201,7 +205,13 @@ class GSTA(nn.Module):
             return hip_forward(self, x, adj)
 
         B, S, C, H, W = x.size()
-        x4_1, x4_2 = self.featuremaps(x.view(B * S, C, H, W))
+        if x.is_cuda and self.training and self.hip_train:
+            # train step on the GPU: the conv trunk -- forward with batch-statistics BatchNorm and its whole backward -- on the
+            # gfx950 kernels (models/_train_hip.py); the graph stays torch.autograd's
+            from torchreid.models._train_hip import featuremaps_train
+            x4_1, x4_2 = [t.contiguous() for t in featuremaps_train(self, x.view(B * S, C, H, W))]
+        else:
+            x4_1, x4_2 = self.featuremaps(x.view(B * S, C, H, W))
         c = x4_1.size(1)
         g_f, f = self._pooled_nodes(x4_1, x4_2, B, S)
         g_bn = self.global_bottleneck(g_f)

@@ -286,6 +286,51 @@ int agrl_re_ranking(const float* q_g, const float* q_q, const float* g_g, int m,
                     double lambda_value, float* final_dist, int ldf, void* workspace, size_t workspace_bytes,
                     agrl_stream_t stream);
 
+/* ---- train step of the conv trunk (BASELINE config 4) --------------------------------------------------------
+ * model.train() forward + backward of Bottleneck (torchreid/models/vmgn.py:45-65) as driven by the reference's train()
+ * (train_vidreid_xent_htri.py:397-413). The three conv GEMMs -- forward, data gradient (a conv with the flipped /
+ * transposed filter), weight gradient (dW[co][tap,ci] = sum_pixels dy[pixel][co] x[pixel+tap][ci], K = pixels) -- run on
+ * agrl_conv2d_bn_act / agrl_linear_nobias / agrl_gemm_nt_splitk in the exact-fp32 mode; the entry points below are
+ * everything between them. Activations NHWC fp32 viewed as (M = N*H*W, C). */
+
+/* scratch for agrl_bn_stats / agrl_bn_backward: partial sums in double, bytes */
+size_t agrl_bn_workspace(int M, int C);
+
+/* BatchNorm2d batch statistics (train mode, vmgn.py:49/53/57/61): mean[c], biased var[c] over the M rows of y (M,C). */
+int agrl_bn_stats(const float* y, float* mean, float* var, int M, int C, void* workspace, size_t workspace_bytes,
+                  agrl_stream_t stream);
+
+/* out = act(y * scale[c] + shift[c] (+ residual)): the normalisation with scale = gamma / sqrt(var + eps), shift = beta -
+ * mean * scale, the shortcut add and the ReLU of vmgn.py:49-64 in one pass. C % 4 == 0. */
+int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, int M, int C,
+                  int relu, agrl_stream_t stream);
+
+/* Backward of agrl_bn_apply + batch statistics: dz = relu ? (out > 0 ? dout : 0) : dout; dbeta = sum dz;
+ * dgamma = sum dz * xhat (xhat = (y - mean) * invstd); dy = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M).
+ * dz (optional) is the gradient that continues into the residual branch. */
+int agrl_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
+                     const float* gamma, int relu, float* dy, float* dz, float* dgamma, float* dbeta, int M, int C,
+                     void* workspace, size_t workspace_bytes, agrl_stream_t stream);
+
+/* T[(tap*C + c)][m] = x[f][oh*stride - pad + r][ow*stride - pad + s][c] (0 outside), tap = r*S + s, m = (f, oh, ow):
+ * the channel-major, tap-expanded transpose of x (F,H,W,C) fp32 -> T (R*S*C, ldT) fp32, ldT >= F*OH*OW (columns past the last
+ * pixel are written as zeros: K padding for the GEMM) -- the K-contiguous operand of the weight-gradient GEMM (with R = S = 1
+ * it is the plain transpose used for dy). */
+int agrl_im2col_t(const float* x, float* T, int ldT, int F, int H, int W, int C, int R, int S, int stride, int pad,
+                  agrl_stream_t stream);
+
+/* y (M,Nout) fp32 = x (M,K) @ w (Nout,K)^T with the K axis split over workgroups when there are few output tiles (weight
+ * gradients: K = pixels); workspace >= 256 * M * Nout * 4 bytes allows every split the entry point may choose (smaller
+ * workspaces reduce the split). Deterministic: partials are summed in slice order. */
+int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M, int K, int Nout, int in_dtype, void* workspace,
+                        size_t workspace_bytes, agrl_stream_t stream);
+
+/* nn.MaxPool2d(kernel 3, stride 2, padding 1) of the stem (vmgn.py:284) on NHWC fp32: out (F,OH,OW,C) and the arg-max tap
+ * (0..8, first maximum in scan order) per output; backward gathers dout through the taps (no atomics). */
+int agrl_maxpool3x3s2(const float* x, float* out, unsigned char* idx, int F, int H, int W, int C, agrl_stream_t stream);
+int agrl_maxpool3x3s2_backward(const float* dout, const unsigned char* idx, float* dx, int F, int H, int W, int C,
+                               agrl_stream_t stream);
+
 /* ---- batch-hard triplet mining (train step, BASELINE config 4) ----------------------------------- */
 
 /* dist = sqrt(clamp(||x_i||^2+||x_j||^2-2x_i.x_j, 1e-12)); per anchor hardest positive (max over

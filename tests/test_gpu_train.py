@@ -1,0 +1,173 @@
+"""Native train step (BASELINE config 4; reference train(), train_vidreid_xent_htri.py:397-413): the conv trunk's forward
+with batch-statistics BatchNorm and its whole backward on the HIP kernels, against the SAME step computed on the CPU by the
+stock-torch module tree (the reference's arithmetic: nn.Conv2d / nn.BatchNorm2d / autograd)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item()
+
+
+@pytest.mark.parametrize("cfg", [(3, 16, 8, 64, 128, 1, 1, 0), (4, 16, 8, 64, 64, 3, 1, 1), (4, 16, 8, 64, 96, 3, 2, 1), (5, 8, 4, 128, 256, 1, 2, 0),
+                                 (2, 9, 5, 32, 64, 3, 2, 1), (2, 32, 16, 32, 64, 7, 2, 3)])
+def test_conv_forward_dgrad_wgrad(cfg):
+    """HipConv2d: forward, data gradient (flipped-filter conv / W^T GEMM, zero-inserted for stride 2) and weight gradient
+    (im2col-transposes + split-K GEMM over the pixel axis) against F.conv2d + autograd in fp32 on the CPU."""
+    from torchreid.models._train_hip import HipConv2d
+    N, H, W, Cin, Cout, R, stride, pad = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn((N, Cin, H, W), generator=g, requires_grad=True)
+    w = (torch.randn((Cout, Cin, R, R), generator=g) / np.sqrt(Cin * R * R)).requires_grad_(True)
+    y = F.conv2d(x, w, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    yd = HipConv2d.apply(xd, wd, stride, pad)
+    yd.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    torch.cuda.synchronize()
+    e = (rel(yd.permute(0, 3, 1, 2), y), rel(xd.grad.permute(0, 3, 1, 2), x.grad), rel(wd.grad, w.grad))
+    print("conv", cfg, "fwd %.2e dgrad %.2e wgrad %.2e" % e)
+    assert max(e) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(4, 16, 8, 64, True, True), (3, 9, 5, 128, False, True), (6, 4, 2, 256, True, False), (2, 64, 32, 64, False, False)])
+def test_batchnorm_act_forward_backward(cfg):
+    """HipBatchNormAct (batch statistics, shortcut add, ReLU) and the running-statistics update against nn.BatchNorm2d in
+    train mode + autograd on the CPU."""
+    from torchreid.models._train_hip import _bn_act
+    N, H, W, C, use_res, relu = cfg
+    g = torch.Generator().manual_seed(N + H + C)
+    y = (2.0 * torch.randn((N, C, H, W), generator=g) + 0.5).requires_grad_(True)
+    res = torch.randn((N, C, H, W), generator=g).requires_grad_(True) if use_res else None
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(C, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(C, generator=g))
+        bn.running_mean.copy_(0.1 * torch.randn(C, generator=g))
+        bn.running_var.copy_(0.5 + torch.rand(C, generator=g))
+    import copy
+    bnd = copy.deepcopy(bn).to(DEV)
+    bn.train()
+    bnd.train()
+    out = bn(y)
+    if use_res:
+        out = out + res
+    if relu:
+        out = F.relu(out)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    yd = nh(y).requires_grad_(True)
+    rd = nh(res).requires_grad_(True) if use_res else None
+    outd = _bn_act(bnd, yd, rd, relu)
+    outd.backward(nh(dout))
+    torch.cuda.synchronize()
+    errs = {"out": rel(outd.permute(0, 3, 1, 2), out), "dy": rel(yd.grad.permute(0, 3, 1, 2), y.grad),
+            "dgamma": rel(bnd.weight.grad, bn.weight.grad), "dbeta": rel(bnd.bias.grad, bn.bias.grad),
+            "running_mean": rel(bnd.running_mean, bn.running_mean), "running_var": rel(bnd.running_var, bn.running_var)}
+    if use_res:
+        errs["dres"] = rel(rd.grad.permute(0, 3, 1, 2), res.grad)
+    print("bn", cfg, " ".join("%s %.2e" % kv for kv in errs.items()))
+    assert max(errs.values()) < 2e-5 and int(bnd.num_batches_tracked) == 1
+
+
+def test_maxpool_forward_backward():
+    from torchreid.models._train_hip import HipMaxPool
+    g = torch.Generator().manual_seed(5)
+    for shape in ((3, 64, 16, 8), (2, 32, 9, 7), (1, 8, 128, 64)):
+        x = torch.randn(shape, generator=g).relu().requires_grad_(True)   # post-ReLU maps: ties at zero are part of the case
+        y = F.max_pool2d(x, 3, 2, 1)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+        yd = HipMaxPool.apply(xd)
+        yd.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(yd.permute(0, 3, 1, 2).cpu(), y)
+        # gradients may only differ where a window holds several equal maxima (zeros): compare where the input is positive
+        pos = x.detach() > 0
+        assert torch.equal(xd.grad.permute(0, 3, 1, 2).cpu()[pos], x.grad[pos])
+        assert abs(xd.grad.sum().item() - x.grad.sum().item()) < 1e-3
+
+
+def _problem(S, H, W, P=2, K=2, ncls=5, seed=3, consistent=True):
+    from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+    from torchreid import models
+    kw = dict(num_classes=ncls, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1, pyramid_part=True,
+              use_pose=True, learn_graph=True, consistent_loss=consistent)
+    ref = models.init_model("vmgn", **kw)
+    sd = recipe_state_dict(ref.state_dict(), seed=seed)
+    ref.load_state_dict(sd)
+    dev = models.init_model("vmgn", **kw)
+    dev.load_state_dict(sd)
+    pids = torch.arange(P).repeat_interleave(K)
+    x = synthetic_clips(P * K, S, H=H, W=W, seed=9, identities=pids.tolist())
+    adj = synthetic_adj(P * K, S, seed=9)
+    return ref, dev.to(DEV), x, adj, pids, ncls
+
+
+def _step(model, x, adj, y, use_gpu):
+    from torchreid import losses
+    ce = losses.CrossEntropyLabelSmooth(num_classes=5, use_gpu=use_gpu)
+    htri = losses.TripletLoss(margin=0.3, soft=True)
+    model.train()
+    torch.manual_seed(1234)  # the consistent loss draws its frame subsets with torch.randperm on the host
+    outs, feats = model(x, adj)
+    loss = losses.DeepSupervision(ce, outs, y) + losses.DeepSupervision(htri, feats, y)
+    model.zero_grad()
+    loss.backward()
+    return loss
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 32), (16, 256, 128)])
+def test_train_step_loss_and_every_parameter_gradient_match_cpu_step(shape):
+    """One xent + htri step (consistent loss on) with the native trunk: loss, EVERY parameter's gradient and the updated
+    BatchNorm running statistics against the CPU step, at a small size and at BASELINE config 4's clip shape (seq_len 16,
+    V = 112, 256 x 128 frames)."""
+    S, H, W = shape
+    ref, dev, x, adj, pids, _ = _problem(S, H, W)
+    assert dev.hip_train
+    l_ref = _step(ref, x, adj, pids, False)
+    l_dev = _step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), True)
+    torch.cuda.synchronize()
+    assert abs(l_ref.item() - l_dev.item()) < 1e-4 * abs(l_ref.item())
+    worst, worst_name = 0.0, None
+    gref = dict(ref.named_parameters())
+    n = 0
+    for name, p in dev.named_parameters():
+        if gref[name].grad is None:
+            assert p.grad is None
+            continue
+        e = rel(p.grad, gref[name].grad)
+        n += 1
+        if e > worst:
+            worst, worst_name = e, name
+    bref = dict(ref.named_buffers())
+    bworst = max(rel(b, bref[name]) for name, b in dev.named_buffers() if b.dtype.is_floating_point)
+    print("train step S=%d %dx%d: loss cpu %.6f gpu %.6f | %d parameter gradients, worst rel err %.2e (%s) | running stats %.2e" % (
+        S, H, W, l_ref.item(), l_dev.item(), n, worst, worst_name, bworst))
+    assert n > 150 and worst < 1e-3 and bworst < 1e-4
+
+
+def test_native_trunk_is_what_runs(monkeypatch):
+    """The train forward on CUDA goes through the C-ABI (conv, batch-norm statistics, max pooling entry points are called),
+    and AGRL_HIP_TRAIN=0 style opt-out (model.hip_train = False) gives the same loss through the stock module tree."""
+    from torchreid import _hip
+    ref, dev, x, adj, pids, _ = _problem(6, 64, 32, consistent=False)
+    _hip.PROFILE = []
+    l1 = _step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), True)
+    names = {r[0] for r in _hip.PROFILE}
+    _hip.PROFILE = None
+    assert {"agrl_conv2d_bn_act", "agrl_bn_stats", "agrl_bn_apply", "agrl_bn_backward", "agrl_im2col_t", "agrl_gemm_nt_splitk",
+            "agrl_maxpool3x3s2", "agrl_maxpool3x3s2_backward", "agrl_linear_nobias"} <= names
+    dev.hip_train = False
+    l2 = _step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), True)
+    assert abs(l1.item() - l2.item()) < 1e-4 * abs(l2.item())
