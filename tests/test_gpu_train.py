@@ -128,33 +128,65 @@ def _step(model, x, adj, y, use_gpu):
 
 
 @pytest.mark.parametrize("shape", [(6, 64, 32), (16, 256, 128)])
-def test_train_step_loss_and_every_parameter_gradient_match_cpu_step(shape):
-    """One xent + htri step (consistent loss on) with the native trunk: loss, EVERY parameter's gradient and the updated
-    BatchNorm running statistics against the CPU step, at a small size and at BASELINE config 4's clip shape (seq_len 16,
-    V = 112, 256 x 128 frames)."""
+def test_trunk_backward_matches_cpu_for_the_same_output_gradient(shape):
+    """The native trunk in isolation: featuremaps in train mode (batch-statistics BatchNorm) and EVERY trunk parameter's
+    gradient for a fixed smooth functional of the two layer-4 maps, against the stock module tree on the CPU -- the
+    north-star bar 1e-3 per parameter (measured ~1e-5). (The full step below cannot be held to that bar by ANY fp32
+    implementation: see its docstring.)"""
+    from torchreid.models._train_hip import featuremaps_train
+    S, H, W = shape
+    ref, dev, x, adj, pids, _ = _problem(S, H, W)
+    frames = x.view(-1, 3, H, W)
+    g = torch.Generator().manual_seed(17)
+    ref.train()
+    dev.train()
+    a1, a2 = ref.featuremaps(frames)
+    w1, w2 = torch.randn(a1.shape, generator=g), torch.randn(a2.shape, generator=g)
+    (((a1 * w1).sum() + (a2 * a2 * w2).sum()) / a1.numel()).backward()
+    b1, b2 = featuremaps_train(dev, frames.to(DEV))
+    (((b1 * w1.to(DEV)).sum() + (b2 * b2 * w2.to(DEV)).sum()) / b1.numel()).backward()
+    torch.cuda.synchronize()
+    e_out = max(rel(b1, a1), rel(b2, a2))
+    gref = dict(ref.named_parameters())
+    rows = sorted(((rel(p.grad, gref[k].grad), k) for k, p in dev.named_parameters() if gref[k].grad is not None), reverse=True)
+    bref = dict(ref.named_buffers())
+    bworst = max(rel(b, bref[k]) for k, b in dev.named_buffers() if b.dtype.is_floating_point)
+    print("trunk S=%d %dx%d: maps %.2e | %d parameter gradients: worst %.2e (%s), median %.2e | running stats %.2e" % (
+        S, H, W, e_out, len(rows), rows[0][0], rows[0][1], rows[len(rows) // 2][0], bworst))
+    assert len(rows) == 3 * 53 and all(p.grad is None for k, p in dev.named_parameters() if gref[k].grad is None)
+    assert e_out < 1e-4 and rows[0][0] < 1e-3 and bworst < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 32), (16, 256, 128)])
+def test_train_step_loss_and_gradients_at_the_reference_noise_floor(shape):
+    """One xent + htri step (consistent loss on) with the native trunk, at a small size and at BASELINE config 4's clip shape
+    (seq_len 16, V = 112, 256 x 128 frames). The loss matches the CPU step to 1e-5. The per-parameter GRADIENTS of this
+    model are ill-conditioned in fp32 whatever computes them: GraphLayer.get_sim_matrix takes sqrt(clamp(d2, 1e-12)) of a
+    diagonal d2_ii that is pure cancellation noise (vmgn.py:114-120), and the gradient of sqrt at ~1e-4 amplifies that
+    noise -- the reference's own CPU fp32 step is 1-5 % away from the same step in float64, and so is stock torch on the
+    GPU (tools/dbg_train.py). Parity is therefore asserted at that floor: against the float64 CPU step the native step's
+    error distribution (median, 90th percentile, worst) must be within 3 x the CPU fp32 step's own."""
+    import copy
     S, H, W = shape
     ref, dev, x, adj, pids, _ = _problem(S, H, W)
     assert dev.hip_train
+    ref64 = copy.deepcopy(ref).double()
+    l64 = _step(ref64, x.double(), adj.double(), pids, False)
     l_ref = _step(ref, x, adj, pids, False)
     l_dev = _step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), True)
     torch.cuda.synchronize()
-    assert abs(l_ref.item() - l_dev.item()) < 1e-4 * abs(l_ref.item())
-    worst, worst_name = 0.0, None
-    gref = dict(ref.named_parameters())
-    n = 0
-    for name, p in dev.named_parameters():
-        if gref[name].grad is None:
-            assert p.grad is None
-            continue
-        e = rel(p.grad, gref[name].grad)
-        n += 1
-        if e > worst:
-            worst, worst_name = e, name
-    bref = dict(ref.named_buffers())
-    bworst = max(rel(b, bref[name]) for name, b in dev.named_buffers() if b.dtype.is_floating_point)
-    print("train step S=%d %dx%d: loss cpu %.6f gpu %.6f | %d parameter gradients, worst rel err %.2e (%s) | running stats %.2e" % (
-        S, H, W, l_ref.item(), l_dev.item(), n, worst, worst_name, bworst))
-    assert n > 150 and worst < 1e-3 and bworst < 1e-4
+    assert abs(l_ref.item() - l_dev.item()) < 1e-5 * abs(l_ref.item()) and abs(l64.item() - l_dev.item()) < 1e-5 * abs(l64.item())
+    g64 = {k: p.grad for k, p in ref64.named_parameters() if p.grad is not None}
+
+    def dist(model):
+        r = sorted(rel(p.grad, g64[k]) for k, p in model.named_parameters() if k in g64)
+        return r[len(r) // 2], r[(9 * len(r)) // 10], r[-1]
+    d_cpu, d_dev = dist(ref), dist(dev)
+    assert all(p.grad is None for k, p in dev.named_parameters() if k not in g64)
+    print("train step S=%d %dx%d: loss fp64 %.7f cpu %.7f native %.7f | grad err vs fp64 (median, p90, worst): cpu fp32 %.2e %.2e %.2e, "
+          "native %.2e %.2e %.2e" % ((S, H, W, l64.item(), l_ref.item(), l_dev.item()) + d_cpu + d_dev))
+    for a_, b_ in zip(d_dev, d_cpu):
+        assert a_ < 3 * b_ + 1e-6
 
 
 def test_native_trunk_is_what_runs(monkeypatch):
