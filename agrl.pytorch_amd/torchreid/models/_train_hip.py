@@ -71,6 +71,32 @@ class HipConv2d(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class HipStemConv(torch.autograd.Function):
+    """conv1 of the stem (7x7 / 2, 3 -> 64; vmgn.py:281): forward on the implicit-GEMM kernel with the 3 input channels
+    zero-padded to its K granularity (32); the weight gradient from the UNPADDED input (147 = 7*7*3 im2col rows instead of
+    1568); no data gradient (the frames are the leaves of the graph)."""
+
+    @staticmethod
+    def forward(ctx, x3, weight):
+        x3 = x3.contiguous()                                                            # (F,H,W,3)
+        ctx.save_for_backward(x3, weight)
+        xp = torch.nn.functional.pad(x3, (0, 29)).contiguous()
+        wp = torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 29))
+        return _conv_forward(xp, wp, 2, 3)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cout, Cin, R, S = weight.shape
+        dw = None
+        if ctx.needs_input_grad[1]:
+            xt = ops.im2col_t(x3, R, S, 2, 3)                                           # (147, M)
+            dyt = ops.im2col_t(dy, 1, 1, 1, 0)                                          # (64, M)
+            dw = ops.gemm_nt_splitk(dyt, xt).view(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
+        return None, dw
+
+
 class HipBatchNormAct(torch.autograd.Function):
     """BatchNorm2d in train mode (+ shortcut add) (+ ReLU) on NHWC fp32: out = act(bn(y) + residual)."""
 
@@ -143,12 +169,8 @@ def bottleneck_train(unit, x):
 
 
 def stem_train(model, frames_nchw):
-    """conv1 7x7/2 + bn1 + relu + maxpool (vmgn.py:281-284). The 3 input channels are zero-padded to 32 so the stem runs on the
-    same implicit-GEMM kernel (K granularity of the fp32 form); the weight gradient is cut back to 3 channels by autograd."""
-    x = frames_nchw.permute(0, 2, 3, 1)
-    x = torch.nn.functional.pad(x, (0, 29)).contiguous()                              # (F,H,W,32)
-    w = torch.nn.functional.pad(model.conv1.weight, (0, 0, 0, 0, 0, 29))              # (64,32,7,7), differentiable view of conv1.weight
-    y = HipConv2d.apply(x, w, 2, 3)
+    """conv1 7x7/2 + bn1 + relu + maxpool (vmgn.py:281-284)."""
+    y = HipStemConv.apply(frames_nchw.permute(0, 2, 3, 1), model.conv1.weight)
     y = _bn_act(model.bn1, y, None, True)
     return HipMaxPool.apply(y)
 

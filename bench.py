@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true", help="skip the 625-identity Rank-1 / mAP block")
     ap.add_argument("--no-config5", action="store_true", help="skip the 1980 x 12180 x 4096 full-eval timing")
+    ap.add_argument("--no-config4", action="store_true", help="skip the seq_len-16 train-step timing")
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="upper bound of the CPU-baseline thread sweep")
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -278,6 +279,64 @@ def config5_block(device, embeddings, metric):
             out["topk50_ms"] = round(t_topk, 3)
             out["topk50_gbs"] = round(4.0 * QUERY_ROWS * GALLERY_ROWS / (t_topk * 1e-3) / 1e9, 1)
             out["rank_mars_ms"] = round(t_mars, 3)
+    return out
+
+
+def config4_block(device):
+    """BASELINE configs[3] on one GPU: a DukeMTMC-VideoReID-shaped xent + htri train step (seq_len 16, V = 112, 16 tracklets =
+    4 identities x 4 instances, 702 classes, consistent loss, Adam) in fp32 -- forward, losses with on-GPU batch-hard
+    mining, backward, optimizer step -- with the conv trunk on the native kernels, and the same step on the stock-torch
+    module tree (rocBLAS / MIOpen) beside it."""
+    import torch
+    from recipe import recipe_state_dict
+    from torchreid import losses, models
+    B, S, ncls = 16, 16, 702
+    m = models.init_model("vmgn", num_classes=ncls, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)
+    m.load_state_dict(recipe_state_dict(m.state_dict(), seed=4))
+    m = m.to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(4)
+    x = torch.randn((B, S, 3, 256, 128), device=device, generator=gen)
+    adj = synthetic_pose_adjacency(B, S, device, gen)
+    pids = torch.arange(4, device=device).repeat_interleave(4)
+    ce = losses.CrossEntropyLabelSmooth(num_classes=ncls, use_gpu=True)
+    htri = losses.TripletLoss(margin=0.3, soft=True)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=5e-4)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    out = {"tracklets": B, "seq_len": S, "frames": B * S, "dtype": "fp32", "classes": ncls,
+           "gflop_per_step": round(3 * 11.93 * B * S, 1)}
+
+    def run(native, steps=3):
+        m.load_state_dict(sd0)
+        m.hip_train = native
+        m.train()
+        ts, loss = [], None
+        for i in range(steps + 1):
+            torch.manual_seed(1234)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs, feats = m(x, adj)
+            loss = losses.DeepSupervision(ce, outs, pids) + losses.DeepSupervision(htri, feats, pids)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            if i:
+                ts.append(time.perf_counter() - t0)
+        return min(ts), float(loss.detach())
+    try:
+        t_nat, l_nat = run(True)
+        t_ref, l_ref = run(False)
+    except RuntimeError as e:  # noqa: BLE001  (out of memory on a small device)
+        return {"error": str(e)[:200]}
+    fl = 3 * 11.93e9 * B * S
+    out["native_trunk"] = {"ms_per_step": round(1e3 * t_nat, 2), "frames_per_s": round(B * S / t_nat, 1), "tflops": round(fl / t_nat / 1e12, 1),
+                           "last_loss": round(l_nat, 6)}
+    out["stock_torch"] = {"ms_per_step": round(1e3 * t_ref, 2), "frames_per_s": round(B * S / t_ref, 1), "tflops": round(fl / t_ref / 1e12, 1),
+                          "last_loss": round(l_ref, 6)}
+    out["peak_tflops"] = PEAK_TFLOPS["fp32"]
+    out["note"] = "conv trunk forward + backward on libagrl_hip.so (exact-fp32 MFMA); tail and losses torch autograd + native mining"
     return out
 
 
@@ -612,6 +671,10 @@ def main():
                 emb = None
             if not args.no_config5:
                 result["config5"] = config5_block(device, emb, args.metric)
+            if not args.no_config4:
+                del model, clips
+                torch.cuda.empty_cache()
+                result["config4_train_step"] = config4_block(device)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(sd, S, args.metric, gallery_cpu, args.cpu_seconds)
         print(json.dumps(result), flush=True)
