@@ -230,6 +230,71 @@ __global__ __launch_bounds__(256) void triplet_mine_kernel(const float* __restri
 }
 
 
+// Loss value and per-anchor pair coefficients from the mined distances (one workgroup; n is a train batch, <= a few hundred):
+//   soft  : L_i = log(1 + exp(d_ap - d_an)),           dL_i/d(d_ap) = sigmoid(d_ap - d_an)
+//   margin: L_i = max(0, d_ap - d_an + margin),        dL_i/d(d_ap) = [L_i > 0]           (MarginRankingLoss, y = 1)
+// loss = mean_i L_i (summed in anchor order). d = sqrt(clamp(d2, 1e-12)): where the clamp is active the distance is a
+// constant and passes no gradient. ca[i] = dL/d(d_ap) / (n d_ap), cn[i] = -dL/d(d_an) ... / (n d_an): the factors of
+// (x_i - x_j) in the feature gradient. An anchor without a negative (idx_an < 0) makes the loss NaN.
+__device__ inline void triplet_term(float ap, float an, int has_neg, float margin, int soft, float& L, float& g) {
+    if (!has_neg) {
+        L = __builtin_nanf("");
+        g = 0.f;
+    } else if (soft) {
+        const float e = expf(ap - an);
+        L = logf(1.f + e);
+        g = e < INFINITY ? e / (1.f + e) : 1.f;
+    } else {
+        L = fmaxf(0.f, (ap - an) + margin);
+        g = L > 0.f ? 1.f : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void triplet_coeff_kernel(const float* __restrict__ dist_ap, const float* __restrict__ dist_an,
+                                                            const int32_t* __restrict__ idx_an, int n, float margin, int soft,
+                                                            float* __restrict__ loss, float* __restrict__ ca, float* __restrict__ cn) {
+    const float tiny = sqrtf(1e-12f);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float ap = dist_ap[i], an = dist_an[i];
+        float L, g;
+        triplet_term(ap, an, idx_an[i] >= 0, margin, soft, L, g);
+        ca[i] = ap > tiny ? g / ((float)n * ap) : 0.f;
+        cn[i] = (idx_an[i] >= 0 && an > tiny) ? -g / ((float)n * an) : 0.f;
+    }
+    if (threadIdx.x == 0) {  // anchor-ordered sum by one thread: n is a train batch; fixed order = deterministic
+        float tot = 0.f;
+        for (int i = 0; i < n; ++i) {
+            float L, g;
+            triplet_term(dist_ap[i], dist_an[i], idx_an[i] >= 0, margin, soft, L, g);
+            tot += L;
+        }
+        loss[0] = tot / (float)n;
+    }
+}
+
+// grad[r] = ca[r] (x_r - x_p(r)) + cn[r] (x_r - x_q(r)) - sum_{i: p(i) = r} ca[i] (x_i - x_r) - sum_{i: q(i) = r} cn[i] (x_i - x_r)
+// grid = n rows, threads over the feature dim; a gather over the anchors (no atomics).
+__global__ __launch_bounds__(256) void triplet_grad_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx_ap,
+                                                           const int32_t* __restrict__ idx_an, const float* __restrict__ ca,
+                                                           const float* __restrict__ cn, int n, int d, float* __restrict__ grad) {
+    const int r = blockIdx.x;
+    const float* xr = x + (size_t)r * d;
+    const int pr = idx_ap[r], qr = idx_an[r];
+    const float car = ca[r], cnr = cn[r];
+    for (int c = threadIdx.x; c < d; c += 256) {
+        const float v = xr[c];
+        float g = 0.f;
+        if (pr >= 0) g = fmaf(car, v - x[(size_t)pr * d + c], g);
+        if (qr >= 0) g = fmaf(cnr, v - x[(size_t)qr * d + c], g);
+        for (int i = 0; i < n; ++i) {
+            const float xi = x[(size_t)i * d + c];
+            if (idx_ap[i] == r) g = fmaf(-ca[i], xi - v, g);
+            if (idx_an[i] == r) g = fmaf(-cn[i], xi - v, g);
+        }
+        grad[(size_t)r * d + c] = g;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // market1501 protocol (torchreid/metrics/rank.py:95-150; Cython twin rank_cylib/rank_cy.pyx:154-241) WITHOUT sorting
 // the row. The reference argsorts all n distances of a query and walks the ranking; but AP and CMC only depend on the
@@ -337,6 +402,18 @@ extern "C" int agrl_triplet_hard_mine(const float* x, const int32_t* pids, int n
     hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, x, pids, n, d, dist_ap, dist_an,
                        idx_ap, idx_an);
     AGRL_CHECK_LAUNCH("agrl_triplet_hard_mine");
+    return 0;
+}
+
+extern "C" int agrl_triplet_loss(const float* x, const int32_t* pids, int n, int d, float margin, int soft, float* loss, float* grad,
+                                 float* dist_ap, float* dist_an, int32_t* idx_ap, int32_t* idx_an, float* coeff, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && pids && loss && grad && dist_ap && dist_an && idx_ap && idx_an && coeff, "agrl_triplet_loss: null pointer");
+    AGRL_CHECK_ARG(n > 0 && d > 0, "agrl_triplet_loss: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(triplet_mine_kernel, dim3(n), dim3(256), 0, st, x, pids, n, d, dist_ap, dist_an, idx_ap, idx_an);
+    hipLaunchKernelGGL(triplet_coeff_kernel, dim3(1), dim3(256), 0, st, dist_ap, dist_an, idx_an, n, margin, soft, loss, coeff, coeff + n);
+    hipLaunchKernelGGL(triplet_grad_kernel, dim3(n), dim3(256), 0, st, x, idx_ap, idx_an, coeff, coeff + n, n, d, grad);
+    AGRL_CHECK_LAUNCH("agrl_triplet_loss");
     return 0;
 }
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
+    "agrl_triplet_loss": [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "agrl_bn_workspace": [_i, _i],   # returns size_t
     "agrl_bn_stats": [_p, _p, _p, _i, _i, _p, C.c_size_t, _p],
     "agrl_bn_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _p],

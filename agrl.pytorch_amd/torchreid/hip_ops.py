@@ -576,3 +576,19 @@ def maxpool3x3s2_backward(dout, idx, H, W):
     with _dev(dout):
         call("agrl_maxpool3x3s2_backward", ptr(dout), ptr(idx), ptr(dx), F_, H, W, Cc, _stream(dout))
     return dx
+
+
+def triplet_loss(x, pids, margin, soft):
+    """Batch-hard triplet loss value + feature gradient in one native call (no host sync). -> loss (1,), grad (n,d)."""
+    n, d = x.shape
+    assert x.dtype == torch.float32 and pids.dtype == torch.int32
+    dev = x.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    grad = torch.empty((n, d), dtype=torch.float32, device=dev)
+    dap, dan = torch.empty((n,), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev)
+    iap, ian = torch.empty((n,), dtype=torch.int32, device=dev), torch.empty((n,), dtype=torch.int32, device=dev)
+    coeff = torch.empty((2 * n,), dtype=torch.float32, device=dev)
+    with _dev(x):
+        call("agrl_triplet_loss", ptr(x), ptr(pids), n, d, float(margin), 1 if soft else 0, ptr(loss), ptr(grad), ptr(dap), ptr(dan),
+             ptr(iap), ptr(ian), ptr(coeff), _stream(x))
+    return loss, grad

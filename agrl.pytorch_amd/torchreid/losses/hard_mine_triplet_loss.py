@@ -1,10 +1,10 @@
 """Batch-hard triplet loss (reference: torchreid/losses/hard_mine_triplet_loss.py:8-50).
 
-The O(n^2) mining -- pairwise distances, hardest positive (max over same id, self included) and hardest
-negative (min over other ids) per anchor -- runs in one gfx950 kernel (``agrl_triplet_hard_mine``) when the
-features are CUDA tensors, replacing the reference's Python loop of 2n masked reductions. The loss value and
-its gradient are then formed by autograd on the 2n selected pairs only, with the reference's distance formula
-``sqrt(clamp(|a|^2 + |b|^2 - 2ab, 1e-12))``. CPU tensors use the stock-torch formulation (no GPU: plumbing).
+CUDA fp32 features: ONE native call (``agrl_triplet_loss``) does the O(n^2) mining -- pairwise distances
+``sqrt(clamp(|a|^2 + |b|^2 - 2ab, 1e-12))``, hardest positive (max over same id, self included) and hardest negative (min over
+other ids) per anchor, replacing the reference's Python loop of 2n masked reductions -- the loss value and the gradient w.r.t.
+the features through the 2n selected pairs; nothing returns to the host (an anchor without a negative makes the loss NaN instead
+of raising). ``mine`` (``agrl_triplet_hard_mine``) stays available on its own. CPU tensors use the stock-torch formulation.
 """
 from __future__ import absolute_import
 from __future__ import division
@@ -18,6 +18,23 @@ def _pair_dist(x, idx):
     other = x.index_select(0, idx)
     d2 = sq + sq.index_select(0, idx) - 2 * (x * other).sum(dim=1)
     return d2.clamp(min=1e-12).sqrt()
+
+
+class _NativeTriplet(torch.autograd.Function):
+    """Loss value and d loss / d features from ONE C-ABI call (``agrl_triplet_loss``: mining, loss, gradient through the 2n
+    selected pairs); backward only scales the stored gradient by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, inputs, targets, margin, soft):
+        from torchreid import hip_ops as ops
+        loss, grad = ops.triplet_loss(inputs.detach().float().contiguous(), targets.detach().to(torch.int32).contiguous(), margin, soft)
+        ctx.save_for_backward(grad)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (grad,) = ctx.saved_tensors
+        return grad * go, None, None, None
 
 
 class TripletLoss(nn.Module):
@@ -51,6 +68,8 @@ class TripletLoss(nn.Module):
         return idx_ap, idx_an
 
     def forward(self, inputs, targets):
+        if inputs.is_cuda and inputs.dtype == torch.float32:
+            return _NativeTriplet.apply(inputs, targets, self.margin, self.soft)
         idx_ap, idx_an = self.mine(inputs, targets)
         dist_ap = _pair_dist(inputs, idx_ap)
         missing = idx_an < 0

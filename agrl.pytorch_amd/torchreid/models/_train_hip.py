@@ -22,6 +22,11 @@ import torch
 from torchreid import hip_ops as ops
 
 
+def _split_mode():
+    """The calling thread's GEMM arithmetic switch (ops.f32_split) at forward time; backward re-enters it."""
+    return bool(getattr(ops._MODE, 'split', False))
+
+
 def _conv_forward(x, w_oihw, stride, pad):
     w = w_oihw.detach().permute(0, 2, 3, 1).contiguous()          # OHWI
     return ops.conv_bn_act(x, w, None, stride, pad, False)
@@ -35,10 +40,16 @@ class HipConv2d(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, weight)
         ctx.geom = (int(stride), int(pad))
+        ctx.split = _split_mode()
         return _conv_forward(x, weight, stride, pad)
 
     @staticmethod
     def backward(ctx, dy):
+        with ops.f32_split(ctx.split):
+            return HipConv2d._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, weight = ctx.saved_tensors
         stride, pad = ctx.geom
         dy = dy.contiguous()
@@ -80,6 +91,7 @@ class HipStemConv(torch.autograd.Function):
     def forward(ctx, x3, weight):
         x3 = x3.contiguous()                                                            # (F,H,W,3)
         ctx.save_for_backward(x3, weight)
+        ctx.split = _split_mode()
         xp = torch.nn.functional.pad(x3, (0, 29)).contiguous()
         wp = torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 29))
         return _conv_forward(xp, wp, 2, 3)
@@ -93,7 +105,8 @@ class HipStemConv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             xt = ops.im2col_t(x3, R, S, 2, 3)                                           # (147, M)
             dyt = ops.im2col_t(dy, 1, 1, 1, 0)                                          # (64, M)
-            dw = ops.gemm_nt_splitk(dyt, xt).view(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
+            with ops.f32_split(ctx.split):
+                dw = ops.gemm_nt_splitk(dyt, xt).view(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
         return None, dw
 
 
@@ -176,7 +189,17 @@ def stem_train(model, frames_nchw):
 
 
 def featuremaps_train(model, frames_nchw):
-    """GSTA.featuremaps (vmgn.py:280-290) under model.train() on the GPU -> x4_1, x4_2 as NCHW views for the tail."""
+    """GSTA.featuremaps (vmgn.py:280-290) under model.train() on the GPU -> x4_1, x4_2 as NCHW views for the tail.
+    ``model.hip_train_precision``: 'fp32' = exact-fp32 MFMA (bitwise an fp32 fma chain, the parity mode); 'bf16x3' = fp32 tensors,
+    every GEMM product as three bf16 MFMAs on the high / low halves of the operands (~1e-5 relative, 1.6 x the rate)."""
+    prec = getattr(model, 'hip_train_precision', 'fp32')
+    if prec not in ('fp32', 'bf16x3'):
+        raise ValueError("hip_train_precision must be 'fp32' or 'bf16x3', got {!r}".format(prec))
+    with ops.f32_split(prec == 'bf16x3'):
+        return _featuremaps_train(model, frames_nchw)
+
+
+def _featuremaps_train(model, frames_nchw):
     a = stem_train(model, frames_nchw)
     for stage in (model.layer1, model.layer2, model.layer3):
         for unit in stage:

@@ -179,6 +179,7 @@ class GSTA(nn.Module):
         self.hip_branch_streams = os.environ.get('AGRL_HIP_BRANCH_STREAMS', '0') != '0'
         self.hip_fuse_tail = os.environ.get('AGRL_HIP_FUSE_TAIL', '1') != '0'
         self.hip_train = os.environ.get('AGRL_HIP_TRAIN', '1') != '0'   # train-mode conv trunk (fwd + bwd) on the HIP kernels
+        self.hip_train_precision = os.environ.get('AGRL_HIP_TRAIN_PRECISION', 'fp32')   # 'fp32' exact | 'bf16x3' split-bf16 MFMA
         self._hip_packs = {}
 
     # ------------------------------------------------------------------ stock-torch path (CPU / train)

@@ -302,15 +302,16 @@ def config4_block(device):
     pids = torch.arange(4, device=device).repeat_interleave(4)
     ce = losses.CrossEntropyLabelSmooth(num_classes=ncls, use_gpu=True)
     htri = losses.TripletLoss(margin=0.3, soft=True)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=5e-4)
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     out = {"tracklets": B, "seq_len": S, "frames": B * S, "dtype": "fp32", "classes": ncls,
            "gflop_per_step": round(3 * 11.93 * B * S, 1)}
 
-    def run(native, steps=3):
+    def run(native, steps=3, precision="fp32"):
         m.load_state_dict(sd0)
         m.hip_train = native
+        m.hip_train_precision = precision
         m.train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=5e-4)
         ts, loss = [], None
         for i in range(steps + 1):
             torch.manual_seed(1234)
@@ -327,12 +328,15 @@ def config4_block(device):
         return min(ts), float(loss.detach())
     try:
         t_nat, l_nat = run(True)
+        t_x3, l_x3 = run(True, precision="bf16x3")
         t_ref, l_ref = run(False)
     except RuntimeError as e:  # noqa: BLE001  (out of memory on a small device)
         return {"error": str(e)[:200]}
     fl = 3 * 11.93e9 * B * S
     out["native_trunk"] = {"ms_per_step": round(1e3 * t_nat, 2), "frames_per_s": round(B * S / t_nat, 1), "tflops": round(fl / t_nat / 1e12, 1),
                            "last_loss": round(l_nat, 6)}
+    out["native_trunk_bf16x3"] = {"ms_per_step": round(1e3 * t_x3, 2), "frames_per_s": round(B * S / t_x3, 1),
+                                  "tflops": round(fl / t_x3 / 1e12, 1), "last_loss": round(l_x3, 6)}
     out["stock_torch"] = {"ms_per_step": round(1e3 * t_ref, 2), "frames_per_s": round(B * S / t_ref, 1), "tflops": round(fl / t_ref / 1e12, 1),
                           "last_loss": round(l_ref, 6)}
     out["peak_tflops"] = PEAK_TFLOPS["fp32"]

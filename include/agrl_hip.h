@@ -348,6 +348,14 @@ int agrl_triplet_hard_mine(const float* x, const int32_t* pids, int n, int d, fl
  * kernels of the path (reference call sites they replace: vmgn.py:142-172, distance.py:59-89). sink: one device float. */
 int agrl_diag_read_stream(const void* src, size_t bytes, float* sink, int workgroups, agrl_stream_t stream);
 
+/* Batch-hard triplet loss, value AND feature gradient in one call, no host round trip: the mining above, then
+ *   soft  : loss = mean_i log(1 + exp(d_ap_i - d_an_i))          margin: loss = mean_i max(0, d_ap_i - d_an_i + margin)
+ * (torchreid/losses/hard_mine_triplet_loss.py:45-50) and grad (n,d) = d loss / d x through the 2n selected distances
+ * (sqrt(clamp(., 1e-12)): a clamped distance passes no gradient). An anchor without any negative makes loss NaN.
+ *   loss fp32 (1); grad fp32 (n,d); dist_ap / dist_an / idx_ap / idx_an as agrl_triplet_hard_mine; coeff: scratch fp32 (2n). */
+int agrl_triplet_loss(const float* x, const int32_t* pids, int n, int d, float margin, int soft, float* loss, float* grad,
+                      float* dist_ap, float* dist_an, int32_t* idx_ap, int32_t* idx_an, float* coeff, agrl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -827,3 +827,30 @@ def test_triplet_mining_and_loss():
     assert rel_err(xd.grad, xr.grad) < 1e-4
     hard = losses.TripletLoss(margin=0.3, soft=False)(x.to(DEV), pids.to(DEV))
     assert abs(hard.item() - O.triplet_hard(x, pids, 0.3, soft=False)[0].item()) < 1e-5
+    # the fused native loss (agrl_triplet_loss: mining + value + feature gradient, no host round trip) against the REFERENCE's
+    # own TripletLoss (golden fixture: loss and d loss / d features, soft and margin form) ...
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "triplet.npz"))
+    n, d, seed = [int(v) for v in z["meta"]]
+    feats = torch.randn((n, d), generator=torch.Generator().manual_seed(seed))
+    gp = torch.from_numpy(z["pids"])
+    for soft, key in ((True, "soft"), (False, "margin")):
+        fx = feats.to(DEV).requires_grad_(True)
+        val = losses.TripletLoss(margin=0.3, soft=soft)(fx, gp.to(DEV))
+        (3.0 * val).backward()   # a non-trivial incoming gradient
+        assert abs(val.item() - float(z["loss_" + key])) < 1e-6
+        assert rel_err(fx.grad / 3.0, torch.from_numpy(z["grad_" + key])) < 1e-4
+    # ... an identity with a single sample (its hardest positive is itself: clamped distance, no gradient through it), tied
+    # features, and against the oracle with autograd
+    x2 = torch.randn((9, 256), generator=g)
+    x2[4] = x2[3]
+    p2 = torch.tensor([0, 0, 1, 1, 1, 2, 3, 3, 3])
+    for soft in (True, False):
+        a = x2.to(DEV).requires_grad_(True)
+        la = losses.TripletLoss(margin=0.3, soft=soft)(a, p2.to(DEV))
+        la.backward()
+        b = x2.clone().requires_grad_(True)
+        lb = O.triplet_hard(b, p2, 0.3, soft=soft)[0]
+        lb.backward()
+        assert abs(la.item() - lb.item()) < 1e-6 and rel_err(a.grad, b.grad) < 1e-4
+    # ... and an anchor without any negative: NaN loss instead of the reference's exception (no host sync to raise from)
+    assert torch.isnan(losses.TripletLoss()(x2[:3].to(DEV), torch.zeros(3, dtype=torch.long, device=DEV)))
