@@ -837,7 +837,7 @@ def test_triplet_mining_and_loss():
         fx = feats.to(DEV).requires_grad_(True)
         val = losses.TripletLoss(margin=0.3, soft=soft)(fx, gp.to(DEV))
         (3.0 * val).backward()   # a non-trivial incoming gradient
-        assert abs(val.item() - float(z["loss_" + key])) < 1e-6
+        assert abs(val.item() - float(z["loss_" + key])) < 2e-5 * max(1.0, abs(float(z["loss_" + key])))
         assert rel_err(fx.grad / 3.0, torch.from_numpy(z["grad_" + key])) < 1e-4
     # ... an identity with a single sample (its hardest positive is itself: clamped distance, no gradient through it), tied
     # features, and against the oracle with autograd
@@ -851,6 +851,6 @@ def test_triplet_mining_and_loss():
         b = x2.clone().requires_grad_(True)
         lb = O.triplet_hard(b, p2, 0.3, soft=soft)[0]
         lb.backward()
-        assert abs(la.item() - lb.item()) < 1e-6 and rel_err(a.grad, b.grad) < 1e-4
+        assert abs(la.item() - lb.item()) < 2e-5 * max(1.0, abs(lb.item())) and rel_err(a.grad, b.grad) < 1e-4
     # ... and an anchor without any negative: NaN loss instead of the reference's exception (no host sync to raise from)
     assert torch.isnan(losses.TripletLoss()(x2[:3].to(DEV), torch.zeros(3, dtype=torch.long, device=DEV)))
