@@ -234,15 +234,34 @@ def hip_features_pooled(model, frames, pack, splits):
     return gsum.view(gsum.shape[0], gsum.shape[2]), nodes, nodes_lp, 128
 
 
-def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None):
-    """GraphLayer x num_gb on (B,V,C) fp32 nodes. reference vmgn.py:311-312 -> :142-172."""
+def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False):
+    """GraphLayer x num_gb on (B,V,C) fp32 nodes. reference vmgn.py:311-312 -> :142-172.
+    ``overlap``: the adaptive graph (Gram partials + finalize: 2 short latency-bound launches) is built on a side HIP stream
+    while the Linear (a 448-workgroup GEMM that does not fill the chip either) runs on the main one -- both only read the
+    layer's input nodes; the message pass joins them."""
     lp = pack['dtype'] == torch.bfloat16
     B, V, C = nodes.shape
     n_layers = len(pack['graph'])
+    main = torch.cuda.current_stream(nodes.device)
+    side = _side_stream(nodes.device) if overlap else None
     for i, g in enumerate(pack['graph']):
         operand = nodes_lp if lp else nodes
-        h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
-        G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+        if side is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+                done = torch.cuda.Event()
+                done.record(side)
+            nodes.record_stream(side)
+            adj.record_stream(side)
+            h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
+            main.wait_event(done)
+            G.record_stream(main)
+        else:
+            h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
+            G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
         if stages is not None:
             stages['G%d' % i] = G
         nodes, nodes_lp = ops.graph_propagate(nodes, h, G, g['scale'], g['shift'], g['gamma'], g['slope'],
@@ -282,7 +301,7 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
         adj32 = adj.detach().to(torch.float32).contiguous()
         if stages is not None:
             stages.update(gsum=gsum, hw=hw, nodes=nodes)
-        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages)
+        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages, overlap=getattr(model, 'hip_gcn_overlap', False))
         sqn = ops.row_sqnorm(nodes.view(B * V, C))
         res = ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
                                    pack['a_bn'][1], B, S, P, hw, want_feats=return_feats or stages is not None)

@@ -1,10 +1,11 @@
 """Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/traffic_r01.json (the conv
 family = every igemm_* / conv3x3_* / bottleneck_tail kernel).
-usage: pmc_traffic.py <fetch_csv> <write_csv> <steps_total> <precision>
+usage: pmc_traffic.py <fetch_csv> <write_csv> <steps_total> <precision> [out.json]
 FETCH_SIZE / WRITE_SIZE are in KiB (x1024); on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide
 coalesced reads (MI355X_MICROARCH.md, HBM section) -> the read side is doubled."""
 import csv, json, sys, collections
 fetch_csv, write_csv, steps, prec = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r02.json"
 def load(path, counter):
     per = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(path)):
@@ -24,7 +25,7 @@ launches = fi[1]
 fetch_b = fi[0] * 1024 * 2.0   # gfx950 correction for wide coalesced reads
 write_b = wi[0] * 1024
 extra = {}
-for k in ("graph_propagate_stream_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel"):
+for k in ("graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel"):
     for kk in f:
         if k in kk and not (k == "conv3x3_wide_kernel" and kk != k):
             extra[k] = {"fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
@@ -34,4 +35,4 @@ out = {prec: {"igemm_launches": launches, "steps": steps, "other_kernels": extra
               "igemm_bytes_per_launch": (fetch_b + write_b) / launches,
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB units, FETCH_SIZE x2 (gfx950)"}}
 print(json.dumps(out, indent=1))
-json.dump(out, open("profiles/traffic_r01.json", "w"), indent=1)
+json.dump(out, open(out_path, "w"), indent=1)
