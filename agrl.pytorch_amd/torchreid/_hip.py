@@ -46,6 +46,7 @@ SIGNATURES = {
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_block": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_bottleneck_frame": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_conv1x1_dual_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_conv1x1_bn_act_pool": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_linear_nobias": [_p, _p, _p, _i, _i, _i, _i, _p],

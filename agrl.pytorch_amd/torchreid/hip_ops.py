@@ -229,6 +229,27 @@ def bottleneck_block(z, w2, b2, w3, b3, residual, w1_next, b1_next, shortcut=Non
     return out, zn
 
 
+def bottleneck_frame_supported(x, w1, w2, w3, stride, has_downsample):
+    """The frame-resident whole-block kernel exists for bf16 identity-shortcut blocks of width 256 on 16 x 8 maps (layer 3)."""
+    return (x.dtype == torch.bfloat16 and not has_downsample and stride == 1 and tuple(x.shape[1:3]) == (16, 8)
+            and tuple(w1.shape) == (256, 1, 1, x.shape[3]) and tuple(w2.shape) == (256, 3, 3, 256)
+            and tuple(w3.shape) == (x.shape[3], 1, 1, 256) and x.shape[3] % 256 == 0 and os.environ.get('AGRL_HIP_FUSE_FRAME', '1') != '0')
+
+
+def bottleneck_frame(x, w1, b1, w2, b2, w3, b3):
+    """out = relu(conv3(relu(conv2(relu(conv1(x))))) + x): a whole identity-shortcut Bottleneck in one pass, y1 / y2 LDS-resident.
+    vmgn.py:45-65. x (F,16,8,Cin) bf16 NHWC -> (F,16,8,Cin)."""
+    F_, H, W, Cin = x.shape
+    out = torch.empty_like(x)
+    if _hip.PROFILE is not None:
+        M = F_ * H * W
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * (Cin * 256 + 9 * 256 * 256 + 256 * Cin), "bytes": 2.0 * (2 * x.numel() + w1.numel() + w2.numel() + w3.numel()),
+                            "conv": (3, 1, 256, 256, H, W)}
+    with _dev(x):
+        call("agrl_bottleneck_frame", ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), F_, H, W, Cin, 256, _stream(x))
+    return out
+
+
 def linear_nobias(x, w):
     """(M,K) @ (N,K)^T -> fp32 (M,N). vmgn.py:148."""
     M, K = x.shape

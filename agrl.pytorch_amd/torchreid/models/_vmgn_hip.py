@@ -113,6 +113,10 @@ def _run_trunk(a, blocks, fuse_tail=True):
     z = None  # conv1 output of the current block, when the previous block's tail already computed it
     for i, blk in enumerate(blocks):
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        if z is None and fuse_tail and ops.bottleneck_frame_supported(a, blk['c1'][0], blk['c2'][0], blk['c3'][0], blk['stride'], blk['ds'] is not None):
+            # layer 3 identity blocks on 16 x 8 maps: the whole Bottleneck in one pass, one frame per workgroup (ops.bottleneck_frame)
+            a = ops.bottleneck_frame(a, blk['c1'][0], blk['c1'][1], blk['c2'][0], blk['c2'][1], blk['c3'][0], blk['c3'][1])
+            continue
         y = z if z is not None else ops.conv_bn_act(a, blk['c1'][0], blk['c1'][1], 1, 0, True)
         if fuse_tail and nxt is not None:
             # layer 1: 3x3 + conv3 (+ shortcut) + next conv1 in ONE pass over 8 x 8 pixel tiles (ops.bottleneck_block)

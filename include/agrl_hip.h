@@ -126,6 +126,15 @@ int agrl_bottleneck_block(const void* z, const void* w2, const float* b2, const 
                           void* out, const void* w1_next, const float* b1_next, void* z_next, int F, int H, int W,
                           int Cmid, int Cout, int Cnext, agrl_stream_t stream);
 
+/* A whole identity-shortcut Bottleneck on 16 x 8 maps (layer 3 of the 256 x 128 configuration) in ONE pass, one frame per
+ * workgroup (bf16; torchreid/models/vmgn.py:45-65 with the three BatchNorms folded):
+ *   y1 = relu(x @ w1^T + b1); y2 = relu(conv3x3(y1, w2, pad 1) + b2); out = relu(y2 @ w3^T + b3 + x)
+ * x, out (F,16,8,Cin); w1 (Cmid,Cin); w2 (Cmid,3,3,Cmid) OHWI; w3 (Cin,Cmid); biases fp32. y1 / y2 never leave the CU (the
+ * frame border is the 3x3 conv's zero padding, so a frame needs no halo), x is read from HBM once and out written once.
+ * Built for Cmid = 256, Cin a multiple of 256; other shapes are rejected (the caller runs the three convs separately). */
+int agrl_bottleneck_frame(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
+                          const float* b3, void* out, int F, int H, int W, int Cin, int Cmid, agrl_stream_t stream);
+
 /* y = x @ w^T (no bias): x (M,K) in_dtype, w (Nout,K) in_dtype, y (M,Nout) fp32.
  * Replaces GraphLayer's nn.Linear(2048,2048,bias=False), torchreid/models/vmgn.py:148. */
 int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,

@@ -262,6 +262,40 @@ def test_conv_wide_tile_strided(case, tile, monkeypatch):
     assert torch.equal(wide, narrow)
 
 
+@pytest.mark.parametrize("case", [(256, 1024), (3, 1024), (300, 1024), (5, 512), (2, 256)])
+def test_bottleneck_frame_resident(case, monkeypatch):
+    """agrl_bottleneck_frame: a whole identity-shortcut Bottleneck on 16 x 8 frames in one pass (y1 / y2 LDS-resident, three
+    weight matrices streamed) against the fp32 reference with the same bf16 roundings of y1 / y2 as the three separate
+    launches, and against those launches themselves; full layer-3 size (256 frames: one per CU), more frames than CUs (the
+    persistent walk), the frame borders (= the 3x3 conv's zero padding) included by construction."""
+    from torchreid import hip_ops as ops
+    Fr, Cin = case
+    g = torch.Generator().manual_seed(Fr + Cin)
+    x = torch.randn((Fr, Cin, 16, 8), generator=g).relu().bfloat16().float()
+    w1 = (torch.randn((256, Cin, 1, 1), generator=g) / np.sqrt(Cin)).bfloat16().float()
+    w2 = (torch.randn((256, 256, 3, 3), generator=g) / np.sqrt(9 * 256)).bfloat16().float()
+    w3 = (0.5 * torch.randn((Cin, 256, 1, 1), generator=g) / np.sqrt(256)).bfloat16().float()
+    b1, b2, b3 = (0.3 * torch.randn((c,), generator=g) for c in (256, 256, Cin))
+    y1 = F.relu(F.conv2d(x, w1, bias=b1)).bfloat16().float()
+    y2 = F.relu(F.conv2d(y1, w2, bias=b2, padding=1)).bfloat16().float()
+    ref = F.relu(F.conv2d(y2, w3, bias=b3) + x)
+    ohwi = lambda w: w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    xd = nhwc(x, torch.bfloat16)
+    args = (xd, ohwi(w1), b1.to(DEV), ohwi(w2), b2.to(DEV), ohwi(w3), b3.to(DEV))
+    assert ops.bottleneck_frame_supported(xd, args[1], args[3], args[5], 1, False)
+    out = ops.bottleneck_frame(*args)
+    a = ops.conv_bn_act(xd, args[1], args[2], 1, 0, True)
+    a = ops.conv_bn_act(a, args[3], args[4], 1, 1, True)
+    sep = ops.conv_bn_act(a, args[5], args[6], 1, 0, True, residual=xd)
+    again = ops.bottleneck_frame(*args)
+    torch.cuda.synchronize()
+    e, es = rel_err(out.float().permute(0, 3, 1, 2), ref), rel_err(sep.float().permute(0, 3, 1, 2), ref)
+    mism = (out != sep).float().mean().item()
+    print("frame-resident bottleneck", case, "rel err %.3e (three launches %.3e), %.4f %% of the outputs differ from the three launches" % (e, es, 100 * mism))
+    assert e < 6e-3 and torch.equal(out, again)
+    assert rel_err(out.float(), sep.float()) < 1e-2
+
+
 DUAL_CASES = [(256, 16, 8, 1024, 512, 2048), (3, 16, 8, 1024, 512, 2048), (90, 16, 8, 128, 64, 512), (81, 16, 8, 512, 256, 256)]
 
 
