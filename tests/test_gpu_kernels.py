@@ -282,7 +282,7 @@ def test_bottleneck_frame_resident(case, monkeypatch):
     ohwi = lambda w: w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
     xd = nhwc(x, torch.bfloat16)
     args = (xd, ohwi(w1), b1.to(DEV), ohwi(w2), b2.to(DEV), ohwi(w3), b3.to(DEV))
-    assert ops.bottleneck_frame_supported(xd, args[1], args[3], args[5], 1, False)
+    assert ops.bottleneck_frame_supported(xd, args[1], args[3], args[5], 1, False, force=True)
     out = ops.bottleneck_frame(*args)
     a = ops.conv_bn_act(xd, args[1], args[2], 1, 0, True)
     a = ops.conv_bn_act(a, args[3], args[4], 1, 1, True)
