@@ -544,6 +544,201 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------
+// The WHOLE message-pass unit of a GraphLayer (similarity + normalise + mix + G h + BatchNorm + LeakyReLU +
+// residual; everything of vmgn.py:155-172 but the Linear) in ONE launch, every byte of f / h / out crossing HBM exactly once.
+//
+// grid = (groups * NS), NS = C / 256 workgroups per tracklet, 256 threads = 4 waves, each wave 64 channels. A tracklet's
+// graph needs the Gram matrix over ALL channels before a single output can be formed, so its NS workgroups hand their partial
+// Gram matrices to each other INSIDE the launch:
+//   A  the workgroup loads its f slice (V x 256 fp32, 57 KB at V = 56) into LDS -- it stays there as the residual input of
+//      phase C -- and forms the partial Gram over its 256 channels with v_mfma_f32_16x16x4_f32 (exact fp32), stores it, and
+//      publishes: __syncthreads -> lane 0: agent-scope release fence -> s_waitcnt vmcnt(0) -> relaxed agent atomic add on the
+//      tracklet's counter (cdna_hip_programming.md Guideline 16, counter form; placement-independent);
+//      its h slice (the operand of phase C) is requested into registers BEFORE the wait, so the hand-off latency is covered;
+//   B  lane 0 polls the counter (relaxed, s_sleep) until all NS partials are in, ONE agent-scope acquire fence,
+//      __syncthreads; then every workgroup of the tracklet redundantly sums the NS partials in slice order (deterministic),
+//      d -> sim -> row-L1 normalise -> mix with the pose graph, into LDS (one wavefront per graph row);
+//   C  G h for the workgroup's channels (exact-fp32 MFMA, the channel <-> MFMA-row assignment of graph_propagate_stream_kernel)
+//      + BatchNorm + LeakyReLU + residual from the LDS-resident f -> out (+ bf16 copy).
+// All workgroups of a tracklet must be resident together: the host sizes the grid by the occupancy query (83 KB of LDS: one
+// workgroup per CU) and larger batches are walked persistently by `groups` tracklet groups. The spin is bounded (a lost
+// partner would otherwise hang the device): on time-out the workgroup raises the error word and carries on.
+template <int PS_NT>  // V = 4 PS_NT exactly, V <= 64
+__global__ __launch_bounds__(256) void graph_message_pass_kernel(
+    const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ adj, const float* __restrict__ bn_scale,
+    const float* __restrict__ bn_shift, float keep, float gamma, float slope, int use_pose, int learn_graph, int mask_diag,
+    float* __restrict__ out, bf16_t* __restrict__ out_lp, float* __restrict__ G_out, float* __restrict__ gram_part,
+    int* __restrict__ counters, int* __restrict__ err, int B, int C, int NS) {
+    constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4, VP = NVF * 16;
+    constexpr int ROWB = 256 * 4 + 16;                  // f slice row: 256 channels fp32 + 16 B (conflict-free fragment reads)
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    unsigned char* s_f = s_raw;                          // [VP][ROWB]
+    float* s_g = reinterpret_cast<float*>(s_raw + VP * ROWB);   // [VP][V] graph (rows >= V zero)
+    float* s_n = s_g + VP * V;                           // [V] squared norms
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x % NS, group = blockIdx.x / NS, ngroups = gridDim.x / NS;
+    const int i16 = lane & 15, kg = lane >> 4;
+    for (int b = group; b < B; b += ngroups) {
+        const size_t node0 = (size_t)b * V;
+        const int cs = s * 256;
+        // ---- A: f slice -> LDS (rows >= V zero)
+        {
+            const float* src = f + node0 * C + cs;
+            for (int e = tid; e < VP * 64; e += 256) {
+                const int r = e >> 6, q = e & 63;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < V) v = *reinterpret_cast<const float4*>(src + (size_t)r * C + q * 4);
+                *reinterpret_cast<float4*>(s_f + r * ROWB + q * 16) = v;
+            }
+        }
+        __syncthreads();
+        // this wave's h operand for phase C: requested now, consumed after the hand-off
+        const int c0 = cs + wave * 64;
+        const int cl = c0 + 4 * kg;
+        const int sig = 4 * (i16 & 3) + (i16 >> 2);
+        f32x4_t hreg[PS_NT];
+        {
+            const float* hb = h + node0 * C + c0 + 4 * sig;
+#pragma unroll
+            for (int t = 0; t < PS_NT; ++t) hreg[t] = *reinterpret_cast<const f32x4_t*>(hb + (size_t)(4 * t + kg) * C);
+        }
+        if (learn_graph) {
+            float* dst = gram_part + ((size_t)b * NS + s) * V * V;
+            const int frow = lane & 15, fch = lane >> 4;
+            for (int fr = wave; fr < NVF * NVF; fr += 4) {
+                const int fi = fr / NVF, fj = fr - fi * NVF;
+                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+                const unsigned char* pa = s_f + (fi * 16 + frow) * ROWB + fch * 16;
+                const unsigned char* pb = s_f + (fj * 16 + frow) * ROWB + fch * 16;
+#pragma unroll 4
+                for (int ks = 0; ks < 16; ++ks) {
+                    const float4 av = *reinterpret_cast<const float4*>(pa + ks * 64);
+                    const float4 bv = *reinterpret_cast<const float4*>(pb + ks * 64);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+                }
+                const int j = fj * 16 + frow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = fi * 16 + fch * 4 + r;
+                    if (i < V && j < V) dst[(size_t)i * V + j] = acc[r];
+                }
+            }
+            // publish this slice's partial (Guideline 16, counter form)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&counters[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // ---- B: wait for the NS - 1 partners (bounded: a partner that never arrives must not hang the device)
+                int spins = 0;
+                while (__hip_atomic_load(&counters[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NS) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            const float* gp = gram_part + (size_t)b * NS * V * V;
+            for (int j = tid; j < V; j += 256) {
+                float n = 0.f;
+                for (int z = 0; z < NS; ++z) n += gp[(size_t)z * V * V + (size_t)j * V + j];
+                s_n[j] = n;
+            }
+            __syncthreads();
+        }
+        // graph rows: one wavefront per row (V <= 64: one column per lane)
+        for (int i = wave; i < VP; i += 4) {
+            float g = 0.f;
+            if (i < V) {
+                float sim = 0.f, av = 0.f;
+                const bool live = lane < V;
+                if (learn_graph && live) {
+                    const float* gp = gram_part + (size_t)b * NS * V * V + (size_t)i * V + lane;
+                    float part[8], gsum = 0.f;
+                    for (int z0 = 0; z0 < NS; z0 += 8) {
+#pragma unroll
+                        for (int z = 0; z < 8; ++z) part[z] = z0 + z < NS ? gp[(size_t)(z0 + z) * V * V] : 0.f;
+#pragma unroll
+                        for (int z = 0; z < 8; ++z)
+                            if (z0 + z < NS) gsum += part[z];
+                    }
+                    float d2 = (s_n[lane] + s_n[i]) - 2.f * gsum;
+                    d2 = fmaxf(d2, 1e-12f);
+                    sim = 2.f / (expf(sqrtf(d2)) + 1.f);
+                    if (mask_diag && lane == i) sim = 0.f;
+                }
+                if (use_pose && live) {
+                    av = adj[(node0 + i) * V + lane];
+                    if (mask_diag && lane == i) av = 0.f;
+                }
+                const float sden = fmaxf(wave_sum(fabsf(sim)), 1e-12f), aden = fmaxf(wave_sum(fabsf(av)), 1e-12f);
+                if (learn_graph) {
+                    g = sim / sden;
+                    if (use_pose) g = (av / aden + g) / 2.f;
+                } else {
+                    g = av / aden;
+                }
+                if (live && G_out && s == 0) G_out[(node0 + i) * V + lane] = g;
+            }
+            if (lane < V) s_g[i * V + lane] = g;
+        }
+        __syncthreads();
+        // ---- C: G h + BatchNorm + LeakyReLU + residual (f from LDS)
+        {
+            f32x4_t acc[NVF][4];
+#pragma unroll
+            for (int vf = 0; vf < NVF; ++vf)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[vf][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < PS_NT; ++t) {
+                float gq[NVF];
+#pragma unroll
+                for (int vf = 0; vf < NVF; ++vf) gq[vf] = s_g[(vf * 16 + i16) * V + 4 * t + kg];
+#pragma unroll
+                for (int vf = 0; vf < NVF; ++vf)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[vf][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[t][j], gq[vf], acc[vf][j], 0, 0, 0);
+            }
+            // D_j row 4 kg + r = channel cl + 16 r + j -> float4 r = {acc[vf][0..3][r]}
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 sc = *reinterpret_cast<const float4*>(bn_scale + cl + 16 * r);
+                const float4 sh = *reinterpret_cast<const float4*>(bn_shift + cl + 16 * r);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                for (int vf = 0; vf < NVF; ++vf) {
+                    const int v = vf * 16 + i16;
+                    if (v >= V) continue;
+                    const float4 fv4 = *reinterpret_cast<const float4*>(s_f + v * ROWB + (wave * 64 + 4 * kg + 16 * r) * 4);
+                    const float fv[4] = {fv4.x, fv4.y, fv4.z, fv4.w};
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float y = fmaf(acc[vf][j][r], scv[j], shv[j]);
+                        y = y > 0.f ? y : slope * y;
+                        o[j] = keep * fv[j] + gamma * y;
+                    }
+                    const size_t idx = (node0 + v) * C + cl + 16 * r;
+                    *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (out_lp) *reinterpret_cast<uint2*>(out_lp + idx) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                }
+            }
+        }
+        __syncthreads();  // s_f / s_g are rewritten by the next tracklet
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Pose adjacency on the device: generate_graph + adj_graph(method 'same'), torchreid/dataset_loader.py:218-388.
 // One workgroup per tracklet. Per frame and body part (head / body / leg keypoint groups) the confident keypoints'
 // y coordinates are bucketed into horizontal stripes (bisect_right on the stripe borders, clamped), the stripes
@@ -716,6 +911,66 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     LAUNCH_PROP(0);
 #undef LAUNCH_PROP
     AGRL_CHECK_LAUNCH("agrl_graph_propagate");
+    return 0;
+}
+
+
+extern "C" size_t agrl_graph_message_pass_workspace(int B, int V, int C) {
+    const int NS = C / 256;
+    return (size_t)B * NS * V * V * sizeof(float) + ((size_t)B + 1) * sizeof(int) + 256;
+}
+
+extern "C" int agrl_graph_message_pass(const float* f, const float* h, const float* adj, const float* bn_scale,
+                                       const float* bn_shift, float keep, float gamma, float slope, int use_pose,
+                                       int learn_graph, int mask_diag, float* out, void* out_lp, float* G_out, void* workspace,
+                                       size_t workspace_bytes, int B, int V, int C, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(f && h && bn_scale && bn_shift && out && workspace, "agrl_graph_message_pass: null pointer");
+    AGRL_CHECK_ARG(use_pose || learn_graph, "agrl_graph_message_pass: use_pose or learn_graph must be set");
+    AGRL_CHECK_ARG(!use_pose || adj, "agrl_graph_message_pass: use_pose needs adj");
+    AGRL_CHECK_ARG(B > 0 && V > 0 && V <= 64 && (V % 4) == 0 && C >= 256 && (C % 256) == 0,
+                   "agrl_graph_message_pass: built for V <= 64, V %% 4 == 0, C %% 256 == 0 (got V=%d C=%d): use the three-kernel path", V, C);
+    AGRL_CHECK_ARG(workspace_bytes >= agrl_graph_message_pass_workspace(B, V, C), "agrl_graph_message_pass: workspace too small");
+    const uintptr_t al = (uintptr_t)f | (uintptr_t)h | (uintptr_t)out | (uintptr_t)out_lp | (uintptr_t)bn_scale | (uintptr_t)bn_shift | (uintptr_t)workspace;
+    AGRL_CHECK_ARG((al & 15) == 0, "agrl_graph_message_pass: operands must be 16-byte aligned");
+    const int NS = C / 256;
+    const int nvf = (V + 15) / 16, VP = nvf * 16;
+    const size_t lds = (size_t)VP * (256 * 4 + 16) + (size_t)VP * V * 4 + (size_t)V * 4;
+    float* gram_part = (float*)workspace;
+    int* counters = (int*)((char*)workspace + (((size_t)B * NS * V * V * sizeof(float) + 15) & ~(size_t)15));
+    int* err = counters + B;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(counters, 0, ((size_t)B + 1) * sizeof(int), st);
+    AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_message_pass: memset failed: %s", hipGetErrorString(e));
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+#define LAUNCH_MP(NT_)                                                                                                         \
+    case NT_: {                                                                                                                \
+        const void* fn = (const void*)graph_message_pass_kernel<NT_>;                                                          \
+        if (lds > 64 * 1024) {                                                                                                 \
+            hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
+            AGRL_CHECK_ARG(ea == hipSuccess, "agrl_graph_message_pass: cannot raise dynamic LDS: %s", hipGetErrorString(ea));  \
+        }                                                                                                                      \
+        int per_cu = 0;                                                                                                        \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;       \
+        /* every workgroup of the grid must be resident at once (the in-launch hand-off): whole tracklet groups only, with a */ \
+        /* margin of one workgroup per CU below the occupancy query's answer where it allows more than one                  */ \
+        int slots = n_cu * (per_cu > 1 ? per_cu - 1 : 1);                                                                      \
+        int groups = slots / NS;                                                                                               \
+        if (groups < 1) groups = 1;                                                                                            \
+        if (groups > B) groups = B;                                                                                            \
+        AGRL_CHECK_ARG(groups * NS <= n_cu * per_cu, "agrl_graph_message_pass: C / 256 = %d workgroups per tracklet do not fit the device", NS); \
+        hipLaunchKernelGGL(graph_message_pass_kernel<NT_>, dim3(groups * NS), dim3(256), lds, st, f, h, adj, bn_scale, bn_shift, keep, gamma, \
+                           slope, use_pose, learn_graph, mask_diag, out, (bf16_t*)out_lp, G_out, gram_part, counters, err, B, C, NS); \
+    } break
+    switch (V / 4) {
+        LAUNCH_MP(1); LAUNCH_MP(2); LAUNCH_MP(3); LAUNCH_MP(4); LAUNCH_MP(5); LAUNCH_MP(6); LAUNCH_MP(7); LAUNCH_MP(8);
+        LAUNCH_MP(9); LAUNCH_MP(10); LAUNCH_MP(11); LAUNCH_MP(12); LAUNCH_MP(13); LAUNCH_MP(14); LAUNCH_MP(15); LAUNCH_MP(16);
+    }
+#undef LAUNCH_MP
+    AGRL_CHECK_LAUNCH("agrl_graph_message_pass");
     return 0;
 }
 

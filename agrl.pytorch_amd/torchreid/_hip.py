@@ -57,6 +57,8 @@ SIGNATURES = {
     "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _i, _p],
     "agrl_pam_pool": [_p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_pam_combine": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
+    "agrl_graph_message_pass_workspace": [_i, _i, _i],   # returns size_t
+    "agrl_graph_message_pass": [_p, _p, _p, _p, _p, _f, _f, _f, _i, _i, _i, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _p],
     "agrl_row_sqnorm": [_p, _p, _i, _i, _i, _p],
     "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _i, _p],
@@ -110,6 +112,7 @@ def lib():
             fn.restype = _i
         h.agrl_re_ranking_workspace.restype = C.c_size_t
         h.agrl_bn_workspace.restype = C.c_size_t
+        h.agrl_graph_message_pass_workspace.restype = C.c_size_t
         for name in ("agrl_reload_options", "agrl_built_with_ablation"):
             getattr(h, name).argtypes = []
             getattr(h, name).restype = _i

@@ -351,6 +351,36 @@ def pam_combine(y, bv, xmean, gamma, want_lp):
     return nodes, nodes_lp
 
 
+def graph_message_pass_supported(f):
+    """The one-launch message pass exists for V <= 64, V % 4 == 0, C % 256 == 0 (AGRL_HIP_GCN_FUSED=0 turns it off)."""
+    B, V, Cc = f.shape
+    return V <= 64 and V % 4 == 0 and Cc % 256 == 0 and os.environ.get('AGRL_HIP_GCN_FUSED', '1') != '0'
+
+
+def graph_message_pass(f, h, adj, bn_scale, bn_shift, gamma, slope, use_pose, learn_graph, want_lp, keep=None, mask_diag=False,
+                       want_graph=False):
+    """The whole message-pass unit of a GraphLayer in one launch: -> out (B,V,C) fp32, out_lp bf16 | None, G (B,V,V) | None.
+    vmgn.py:155-172 (ganet.py:253-283 with mask_diag, keep = 1)."""
+    B, V, Cc = f.shape
+    if keep is None:
+        keep = 1.0 - float(gamma)
+    out = torch.empty_like(f)
+    out_lp = torch.empty((B, V, Cc), dtype=torch.bfloat16, device=f.device) if want_lp else None
+    G = torch.empty((B, V, V), dtype=torch.float32, device=f.device) if want_graph else None
+    nbytes = int(_hip.lib().agrl_graph_message_pass_workspace(B, V, Cc))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=f.device)
+    if use_pose:
+        assert adj is not None and tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32
+        adj = adj.contiguous()
+    if _hip.PROFILE is not None:  # SURVEY 8(d): read f + read h + read adj + write out
+        _hip.PROFILE_TAG = {"flops": 2.0 * B * V * V * Cc * 2, "bytes": 4.0 * (3 * B * V * Cc + B * V * V)}
+    with _dev(f):
+        call("agrl_graph_message_pass", ptr(f), ptr(h), ptr(adj) if use_pose else None, ptr(bn_scale), ptr(bn_shift), float(keep),
+             float(gamma), float(slope), 1 if use_pose else 0, 1 if learn_graph else 0, 1 if mask_diag else 0, ptr(out), ptr(out_lp),
+             ptr(G), ptr(ws), nbytes, B, V, Cc, _stream(f))
+    return out, out_lp, G
+
+
 def clip_pool(feats, num_clips, mode="avg"):
     """(T*num_clips, D) fp32 -> (T, D): mean / max over each tracklet's clips. train_vidreid_xent_htri.py:471-476."""
     assert feats.dtype == torch.float32 and feats.dim() == 2 and feats.size(0) % num_clips == 0 and mode in ("avg", "max")

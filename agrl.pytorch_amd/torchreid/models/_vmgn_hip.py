@@ -250,6 +250,14 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False):
     side = _side_stream(nodes.device) if overlap else None
     for i, g in enumerate(pack['graph']):
         operand = nodes_lp if lp else nodes
+        if ops.graph_message_pass_supported(nodes):
+            # the whole message-pass unit (Gram -> graph -> G h -> BN -> LeakyReLU -> residual) in one launch
+            h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
+            nodes, nodes_lp, G = ops.graph_message_pass(nodes, h, adj, g['scale'], g['shift'], g['gamma'], g['slope'], g['use_pose'],
+                                                        g['learn_graph'], want_lp=lp and i + 1 < n_layers, want_graph=stages is not None)
+            if stages is not None:
+                stages['G%d' % i] = G
+            continue
         if side is not None:
             ready = torch.cuda.Event()
             ready.record(main)

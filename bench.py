@@ -636,8 +636,8 @@ def main():
             return nbytes / (best * 1e-3) / 1e9
 
         V, Cc, n_layers = S * 7, 2048, 2
-        gcn_names = [n for n in ("agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_matrix", "agrl_graph_propagate") if n in agg]
-        if "agrl_graph_propagate" in agg:
+        gcn_names = [n for n in ("agrl_graph_message_pass", "agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_propagate") if n in agg]
+        if gcn_names:
             ms = sum(agg[n]["ms"] for n in gcn_names)
             unit_bytes = GCN_UNIT_BYTES(V, Cc) * B            # per launch set (one layer, B tracklets)
             gbs = unit_bytes * n_layers * nprof / (ms * 1e-3) / 1e9
@@ -647,7 +647,7 @@ def main():
                 "bytes_per_layer": unit_bytes, "us_per_layer": round(1e3 * ms / (n_layers * nprof), 2),
                 "kernels": {n: round(1e3 * agg[n]["ms"] / agg[n]["launches"], 2) for n in gcn_names},
                 "what": "SURVEY 8(d) message-pass unit (sim + normalise + mix + G h + BN + LeakyReLU + residual; Linear excluded): "
-                        "1.389 MB per tracklet-layer over the time of ALL its kernels",
+                        "1.389 MB per tracklet-layer over the time of ALL its kernels (one launch: agrl_graph_message_pass)",
                 "read_stream_yardstick_gbs": round(ygbs, 1), "frac_of_yardstick": round(gbs / ygbs, 4)}
         if "agrl_distmat" in agg and agg["agrl_distmat"]["bytes"]:
             names = [n for n in ("agrl_distmat", "agrl_row_l2_normalize") if n in agg]

@@ -193,6 +193,22 @@ int agrl_graph_propagate(const float* f, const float* h, const float* G, const f
                          const float* bn_shift, float keep, float gamma, float slope, float* out, void* out_lp,
                          int B, int V, int C, agrl_stream_t stream);
 
+/* The whole message-pass unit of a GraphLayer in ONE launch (everything of torchreid/models/vmgn.py:155-172 but the Linear:
+ * Gram -> similarity -> row-L1 normalise -> mix with the pose graph -> G h -> BatchNorm1d(eval) -> LeakyReLU -> residual mix;
+ * ganet.py:253-283 with mask_diag = 1, keep = 1): f, h and out cross HBM exactly once. The C / 256 workgroups of a tracklet
+ * exchange their partial Gram matrices inside the launch (agent-scope release / acquire through `workspace`), so the entry
+ * point sizes the grid to what is resident at once and walks larger batches persistently. Same arithmetic and summation
+ * order as agrl_graph_gram (slices of 256 channels) + agrl_graph_finalize + agrl_graph_propagate.
+ *   f, h fp32 (B,V,C); adj fp32 (B,V,V) or NULL; out fp32 (B,V,C); out_lp NULL or bf16 copy; G_out NULL or fp32 (B,V,V);
+ *   workspace >= agrl_graph_message_pass_workspace(B, V, C) bytes of device memory (zeroed counters are set up inside).
+ * Built for V <= 64, V % 4 == 0, C % 256 == 0 (the MARS / PRID clip lengths); other shapes are rejected and the caller uses the
+ * three entry points above. */
+size_t agrl_graph_message_pass_workspace(int B, int V, int C);
+int agrl_graph_message_pass(const float* f, const float* h, const float* adj, const float* bn_scale, const float* bn_shift,
+                            float keep, float gamma, float slope, int use_pose, int learn_graph, int mask_diag, float* out,
+                            void* out_lp, float* G_out, void* workspace, size_t workspace_bytes, int B, int V, int C,
+                            agrl_stream_t stream);
+
 /* ---- position-attention part nodes (sibling model ganet) ---------------------------------------------- */
 
 /* Per frame and pyramid slice (h / n rows of the h x w map, n over splits; remainder rows dropped as the reference does):

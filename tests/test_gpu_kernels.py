@@ -578,6 +578,48 @@ def test_pam_pool(shape, dtype):
     assert torch.equal(xmean, xmean0) and rel_err(nodes_lp.float(), nodes) < 5e-3
 
 
+@pytest.mark.parametrize("cfg", [(3, 56, 2048, True, True, False), (3, 28, 2048, True, False, False), (2, 20, 1024, False, True, False),
+                                 (40, 56, 2048, True, True, False), (3, 64, 512, True, True, False), (3, 56, 2048, True, True, True),
+                                 (300, 8, 256, True, True, False)])
+def test_graph_message_pass_one_launch(cfg):
+    """agrl_graph_message_pass: the whole message-pass unit in ONE launch (the tracklet's C / 256 workgroups exchange their
+    partial Gram matrices inside the launch) against the oracle and against the three-kernel path: a few tracklets, more
+    tracklet groups than the device holds at once (B = 40, 300: the persistent walk), pose-only / learned-only graphs, V = 64
+    (full fragments), and ganet's diagonal-masked form with keep = 1; run twice (the in-launch hand-off must not depend on
+    stale counters) and bitwise repeatable."""
+    from torchreid import hip_ops as ops
+    from recipe import synthetic_adj
+    B, V, C, use_pose, learn_graph, masked = cfg
+    g = torch.Generator().manual_seed(B + V + C)
+    base = torch.rand((B, 1, C), generator=g)
+    f = base + 0.02 * torch.randn((B, V, C), generator=g)
+    adj = synthetic_adj(B, V // 7, seed=V) if V % 7 == 0 else (torch.rand((B, V, V), generator=g) > 0.5).float()
+    W = torch.randn((C, C), generator=g) * 0.02
+    sd = {"gl.linear.weight": W, "gl.bn.weight": 0.8 + 0.4 * torch.rand(C, generator=g), "gl.bn.bias": 0.1 * torch.randn(C, generator=g),
+          "gl.bn.running_mean": 0.1 * torch.randn(C, generator=g), "gl.bn.running_var": 0.5 + torch.rand(C, generator=g)}
+    if masked:
+        ref = O.ganet_graph_layer(f, adj, sd, "gl", use_pose, learn_graph, gamma=0.1)
+        keep = 1.0
+    else:
+        ref = O.graph_layer(f, adj, sd, "gl", use_pose, learn_graph)
+        keep = None
+    fd, adjd = f.to(DEV), adj.to(DEV)
+    h = ops.linear_nobias(fd.view(B * V, C), W.to(DEV)).view(B, V, C)
+    scale = (sd["gl.bn.weight"] / torch.sqrt(sd["gl.bn.running_var"] + 1e-5)).to(DEV)
+    shift = (sd["gl.bn.bias"] - sd["gl.bn.running_mean"] * scale.cpu()).to(DEV)
+    assert ops.graph_message_pass_supported(fd)
+    out, out_lp, G = ops.graph_message_pass(fd, h, adjd, scale, shift, 0.1, 0.1, use_pose, learn_graph, want_lp=True, keep=keep,
+                                            mask_diag=masked, want_graph=True)
+    out2, _, _ = ops.graph_message_pass(fd, h, adjd, scale, shift, 0.1, 0.1, use_pose, learn_graph, want_lp=False, keep=keep, mask_diag=masked)
+    G3 = ops.graph_matrix(fd, adjd, use_pose, learn_graph, mask_diag=masked)
+    out3, _ = ops.graph_propagate(fd, h, G3, scale, shift, 0.1, 0.1, want_lp=False, keep=keep)
+    torch.cuda.synchronize()
+    e_ref, e3, eG = rel_err(out, ref), rel_err(out, out3), rel_err(G, G3)
+    print("one-launch message pass", cfg, "vs oracle %.2e | vs three kernels: out %.2e G %.2e" % (e_ref, e3, eG))
+    assert torch.equal(out, out2)
+    assert e_ref < 1e-3 and e3 < 1e-5 and eG < 1e-3 and rel_err(out_lp.float(), out) < 5e-3
+
+
 def test_attention_tail():
     from torchreid import hip_ops as ops
     B, S, P, C, hw = 3, 8, 7, 2048, 128
