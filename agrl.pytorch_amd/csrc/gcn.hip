@@ -582,27 +582,32 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
     for (int b = group; b < B; b += ngroups) {
         const size_t node0 = (size_t)b * V;
         const int cs = s * 256;
-        // ---- A: f slice -> LDS (rows >= V zero)
-        {
-            const float* src = f + node0 * C + cs;
-            for (int e = tid; e < VP * 64; e += 256) {
-                const int r = e >> 6, q = e & 63;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < V) v = *reinterpret_cast<const float4*>(src + (size_t)r * C + q * 4);
-                *reinterpret_cast<float4*>(s_f + r * ROWB + q * 16) = v;
-            }
-        }
-        __syncthreads();
-        // this wave's h operand for phase C: requested now, consumed after the hand-off
+        // this wave's h operand for phase C and the f slice: ALL requested up front (one latency, not two), h consumed after the hand-off
         const int c0 = cs + wave * 64;
         const int cl = c0 + 4 * kg;
         const int sig = 4 * (i16 & 3) + (i16 >> 2);
         f32x4_t hreg[PS_NT];
+        // ---- A: f slice -> LDS (rows >= V zero)
         {
-            const float* hb = h + node0 * C + c0 + 4 * sig;
+            // all of a thread's loads are issued before its first LDS store (a load -> store loop is a chain of HBM round trips)
+            const float* src = f + node0 * C + cs;
+            constexpr int NLD = VP * 64 / 256;   // float4 per thread: row 4 i + (tid >> 6), float4 column tid & 63
+            float4 v[NLD];
 #pragma unroll
-            for (int t = 0; t < PS_NT; ++t) hreg[t] = *reinterpret_cast<const f32x4_t*>(hb + (size_t)(4 * t + kg) * C);
+            for (int i = 0; i < NLD; ++i) {
+                const int r = 4 * i + (tid >> 6);
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < V) v[i] = *reinterpret_cast<const float4*>(src + (size_t)r * C + (tid & 63) * 4);
+            }
+            {
+                const float* hb = h + node0 * C + c0 + 4 * sig;
+#pragma unroll
+                for (int t = 0; t < PS_NT; ++t) hreg[t] = *reinterpret_cast<const f32x4_t*>(hb + (size_t)(4 * t + kg) * C);
+            }
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4*>(s_f + (4 * i + (tid >> 6)) * ROWB + (tid & 63) * 16) = v[i];
         }
+        __syncthreads();
         if (learn_graph) {
             float* dst = gram_part + ((size_t)b * NS + s) * V * V;
             const int frow = lane & 15, fch = lane >> 4;
@@ -624,15 +629,15 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = fi * 16 + fch * 4 + r;
-                    if (i < V && j < V) dst[(size_t)i * V + j] = acc[r];
+                    // write-through (sc1) stores: the partial is published without a release fence (which would write back the
+                    // XCD's whole dirty L2: ~6.5 us with a fresh 12.5 KB slab per workgroup), read back below with sc1 loads
+                    if (i < V && j < V) __hip_atomic_store(&dst[(size_t)i * V + j], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            // publish this slice's partial (Guideline 16, counter form)
+            // publish this slice's partial (Guideline 16: sc1 payload -> every wave drains its stores -> barrier -> relaxed counter)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __hip_atomic_fetch_add(&counters[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // ---- B: wait for the NS - 1 partners (bounded: a partner that never arrives must not hang the device)
                 int spins = 0;
@@ -643,15 +648,38 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
                         break;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            const float* gp = gram_part + (size_t)b * NS * V * V;
-            for (int j = tid; j < V; j += 256) {
-                float n = 0.f;
-                for (int z = 0; z < NS; ++z) n += gp[(size_t)z * V * V + (size_t)j * V + j];
-                s_n[j] = n;
+            // Gram = sum of the NS partials in slice order, every element by one thread, all of a thread's loads in flight at once
+            // (sc1 loads: served by L2, never by this CU's possibly stale L1) -> LDS; its diagonal = the squared norms
+            {
+                const float* gp = gram_part + (size_t)b * NS * V * V;
+                constexpr int NEL = (V * V + 255) / 256;
+                for (int z0 = 0; z0 < NS; z0 += 8) {
+                    float part[NEL][8];
+#pragma unroll
+                    for (int i = 0; i < NEL; ++i) {
+                        const int e = tid + 256 * i;
+#pragma unroll
+                        for (int z = 0; z < 8; ++z)
+                            part[i][z] = (e < V * V && z0 + z < NS)
+                                             ? __hip_atomic_load(&gp[(size_t)(z0 + z) * V * V + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NEL; ++i) {
+                        const int e = tid + 256 * i;
+                        if (e < V * V) {
+                            float acc = z0 ? s_g[e] : 0.f;
+#pragma unroll
+                            for (int z = 0; z < 8; ++z)
+                                if (z0 + z < NS) acc += part[i][z];
+                            s_g[e] = acc;
+                        }
+                    }
+                }
             }
+            __syncthreads();
+            for (int j = tid; j < V; j += 256) s_n[j] = s_g[j * V + j];
             __syncthreads();
         }
         // graph rows: one wavefront per row (V <= 64: one column per lane)
@@ -661,15 +689,7 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
                 float sim = 0.f, av = 0.f;
                 const bool live = lane < V;
                 if (learn_graph && live) {
-                    const float* gp = gram_part + (size_t)b * NS * V * V + (size_t)i * V + lane;
-                    float part[8], gsum = 0.f;
-                    for (int z0 = 0; z0 < NS; z0 += 8) {
-#pragma unroll
-                        for (int z = 0; z < 8; ++z) part[z] = z0 + z < NS ? gp[(size_t)(z0 + z) * V * V] : 0.f;
-#pragma unroll
-                        for (int z = 0; z < 8; ++z)
-                            if (z0 + z < NS) gsum += part[z];
-                    }
+                    const float gsum = s_g[i * V + lane];   // rewritten in place below: the wave owns the row
                     float d2 = (s_n[lane] + s_n[i]) - 2.f * gsum;
                     d2 = fmaxf(d2, 1e-12f);
                     sim = 2.f / (expf(sqrtf(d2)) + 1.f);
@@ -946,15 +966,19 @@ extern "C" int agrl_graph_message_pass(const float* f, const float* h, const flo
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
+    // per instantiation, once per process: raise the dynamic-LDS limit and ask how many workgroups a CU holds (both are host
+    // calls of several microseconds; the launch path itself is the memset + one launch)
 #define LAUNCH_MP(NT_)                                                                                                         \
     case NT_: {                                                                                                                \
-        const void* fn = (const void*)graph_message_pass_kernel<NT_>;                                                          \
-        if (lds > 64 * 1024) {                                                                                                 \
-            hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                   \
-            AGRL_CHECK_ARG(ea == hipSuccess, "agrl_graph_message_pass: cannot raise dynamic LDS: %s", hipGetErrorString(ea));  \
-        }                                                                                                                      \
-        int per_cu = 0;                                                                                                        \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;       \
+        static const int per_cu_cached = [] {                                                                                  \
+            const void* fn = (const void*)graph_message_pass_kernel<NT_>;                                                      \
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+            constexpr int V_ = 4 * NT_, VP_ = ((NT_ + 3) / 4) * 16;                                                            \
+            int n = 0;                                                                                                         \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, (size_t)VP_ * (256 * 4 + 16) + (size_t)VP_ * V_ * 4 + V_ * 4) != hipSuccess || n < 1) n = 1; \
+            return n;                                                                                                          \
+        }();                                                                                                                   \
+        const int per_cu = per_cu_cached;                                                                                      \
         /* every workgroup of the grid must be resident at once (the in-launch hand-off): whole tracklet groups only, with a */ \
         /* margin of one workgroup per CU below the occupancy query's answer where it allows more than one                  */ \
         int slots = n_cu * (per_cu > 1 ? per_cu - 1 : 1);                                                                      \

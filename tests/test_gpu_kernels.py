@@ -607,7 +607,7 @@ def test_graph_message_pass_one_launch(cfg):
     h = ops.linear_nobias(fd.view(B * V, C), W.to(DEV)).view(B, V, C)
     scale = (sd["gl.bn.weight"] / torch.sqrt(sd["gl.bn.running_var"] + 1e-5)).to(DEV)
     shift = (sd["gl.bn.bias"] - sd["gl.bn.running_mean"] * scale.cpu()).to(DEV)
-    assert ops.graph_message_pass_supported(fd)
+    assert ops.graph_message_pass_supported(fd, force=True)
     out, out_lp, G = ops.graph_message_pass(fd, h, adjd, scale, shift, 0.1, 0.1, use_pose, learn_graph, want_lp=True, keep=keep,
                                             mask_diag=masked, want_graph=True)
     out2, _, _ = ops.graph_message_pass(fd, h, adjd, scale, shift, 0.1, 0.1, use_pose, learn_graph, want_lp=False, keep=keep, mask_diag=masked)
