@@ -26,7 +26,7 @@ namespace {
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                         const float* __restrict__ out, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, int relu, int M, int C,
+                                                        const float* __restrict__ invstd, int relu, float slope, int M, int C,
                                                         int rows_per_chunk, double* __restrict__ partial) {
     __shared__ float s_a[4][64], s_b[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
                 b = fmaf(v, v, b);
             } else {
                 float dz = dout[i];
-                if (relu && !(out[i] > 0.f)) dz = 0.f;
+                if (relu && !(out[i] > 0.f)) dz *= slope;   // ReLU: slope 0; LeakyReLU keeps the sign, so out > 0 <=> pre-activation > 0
                 a += dz;
                 b = fmaf(dz, (y[i] - mu) * is, b);
             }
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __re
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
-                                                       float* __restrict__ out, int relu, size_t total4, int C4) {
+                                                       float* __restrict__ out, int relu, float slope, size_t total4, int C4) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
         const int c4 = (int)(e % C4);
         const float4 v = reinterpret_cast<const float4*>(y)[e];
@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             const float4 r = reinterpret_cast<const float4*>(res)[e];
             o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (relu) {
+            o.x = o.x > 0.f ? o.x : slope * o.x; o.y = o.y > 0.f ? o.y : slope * o.y;
+            o.z = o.z > 0.f ? o.z : slope * o.z; o.w = o.w > 0.f ? o.w : slope * o.w;
+        }
         reinterpret_cast<float4*>(out)[e] = o;
     }
 }
@@ -107,12 +110,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ s1, const float* __restrict__ s2, int relu,
-                                                           float inv_m, float* __restrict__ dy, float* __restrict__ dz_out,
+                                                           float slope, float inv_m, float* __restrict__ dy, float* __restrict__ dz_out,
                                                            size_t total, int C) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int c = (int)(e % C);
         float dz = dout[e];
-        if (relu && !(out[e] > 0.f)) dz = 0.f;
+        if (relu && !(out[e] > 0.f)) dz *= slope;
         const float is = invstd[c];
         const float xhat = (y[e] - mean[c]) * is;
         dy[e] = gamma[c] * is * (dz - s1[c] * inv_m - xhat * (s2[c] * inv_m));
@@ -231,7 +234,7 @@ extern "C" int agrl_bn_stats(const float* y, float* mean, float* var, int M, int
     int rpc;
     const int chunks = reduce_chunks(M, C, &rpc);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0, M, C,
+    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0, 0.f, M, C,
                        rpc, (double*)workspace);
     hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, mean, var);
     AGRL_CHECK_LAUNCH("agrl_bn_stats");
@@ -239,20 +242,20 @@ extern "C" int agrl_bn_stats(const float* y, float* mean, float* var, int M, int
 }
 
 extern "C" int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, int M,
-                             int C, int relu, agrl_stream_t stream) {
+                             int C, int relu, float slope, agrl_stream_t stream) {
     AGRL_CHECK_ARG(y && scale && shift && out && M > 0 && C > 0 && (C % 4) == 0, "agrl_bn_apply: bad arguments (C %% 4 == 0)");
     const uintptr_t al = (uintptr_t)y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)residual | (uintptr_t)out;
     AGRL_CHECK_ARG((al & 15) == 0, "agrl_bn_apply: operands must be 16-byte aligned");
     const size_t total4 = (size_t)M * C / 4;
     const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual, out, relu, total4, C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual, out, relu, slope, total4, C / 4);
     AGRL_CHECK_LAUNCH("agrl_bn_apply");
     return 0;
 }
 
 extern "C" int agrl_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
-                                const float* gamma, int relu, float* dy, float* dz, float* dgamma, float* dbeta, int M, int C,
-                                void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
+                                const float* gamma, int relu, float slope, float* dy, float* dz, float* dgamma, float* dbeta, int M,
+                                int C, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
     AGRL_CHECK_ARG(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace, "agrl_bn_backward: null pointer");
     AGRL_CHECK_ARG(!relu || out, "agrl_bn_backward: the ReLU mask needs the forward output");
     AGRL_CHECK_ARG(M > 0 && C > 0, "agrl_bn_backward: bad shape");
@@ -260,13 +263,13 @@ extern "C" int agrl_bn_backward(const float* dout, const float* out, const float
     int rpc;
     const int chunks = reduce_chunks(M, C, &rpc);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, M, C, rpc,
+    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, slope, M, C, rpc,
                        (double*)workspace);
     hipLaunchKernelGGL(colreduce_final_kernel<1>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, dbeta, dgamma);
     const size_t total = (size_t)M * C;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, mean, invstd, gamma, dbeta, dgamma, relu,
-                       1.f / (float)M, dy, dz, total, C);
+                       slope, 1.f / (float)M, dy, dz, total, C);
     AGRL_CHECK_LAUNCH("agrl_bn_backward");
     return 0;
 }

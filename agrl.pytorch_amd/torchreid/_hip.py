@@ -70,11 +70,16 @@ SIGNATURES = {
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
+    "agrl_axpby": [_p, _p, _f, _f, _p, C.c_size_t, _p],
+    "agrl_part_pool_backward": [_p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _p],
+    "agrl_attn_pool_backward": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "agrl_graph_matrix_backward": [_p, _i, _p, _p, _i, _i, _i, _i, _p],
+    "agrl_xent_label_smooth": [_p, _p, _i, _i, _f, _p, _p, _p, _p],
     "agrl_triplet_loss": [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "agrl_bn_workspace": [_i, _i],   # returns size_t
     "agrl_bn_stats": [_p, _p, _p, _i, _i, _p, C.c_size_t, _p],
-    "agrl_bn_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _p],
-    "agrl_bn_backward": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _i, _p, C.c_size_t, _p],
+    "agrl_bn_apply": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "agrl_bn_backward": [_p, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _i, _i, _p, C.c_size_t, _p],
     "agrl_im2col_t": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_gemm_nt_splitk": [_p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p],
     "agrl_maxpool3x3s2": [_p, _p, _p, _i, _i, _i, _i, _p],

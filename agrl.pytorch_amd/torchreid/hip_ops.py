@@ -565,15 +565,16 @@ def bn_stats(y2d):
     return mean, var
 
 
-def bn_apply(y2d, scale, shift, residual, relu):
+def bn_apply(y2d, scale, shift, residual, relu, slope=0.0):
+    """relu: activation on; slope 0 = ReLU, > 0 = LeakyReLU(slope)."""
     M, Cc = y2d.shape
     out = torch.empty_like(y2d)
     with _dev(y2d):
-        call("agrl_bn_apply", ptr(y2d), ptr(scale), ptr(shift), ptr(residual), ptr(out), M, Cc, 1 if relu else 0, _stream(y2d))
+        call("agrl_bn_apply", ptr(y2d), ptr(scale), ptr(shift), ptr(residual), ptr(out), M, Cc, 1 if relu else 0, float(slope), _stream(y2d))
     return out
 
 
-def bn_backward(dout, out, y2d, mean, invstd, gamma, relu, want_dz):
+def bn_backward(dout, out, y2d, mean, invstd, gamma, relu, want_dz, slope=0.0):
     """-> dy (M,C), dz (M,C) or None, dgamma (C), dbeta (C)."""
     M, Cc = y2d.shape
     dy = torch.empty_like(y2d)
@@ -583,7 +584,7 @@ def bn_backward(dout, out, y2d, mean, invstd, gamma, relu, want_dz):
     ws, nbytes = _bn_ws(M, Cc, y2d.device)
     with _dev(y2d):
         call("agrl_bn_backward", ptr(dout), ptr(out) if relu else None, ptr(y2d), ptr(mean), ptr(invstd), ptr(gamma), 1 if relu else 0,
-             ptr(dy), ptr(dz), ptr(dgamma), ptr(dbeta), M, Cc, ptr(ws), nbytes, _stream(y2d))
+             float(slope), ptr(dy), ptr(dz), ptr(dgamma), ptr(dbeta), M, Cc, ptr(ws), nbytes, _stream(y2d))
     return dy, dz, dgamma, dbeta
 
 
@@ -648,3 +649,85 @@ def triplet_loss(x, pids, margin, soft):
         call("agrl_triplet_loss", ptr(x), ptr(pids), n, d, float(margin), 1 if soft else 0, ptr(loss), ptr(grad), ptr(dap), ptr(dan),
              ptr(iap), ptr(ian), ptr(coeff), _stream(x))
     return loss, grad
+
+
+# ---- train step of the tail (include/agrl_hip.h, "train step of the tail" section) ------------------------------------------
+def axpby(a, x, b=0.0, y=None):
+    out = torch.empty_like(x)
+    with _dev(x):
+        call("agrl_axpby", ptr(x.contiguous()), ptr(y.contiguous()) if y is not None else None, float(a), float(b), ptr(out), x.numel(), _stream(x))
+    return out
+
+
+def part_pool_backward(dg, dnodes, S, h, w, splits):
+    """dg (B,C) | None, dnodes (F,P,C) -> dx1 (F,h,w,C) | None, dx2 (F,h,w,C): backward of part_pool. vmgn.py:298-308."""
+    F_, P, Cc = dnodes.shape
+    dx2 = torch.empty((F_, h, w, Cc), dtype=torch.float32, device=dnodes.device)
+    dx1 = torch.empty_like(dx2) if dg is not None else None
+    arr = (C.c_int * len(splits))(*[int(v) for v in splits])
+    with _dev(dnodes):
+        call("agrl_part_pool_backward", ptr(dg.contiguous()) if dg is not None else None, ptr(dnodes.contiguous()), ptr(dx1), ptr(dx2), F_, S, h, w,
+             Cc, arr, len(splits), _stream(dnodes))
+    return dx1, dx2
+
+
+def attn_pool_backward(nodes, datt):
+    """nodes (B,S,P,C), datt (B,C) -> dnodes (B,S,P,C). vmgn.py:270-278, :313-317."""
+    B, S, P, Cc = nodes.shape
+    dn = torch.empty_like(nodes)
+    with _dev(nodes):
+        call("agrl_attn_pool_backward", ptr(nodes.contiguous()), ptr(datt.contiguous()), ptr(dn), B, S, P, Cc, _stream(nodes))
+    return dn
+
+
+def graph_gram(f):
+    """f (B,V,C) fp32 -> Gram partials (B, C/128, V, V) (first half of graph_matrix, kept for the backward pass)."""
+    B, V, Cc = f.shape
+    nz = Cc // GRAM_CSLICE
+    gram = torch.empty((B, nz, V, V), dtype=torch.float32, device=f.device)
+    with _dev(f):
+        call("agrl_graph_gram", ptr(f), ptr(gram), B, V, Cc, GRAM_CSLICE, _stream(f))
+    return gram
+
+
+def graph_finalize(gram, adj, B, V, use_pose, learn_graph, mask_diag=False):
+    G = torch.empty((B, V, V), dtype=torch.float32, device=(gram if gram is not None else adj).device)
+    nz = gram.shape[1] if gram is not None else 0
+    with _dev(G):
+        call("agrl_graph_finalize", ptr(gram), nz, ptr(adj.contiguous()) if use_pose else None, ptr(G), B, V, 1 if use_pose else 0,
+             1 if learn_graph else 0, 1 if mask_diag else 0, _stream(G))
+    return G
+
+
+def graph_matrix_backward(gram, dG, use_pose, mask_diag=False):
+    """Gram partials (B,nz,V,V), dG (B,V,V) -> M (B,V,V) with d loss / d f = M f. vmgn.py:114-120, :155-166."""
+    B, nz, V, _ = gram.shape
+    M = torch.empty((B, V, V), dtype=torch.float32, device=gram.device)
+    with _dev(gram):
+        call("agrl_graph_matrix_backward", ptr(gram), nz, ptr(dG.contiguous()), ptr(M), B, V, 1 if use_pose else 0, 1 if mask_diag else 0, _stream(gram))
+    return M
+
+
+def graph_apply(G, h):
+    """G (B,V,V) @ h (B,V,C) on the message-pass kernel (unit BatchNorm, no activation, no residual)."""
+    Cc = h.shape[-1]
+    key = (h.device, Cc)
+    if key not in _UNIT:
+        _UNIT[key] = (torch.ones((Cc,), dtype=torch.float32, device=h.device), torch.zeros((Cc,), dtype=torch.float32, device=h.device))
+    one, zero = _UNIT[key]
+    out, _ = graph_propagate(h, h, G, one, zero, 1.0, 1.0, want_lp=False, keep=0.0)
+    return out
+
+
+_UNIT = {}
+
+
+def xent_label_smooth(logits, targets, eps):
+    """-> loss (1,), dlogits (n,K): CrossEntropyLabelSmooth value + gradient in one call. cross_entropy_loss.py:26-37."""
+    n, K = logits.shape
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits)
+    rows = torch.empty((n,), dtype=torch.float32, device=logits.device)
+    with _dev(logits):
+        call("agrl_xent_label_smooth", ptr(logits), ptr(targets), n, K, float(eps), ptr(loss), ptr(dl), ptr(rows), _stream(logits))
+    return loss, dl

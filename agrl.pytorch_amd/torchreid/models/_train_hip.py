@@ -59,7 +59,11 @@ class HipConv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if R == 1 and S == 1:
                 wt = weight.detach().view(Cout, Cin).t().contiguous()                 # (Cin, Cout): dx = dy @ W
-                d = ops.linear_nobias(dy.view(-1, Cout), wt).view(dy.shape[0], dy.shape[1], dy.shape[2], Cin)
+                dy2 = dy.view(-1, Cout)
+                if Cout % 32:                                                        # K granularity of the fp32 GEMM (classifier heads)
+                    pad = 32 - Cout % 32
+                    wt, dy2 = torch.nn.functional.pad(wt, (0, pad)), torch.nn.functional.pad(dy2, (0, pad))
+                d = ops.linear_nobias(dy2.contiguous(), wt.contiguous()).view(dy.shape[0], dy.shape[1], dy.shape[2], Cin)
                 if stride == 1:
                     dx = d
                 else:                                                                # strided 1x1: gradient lands on the sampled pixels
@@ -114,7 +118,7 @@ class HipBatchNormAct(torch.autograd.Function):
     """BatchNorm2d in train mode (+ shortcut add) (+ ReLU) on NHWC fp32: out = act(bn(y) + residual)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, relu, eps):
+    def forward(ctx, y, gamma, beta, residual, relu, eps, slope=0.0):
         C = y.shape[-1]
         y2 = y.contiguous().view(-1, C)
         mean, var = ops.bn_stats(y2)
@@ -122,20 +126,20 @@ class HipBatchNormAct(torch.autograd.Function):
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
         res2 = None if residual is None else residual.contiguous().view(-1, C)
-        out = ops.bn_apply(y2, scale, shift, res2, relu)
+        out = ops.bn_apply(y2, scale, shift, res2, relu, slope)
         ctx.save_for_backward(y2, out, mean, invstd, gamma)
-        ctx.cfg = (bool(relu), residual is not None, tuple(y.shape))
+        ctx.cfg = (bool(relu), residual is not None, tuple(y.shape), float(slope))
         ctx.mark_non_differentiable(mean, var)
         return out.view(y.shape), mean, var
 
     @staticmethod
     def backward(ctx, dout, _dmean, _dvar):
         y2, out, mean, invstd, gamma = ctx.saved_tensors
-        relu, has_res, shape = ctx.cfg
+        relu, has_res, shape, slope = ctx.cfg
         C = shape[-1]
         dy, dz, dgamma, dbeta = ops.bn_backward(dout.contiguous().view(-1, C), out, y2, mean, invstd, gamma.detach().contiguous(),
-                                                relu, want_dz=has_res)
-        return dy.view(shape), dgamma, dbeta, (dz.view(shape) if has_res else None), None, None
+                                                relu, want_dz=has_res, slope=slope)
+        return dy.view(shape), dgamma, dbeta, (dz.view(shape) if has_res else None), None, None, None
 
 
 class HipMaxPool(torch.autograd.Function):
@@ -153,11 +157,12 @@ class HipMaxPool(torch.autograd.Function):
         return ops.maxpool3x3s2_backward(dout.contiguous(), idx, ctx.hw[0], ctx.hw[1])
 
 
-def _bn_act(bn, y, residual, relu):
-    """nn.BatchNorm2d(train) semantics around HipBatchNormAct, including the running-statistics update."""
+def _bn_act(bn, y, residual, relu, slope=0.0):
+    """nn.BatchNorm{1,2}d(train) semantics around HipBatchNormAct, including the running-statistics update. ``slope`` > 0:
+    LeakyReLU instead of ReLU."""
     if not bn.training or not bn.track_running_stats:
         raise RuntimeError('the native train path expects BatchNorm layers in train mode with running statistics')
-    out, mean, var = HipBatchNormAct.apply(y, bn.weight, bn.bias, residual, relu, bn.eps)
+    out, mean, var = HipBatchNormAct.apply(y, bn.weight, bn.bias, residual, relu, bn.eps, slope)
     with torch.no_grad():
         n = y.numel() // y.shape[-1]
         bn.num_batches_tracked += 1
@@ -211,3 +216,188 @@ def _featuremaps_train(model, frames_nchw):
             b = bottleneck_train(unit, b)
         outs.append(b.permute(0, 3, 1, 2))
     return outs
+
+
+# =====================================================================================================================
+# The tail of the train forward (vmgn.py:296-357) on the same footing: autograd Functions over C-ABI calls.
+# =====================================================================================================================
+def linear_train(x2d, weight):
+    """nn.Linear without bias, forward and backward, as a 1x1 conv node: (M,K) @ (N,K)^T."""
+    M, K = x2d.shape
+    y = HipConv2d.apply(x2d.contiguous().view(1, M, 1, K), weight.view(weight.shape[0], K, 1, 1), 1, 0)
+    return y.view(M, weight.shape[0])
+
+
+class HipPartPool(torch.autograd.Function):
+    """Global feature (mean over S, h, w of x4_1) and part nodes (row-band means of x4_2), vmgn.py:298-308. NHWC in."""
+
+    @staticmethod
+    def forward(ctx, x4_1, x4_2, S, splits):
+        F_, h, w, C = x4_2.shape
+        x4_2 = x4_2.contiguous()
+        x41 = x4_2 if x4_1 is None else x4_1.contiguous()
+        gsum, nodes, _ = ops.part_pool(x41, x4_2, list(splits), want_lp=False)
+        ctx.cfg = (int(S), h, w, tuple(splits), x4_1 is not None)
+        g_f = gsum.view(F_ // S, S, C).sum(dim=1) / float(S * h * w)
+        return g_f, nodes
+
+    @staticmethod
+    def backward(ctx, dg, dnodes):
+        S, h, w, splits, two = ctx.cfg
+        dx1, dx2 = ops.part_pool_backward(dg.contiguous() if two else None, dnodes.contiguous(), S, h, w, list(splits))
+        return dx1, dx2, None, None
+
+
+class HipGraphMatrix(torch.autograd.Function):
+    """G = mix(rowL1(adj), rowL1(sim(f))), vmgn.py:114-120, :155-166; gradient w.r.t. f through the similarity."""
+
+    @staticmethod
+    def forward(ctx, f, adj, use_pose, learn_graph, mask_diag):
+        f = f.contiguous()
+        B, V, C = f.shape
+        gram = ops.graph_gram(f) if learn_graph else None
+        G = ops.graph_finalize(gram, adj, B, V, use_pose, learn_graph, mask_diag)
+        ctx.cfg = (bool(use_pose), bool(learn_graph), bool(mask_diag))
+        ctx.save_for_backward(f, gram if gram is not None else f.new_zeros(1))
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        use_pose, learn_graph, mask_diag = ctx.cfg
+        f, gram = ctx.saved_tensors
+        if not learn_graph:
+            return None, None, None, None, None
+        M = ops.graph_matrix_backward(gram, dG.contiguous(), use_pose, mask_diag)
+        return ops.graph_apply(M, f), None, None, None, None
+
+
+class HipGraphBmm(torch.autograd.Function):
+    """msg = bmm(G, h), vmgn.py:168, both gradients."""
+
+    @staticmethod
+    def forward(ctx, G, h):
+        G, h = G.contiguous(), h.contiguous()
+        ctx.save_for_backward(G, h)
+        return ops.graph_apply(G, h)
+
+    @staticmethod
+    def backward(ctx, dmsg):
+        G, h = ctx.saved_tensors
+        dmsg = dmsg.contiguous()
+        B, V, C = h.shape
+        dh = ops.graph_apply(G.transpose(1, 2).contiguous(), dmsg)
+        # dG[b] = dmsg[b] h[b]^T: one GEMM over all (B V) rows, its diagonal V x V blocks are the answer (B is a train batch)
+        full = ops.linear_nobias(dmsg.view(B * V, C), h.view(B * V, C)).view(B, V, B, V)
+        idx = torch.arange(B, device=h.device)
+        dG = full[idx, :, idx, :].contiguous()
+        return dG, dh
+
+
+class HipAxpby(torch.autograd.Function):
+    """a x + b y (the residual mix of vmgn.py:172)."""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        ctx.ab = (float(a), float(b))
+        return ops.axpby(a, x, b, y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.ab
+        dout = dout.contiguous()
+        return ops.axpby(a, dout), ops.axpby(b, dout), None, None
+
+
+class HipAttnPool(torch.autograd.Function):
+    """GSTA._attention_op + mean over parts, vmgn.py:270-278, :313-317: (B,S,P,C) -> (B,C)."""
+
+    @staticmethod
+    def forward(ctx, nodes):
+        nodes = nodes.contiguous()
+        B, S, P, C = nodes.shape
+        ctx.save_for_backward(nodes)
+        sqn = ops.row_sqnorm(nodes.view(B * S * P, C))
+        key = (nodes.device, C)
+        if key not in ops._UNIT:
+            ops._UNIT[key] = (torch.ones((C,), dtype=torch.float32, device=nodes.device), torch.zeros((C,), dtype=torch.float32, device=nodes.device))
+        one, zero = ops._UNIT[key]
+        gsum = torch.zeros((B * S, C), dtype=torch.float32, device=nodes.device)
+        _, _, att_f = ops.attn_pool_bnneck(nodes, sqn, gsum, one, zero, one, zero, B, S, P, 1, want_feats=True)
+        return att_f
+
+    @staticmethod
+    def backward(ctx, datt):
+        (nodes,) = ctx.saved_tensors
+        return ops.attn_pool_backward(nodes, datt.contiguous())
+
+
+class HipXent(torch.autograd.Function):
+    """CrossEntropyLabelSmooth value + gradient from one native call."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, eps):
+        loss, dl = ops.xent_label_smooth(logits.detach().float().contiguous(), targets.detach().to(torch.int32).contiguous(), eps)
+        ctx.save_for_backward(dl)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (dl,) = ctx.saved_tensors
+        return dl * go, None, None
+
+
+def graph_layer_train(layer, f, adj):
+    """GraphLayer.forward (vmgn.py:142-172) in train mode (BatchNorm1d over the N*V rows with batch statistics)."""
+    B, V, C = f.shape
+    h = linear_train(f.reshape(B * V, C), layer.linear.weight).view(B, V, C)
+    G = HipGraphMatrix.apply(f, adj, layer.use_pose, layer.learn_graph, False)
+    msg = HipGraphBmm.apply(G, h)
+    y = _bn_act(layer.bn, msg.view(B * V, C), None, True, layer.relu.negative_slope).view(B, V, C)
+    return HipAxpby.apply(f, y, 1.0 - layer.gamma, layer.gamma)
+
+
+def tail_train(model, x4_1, x4_2, adj, B, S):
+    """Everything of GSTA.forward behind featuremaps under model.train() (vmgn.py:296-357), NHWC maps in ->
+    (out_list, f_list) exactly as the module tree returns them."""
+    P = model.total_split
+    g_f, nodes = HipPartPool.apply(x4_1, x4_2, S, tuple(model.total_split_list))
+    C = nodes.shape[-1]
+    g_bn = _bn_act(model.global_bottleneck, g_f, None, False)
+    f = nodes.view(B, S * P, C)
+    adj = adj.detach().to(torch.float32).contiguous()
+    for layer in model.graph_layers:
+        f = graph_layer_train(layer, f, adj)
+    f = f.view(B, S, P, C)
+    att_f = HipAttnPool.apply(f)
+    att_bn = _bn_act(model.att_bottleneck, att_f, None, False)
+    out_list = [linear_train(g_bn, model.global_classifier.weight), linear_train(att_bn, model.att_classifier.weight)]
+    f_list = [g_f, att_f]
+    if model.consistent_loss:
+        assert S >= 5
+        for num_frame in [S - 3, S - 2, S - 1]:   # three random frame subsets share the attention head (vmgn.py:327-342)
+            pick = torch.sort(torch.randperm(S)[:num_frame])[0].long().to(f.device)
+            sub = torch.gather(f, dim=1, index=pick.view(1, num_frame, 1, 1).repeat(B, 1, P, C))
+            satt_f = HipAttnPool.apply(sub)
+            out_list.append(linear_train(_bn_act(model.att_bottleneck, satt_f, None, False), model.att_classifier.weight))
+            f_list.append(satt_f)
+    return out_list, f_list
+
+
+def forward_train(model, x, adj):
+    """GSTA.forward under model.train() on the GPU, every arithmetic step a C-ABI call."""
+    B, S, C, H, W = x.shape
+    prec = getattr(model, 'hip_train_precision', 'fp32')
+    if prec not in ('fp32', 'bf16x3'):
+        raise ValueError("hip_train_precision must be 'fp32' or 'bf16x3', got {!r}".format(prec))
+    with ops.f32_split(prec == 'bf16x3'):
+        a = stem_train(model, x.view(B * S, C, H, W))
+        for stage in (model.layer1, model.layer2, model.layer3):
+            for unit in stage:
+                a = bottleneck_train(unit, a)
+        maps = []
+        for stage in (model.layer4_1, model.layer4_2):
+            b = a
+            for unit in stage:
+                b = bottleneck_train(unit, b)
+            maps.append(b)
+        return tail_train(model, maps[0], maps[1], adj, B, S)

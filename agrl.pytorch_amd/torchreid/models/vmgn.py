@@ -183,6 +183,7 @@ class GSTA(nn.Module):
         self.hip_gcn_overlap = os.environ.get('AGRL_HIP_GCN_OVERLAP', '0') != '0' 
         self.hip_train = os.environ.get('AGRL_HIP_TRAIN', '1') != '0'   # train-mode conv trunk (fwd + bwd) on the HIP kernels
         self.hip_train_precision = os.environ.get('AGRL_HIP_TRAIN_PRECISION', 'fp32')   # 'fp32' exact | 'bf16x3' split-bf16 MFMA
+        self.hip_train_tail = os.environ.get('AGRL_HIP_TRAIN_TAIL', '1') != '0'         # tail of the train forward native as well
         self._hip_packs = {}
 
     # ------------------------------------------------------------------ stock-torch path (CPU / train)
@@ -209,6 +210,16 @@ class GSTA(nn.Module):
             return hip_forward(self, x, adj)
 
         B, S, C, H, W = x.size()
+        if x.is_cuda and self.training and self.hip_train and self.hip_train_tail and x.dtype == torch.float32:
+            # the whole train forward -- trunk, pooling, graph layers, attention pooling, BNNecks, classifiers -- as autograd
+            # Functions over C-ABI calls (models/_train_hip.py); the losses have native forms too (torchreid/losses)
+            from torchreid.models._train_hip import forward_train
+            out_list, f_list = forward_train(self, x, adj)
+            if self.loss == {'xent'}:
+                return out_list
+            elif self.loss == {'xent', 'htri'}:
+                return out_list, f_list
+            raise KeyError('Unsupported loss: {}'.format(self.loss))
         if x.is_cuda and self.training and self.hip_train:
             # train step on the GPU: the conv trunk -- forward with batch-statistics BatchNorm and its whole backward -- on the
             # gfx950 kernels (models/_train_hip.py); the graph stays torch.autograd's

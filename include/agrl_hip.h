@@ -326,15 +326,16 @@ int agrl_bn_stats(const float* y, float* mean, float* var, int M, int C, void* w
                   agrl_stream_t stream);
 
 /* out = act(y * scale[c] + shift[c] (+ residual)): the normalisation with scale = gamma / sqrt(var + eps), shift = beta -
- * mean * scale, the shortcut add and the ReLU of vmgn.py:49-64 in one pass. C % 4 == 0. */
+ * mean * scale, the shortcut add and the activation in one pass: relu != 0 -> v > 0 ? v : slope * v (slope 0: the ReLU of
+ * vmgn.py:49-64; slope 0.1: the LeakyReLU behind GraphLayer's BatchNorm1d, vmgn.py:169-170). C % 4 == 0. */
 int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, int M, int C,
-                  int relu, agrl_stream_t stream);
+                  int relu, float slope, agrl_stream_t stream);
 
-/* Backward of agrl_bn_apply + batch statistics: dz = relu ? (out > 0 ? dout : 0) : dout; dbeta = sum dz;
+/* Backward of agrl_bn_apply + batch statistics: dz = relu ? (out > 0 ? dout : slope * dout) : dout; dbeta = sum dz;
  * dgamma = sum dz * xhat (xhat = (y - mean) * invstd); dy = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M).
  * dz (optional) is the gradient that continues into the residual branch. */
 int agrl_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
-                     const float* gamma, int relu, float* dy, float* dz, float* dgamma, float* dbeta, int M, int C,
+                     const float* gamma, int relu, float slope, float* dy, float* dz, float* dgamma, float* dbeta, int M, int C,
                      void* workspace, size_t workspace_bytes, agrl_stream_t stream);
 
 /* T[(tap*C + c)][m] = x[f][oh*stride - pad + r][ow*stride - pad + s][c] (0 outside), tap = r*S + s, m = (f, oh, ow):
@@ -355,6 +356,35 @@ int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M, int K, in
 int agrl_maxpool3x3s2(const float* x, float* out, unsigned char* idx, int F, int H, int W, int C, agrl_stream_t stream);
 int agrl_maxpool3x3s2_backward(const float* dout, const unsigned char* idx, float* dx, int F, int H, int W, int C,
                                agrl_stream_t stream);
+
+/* ---- train step of the tail (pooling, graph layers, attention pooling, losses) ---------------------------------------
+ * Forward passes reuse the eval entry points; these are the backward passes without a forward twin and the fused loss. */
+
+/* out = a x + b y (y may be NULL: out = a x): the residual mix (1 - gamma) f + gamma h' of vmgn.py:172 and its backward. */
+int agrl_axpby(const float* x, const float* y, float a, float b, float* out, size_t total, agrl_stream_t stream);
+
+/* Backward of agrl_part_pool (vmgn.py:298-308): dg fp32 (F/S, C) gradient of the global feature (mean over S*h*w) and dnodes
+ * fp32 (F, P, C) gradient of the part means -> dx1, dx2 fp32 NHWC (F, h, w, C). dg / dx1 may both be NULL (single-branch). */
+int agrl_part_pool_backward(const float* dg, const float* dnodes, float* dx1, float* dx2, int F, int S, int h, int w, int C,
+                            const int* splits, int n_splits, agrl_stream_t stream);
+
+/* Backward of the attention temporal pooling (GSTA._attention_op + mean over parts, vmgn.py:270-278, :313-317):
+ * nodes fp32 (B,S,P,C), datt fp32 (B,C) = d loss / d att_f -> dnodes fp32 (B,S,P,C). C % 4 == 0. */
+int agrl_attn_pool_backward(const float* nodes, const float* datt, float* dnodes, int B, int S, int P, int C,
+                            agrl_stream_t stream);
+
+/* Backward of the adaptive graph (agrl_graph_gram + agrl_graph_finalize; vmgn.py:114-120, :155-166) w.r.t. the node
+ * features: from the forward's Gram partials and dG fp32 (B,V,V) -> M fp32 (B,V,V) with d loss / d f[b] = M[b] f[b] (apply it
+ * with agrl_graph_propagate: keep 0, gamma 1, unit scale, zero shift, slope 1). The diagonal D2_ii == 0 passes no gradient
+ * (exact arithmetic; the reference's autograd forms it as two cancelling fp32 terms). V <= 115. */
+int agrl_graph_matrix_backward(const float* gram_part, int nz, const float* dG, float* M, int B, int V, int use_pose,
+                               int mask_diag, agrl_stream_t stream);
+
+/* CrossEntropyLabelSmooth (torchreid/losses/cross_entropy_loss.py:26-37), value and gradient in one call:
+ * loss (1) = (-q * log_softmax(logits)).mean(0).sum(), q = (1 - eps) onehot + eps / K; dlogits (n,K) = (softmax - q) / n.
+ * logits fp32 (n,K); targets int32 (n); row_loss: scratch fp32 (n). */
+int agrl_xent_label_smooth(const float* logits, const int32_t* targets, int n, int K, float eps, float* loss, float* dlogits,
+                           float* row_loss, agrl_stream_t stream);
 
 /* ---- batch-hard triplet mining (train step, BASELINE config 4) ----------------------------------- */
 

@@ -98,6 +98,145 @@ def test_maxpool_forward_backward():
         assert abs(xd.grad.sum().item() - x.grad.sum().item()) < 1e-3
 
 
+def test_tail_nodes_forward_backward():
+    """The tail's autograd nodes one by one against torch autograd on the CPU: part / global pooling, Linear (classifier
+    widths 5 and 702 included), G h, attention temporal pooling, label-smoothed cross entropy, the residual mix."""
+    from torchreid.models import _train_hip as T
+    from torchreid import losses
+    g = torch.Generator().manual_seed(11)
+    # pooling: (F, h, w, C) NHWC maps, S = 4 frames per tracklet
+    F_, S, h, w, C = 8, 4, 16, 8, 64
+    x1 = torch.randn((F_, C, h, w), generator=g, requires_grad=True)
+    x2 = torch.randn((F_, C, h, w), generator=g, requires_grad=True)
+    B = F_ // S
+    g_ref = x1.view(B, S, C, h * w).permute(0, 2, 1, 3).reshape(B, C, -1).mean(2)
+    parts = [torch.nn.functional.adaptive_avg_pool2d(x2, (n, 1)).view(F_, C, n) for n in (4, 2, 1)]
+    n_ref = torch.cat(parts, dim=2).transpose(1, 2)                                   # (F, P, C)
+    wg, wn = torch.randn(g_ref.shape, generator=g), torch.randn(n_ref.shape, generator=g)
+    ((g_ref * wg).sum() + (n_ref * wn).sum()).backward()
+    d1 = x1.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    d2 = x2.detach().permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    g_dev, n_dev = T.HipPartPool.apply(d1, d2, S, (4, 2, 1))
+    ((g_dev * wg.to(DEV)).sum() + (n_dev * wn.to(DEV)).sum()).backward()
+    e = [rel(g_dev, g_ref), rel(n_dev, n_ref), rel(d1.grad.permute(0, 3, 1, 2), x1.grad), rel(d2.grad.permute(0, 3, 1, 2), x2.grad)]
+    print("part pool fwd %.1e %.1e bwd %.1e %.1e" % tuple(e))
+    assert max(e) < 1e-5
+    # Linear
+    for M, K, N in ((16, 2048, 702), (8, 2048, 5), (224, 256, 256)):
+        x = torch.randn((M, K), generator=g, requires_grad=True)
+        wt = (torch.randn((N, K), generator=g) / K ** 0.5).requires_grad_(True)
+        y = x @ wt.t()
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        xd, wd = x.detach().to(DEV).requires_grad_(True), wt.detach().to(DEV).requires_grad_(True)
+        yd = T.linear_train(xd, wd)
+        yd.backward(dy.to(DEV))
+        e = [rel(yd, y), rel(xd.grad, x.grad), rel(wd.grad, wt.grad)]
+        print("linear", (M, K, N), "fwd %.1e dx %.1e dw %.1e" % tuple(e))
+        assert max(e) < 1e-5
+    # G h
+    Bq, V, Cq = 3, 28, 256
+    G = torch.rand((Bq, V, V), generator=g).requires_grad_(True)
+    hh = torch.randn((Bq, V, Cq), generator=g, requires_grad=True)
+    m = torch.bmm(G, hh)
+    dm = torch.randn(m.shape, generator=g)
+    m.backward(dm)
+    Gd, hd = G.detach().to(DEV).requires_grad_(True), hh.detach().to(DEV).requires_grad_(True)
+    md = T.HipGraphBmm.apply(Gd, hd)
+    md.backward(dm.to(DEV))
+    e = [rel(md, m), rel(Gd.grad, G.grad), rel(hd.grad, hh.grad)]
+    print("graph bmm fwd %.1e dG %.1e dh %.1e" % tuple(e))
+    assert max(e) < 1e-5
+    # attention pooling (one all-zero node: its norm passes no gradient)
+    nodes = torch.rand((3, 6, 7, 128), generator=g)
+    nodes[1, 2, 3] = 0
+    nodes.requires_grad_(True)
+    att = torch.nn.functional.normalize(nodes.norm(p=2, dim=3, keepdim=True), p=1, dim=1)
+    a_ref = (nodes * att).sum(1).mean(1)
+    da = torch.randn(a_ref.shape, generator=g)
+    a_ref.backward(da)
+    nd = nodes.detach().to(DEV).requires_grad_(True)
+    a_dev = T.HipAttnPool.apply(nd)
+    a_dev.backward(da.to(DEV))
+    e = [rel(a_dev, a_ref), rel(nd.grad, nodes.grad)]
+    print("attention pool fwd %.1e bwd %.1e" % tuple(e))
+    assert max(e) < 1e-5
+    # label-smoothed cross entropy (reference arithmetic = this build's CPU path, pinned in tests/test_boundary.py)
+    for n, K in ((16, 702), (4, 5)):
+        z = (3 * torch.randn((n, K), generator=g)).requires_grad_(True)
+        y = torch.randint(0, K, (n,), generator=g)
+        l_ref = losses.CrossEntropyLabelSmooth(K, use_gpu=False)(z, y)
+        (2.5 * l_ref).backward()
+        zd = z.detach().to(DEV).requires_grad_(True)
+        l_dev = losses.CrossEntropyLabelSmooth(K, use_gpu=True)(zd, y.to(DEV))
+        (2.5 * l_dev).backward()
+        assert abs(l_dev.item() - l_ref.item()) < 1e-5 * abs(l_ref.item()) and rel(zd.grad, z.grad) < 1e-5
+    # residual mix
+    a_, b_ = torch.randn((5, 7, 64), generator=g, requires_grad=True), torch.randn((5, 7, 64), generator=g, requires_grad=True)
+    (0.9 * a_ + 0.1 * b_).backward(torch.ones(5, 7, 64))
+    ad, bd = a_.detach().to(DEV).requires_grad_(True), b_.detach().to(DEV).requires_grad_(True)
+    od = T.HipAxpby.apply(ad, bd, 0.9, 0.1)
+    od.backward(torch.ones(5, 7, 64, device=DEV))
+    assert rel(od, 0.9 * a_ + 0.1 * b_) < 1e-6 and rel(ad.grad, a_.grad) < 1e-6 and rel(bd.grad, b_.grad) < 1e-6
+
+
+@pytest.mark.parametrize("cfg", [(3, 56, 256, True, True), (2, 112, 2048, True, True), (2, 28, 512, False, True)])
+def test_graph_matrix_gradient_against_float64_autograd(cfg):
+    """d loss / d f through the adaptive graph (sim -> row-L1 normalise -> mix): the native backward (agrl_graph_matrix_backward:
+    M with d f = M f) against torch autograd of the reference formula in FLOAT64 -- in fp32 the reference's own gradient through
+    the diagonal d2_ii (pure cancellation noise under a sqrt) is noise; exact arithmetic passes no gradient there, which is
+    what the kernel implements."""
+    from torchreid.models import _train_hip as T
+    from recipe import synthetic_adj
+    B, V, C, use_pose, learn_graph = cfg
+    g = torch.Generator().manual_seed(V + C)
+    f = torch.rand((B, 1, C), generator=g) * 0.2 + 0.05 * torch.randn((B, V, C), generator=g)
+    adj = synthetic_adj(B, V // 7, seed=V)
+    f64 = f.double().requires_grad_(True)
+    G_ref = O.graph_matrix(f64, adj.double(), use_pose, learn_graph)
+    wG = torch.randn(G_ref.shape, generator=g)
+    (G_ref * wG.double()).sum().backward()
+    fd = f.to(DEV).requires_grad_(True)
+    G_dev = T.HipGraphMatrix.apply(fd, adj.to(DEV), use_pose, learn_graph, False)
+    (G_dev * wG.to(DEV)).sum().backward()
+    e_g, e_f = rel(G_dev, G_ref), rel(fd.grad, f64.grad)
+    print("graph matrix", cfg, "G %.1e df %.1e (|df|max %.2e)" % (e_g, e_f, f64.grad.abs().max().item()))
+    assert e_g < 1e-4 and e_f < 2e-3
+
+
+@pytest.mark.parametrize("cfg", [(3, 56, 256), (2, 112, 2048)])
+def test_graph_layer_train_forward_backward(cfg):
+    """A whole GraphLayer in train mode (Linear, adaptive graph, G h, BatchNorm1d with batch statistics, LeakyReLU, residual
+    mix) through the native nodes against the module in float64 on the CPU: output, input gradient, parameter gradients."""
+    import copy
+    from torchreid.models.vmgn import GraphLayer
+    from torchreid.models import _train_hip as T
+    from recipe import synthetic_adj
+    B, V, C = cfg
+    g = torch.Generator().manual_seed(B * V + C)
+    layer = GraphLayer(C, C)
+    with torch.no_grad():
+        layer.linear.weight.copy_(torch.randn((C, C), generator=g) * 0.02)
+        layer.bn.weight.copy_(0.5 + torch.rand(C, generator=g))
+        layer.bn.bias.copy_(0.1 * torch.randn(C, generator=g))
+    dev = copy.deepcopy(layer).to(DEV).train()
+    ref = copy.deepcopy(layer).double().train()
+    f = torch.rand((B, 1, C), generator=g) * 0.2 + 0.05 * torch.randn((B, V, C), generator=g)
+    adj = synthetic_adj(B, V // 7, seed=V)
+    f64 = f.double().requires_grad_(True)
+    out = ref(f64, adj.double())
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout.double())
+    fd = f.to(DEV).requires_grad_(True)
+    outd = T.graph_layer_train(dev, fd, adj.to(DEV))
+    outd.backward(dout.to(DEV))
+    errs = {"out": rel(outd, out), "df": rel(fd.grad, f64.grad), "dW": rel(dev.linear.weight.grad, ref.linear.weight.grad),
+            "dgamma": rel(dev.bn.weight.grad, ref.bn.weight.grad), "dbeta": rel(dev.bn.bias.grad, ref.bn.bias.grad),
+            "running_var": rel(dev.bn.running_var, ref.bn.running_var)}
+    print("graph layer train", cfg, " ".join("%s %.1e" % kv for kv in errs.items()))
+    assert max(errs.values()) < 2e-3 and errs["out"] < 1e-5
+
+
 def _problem(S, H, W, P=2, K=2, ncls=5, seed=3, consistent=True):
     from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
     from torchreid import models
@@ -244,13 +383,32 @@ def test_native_trunk_is_what_runs(monkeypatch):
     """The train forward on CUDA goes through the C-ABI (conv, batch-norm statistics, max pooling entry points are called),
     and AGRL_HIP_TRAIN=0 style opt-out (model.hip_train = False) gives the same loss through the stock module tree."""
     from torchreid import _hip
-    ref, dev, x, adj, pids, _ = _problem(6, 64, 32, consistent=False)
+    ref, dev, x, adj, pids, _ = _problem(6, 64, 32, consistent=True)
     _hip.PROFILE = []
     l1 = _step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), True)
     names = {r[0] for r in _hip.PROFILE}
     _hip.PROFILE = None
     assert {"agrl_conv2d_bn_act", "agrl_bn_stats", "agrl_bn_apply", "agrl_bn_backward", "agrl_im2col_t", "agrl_gemm_nt_splitk",
-            "agrl_maxpool3x3s2", "agrl_maxpool3x3s2_backward", "agrl_linear_nobias"} <= names
+            "agrl_maxpool3x3s2", "agrl_maxpool3x3s2_backward", "agrl_linear_nobias", "agrl_part_pool", "agrl_part_pool_backward",
+            "agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_propagate", "agrl_graph_matrix_backward", "agrl_row_sqnorm",
+            "agrl_attn_pool_bnneck", "agrl_attn_pool_backward", "agrl_axpby", "agrl_xent_label_smooth", "agrl_triplet_loss"} <= names
+    # ... and no stock-torch arithmetic kernel is left between the input frames and the loss: the autograd graph of the loss
+    # consists of the native nodes plus views / gathers / the scalar sums of DeepSupervision
+    native = ("HipConv2d", "HipStemConv", "HipBatchNormAct", "HipMaxPool", "HipPartPool", "HipGraphMatrix", "HipGraphBmm", "HipAxpby",
+              "HipAttnPool", "HipXent", "_NativeTriplet")
+    plumbing = ("View", "Reshape", "Permute", "Transpose", "Gather", "Add", "Div", "Mul", "AccumulateGrad", "Alias", "Unsafe", "Expand",
+                "Squeeze", "Unsqueeze", "Clone", "T", "Select", "Slice", "Copy", "Constant", "AsStrided", "Repeat", "ToCopy", "Contiguous")
+    seen, stack, foreign = set(), [l1.grad_fn], set()
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        name = type(fn).__name__
+        if not (any(name.startswith(n) for n in native) or any(p_ in name for p_ in plumbing)):
+            foreign.add(name)
+        stack.extend(nf for nf, _ in fn.next_functions)
+    assert not foreign, foreign
     dev.hip_train = False
     l2 = _step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), True)
     assert abs(l1.item() - l2.item()) < 1e-4 * abs(l2.item())
