@@ -61,8 +61,8 @@ class HipConv2d(torch.autograd.Function):
                 wt = weight.detach().view(Cout, Cin).t().contiguous()                 # (Cin, Cout): dx = dy @ W
                 dy2 = dy.view(-1, Cout)
                 if Cout % 32:                                                        # K granularity of the fp32 GEMM (classifier heads)
-                    pad = 32 - Cout % 32
-                    wt, dy2 = torch.nn.functional.pad(wt, (0, pad)), torch.nn.functional.pad(dy2, (0, pad))
+                    kpad = 32 - Cout % 32
+                    wt, dy2 = torch.nn.functional.pad(wt, (0, kpad)), torch.nn.functional.pad(dy2, (0, kpad))
                 d = ops.linear_nobias(dy2.contiguous(), wt.contiguous()).view(dy.shape[0], dy.shape[1], dy.shape[2], Cin)
                 if stride == 1:
                     dx = d

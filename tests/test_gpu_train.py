@@ -6,6 +6,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import vmgn_oracle as O
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
