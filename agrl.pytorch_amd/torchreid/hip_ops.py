@@ -351,10 +351,12 @@ def pam_combine(y, bv, xmean, gamma, want_lp):
     return nodes, nodes_lp
 
 
-def graph_message_pass_supported(f):
-    """The one-launch message pass exists for V <= 64, V % 4 == 0, C % 256 == 0 (AGRL_HIP_GCN_FUSED=0 turns it off)."""
+def graph_message_pass_supported(f, force=False):
+    """The one-launch message pass exists for V <= 64, V % 4 == 0, C % 256 == 0. Measured SLOWER than the three-kernel unit at
+    the bench shape (47-51 us vs 31-34 us per layer, DESIGN.md section 5), so the model only takes it with AGRL_HIP_GCN_FUSED=1;
+    ``force`` is the tests' way in."""
     B, V, Cc = f.shape
-    return V <= 64 and V % 4 == 0 and Cc % 256 == 0 and os.environ.get('AGRL_HIP_GCN_FUSED', '1') != '0'
+    return V <= 64 and V % 4 == 0 and Cc % 256 == 0 and (force or os.environ.get('AGRL_HIP_GCN_FUSED', '0') == '1')
 
 
 def graph_message_pass(f, h, adj, bn_scale, bn_shift, gamma, slope, use_pose, learn_graph, want_lp, keep=None, mask_diag=False,

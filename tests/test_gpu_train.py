@@ -381,7 +381,7 @@ def test_train_step_loss_and_gradients_at_the_reference_noise_floor(shape):
         assert a_ < 3 * b_ + 1e-6
 
 
-def test_native_trunk_is_what_runs(monkeypatch):
+def test_native_step_is_what_runs(monkeypatch):
     """The train forward on CUDA goes through the C-ABI (conv, batch-norm statistics, max pooling entry points are called),
     and AGRL_HIP_TRAIN=0 style opt-out (model.hip_train = False) gives the same loss through the stock module tree."""
     from torchreid import _hip
