@@ -63,17 +63,116 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
+// The same reductions for C % 4 == 0 and 16-byte aligned operands (every layer of the model): a thread owns FOUR channels
+// (16-byte loads; a 64-channel row is one 256-byte segment of 16 lanes, so a wave covers 4 rows of layer 1 per load instead of
+// one 4-byte element per lane) and keeps four row-steps in flight. ``lanes`` = 16 / 32 / 64 float4 columns per block;
+// 256 / lanes row lanes. grid = (ceil(C/4/lanes), chunks).
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_vec_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                            const float* __restrict__ out, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int relu, float slope, int M, int C,
+                                                            int rows_per_chunk, int lanes, double* __restrict__ partial) {
+    __shared__ float4 s_a[256], s_b[256];
+    const int lc = threadIdx.x % lanes, rl = threadIdx.x / lanes, nrl = 256 / lanes;
+    const int c4 = blockIdx.x * lanes + lc, C4 = C >> 2;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(M, r0 + rows_per_chunk);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (c4 < C4) {
+        float4 mu = a, is = a;
+        if (MODE == 1) { mu = reinterpret_cast<const float4*>(mean)[c4]; is = reinterpret_cast<const float4*>(invstd)[c4]; }
+        const float4* y4 = reinterpret_cast<const float4*>(y) + c4;
+        const float4* d4 = reinterpret_cast<const float4*>(dout) + c4;
+        const float4* o4 = reinterpret_cast<const float4*>(out) + c4;
+        auto acc = [&](const float4 v, float4 dz, const float4 o) {
+            if (MODE == 0) {
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                b.x = fmaf(v.x, v.x, b.x); b.y = fmaf(v.y, v.y, b.y); b.z = fmaf(v.z, v.z, b.z); b.w = fmaf(v.w, v.w, b.w);
+            } else {
+                if (relu) {
+                    if (!(o.x > 0.f)) dz.x *= slope;
+                    if (!(o.y > 0.f)) dz.y *= slope;
+                    if (!(o.z > 0.f)) dz.z *= slope;
+                    if (!(o.w > 0.f)) dz.w *= slope;
+                }
+                a.x += dz.x; a.y += dz.y; a.z += dz.z; a.w += dz.w;
+                b.x = fmaf(dz.x, (v.x - mu.x) * is.x, b.x); b.y = fmaf(dz.y, (v.y - mu.y) * is.y, b.y);
+                b.z = fmaf(dz.z, (v.z - mu.z) * is.z, b.z); b.w = fmaf(dz.w, (v.w - mu.w) * is.w, b.w);
+            }
+        };
+        int r = r0 + rl;
+        for (; r + 3 * nrl < r1; r += 4 * nrl) {
+            float4 v[4], d[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = (size_t)(r + u * nrl) * C4;
+                v[u] = y4[i];
+                if (MODE == 1) {
+                    d[u] = d4[i];
+                    o[u] = relu ? o4[i] : v[u];
+                } else {
+                    d[u] = v[u]; o[u] = v[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc(v[u], d[u], o[u]);
+        }
+        for (; r < r1; r += nrl) {
+            const size_t i = (size_t)r * C4;
+            const float4 v = y4[i];
+            acc(v, MODE == 1 ? d4[i] : v, (MODE == 1 && relu) ? o4[i] : v);
+        }
+    }
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = b;
+    __syncthreads();
+    if (rl == 0 && c4 < C4) {
+        double sa[4] = {0.0, 0.0, 0.0, 0.0}, sb[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = 0; k < nrl; ++k) {                      // fixed order: deterministic
+            const float4 pa = s_a[k * lanes + lc], pb = s_b[k * lanes + lc];
+            sa[0] += (double)pa.x; sa[1] += (double)pa.y; sa[2] += (double)pa.z; sa[3] += (double)pa.w;
+            sb[0] += (double)pb.x; sb[1] += (double)pb.y; sb[2] += (double)pb.z; sb[3] += (double)pb.w;
+        }
+        double* pa = partial + ((size_t)blockIdx.y * 2 + 0) * C + 4 * c4;
+        double* pb = partial + ((size_t)blockIdx.y * 2 + 1) * C + 4 * c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] = sa[j]; pb[j] = sb[j]; }
+    }
+}
+
 // MODE 0 -> mean, biased variance; MODE 1 -> the two sums themselves (dbeta, dgamma)
+// grid = ceil(C/16) blocks of 16 channels x 16 chunk lanes: a lane adds every 16th partial (loads independent, four in flight),
+// the 16 lane sums are added in lane order by the first 16 threads -- the summation order depends on ``chunks`` only.
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partial, int chunks, int C, int M,
                                                               float* __restrict__ o1, float* __restrict__ o2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double s_a[16][17], s_b[16][17];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double sa = 0.0, sb = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-        sa += partial[((size_t)k * 2 + 0) * C + c];
-        sb += partial[((size_t)k * 2 + 1) * C + c];
+    if (c < C) {
+        int k = kl;
+        for (; k + 48 < chunks; k += 64) {
+            double pa[4], pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                pa[u] = partial[((size_t)(k + 16 * u) * 2 + 0) * C + c];
+                pb[u] = partial[((size_t)(k + 16 * u) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sa += pa[u]; sb += pb[u]; }
+        }
+        for (; k < chunks; k += 16) {
+            sa += partial[((size_t)k * 2 + 0) * C + c];
+            sb += partial[((size_t)k * 2 + 1) * C + c];
+        }
     }
+    s_a[kl][cl] = sa;
+    s_b[kl][cl] = sb;
+    __syncthreads();
+    if (kl != 0 || c >= C) return;
+    sa = 0.0; sb = 0.0;
+    for (int k = 0; k < 16; ++k) { sa += s_a[k][cl]; sb += s_b[k][cl]; }
     if (MODE == 0) {
         const double mu = sa / (double)M;
         o1[c] = (float)mu;
@@ -120,6 +219,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const float xhat = (y[e] - mean[c]) * is;
         dy[e] = gamma[c] * is * (dz - s1[c] * inv_m - xhat * (s2[c] * inv_m));
         if (dz_out) dz_out[e] = dz;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                               const float* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ s1, const float* __restrict__ s2, int relu,
+                                                               float slope, float inv_m, float* __restrict__ dy,
+                                                               float* __restrict__ dz_out, size_t total4, int C4) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(e % C4);
+        float4 dz = reinterpret_cast<const float4*>(dout)[e];
+        const float4 v = reinterpret_cast<const float4*>(y)[e];
+        if (relu) {
+            const float4 o = reinterpret_cast<const float4*>(out)[e];
+            if (!(o.x > 0.f)) dz.x *= slope;
+            if (!(o.y > 0.f)) dz.y *= slope;
+            if (!(o.z > 0.f)) dz.z *= slope;
+            if (!(o.w > 0.f)) dz.w *= slope;
+        }
+        const float4 is = reinterpret_cast<const float4*>(invstd)[c4], mu = reinterpret_cast<const float4*>(mean)[c4];
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c4];
+        const float4 a = reinterpret_cast<const float4*>(s1)[c4], b = reinterpret_cast<const float4*>(s2)[c4];
+        float4 r;
+        r.x = g.x * is.x * (dz.x - a.x * inv_m - (v.x - mu.x) * is.x * (b.x * inv_m));
+        r.y = g.y * is.y * (dz.y - a.y * inv_m - (v.y - mu.y) * is.y * (b.y * inv_m));
+        r.z = g.z * is.z * (dz.z - a.z * inv_m - (v.z - mu.z) * is.z * (b.z * inv_m));
+        r.w = g.w * is.w * (dz.w - a.w * inv_m - (v.w - mu.w) * is.w * (b.w * inv_m));
+        reinterpret_cast<float4*>(dy)[e] = r;
+        if (dz_out) reinterpret_cast<float4*>(dz_out)[e] = dz;
     }
 }
 
@@ -207,14 +336,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// float4 columns per block of the vectorised reduction (0: the scalar kernel -- C % 4 != 0)
+static int reduce_lanes(int C) { return (C & 3) ? 0 : (C >= 256 ? 64 : (C >= 128 ? 32 : 16)); }
+
 static int reduce_chunks(int M, int C, int* rows_per_chunk) {
-    const int cg = cdiv(C, 64);
-    int chunks = 1024 / cg;
+    const int lanes = reduce_lanes(C);
+    const int cg = lanes ? cdiv(C / 4, lanes) : cdiv(C, 64);
+    int chunks = 2048 / cg;
     if (chunks < 1) chunks = 1;
-    if (chunks > 256) chunks = 256;
+    if (chunks > 512) chunks = 512;
     int rpc = cdiv(M, chunks);
-    rpc = (rpc + 3) & ~3;
-    if (rpc < 4) rpc = 4;
+    rpc = (rpc + 15) & ~15;                 // whole row-lane passes of either kernel
     *rows_per_chunk = rpc;
     return cdiv(M, rpc);
 }
@@ -234,9 +366,14 @@ extern "C" int agrl_bn_stats(const float* y, float* mean, float* var, int M, int
     int rpc;
     const int chunks = reduce_chunks(M, C, &rpc);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colreduce_kernel<0>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0, 0.f, M, C,
-                       rpc, (double*)workspace);
-    hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, mean, var);
+    const int lanes = ((uintptr_t)y & 15) ? 0 : reduce_lanes(C);
+    if (lanes)
+        hipLaunchKernelGGL(colreduce_vec_kernel<0>, dim3(cdiv(C / 4, lanes), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0,
+                           0.f, M, C, rpc, lanes, (double*)workspace);
+    else
+        hipLaunchKernelGGL(colreduce_kernel<0>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0, 0.f, M,
+                           C, rpc, (double*)workspace);
+    hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, mean, var);
     AGRL_CHECK_LAUNCH("agrl_bn_stats");
     return 0;
 }
@@ -263,13 +400,27 @@ extern "C" int agrl_bn_backward(const float* dout, const float* out, const float
     int rpc;
     const int chunks = reduce_chunks(M, C, &rpc);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colreduce_kernel<1>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, slope, M, C, rpc,
-                       (double*)workspace);
-    hipLaunchKernelGGL(colreduce_final_kernel<1>, dim3(cdiv(C, 256)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, dbeta, dgamma);
+    const uintptr_t al = (uintptr_t)dout | (uintptr_t)out | (uintptr_t)y | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma |
+                         (uintptr_t)dy | (uintptr_t)dz | (uintptr_t)dgamma | (uintptr_t)dbeta;
+    const int lanes = (al & 15) ? 0 : reduce_lanes(C);
+    if (lanes)
+        hipLaunchKernelGGL(colreduce_vec_kernel<1>, dim3(cdiv(C / 4, lanes), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, slope,
+                           M, C, rpc, lanes, (double*)workspace);
+    else
+        hipLaunchKernelGGL(colreduce_kernel<1>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, slope, M, C,
+                           rpc, (double*)workspace);
+    hipLaunchKernelGGL(colreduce_final_kernel<1>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, dbeta, dgamma);
     const size_t total = (size_t)M * C;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, mean, invstd, gamma, dbeta, dgamma, relu,
-                       slope, 1.f / (float)M, dy, dz, total, C);
+    if (lanes) {
+        const size_t total4 = total / 4;
+        const int blocks = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, mean, invstd, gamma, dbeta, dgamma, relu,
+                           slope, 1.f / (float)M, dy, dz, total4, C / 4);
+    } else {
+        const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, mean, invstd, gamma, dbeta, dgamma, relu,
+                           slope, 1.f / (float)M, dy, dz, total, C);
+    }
     AGRL_CHECK_LAUNCH("agrl_bn_backward");
     return 0;
 }
