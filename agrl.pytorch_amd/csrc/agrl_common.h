@@ -126,6 +126,7 @@ struct AgrlOpts {
     int distmat_tiled, distmat_ring;                                                             // flags
     int gcn_lds, gcn_valu, gcn_nwv, gcn_split;                                                   // AGRL_GCN_*
     int stem_wgs;
+    int wgrad_wgs;   // AGRL_WGRAD_WGS: workgroups the pixel-axis split of agrl_conv_wgrad aims for
     int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library
 };
 const AgrlOpts& agrl_opts();

@@ -45,6 +45,7 @@ static AgrlOpts load_opts() {
     o.gcn_nwv = opt_int("AGRL_GCN_NWV");
     o.gcn_split = opt_flag("AGRL_GCN_SPLIT");
     o.stem_wgs = opt_int("AGRL_STEM_WGS");
+    o.wgrad_wgs = opt_int("AGRL_WGRAD_WGS");
 #ifdef AGRL_ABLATE
     o.igemm_dbg = agrl_opt_set(opt_int("AGRL_IGEMM_DBG")) ? opt_int("AGRL_IGEMM_DBG") : 0;
     o.conv3x3_dbg = agrl_opt_set(opt_int("AGRL_CONV3X3_DBG")) ? opt_int("AGRL_CONV3X3_DBG") : 0;

@@ -82,6 +82,8 @@ SIGNATURES = {
     "agrl_bn_backward": [_p, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _i, _i, _p, C.c_size_t, _p],
     "agrl_im2col_t": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_gemm_nt_splitk": [_p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p],
+    "agrl_conv_wgrad_workspace": [_i] * 9,   # returns size_t
+    "agrl_conv_wgrad": [_p, _p, _p] + [_i] * 10 + [_p, C.c_size_t, _p],
     "agrl_maxpool3x3s2": [_p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_maxpool3x3s2_backward": [_p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_diag_read_stream": [_p, C.c_size_t, _p, _i, _p],
@@ -117,6 +119,7 @@ def lib():
             fn.restype = _i
         h.agrl_re_ranking_workspace.restype = C.c_size_t
         h.agrl_bn_workspace.restype = C.c_size_t
+        h.agrl_conv_wgrad_workspace.restype = C.c_size_t
         h.agrl_graph_message_pass_workspace.restype = C.c_size_t
         for name in ("agrl_reload_options", "agrl_built_with_ablation"):
             getattr(h, name).argtypes = []

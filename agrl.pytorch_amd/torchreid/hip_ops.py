@@ -619,6 +619,26 @@ def gemm_nt_splitk(x, w):
     return y
 
 
+def conv_wgrad_supported(Cin, Cout):
+    return Cin % 4 == 0 and Cout % 4 == 0
+
+
+def conv_wgrad(x, dy, wshape, stride, pad):
+    """Weight gradient of a conv from the NHWC activations: x (F,H,W,Cin), dy (F,OH,OW,Cout) fp32 -> dw (Cout,Cin,R,S) fp32
+    (the nn.Conv2d.weight.grad layout); exact fp32 or, under ``f32_split``, the split-bf16 arithmetic."""
+    Cout, Cin, R, S = (int(v) for v in wshape)
+    F_, H, W, Cc = x.shape
+    assert Cc == Cin and dy.shape[-1] == Cout and x.dtype == torch.float32 and dy.dtype == torch.float32
+    x, dy = x.contiguous(), dy.contiguous()
+    dw = torch.empty((Cout, Cin, R, S), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        nbytes = _hip.lib().agrl_conv_wgrad_workspace(F_, H, W, Cin, Cout, R, S, stride, pad)
+        ws = torch.empty((max(int(nbytes) // 4, 4),), dtype=torch.float32, device=x.device)
+        call("agrl_conv_wgrad", ptr(x), ptr(dy), ptr(dw), F_, H, W, Cin, Cout, R, S, stride, pad, _gemm_code(torch.float32), ptr(ws),
+             ws.numel() * 4, _stream(x))
+    return dw
+
+
 def maxpool3x3s2(x):
     F_, H, W, Cc = x.shape
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1

@@ -80,9 +80,12 @@ class HipConv2d(torch.autograd.Function):
                     dyz[:, ::stride, ::stride][:, :dy.shape[1], :dy.shape[2]] = dy
                 dx = ops.conv_bn_act(dyz, wf, None, 1, R - 1 - pad, False)
         if ctx.needs_input_grad[1]:
-            xt = ops.im2col_t(x, R, S, stride, pad)                                    # (R*S*Cin, M)
-            dyt = ops.im2col_t(dy, 1, 1, 1, 0)                                         # (Cout, M)
-            dw = ops.gemm_nt_splitk(dyt, xt).view(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
+            if ops.conv_wgrad_supported(Cin, Cout):
+                dw = ops.conv_wgrad(x, dy, weight.shape, stride, pad)                  # contraction over the pixel axis, in place
+            else:                                                                      # classifier widths (702, 625, ...)
+                xt = ops.im2col_t(x, R, S, stride, pad)                                # (R*S*Cin, M)
+                dyt = ops.im2col_t(dy, 1, 1, 1, 0)                                     # (Cout, M)
+                dw = ops.gemm_nt_splitk(dyt, xt).view(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
         return dx, dw, None, None
 
 

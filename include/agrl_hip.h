@@ -351,6 +351,15 @@ int agrl_im2col_t(const float* x, float* T, int ldT, int F, int H, int W, int C,
 int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M, int K, int Nout, int in_dtype, void* workspace,
                         size_t workspace_bytes, agrl_stream_t stream);
 
+/* Weight gradient of a conv layer straight from the NHWC activations (no transposed copies): x (F,H,W,Cin) fp32, dy
+ * (F,OH,OW,Cout) fp32 -> dw (Cout,Cin,R,S) fp32, the layout of nn.Conv2d.weight.grad (what loss.backward(),
+ * train_vidreid_xent_htri.py:411, produces for every conv of torchreid/models/vmgn.py:45-65). Cin % 4 == Cout % 4 == 0,
+ * operands 16-byte aligned. dtype 0 = exact fp32 MFMA, 2 = split-bf16 (three bf16 MFMAs per product). The pixel axis is split
+ * over workgroups; partials live in ``workspace`` (agrl_conv_wgrad_workspace bytes) and are summed in slice order. */
+size_t agrl_conv_wgrad_workspace(int F, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad);
+int agrl_conv_wgrad(const float* x, const float* dy, float* dw, int F, int H, int W, int Cin, int Cout, int R, int S, int stride,
+                    int pad, int dtype, void* workspace, size_t workspace_bytes, agrl_stream_t stream);
+
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) of the stem (vmgn.py:284) on NHWC fp32: out (F,OH,OW,C) and the arg-max tap
  * (0..8, first maximum in scan order) per output; backward gathers dout through the taps (no atomics). */
 int agrl_maxpool3x3s2(const float* x, float* out, unsigned char* idx, int F, int H, int W, int C, agrl_stream_t stream);
