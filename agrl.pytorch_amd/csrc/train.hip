@@ -282,6 +282,42 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const float* __restrict__
     }
 }
 
+// ---- pixel-major patches (the stem conv as a pointwise GEMM) ---------------------------------------------------------------
+// P[m][(r * S + s) * C + c] = x[f][oh * stride - pad + r][ow * stride - pad + s][c] (0 outside the frame and in the padding
+// columns R*S*C .. ldP-1), m = (f, oh, ow). With 3 input channels the implicit-GEMM kernels would pad every tap to their
+// 32-channel k granularity (10.7 x the arithmetic); 7*7*3 = 147 patch columns padded to 160 make conv1 a 160 -> 64 pointwise
+// layer whose forward and weight gradient run on the same kernels as every other 1x1. x is NHWC or (``nchw``) the frames as
+// the data loader delivers them. CC / RR / SS: compile-time copies of C / R / S (0 = run time) so that the column -> (tap,
+// channel) split costs multiplications, not divisions.
+template <int CC, int RR, int SS>
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ x, float* __restrict__ P, int ldP4, int H, int W,
+                                                          int C_, int OH, int OW, int R_, int S_, int stride, int pad, int nchw,
+                                                          size_t total4) {
+    const int C = CC ? CC : C_, R = RR ? RR : R_, S = SS ? SS : S_;
+    const int ncol = R * S * C;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+        const size_t m = e / (size_t)ldP4;
+        const int c4 = (int)(e - m * (size_t)ldP4);
+        const int ow = (int)(m % (size_t)OW);
+        const size_t t = m / (size_t)OW;
+        const int oh = (int)(t % (size_t)OH), f = (int)(t / (size_t)OH);
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 4 * c4 + j;
+            v[j] = 0.f;
+            if (n < ncol) {
+                const int tap = n / C, c = n - tap * C;
+                const int r = tap / S, s_ = tap - r * S;
+                const int ih = oh * stride - pad + r, iw = ow * stride - pad + s_;
+                if (ih >= 0 && ih < H && iw >= 0 && iw < W)
+                    v[j] = nchw ? x[(((size_t)f * C + c) * H + ih) * W + iw] : x[(((size_t)f * H + ih) * W + iw) * C + c];
+            }
+        }
+        reinterpret_cast<float4*>(P)[e] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // ---- 3x3 / stride 2 / pad 1 max pooling (nn.MaxPool2d of the stem, vmgn.py:284) ------------------------------------------------
 // forward: first maximum in window scan order wins (strict >), its tap index 0..8 is kept for the backward pass
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
@@ -435,6 +471,24 @@ extern "C" int agrl_im2col_t(const float* x, float* T, int ldT, int F, int H, in
     hipLaunchKernelGGL(im2col_t_kernel, dim3(cdiv(ldT, 32), cdiv(C, 32), R * S), dim3(256), 0, (hipStream_t)stream, x, T, H, W, C, OH,
                        OW, R, S, stride, pad, Mout, ldT);
     AGRL_CHECK_LAUNCH("agrl_im2col_t");
+    return 0;
+}
+
+extern "C" int agrl_im2col_rows(const float* x, float* P, int ldP, int F, int H, int W, int C, int R, int S, int stride, int pad,
+                                int nchw, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && P && F > 0 && H > 0 && W > 0 && C > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_im2col_rows: bad arguments");
+    AGRL_CHECK_ARG(ldP >= R * S * C && (ldP % 4) == 0 && (((uintptr_t)P) & 15) == 0, "agrl_im2col_rows: ldP=%d must be >= R*S*C=%d, a multiple of 4, P 16-byte aligned", ldP, R * S * C);
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    AGRL_CHECK_ARG(OH > 0 && OW > 0, "agrl_im2col_rows: empty output");
+    const size_t total4 = (size_t)F * OH * OW * (ldP / 4);
+    const int blocks = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+    if (C == 3 && R == 7 && S == 7)
+        hipLaunchKernelGGL((im2col_rows_kernel<3, 7, 7>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, P, ldP / 4, H, W, C, OH, OW, R, S,
+                           stride, pad, nchw, total4);
+    else
+        hipLaunchKernelGGL((im2col_rows_kernel<0, 0, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, P, ldP / 4, H, W, C, OH, OW, R, S,
+                           stride, pad, nchw, total4);
+    AGRL_CHECK_LAUNCH("agrl_im2col_rows");
     return 0;
 }
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "agrl_bn_backward": [_p, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _i, _i, _p, C.c_size_t, _p],
     "agrl_im2col_t": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_gemm_nt_splitk": [_p, _p, _p, _i, _i, _i, _i, _p, C.c_size_t, _p],
+    "agrl_im2col_rows": [_p, _p] + [_i] * 10 + [_p],
     "agrl_conv_wgrad_workspace": [_i] * 9,   # returns size_t
     "agrl_conv_wgrad": [_p, _p, _p] + [_i] * 10 + [_p, C.c_size_t, _p],
     "agrl_maxpool3x3s2": [_p, _p, _p, _i, _i, _i, _i, _p],

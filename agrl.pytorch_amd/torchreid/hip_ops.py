@@ -619,6 +619,20 @@ def gemm_nt_splitk(x, w):
     return y
 
 
+def im2col_rows(x, R, S, stride, pad, ld, nchw=False):
+    """Pixel-major patches of an NHWC (or NCHW) fp32 tensor: -> (F*OH*OW, ld), columns (r, s, c), zero padded to ``ld``."""
+    if nchw:
+        F_, Cc, H, W = x.shape
+    else:
+        F_, H, W, Cc = x.shape
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    x = x.contiguous()
+    P = torch.empty((F_ * OH * OW, ld), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        call("agrl_im2col_rows", ptr(x), ptr(P), ld, F_, H, W, Cc, R, S, stride, pad, 1 if nchw else 0, _stream(x))
+    return P, OH, OW
+
+
 def conv_wgrad_supported(Cin, Cout):
     return Cin % 4 == 0 and Cout % 4 == 0
 

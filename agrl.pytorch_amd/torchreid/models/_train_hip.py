@@ -89,34 +89,6 @@ class HipConv2d(torch.autograd.Function):
         return dx, dw, None, None
 
 
-class HipStemConv(torch.autograd.Function):
-    """conv1 of the stem (7x7 / 2, 3 -> 64; vmgn.py:281): forward on the implicit-GEMM kernel with the 3 input channels
-    zero-padded to its K granularity (32); the weight gradient from the UNPADDED input (147 = 7*7*3 im2col rows instead of
-    1568); no data gradient (the frames are the leaves of the graph)."""
-
-    @staticmethod
-    def forward(ctx, x3, weight):
-        x3 = x3.contiguous()                                                            # (F,H,W,3)
-        ctx.save_for_backward(x3, weight)
-        ctx.split = _split_mode()
-        xp = torch.nn.functional.pad(x3, (0, 29)).contiguous()
-        wp = torch.nn.functional.pad(weight.detach(), (0, 0, 0, 0, 0, 29))
-        return _conv_forward(xp, wp, 2, 3)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x3, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        Cout, Cin, R, S = weight.shape
-        dw = None
-        if ctx.needs_input_grad[1]:
-            xt = ops.im2col_t(x3, R, S, 2, 3)                                           # (147, M)
-            dyt = ops.im2col_t(dy, 1, 1, 1, 0)                                          # (64, M)
-            with ops.f32_split(ctx.split):
-                dw = ops.gemm_nt_splitk(dyt, xt).view(Cout, R, S, Cin).permute(0, 3, 1, 2).contiguous()
-        return None, dw
-
-
 class HipBatchNormAct(torch.autograd.Function):
     """BatchNorm2d in train mode (+ shortcut add) (+ ReLU) on NHWC fp32: out = act(bn(y) + residual)."""
 
@@ -191,7 +163,15 @@ def bottleneck_train(unit, x):
 
 def stem_train(model, frames_nchw):
     """conv1 7x7/2 + bn1 + relu + maxpool (vmgn.py:281-284)."""
-    y = HipStemConv.apply(frames_nchw.permute(0, 2, 3, 1), model.conv1.weight)
+    w = model.conv1.weight                                                            # (64, 3, 7, 7)
+    Cout, Cin, R, S = w.shape
+    ncol = R * S * Cin
+    ld = -(-ncol // 32) * 32                                                          # 147 -> 160: the GEMM's k granularity
+    patches, OH, OW = ops.im2col_rows(frames_nchw.detach(), R, S, 2, 3, ld, nchw=True)  # (F*OH*OW, 160), columns (r, s, c)
+    # the weight in the patches' column order; its gradient returns through these (tiny) torch ops
+    wp = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(Cout, ncol), (0, ld - ncol))
+    y = HipConv2d.apply(patches.view(1, patches.shape[0], 1, ld), wp.view(Cout, ld, 1, 1), 1, 0)
+    y = y.view(frames_nchw.shape[0], OH, OW, Cout)
     y = _bn_act(model.bn1, y, None, True)
     return HipMaxPool.apply(y)
 

@@ -345,6 +345,13 @@ int agrl_bn_backward(const float* dout, const float* out, const float* y, const 
 int agrl_im2col_t(const float* x, float* T, int ldT, int F, int H, int W, int C, int R, int S, int stride, int pad,
                   agrl_stream_t stream);
 
+/* Pixel-major patch matrix P (F*OH*OW, ldP) fp32: P[m][(r*S + s)*C + c] = x[f][oh*stride - pad + r][ow*stride - pad + s][c],
+ * zeros outside the frame and in the padding columns R*S*C .. ldP-1 (ldP % 4 == 0). x is NHWC (nchw = 0) or NCHW (nchw = 1).
+ * Turns conv1 of the stem (7x7 / 2, 3 -> 64; torchreid/models/vmgn.py:281) into a 160 -> 64 pointwise layer for the train
+ * step: forward, and weight gradient, on the kernels of every other 1x1 conv. */
+int agrl_im2col_rows(const float* x, float* P, int ldP, int F, int H, int W, int C, int R, int S, int stride, int pad, int nchw,
+                     agrl_stream_t stream);
+
 /* y (M,Nout) fp32 = x (M,K) @ w (Nout,K)^T with the K axis split over workgroups when there are few output tiles (weight
  * gradients: K = pixels); workspace >= 256 * M * Nout * 4 bytes allows every split the entry point may choose (smaller
  * workspaces reduce the split). Deterministic: partials are summed in slice order. */

@@ -48,6 +48,23 @@ def test_conv_forward_dgrad_wgrad(cfg, split):
     assert max(e) < (1e-4 if split else 1e-5)
 
 
+@pytest.mark.parametrize("cfg", [(3, 3, 32, 16, 7, 2, 3, 160, True), (2, 3, 9, 7, 7, 2, 3, 148, False), (2, 8, 6, 5, 3, 1, 1, 72, False),
+                                 (1, 5, 4, 4, 1, 1, 0, 8, True)])
+def test_im2col_rows_matches_unfold(cfg):
+    """agrl_im2col_rows (the stem conv as a pointwise layer over pixel-major patches) against F.unfold: bitwise."""
+    from torchreid import hip_ops
+    N, C, H, W, R, stride, pad, ld, nchw = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:8]))
+    x = torch.randn((N, C, H, W), generator=g)
+    ref = F.unfold(x, R, padding=pad, stride=stride)                                   # (N, C*R*R, L), rows (c, r, s)
+    L = ref.shape[-1]
+    ref = ref.view(N, C, R * R, L).permute(0, 3, 2, 1).reshape(N * L, R * R * C)        # pixel-major, columns (r, s, c)
+    xd = x.to(DEV) if nchw else x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    P, OH, OW = hip_ops.im2col_rows(xd, R, R, stride, pad, ld, nchw=nchw)
+    assert OH * OW == L and tuple(P.shape) == (N * L, ld)
+    assert torch.equal(P[:, :R * R * C].cpu(), ref) and (P[:, R * R * C:] == 0).all()
+
+
 @pytest.mark.parametrize("cfg", [(3, 7, 5, 36, 20, 3, 1, 1), (2, 6, 4, 8, 12, 1, 1, 0), (5, 9, 6, 68, 132, 3, 2, 1), (1, 4, 4, 4, 4, 5, 1, 2),
                                  (70, 8, 4, 192, 320, 1, 2, 0)])
 def test_conv_wgrad_ragged_shapes(cfg):
@@ -425,7 +442,7 @@ def test_native_step_is_what_runs(monkeypatch):
             "agrl_attn_pool_bnneck", "agrl_attn_pool_backward", "agrl_axpby", "agrl_xent_label_smooth", "agrl_triplet_loss"} <= names
     # ... and no stock-torch arithmetic kernel is left between the input frames and the loss: the autograd graph of the loss
     # consists of the native nodes plus views / gathers / the scalar sums of DeepSupervision
-    native = ("HipConv2d", "HipStemConv", "HipBatchNormAct", "HipMaxPool", "HipPartPool", "HipGraphMatrix", "HipGraphBmm", "HipAxpby",
+    native = ("HipConv2d", "HipBatchNormAct", "HipMaxPool", "HipPartPool", "HipGraphMatrix", "HipGraphBmm", "HipAxpby",
               "HipAttnPool", "HipXent", "_NativeTriplet")
     plumbing = ("View", "Reshape", "Permute", "Transpose", "Gather", "Add", "Div", "Mul", "AccumulateGrad", "Alias", "Unsafe", "Expand",
                 "Squeeze", "Unsqueeze", "Clone", "T", "Select", "Slice", "Copy", "Constant", "AsStrided", "Repeat", "ToCopy", "Contiguous")
