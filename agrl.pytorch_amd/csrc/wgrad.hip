@@ -36,6 +36,8 @@ __device__ inline float comp(const float4& v, int j) { return j == 0 ? v.x : (j 
 template <typename TIN, int BM, int BN>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradParams p) {
     constexpr int FM = BM / 32, FN = BN / 32;   // 16-channel fragments per wave: co (MFMA columns), ci (MFMA rows)
+    // ONE k-tile in the LDS (32 KB at 128 x 128): three workgroups per CU. A second buffer (one barrier per k-tile instead of
+    // two) was measured: two workgroups per CU, 11.1 -> 13.8 ms over the model's shapes -- occupancy is worth more here.
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * 128];
     unsigned char* sA = smem;              // dy tile: BM channel rows x 32 pixels
     unsigned char* sB = smem + BM * 128;   // x tile:  BN channel rows x 32 pixels
@@ -145,27 +147,27 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradParams p) {
     }
 }
 
-// dw[co][ci][tap] = sum_z ws[z][co][tap][ci]; 64 float4 columns x 4 slice lanes per block, lane sums added in lane order
+// dw[co][ci][tap] = sum_z ws[z][co][tap][ci]; 16 float4 columns x 16 slice lanes per block (a lane adds every 16th slice, four
+// loads in flight), lane sums added in lane order: the summation order depends on the slice count only
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int ks, float* __restrict__ dw, int Cout, int Cin,
                                                            int taps) {
-    __shared__ float4 s_p[4][64];
-    const int col = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    __shared__ float4 s_p[16][17];
+    const int col = threadIdx.x & 15, zl = threadIdx.x >> 4;
     const size_t total4 = (size_t)Cout * taps * (Cin >> 2);
-    const size_t e4 = (size_t)blockIdx.x * 64 + col;
-    const size_t slice4 = total4;
+    const size_t e4 = (size_t)blockIdx.x * 16 + col;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e4 < total4) {
         const float4* src = reinterpret_cast<const float4*>(ws) + e4;
         int z = zl;
-        for (; z + 12 < ks; z += 16) {
+        for (; z + 48 < ks; z += 64) {
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(z + 4 * u) * slice4];
+            for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(z + 16 * u) * total4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
-        for (; z < ks; z += 4) {
-            const float4 v = src[(size_t)z * slice4];
+        for (; z < ks; z += 16) {
+            const float4 v = src[(size_t)z * total4];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (zl != 0 || e4 >= total4) return;
     float4 t = s_p[0][col];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) { t.x += s_p[k][col].x; t.y += s_p[k][col].y; t.z += s_p[k][col].z; t.w += s_p[k][col].w; }
+    for (int k = 1; k < 16; ++k) { t.x += s_p[k][col].x; t.y += s_p[k][col].y; t.z += s_p[k][col].z; t.w += s_p[k][col].w; }
     const int c4n = Cin >> 2;
     const int ci = 4 * (int)(e4 % c4n);
     const size_t rest = e4 / c4n;
@@ -192,7 +194,36 @@ struct WgradPlan {
     int bm, bn, m_tiles, n_tiles, nk, ks, cps;
 };
 
-static WgradPlan wgrad_plan(int Mtot, int Cin, int Cout, int taps) {
+// Workgroups of one kernel variant the device holds at once (occupancy x compute units), queried once per variant. The slices
+// are equally long, so a grid of exactly one resident round has no tail: 144 tiles x 6 slices = 864 workgroups on 768 slots ran
+// two rounds (56 % of the slots busy on average), 144 x 5 = 720 runs one.
+template <typename TIN, int BM, int BN>
+static int wgrad_capacity_of() {
+    static int cap = 0;
+    if (cap == 0) {
+        int dev = 0, cus = 256, per_cu = 2;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_tn_kernel<TIN, BM, BN>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        (void)hipGetLastError();
+        cap = per_cu * (cus > 0 ? cus : 256);
+    }
+    return cap;
+}
+
+static int wgrad_capacity(int dtype, int bm, int bn) {
+    if (dtype == AGRL_F32) {
+        if (bm == 128 && bn == 128) return wgrad_capacity_of<float, 128, 128>();
+        if (bm == 128) return wgrad_capacity_of<float, 128, 64>();
+        if (bn == 128) return wgrad_capacity_of<float, 64, 128>();
+        return wgrad_capacity_of<float, 64, 64>();
+    }
+    if (bm == 128 && bn == 128) return wgrad_capacity_of<f32s_t, 128, 128>();
+    if (bm == 128) return wgrad_capacity_of<f32s_t, 128, 64>();
+    if (bn == 128) return wgrad_capacity_of<f32s_t, 64, 128>();
+    return wgrad_capacity_of<f32s_t, 64, 64>();
+}
+
+static WgradPlan wgrad_plan(int Mtot, int Cin, int Cout, int taps, int dtype) {
     WgradPlan pl;
     pl.bm = Cout >= 128 ? 128 : 64;
     pl.bn = Cin >= 128 ? 128 : 64;
@@ -201,9 +232,9 @@ static WgradPlan wgrad_plan(int Mtot, int Cin, int Cout, int taps) {
     pl.n_tiles = cdiv(Cin, pl.bn);
     pl.nk = cdiv(Mtot, 32);
     const int tiles = pl.m_tiles * pl.n_tiles * taps;
-    const int target = agrl_opt_set(agrl_opts().wgrad_wgs) ? agrl_opts().wgrad_wgs : 768;
-    int ks = cdiv(target, tiles);         // cover the 256 CUs three times
-    if (ks > 256) ks = 256;
+    const int target = agrl_opt_set(agrl_opts().wgrad_wgs) ? agrl_opts().wgrad_wgs : wgrad_capacity(dtype, pl.bm, pl.bn);
+    int ks = target / tiles;              // one resident round, as full as the tile count allows
+    if (ks > 1024) ks = 1024;
     if (ks > pl.nk / 4) ks = pl.nk / 4;   // at least four k-tiles per slice
     if (ks < 1) ks = 1;
     pl.cps = cdiv(pl.nk, ks);
@@ -226,8 +257,8 @@ extern "C" size_t agrl_conv_wgrad_workspace(int F, int H, int W, int Cin, int Co
     if (F <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 0;
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     if (OH <= 0 || OW <= 0) return 0;
-    const WgradPlan pl = wgrad_plan(F * OH * OW, Cin, Cout, R * S);
-    return (size_t)pl.ks * Cout * R * S * Cin * sizeof(float);
+    const WgradPlan p0 = wgrad_plan(F * OH * OW, Cin, Cout, R * S, AGRL_F32), p1 = wgrad_plan(F * OH * OW, Cin, Cout, R * S, AGRL_F32X3);
+    return (size_t)(p0.ks > p1.ks ? p0.ks : p1.ks) * Cout * R * S * Cin * sizeof(float);   // enough for either arithmetic mode
 }
 
 extern "C" int agrl_conv_wgrad(const float* x, const float* dy, float* dw, int F, int H, int W, int Cin, int Cout, int R, int S,
@@ -242,7 +273,7 @@ extern "C" int agrl_conv_wgrad(const float* x, const float* dy, float* dw, int F
     AGRL_CHECK_ARG(OH > 0 && OW > 0, "agrl_conv_wgrad: empty output");
     AGRL_CHECK_ARG((long long)F * OH * OW < (1ll << 31) - 64, "agrl_conv_wgrad: too many pixels");
     const int taps = R * S;
-    const WgradPlan pl = wgrad_plan(F * OH * OW, Cin, Cout, taps);
+    const WgradPlan pl = wgrad_plan(F * OH * OW, Cin, Cout, taps, dtype);
     AGRL_CHECK_ARG(workspace_bytes >= (size_t)pl.ks * Cout * taps * Cin * sizeof(float), "agrl_conv_wgrad: workspace too small (agrl_conv_wgrad_workspace)");
     WgradParams p;
     p.x = x; p.dy = dy; p.ws = (float*)workspace;
@@ -255,7 +286,7 @@ extern "C" int agrl_conv_wgrad(const float* x, const float* dy, float* dw, int F
     else launch_wgrad<f32s_t>(p, pl, taps, st);
     AGRL_CHECK_LAUNCH("agrl_conv_wgrad");
     const size_t total4 = (size_t)Cout * taps * (Cin / 4);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(256), 0, st, (const float*)workspace, pl.ks, dw, Cout, Cin,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, st, (const float*)workspace, pl.ks, dw, Cout, Cin,
                        taps);
     AGRL_CHECK_LAUNCH("agrl_conv_wgrad(reduce)");
     return 0;

@@ -54,6 +54,59 @@ __global__ __launch_bounds__(512) void k32(int iters, float* sink, const bf16x8*
     if (s == 12345.678f) *sink = s;
 }
 
+// exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, the train step's arithmetic): 8 accumulator tiles (wave tile 32 x 64 of the fp32
+// implicit GEMM), four MFMAs per tile and 16-byte chunk. CHAINED: the four back to back on one accumulator (program order of
+// Frag<float>::mma); otherwise tile-interleaved (dependent distance 8 MFMAs).
+template <bool CHAINED>
+__global__ __launch_bounds__(512) void kf32(int iters, float* sink, const bf16x8* src) {
+    f32x4 a[2], b[4];
+    for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&src[threadIdx.x + 64 * i]);
+    for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const f32x4*>(&src[threadIdx.x + 64 * (2 + i)]);
+    f32x4 acc[2][4];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        if (CHAINED) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) *sink = s;
+}
+
+template <typename K>
+static void run_f32(const char* name, K kern, int waves, int iters, float* sink, const bf16x8* src) {
+    hipEvent_t s, e;
+    hipEventCreate(&s);
+    hipEventCreate(&e);
+    float best = 1e9f, ms = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(s);
+        hipLaunchKernelGGL(kern, dim3(256), dim3(waves * 64), 0, 0, iters, sink, src);
+        hipEventRecord(e);
+        hipEventSynchronize(e);
+        hipEventElapsedTime(&ms, s, e);
+        if (ms < best) best = ms;
+    }
+    const double fl = 2.0 * 32 * 64 * 16 * (double)iters * waves * 256;   // one iteration = 32 x 64 x 16
+    printf("%-34s waves/CU %d iters %7d  best %8.3f ms %7.1f TFLOP/s\n", name, waves, iters, best, fl / best / 1e9);
+}
+
 template <typename K>
 static void run(const char* name, K kern, int waves, int iters, float* sink, const bf16x8* src) {
     hipEvent_t s, e;
@@ -96,6 +149,10 @@ int main() {
             run("16x16x32 (32 acc x 4 regs)", k16, 8, iters, sink, src);
             run("32x32x16 (8 acc x 16 regs)", k32, 4, iters, sink, src);
             run("32x32x16 (8 acc x 16 regs)", k32, 8, iters, sink, src);
+        }
+        for (int waves : {4, 8}) {
+            run_f32("fp32 16x16x4, chained per tile", kf32<true>, waves, 100000, sink, src);
+            run_f32("fp32 16x16x4, tile-interleaved", kf32<false>, waves, 100000, sink, src);
         }
     }
     return 0;
