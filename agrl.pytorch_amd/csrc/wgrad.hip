@@ -34,16 +34,17 @@ struct WgradParams {
 __device__ inline float comp(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 template <typename TIN, int BM, int BN>
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradParams p) {
-    constexpr int FM = BM / 32, FN = BN / 32;   // 16-channel fragments per wave: co (MFMA columns), ci (MFMA rows)
-    // ONE k-tile in the LDS (32 KB at 128 x 128): three workgroups per CU. A second buffer (one barrier per k-tile instead of
-    // two) was measured: two workgroups per CU, 11.1 -> 13.8 ms over the model's shapes -- occupancy is worth more here.
+__global__ __launch_bounds__(512) void wgrad_tn_kernel(const WgradParams p) {
+    // 8 waves as 4 (co) x 2 (ci); wave tile (BM / 4) x (BN / 2)
+    constexpr int FM = BM / 64, FN = BN / 32;   // 16-channel fragments per wave: co (MFMA columns), ci (MFMA rows)
+    // ONE k-tile in the LDS (32 KB at 128 x 128). A second buffer (one barrier per k-tile instead of two) was measured with the
+    // 4-wave form: one workgroup less per CU, 11.1 -> 13.8 ms over the model's shapes -- occupancy is worth more here.
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * 128];
     unsigned char* sA = smem;              // dy tile: BM channel rows x 32 pixels
     unsigned char* sB = smem + BM * 128;   // x tile:  BN channel rows x 32 pixels
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 3, wn = wave >> 2;
     int bx = blockIdx.x;
     const int tm = bx % p.m_tiles;
     bx /= p.m_tiles;
@@ -53,17 +54,17 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradParams p) {
     const int co0 = tm * BM, ci0 = tn * BN;
     const int k0 = blockIdx.y * p.cps, k1 = min(p.nk, k0 + p.cps);
 
-    // loader: pixel quad q of the k-tile, channel quad cq of the tile
-    const int q = lane & 7, cq = wave * 8 + (lane >> 3);
-    const bool in_a = 4 * cq < BM, in_b = 4 * cq < BN;
-    const bool la = in_a && co0 + 4 * cq < p.Cout, lb = in_b && ci0 + 4 * cq < p.Cin;
-    const float* a_src = p.dy + co0 + 4 * cq;
-    const float* b_src = p.x + ci0 + 4 * cq;
-    float4 ra[4], rb[4];
+    // loader: waves 0-3 stage the dy tile, waves 4-7 the x tile; a thread owns pixel quad q of the k-tile and channel quad cq
+    const bool ldx = wave >= 4;                       // wave-uniform
+    const int q = lane & 7, cq = (wave & 3) * 8 + (lane >> 3);
+    const bool in_t = 4 * cq < (ldx ? BN : BM);
+    const bool ld_ok = in_t && (ldx ? ci0 + 4 * cq < p.Cin : co0 + 4 * cq < p.Cout);
+    const float* src = ldx ? p.x + ci0 + 4 * cq : p.dy + co0 + 4 * cq;
+    float4 rg[4];
     auto load = [&](int kt) {
         const int pb = kt * 32 + 4 * q;
         int ox = 0, oy = 0, f = 0;
-        if (!p.pointwise) {
+        if (ldx && !p.pointwise) {
             ox = pb % p.OW;
             const int t = pb / p.OW;
             oy = t % p.OH;
@@ -72,36 +73,30 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradParams p) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int pix = pb + rr;
-            ra[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pix < p.Mtot) {
-                if (la) ra[rr] = *reinterpret_cast<const float4*>(a_src + (size_t)pix * p.Cout);
-                if (lb) {
-                    if (p.pointwise) {
-                        rb[rr] = *reinterpret_cast<const float4*>(b_src + (size_t)pix * p.Cin);
-                    } else {
-                        const int iy = oy * p.stride + r - p.pad, ix = ox * p.stride + s - p.pad;
-                        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                            rb[rr] = *reinterpret_cast<const float4*>(b_src + ((size_t)(f * p.H + iy) * p.W + ix) * p.Cin);
-                    }
+            rg[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < p.Mtot && ld_ok) {
+                if (!ldx) {
+                    rg[rr] = *reinterpret_cast<const float4*>(src + (size_t)pix * p.Cout);
+                } else if (p.pointwise) {
+                    rg[rr] = *reinterpret_cast<const float4*>(src + (size_t)pix * p.Cin);
+                } else {
+                    const int iy = oy * p.stride + r - p.pad, ix = ox * p.stride + s - p.pad;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                        rg[rr] = *reinterpret_cast<const float4*>(src + ((size_t)(f * p.H + iy) * p.W + ix) * p.Cin);
                 }
             }
-            if (!p.pointwise && ++ox == p.OW) {
+            if (ldx && !p.pointwise && ++ox == p.OW) {
                 ox = 0;
                 if (++oy == p.OH) { oy = 0; ++f; }
             }
         }
     };
     auto stash = [&]() {
-        if (in_a) {
+        if (in_t) {
+            unsigned char* dst = ldx ? sB : sA;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(sA + lds_off(4 * cq + j, q)) = make_float4(comp(ra[0], j), comp(ra[1], j), comp(ra[2], j), comp(ra[3], j));
-        }
-        if (in_b) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(sB + lds_off(4 * cq + j, q)) = make_float4(comp(rb[0], j), comp(rb[1], j), comp(rb[2], j), comp(rb[3], j));
+                *reinterpret_cast<float4*>(dst + lds_off(4 * cq + j, q)) = make_float4(comp(rg[0], j), comp(rg[1], j), comp(rg[2], j), comp(rg[3], j));
         }
     };
 
@@ -124,7 +119,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradParams p) {
 #pragma unroll
             for (int a = 0; a < FN; ++a) xf[a] = *reinterpret_cast<const uint4*>(sB + lds_off(wn * (BN / 2) + a * 16 + frow, kk * 4 + fchunk));
 #pragma unroll
-            for (int b = 0; b < FM; ++b) df[b] = *reinterpret_cast<const uint4*>(sA + lds_off(wm * (BM / 2) + b * 16 + frow, kk * 4 + fchunk));
+            for (int b = 0; b < FM; ++b) df[b] = *reinterpret_cast<const uint4*>(sA + lds_off(wm * (BM / 4) + b * 16 + frow, kk * 4 + fchunk));
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -136,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const WgradParams p) {
     float* out = p.ws + (size_t)blockIdx.y * p.Cout * ncol + (size_t)tap * p.Cin;
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-        const int co = co0 + wm * (BM / 2) + b * 16 + frow;
+        const int co = co0 + wm * (BM / 4) + b * 16 + frow;
         if (co >= p.Cout) continue;
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
@@ -203,7 +198,7 @@ static int wgrad_capacity_of() {
     if (cap == 0) {
         int dev = 0, cus = 256, per_cu = 2;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_tn_kernel<TIN, BM, BN>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wgrad_tn_kernel<TIN, BM, BN>, 512, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         (void)hipGetLastError();
         cap = per_cu * (cus > 0 ? cus : 256);
     }
@@ -233,10 +228,20 @@ static WgradPlan wgrad_plan(int Mtot, int Cin, int Cout, int taps, int dtype) {
     pl.nk = cdiv(Mtot, 32);
     const int tiles = pl.m_tiles * pl.n_tiles * taps;
     const int target = agrl_opt_set(agrl_opts().wgrad_wgs) ? agrl_opts().wgrad_wgs : wgrad_capacity(dtype, pl.bm, pl.bn);
-    int ks = target / tiles;              // one resident round, as full as the tile count allows
-    if (ks > 1024) ks = 1024;
-    if (ks > pl.nk / 4) ks = pl.nk / 4;   // at least four k-tiles per slice
-    if (ks < 1) ks = 1;
+    // slice count: fill whole resident rounds (at most three) as evenly as the tile count allows -- 144 tiles on 512 slots: 3 slices
+    // fill 84 % of one round, 7 slices 98 % of two
+    int ks_max = pl.nk / 4;               // at least four k-tiles per slice
+    if (ks_max > 1024) ks_max = 1024;
+    if (ks_max < 1) ks_max = 1;
+    int ks = 1;
+    double best = -1.0;
+    for (int c = 1; c <= ks_max; ++c) {
+        const long wgs = (long)tiles * c;
+        const long rounds = (wgs + target - 1) / target;
+        if (rounds > 3) break;
+        const double fill = (double)wgs / (double)(rounds * target);
+        if (fill > best + 0.02) { best = fill; ks = c; }
+    }
     pl.cps = cdiv(pl.nk, ks);
     pl.ks = cdiv(pl.nk, pl.cps);
     return pl;
@@ -245,10 +250,10 @@ static WgradPlan wgrad_plan(int Mtot, int Cin, int Cout, int taps, int dtype) {
 template <typename TIN>
 static void launch_wgrad(const WgradParams& p, const WgradPlan& pl, int taps, hipStream_t st) {
     const dim3 grid(pl.m_tiles * pl.n_tiles * taps, pl.ks);
-    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 128, 128>), grid, dim3(256), 0, st, p);
-    else if (pl.bm == 128) hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 128, 64>), grid, dim3(256), 0, st, p);
-    else if (pl.bn == 128) hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 64, 128>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 64, 64>), grid, dim3(256), 0, st, p);
+    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 128, 128>), grid, dim3(512), 0, st, p);
+    else if (pl.bm == 128) hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 128, 64>), grid, dim3(512), 0, st, p);
+    else if (pl.bn == 128) hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 64, 128>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_tn_kernel<TIN, 64, 64>), grid, dim3(512), 0, st, p);
 }
 
 }  // namespace
