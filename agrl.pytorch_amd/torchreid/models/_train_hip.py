@@ -32,6 +32,28 @@ def _conv_forward(x, w_oihw, stride, pad):
     return ops.conv_bn_act(x, w, None, stride, pad, False)
 
 
+def _dgrad_3x3_stride2(dy, weight, H, W):
+    """Data gradient of a 3x3 / stride 2 / pad 1 conv (the first conv2 of layers 2 and 3) without the zero-inserted dy (four
+    times the pixels, three quarters of them zeros): input pixel (iy, ix) only meets the taps whose parity matches,
+        iy = 2a     : r = 1 -> dy[a]              iy = 2a + 1 : r = 2 -> dy[a],  r = 0 -> dy[a + 1]
+    (columns alike), so dx splits into four parity phases, each a stride-1 conv of dy (one zero row / column appended) with
+    a 1x1, 1x2, 2x1 or 2x2 sub-filter: 9 taps in total = the forward's arithmetic."""
+    F_, OH, OW, Cout = dy.shape
+    Cin = weight.shape[1]
+    dyp = torch.nn.functional.pad(dy, (0, 0, 0, 1, 0, 1))                             # (F, OH + 1, OW + 1, Cout)
+    dx = torch.empty((F_, H, W, Cin), dtype=dy.dtype, device=dy.device)
+    taps = ((1,), (2, 0))                                                            # filter rows met by even / odd input rows
+    for py in (0, 1):
+        for px in (0, 1):
+            nr, nc = (H - py + 1) // 2, (W - px + 1) // 2
+            if nr <= 0 or nc <= 0:
+                continue
+            k = weight[:, :, list(taps[py])][:, :, :, list(taps[px])].permute(1, 2, 3, 0).contiguous()   # (Cin, Rk, Sk, Cout)
+            out = ops.conv_bn_act(dyp, k, None, 1, 0, False)                          # (F, OH + 2 - Rk, OW + 2 - Sk, Cin)
+            dx[:, py::2, px::2] = out[:, :nr, :nc]
+    return dx
+
+
 class HipConv2d(torch.autograd.Function):
     """NHWC conv without bias. x (F,H,W,Cin) fp32, weight OIHW (the nn.Conv2d parameter itself) -> (F,OH,OW,Cout)."""
 
@@ -72,13 +94,16 @@ class HipConv2d(torch.autograd.Function):
             else:
                 # dx[i] = sum_r dyz[i + r - pad'] w[R-1-r]: a stride-1 conv of the (zero-inserted) dy with the flipped filter,
                 # output and input channels exchanged
-                wf = weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()       # (Cin, R, S, Cout) OHWI
-                if stride == 1:
-                    dyz = dy
+                if (R, S, stride, pad) == (3, 3, 2, 1):
+                    dx = _dgrad_3x3_stride2(dy, weight.detach(), H, W)
                 else:
-                    dyz = torch.zeros((F_, H, W, Cout), dtype=dy.dtype, device=dy.device)
-                    dyz[:, ::stride, ::stride][:, :dy.shape[1], :dy.shape[2]] = dy
-                dx = ops.conv_bn_act(dyz, wf, None, 1, R - 1 - pad, False)
+                    wf = weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()   # (Cin, R, S, Cout) OHWI
+                    if stride == 1:
+                        dyz = dy
+                    else:
+                        dyz = torch.zeros((F_, H, W, Cout), dtype=dy.dtype, device=dy.device)
+                        dyz[:, ::stride, ::stride][:, :dy.shape[1], :dy.shape[2]] = dy
+                    dx = ops.conv_bn_act(dyz, wf, None, 1, R - 1 - pad, False)
         if ctx.needs_input_grad[1]:
             if ops.conv_wgrad_supported(Cin, Cout):
                 dw = ops.conv_wgrad(x, dy, weight.shape, stride, pad)                  # contraction over the pixel axis, in place
