@@ -114,6 +114,61 @@ class HipConv2d(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class HipConvFork(torch.autograd.Function):
+    """The two consumers of a Bottleneck's input as ONE node, so that their two data gradients are summed inside a GEMM epilogue
+    instead of by autograd's accumulation (an extra read-read-write pass over the block's largest tensor, 16 times per step):
+
+        identity shortcut (vmgn.py:58):      x -> conv1(x), x                        backward: dx = dy1 W1 + dshortcut
+        downsample shortcut (vmgn.py:60-61): x -> conv1(x), downsample conv(x)       backward: dx = dyd Wd + (dy1 W1)
+
+    both sums as the ``residual`` operand of the data-gradient GEMM (``agrl_conv2d_bn_act``). A strided downsample (first blocks
+    of layers 2 / 3) lands on the sampled pixels only: a strided add on a quarter of the tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w1, wd, stride_d):
+        x = x.contiguous()
+        ctx.split = _split_mode()
+        ctx.stride_d = int(stride_d)
+        y1 = _conv_forward(x, w1, 1, 0)
+        if wd is None:
+            ctx.save_for_backward(x, w1)
+            return y1, x
+        ctx.save_for_backward(x, w1, wd)
+        return y1, _conv_forward(x, wd, ctx.stride_d, 0)
+
+    @staticmethod
+    def backward(ctx, dy1, dsc):
+        with ops.f32_split(ctx.split):
+            return HipConvFork._backward(ctx, dy1, dsc)
+
+    @staticmethod
+    def _backward(ctx, dy1, dsc):
+        saved = ctx.saved_tensors
+        x, w1 = saved[0], saved[1]
+        wd = saved[2] if len(saved) > 2 else None
+        dy1, dsc = dy1.contiguous(), dsc.contiguous()
+        C1, Cin = w1.shape[0], w1.shape[1]
+
+        def w_t(w):      # dgrad of a 1x1 conv = a 1x1 conv of dy with the transposed matrix: OHWI (Cin, 1, 1, Cout)
+            return w.detach().view(w.shape[0], Cin).t().contiguous().view(Cin, 1, 1, w.shape[0])
+        dx = dw1 = dwd = None
+        if ctx.needs_input_grad[0]:
+            if wd is None:
+                dx = ops.conv_bn_act(dy1, w_t(w1), None, 1, 0, False, residual=dsc)
+            else:
+                dx = ops.conv_bn_act(dy1, w_t(w1), None, 1, 0, False)
+                if ctx.stride_d == 1:
+                    dx = ops.conv_bn_act(dsc, w_t(wd), None, 1, 0, False, residual=dx)
+                else:
+                    d = ops.conv_bn_act(dsc, w_t(wd), None, 1, 0, False)
+                    dx[:, ::ctx.stride_d, ::ctx.stride_d] += d
+        if ctx.needs_input_grad[1]:
+            dw1 = ops.conv_wgrad(x, dy1, w1.shape, 1, 0)
+        if wd is not None and ctx.needs_input_grad[2]:
+            dwd = ops.conv_wgrad(x, dsc, wd.shape, ctx.stride_d, 0)
+        return dx, dw1, dwd, None
+
+
 class HipBatchNormAct(torch.autograd.Function):
     """BatchNorm2d in train mode (+ shortcut add) (+ ReLU) on NHWC fp32: out = act(bn(y) + residual)."""
 
@@ -178,11 +233,18 @@ def _conv(conv, x):
 
 def bottleneck_train(unit, x):
     """Bottleneck.forward (vmgn.py:45-65) in train mode, NHWC."""
-    y = _bn_act(unit.bn1, _conv(unit.conv1, x), None, True)
+    ds = unit.downsample
+    C1, Cin = unit.conv1.weight.shape[:2]
+    fork = (x.requires_grad and unit.conv1.stride[0] == 1 and Cin % 32 == 0 and C1 % 32 == 0 and
+            (ds is None or (ds[0].weight.shape[0] % 32 == 0 and ds[0].kernel_size == (1, 1))))
+    if fork:
+        y1, sc = HipConvFork.apply(x, unit.conv1.weight, None if ds is None else ds[0].weight, 1 if ds is None else ds[0].stride[0])
+        shortcut = sc if ds is None else _bn_act(ds[1], sc, None, False)
+    else:                                                                             # the trunk's first block (x = the pooled stem output needs its gradient too, but keep the plain nodes for odd widths)
+        y1 = _conv(unit.conv1, x)
+        shortcut = x if ds is None else _bn_act(ds[1], _conv(ds[0], x), None, False)
+    y = _bn_act(unit.bn1, y1, None, True)
     y = _bn_act(unit.bn2, _conv(unit.conv2, y), None, True)
-    shortcut = x
-    if unit.downsample is not None:
-        shortcut = _bn_act(unit.downsample[1], _conv(unit.downsample[0], x), None, False)
     return _bn_act(unit.bn3, _conv(unit.conv3, y), shortcut, True)
 
 

@@ -442,7 +442,7 @@ def test_native_step_is_what_runs(monkeypatch):
             "agrl_attn_pool_bnneck", "agrl_attn_pool_backward", "agrl_axpby", "agrl_xent_label_smooth", "agrl_triplet_loss"} <= names
     # ... and no stock-torch arithmetic kernel is left between the input frames and the loss: the autograd graph of the loss
     # consists of the native nodes plus views / gathers / the scalar sums of DeepSupervision
-    native = ("HipConv2d", "HipBatchNormAct", "HipMaxPool", "HipPartPool", "HipGraphMatrix", "HipGraphBmm", "HipAxpby",
+    native = ("HipConv2d", "HipConvFork", "HipBatchNormAct", "HipMaxPool", "HipPartPool", "HipGraphMatrix", "HipGraphBmm", "HipAxpby",
               "HipAttnPool", "HipXent", "_NativeTriplet")
     plumbing = ("View", "Reshape", "Permute", "Transpose", "Gather", "Add", "Div", "Mul", "AccumulateGrad", "Alias", "Unsafe", "Expand",
                 "Squeeze", "Unsqueeze", "Clone", "T", "Select", "Slice", "Copy", "Constant", "AsStrided", "Repeat", "ToCopy", "Contiguous")
