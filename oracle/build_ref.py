@@ -5,7 +5,9 @@ imported by the product. Recipe = what the reference's own setup.py does (cython
 
     cython -3 rank_cy.pyx -o oracle/_ref/rank_cy.c ; gcc -O2 -shared -fPIC $(python-config --includes) -I numpy ...
 
-No reference source is copied into the repository: the generated C file and the .so live only under oracle/_ref/.
+No reference source is copied into the repository: only the built .so stays under oracle/_ref/ (the generated C file, which
+quotes the .pyx line by line, is deleted after the compile), so nothing that reads like the reference's source travels to the GPU
+box with the snapshot.
 """
 import os
 import subprocess
@@ -35,6 +37,7 @@ def build(verbose=True):
     cmd = ["gcc", "-O2", "-shared", "-fPIC", "-w", "-I" + sysconfig.get_paths()["include"], "-I" + np.get_include(),
            "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION", c_file, "-o", so]
     subprocess.check_call(cmd)
+    os.remove(c_file)   # the intermediate carries the reference's source text as comments: only the binary is kept (and travels)
     if verbose:
         print("built", so)
     return so
