@@ -200,6 +200,31 @@ def test_vmgn_eval_at_benchmarked_size_stage_by_stage(bench_size_oracle, precisi
     m.hip_precision = "fp32"
 
 
+def test_under_data_parallel_wrapper():
+    """The driver wraps the model in nn.DataParallel (train_vidreid_xent_htri.py:318) and calls it from there in test() and in
+    train(): eval forward through the wrapper equals the oracle, and a train forward + backward through the wrapper (replica
+    thread, scatter / gather around the native nodes) leaves gradients on the wrapped module's parameters."""
+    m, sd = build(num_classes=6, consistent_loss=True)
+    x, adj = synthetic_clips(4, 6, 64, 32, seed=9), synthetic_adj(4, 6, seed=9)
+    with torch.no_grad():
+        ref = O.vmgn_eval(x, adj, sd)
+    m = m.to(DEV)
+    m.hip_precision = "fp32"
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    got = dp(x.to(DEV), adj.to(DEV))
+    assert tuple(got.shape) == (4, 4096) and rel(got, ref) < 1e-3
+    dp.train()
+    from torchreid import losses
+    outs, feats = dp(x.to(DEV), adj.to(DEV))
+    pids = torch.tensor([0, 0, 1, 1], device=DEV)
+    loss = (losses.DeepSupervision(losses.CrossEntropyLabelSmooth(6, use_gpu=True), outs, pids) +
+            losses.DeepSupervision(losses.TripletLoss(0.3, True), feats, pids))
+    loss.backward()
+    grads = [p.grad for p in m.parameters() if p.requires_grad]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads) and float(loss.detach()) > 0
+    m.eval()
+
+
 def test_weight_cache_tracks_parameter_updates():
     m, sd = build()
     m = m.to(DEV)
