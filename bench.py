@@ -334,6 +334,32 @@ def config4_block(device):
     except RuntimeError as e:  # noqa: BLE001  (out of memory on a small device)
         return {"error": str(e)[:200]}
     fl = 3 * 11.93e9 * B * S
+    # where the native step's time goes: HIP events around every C-ABI call of one more step (exact fp32)
+    try:
+        from torchreid import _hip as _h
+        m.load_state_dict(sd0)
+        m.hip_train, m.hip_train_precision = True, "fp32"
+        m.train()
+        _h.PROFILE = []
+        torch.manual_seed(1234)
+        outs, feats = m(x, adj)
+        (losses.DeepSupervision(ce, outs, pids) + losses.DeepSupervision(htri, feats, pids)).backward()
+        torch.cuda.synchronize()
+        prof, _h.PROFILE = _h.PROFILE, None
+        agg = {}
+        for name, s_ev, e_ev, _tag in prof:
+            agg[name] = agg.get(name, 0.0) + s_ev.elapsed_time(e_ev)
+        gemm_ms = sum(v for k, v in agg.items() if k in ("agrl_conv2d_bn_act", "agrl_linear_nobias", "agrl_conv_wgrad", "agrl_gemm_nt_splitk"))
+        out["native_breakdown"] = {"entry_point_ms": {k: round(v, 2) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:8]},
+                                   "launches": len(prof), "gemm_ms": round(gemm_ms, 2), "gemm_tflops": round(fl / gemm_ms / 1e9, 1),
+                                   "gemm_frac_of_fp32_mfma_peak": round(fl / gemm_ms / 1e9 / PEAK_TFLOPS["fp32"], 3),
+                                   "bound": "mfma (v_mfma_f32_16x16x4_f32: 155 TFLOP/s sustained register-only, tools/mfma_peak.hip)"}
+        m.zero_grad()
+    except Exception as e:  # noqa: BLE001
+        out["native_breakdown"] = {"error": str(e)[:200]}
+    finally:
+        from torchreid import _hip as _h2
+        _h2.PROFILE = None
     out["native"] = {"ms_per_step": round(1e3 * t_nat, 2), "frames_per_s": round(B * S / t_nat, 1), "tflops": round(fl / t_nat / 1e12, 1),
                            "last_loss": round(l_nat, 6)}
     out["native_bf16x3"] = {"ms_per_step": round(1e3 * t_x3, 2), "frames_per_s": round(B * S / t_x3, 1),
