@@ -81,9 +81,11 @@ def test_conv_wgrad_ragged_shapes(cfg):
     for split in (False, True):
         with hip_ops.f32_split(split):
             dw = hip_ops.conv_wgrad(x.permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV), w.shape, stride, pad)
+            dw2 = hip_ops.conv_wgrad(x.permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV), w.shape, stride, pad)
         e = rel(dw, w.grad)
         print("wgrad", cfg, "split" if split else "exact", "%.2e" % e)
         assert e < (1e-4 if split else 1e-5)
+        assert torch.equal(dw, dw2), "the slice reduce runs in a fixed order: two runs must agree bitwise"
 
 
 @pytest.mark.parametrize("cfg", [(4, 16, 8, 64, True, True), (3, 9, 5, 128, False, True), (6, 4, 2, 256, True, False), (2, 64, 32, 64, False, False)])
