@@ -63,15 +63,23 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
+// the four sign bits of float4 number e4 (written by bn_apply_kernel) as +1 / -1: stands in for the forward output wherever
+// only "out > 0" is asked of it
+__device__ inline float4 mask_as_float4(const unsigned char* __restrict__ mask, size_t e4) {
+    const unsigned nib = ((unsigned)mask[e4 >> 1] >> ((unsigned)(e4 & 1) * 4)) & 15u;
+    return make_float4((nib & 1u) ? 1.f : -1.f, (nib & 2u) ? 1.f : -1.f, (nib & 4u) ? 1.f : -1.f, (nib & 8u) ? 1.f : -1.f);
+}
+
 // The same reductions for C % 4 == 0 and 16-byte aligned operands (every layer of the model): a thread owns FOUR channels
 // (16-byte loads; a 64-channel row is one 256-byte segment of 16 lanes, so a wave covers 4 rows of layer 1 per load instead of
 // one 4-byte element per lane) and keeps four row-steps in flight. ``lanes`` = 16 / 32 / 64 float4 columns per block;
 // 256 / lanes row lanes. grid = (ceil(C/4/lanes), chunks).
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_vec_kernel(const float* __restrict__ y, const float* __restrict__ dout,
-                                                            const float* __restrict__ out, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, int relu, float slope, int M, int C,
-                                                            int rows_per_chunk, int lanes, double* __restrict__ partial) {
+                                                            const float* __restrict__ out, const unsigned char* __restrict__ mask,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                            float slope, int M, int C, int rows_per_chunk, int lanes,
+                                                            double* __restrict__ partial) {
     __shared__ float4 s_a[256], s_b[256];
     const int lc = threadIdx.x % lanes, rl = threadIdx.x / lanes, nrl = 256 / lanes;
     const int c4 = blockIdx.x * lanes + lc, C4 = C >> 2;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const float* __restr
                 v[u] = y4[i];
                 if (MODE == 1) {
                     d[u] = d4[i];
-                    o[u] = relu ? o4[i] : v[u];
+                    o[u] = relu ? (mask ? mask_as_float4(mask, i + c4) : o4[i]) : v[u];
                 } else {
                     d[u] = v[u]; o[u] = v[u];
                 }
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const float* __restr
         for (; r < r1; r += nrl) {
             const size_t i = (size_t)r * C4;
             const float4 v = y4[i];
-            acc(v, MODE == 1 ? d4[i] : v, (MODE == 1 && relu) ? o4[i] : v);
+            acc(v, MODE == 1 ? d4[i] : v, (MODE == 1 && relu) ? (mask ? mask_as_float4(mask, i + c4) : o4[i]) : v);
         }
     }
     s_a[threadIdx.x] = a;
@@ -183,24 +191,38 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __re
     }
 }
 
+// ``mask`` (optional, with relu): one bit per element in linear order, set where the pre-activation is positive -- the only thing
+// the backward pass needs from the output (8 x fewer bytes than re-reading it, twice)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ res,
-                                                       float* __restrict__ out, int relu, float slope, size_t total4, int C4) {
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(e % C4);
-        const float4 v = reinterpret_cast<const float4*>(y)[e];
-        const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
-        const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
-        float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-        if (res) {
-            const float4 r = reinterpret_cast<const float4*>(res)[e];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                                                       float* __restrict__ out, unsigned char* __restrict__ mask, int relu, float slope,
+                                                       size_t total4, int C4) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    const size_t iters = (total4 + stride - 1) / stride;
+    size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t it = 0; it < iters; ++it, e += stride) {        // uniform trip count: the mask nibbles travel through a shuffle
+        unsigned bits = 0;
+        if (e < total4) {
+            const int c4 = (int)(e % C4);
+            const float4 v = reinterpret_cast<const float4*>(y)[e];
+            const float4 sc = reinterpret_cast<const float4*>(scale)[c4];
+            const float4 sh = reinterpret_cast<const float4*>(shift)[c4];
+            float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+            if (res) {
+                const float4 r = reinterpret_cast<const float4*>(res)[e];
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            if (relu) {
+                bits = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+                o.x = o.x > 0.f ? o.x : slope * o.x; o.y = o.y > 0.f ? o.y : slope * o.y;
+                o.z = o.z > 0.f ? o.z : slope * o.z; o.w = o.w > 0.f ? o.w : slope * o.w;
+            }
+            reinterpret_cast<float4*>(out)[e] = o;
         }
-        if (relu) {
-            o.x = o.x > 0.f ? o.x : slope * o.x; o.y = o.y > 0.f ? o.y : slope * o.y;
-            o.z = o.z > 0.f ? o.z : slope * o.z; o.w = o.w > 0.f ? o.w : slope * o.w;
+        if (mask) {
+            const unsigned hi = __shfl_xor(bits, 1);             // the odd neighbour's nibble (0 past the end)
+            if (!(e & 1) && e < total4) mask[e >> 1] = (unsigned char)(bits | (hi << 4));
         }
-        reinterpret_cast<float4*>(out)[e] = o;
     }
 }
 
@@ -227,13 +249,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ s1, const float* __restrict__ s2, int relu,
                                                                float slope, float inv_m, float* __restrict__ dy,
-                                                               float* __restrict__ dz_out, size_t total4, int C4) {
+                                                               float* __restrict__ dz_out, const unsigned char* __restrict__ mask,
+                                                               size_t total4, int C4) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
         const int c4 = (int)(e % C4);
         float4 dz = reinterpret_cast<const float4*>(dout)[e];
         const float4 v = reinterpret_cast<const float4*>(y)[e];
         if (relu) {
-            const float4 o = reinterpret_cast<const float4*>(out)[e];
+            const float4 o = mask ? mask_as_float4(mask, e) : reinterpret_cast<const float4*>(out)[e];
             if (!(o.x > 0.f)) dz.x *= slope;
             if (!(o.y > 0.f)) dz.y *= slope;
             if (!(o.z > 0.f)) dz.z *= slope;
@@ -404,7 +427,7 @@ extern "C" int agrl_bn_stats(const float* y, float* mean, float* var, int M, int
     hipStream_t st = (hipStream_t)stream;
     const int lanes = ((uintptr_t)y & 15) ? 0 : reduce_lanes(C);
     if (lanes)
-        hipLaunchKernelGGL(colreduce_vec_kernel<0>, dim3(cdiv(C / 4, lanes), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0,
+        hipLaunchKernelGGL(colreduce_vec_kernel<0>, dim3(cdiv(C / 4, lanes), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                            0.f, M, C, rpc, lanes, (double*)workspace);
     else
         hipLaunchKernelGGL(colreduce_kernel<0>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0, 0.f, M,
@@ -414,23 +437,24 @@ extern "C" int agrl_bn_stats(const float* y, float* mean, float* var, int M, int
     return 0;
 }
 
-extern "C" int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, int M,
-                             int C, int relu, float slope, agrl_stream_t stream) {
+extern "C" int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out,
+                             unsigned char* mask, int M, int C, int relu, float slope, agrl_stream_t stream) {
     AGRL_CHECK_ARG(y && scale && shift && out && M > 0 && C > 0 && (C % 4) == 0, "agrl_bn_apply: bad arguments (C %% 4 == 0)");
     const uintptr_t al = (uintptr_t)y | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)residual | (uintptr_t)out;
     AGRL_CHECK_ARG((al & 15) == 0, "agrl_bn_apply: operands must be 16-byte aligned");
     const size_t total4 = (size_t)M * C / 4;
     const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual, out, relu, slope, total4, C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, scale, shift, residual, out, relu ? mask : nullptr, relu,
+                       slope, total4, C / 4);
     AGRL_CHECK_LAUNCH("agrl_bn_apply");
     return 0;
 }
 
-extern "C" int agrl_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
-                                const float* gamma, int relu, float slope, float* dy, float* dz, float* dgamma, float* dbeta, int M,
-                                int C, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
+extern "C" int agrl_bn_backward(const float* dout, const float* out, const unsigned char* mask, const float* y, const float* mean,
+                                const float* invstd, const float* gamma, int relu, float slope, float* dy, float* dz, float* dgamma,
+                                float* dbeta, int M, int C, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
     AGRL_CHECK_ARG(dout && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace, "agrl_bn_backward: null pointer");
-    AGRL_CHECK_ARG(!relu || out, "agrl_bn_backward: the ReLU mask needs the forward output");
+    AGRL_CHECK_ARG(!relu || out || mask, "agrl_bn_backward: the ReLU mask needs the forward output or the sign mask agrl_bn_apply wrote");
     AGRL_CHECK_ARG(M > 0 && C > 0, "agrl_bn_backward: bad shape");
     AGRL_CHECK_ARG(workspace_bytes >= agrl_bn_workspace(M, C) && (((uintptr_t)workspace) & 7) == 0, "agrl_bn_backward: workspace too small");
     int rpc;
@@ -439,9 +463,11 @@ extern "C" int agrl_bn_backward(const float* dout, const float* out, const float
     const uintptr_t al = (uintptr_t)dout | (uintptr_t)out | (uintptr_t)y | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)gamma |
                          (uintptr_t)dy | (uintptr_t)dz | (uintptr_t)dgamma | (uintptr_t)dbeta;
     const int lanes = (al & 15) ? 0 : reduce_lanes(C);
+    AGRL_CHECK_ARG(!relu || out || lanes, "agrl_bn_backward: the sign-mask form needs C %% 4 == 0 and 16-byte aligned operands");
+    const unsigned char* mk = relu ? mask : nullptr;
     if (lanes)
-        hipLaunchKernelGGL(colreduce_vec_kernel<1>, dim3(cdiv(C / 4, lanes), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, slope,
-                           M, C, rpc, lanes, (double*)workspace);
+        hipLaunchKernelGGL(colreduce_vec_kernel<1>, dim3(cdiv(C / 4, lanes), chunks), dim3(256), 0, st, y, dout, out, mk, mean, invstd, relu,
+                           slope, M, C, rpc, lanes, (double*)workspace);
     else
         hipLaunchKernelGGL(colreduce_kernel<1>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, slope, M, C,
                            rpc, (double*)workspace);
@@ -451,7 +477,7 @@ extern "C" int agrl_bn_backward(const float* dout, const float* out, const float
         const size_t total4 = total / 4;
         const int blocks = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
         hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, mean, invstd, gamma, dbeta, dgamma, relu,
-                           slope, 1.f / (float)M, dy, dz, total4, C / 4);
+                           slope, 1.f / (float)M, dy, dz, mk, total4, C / 4);
     } else {
         const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dout, out, y, mean, invstd, gamma, dbeta, dgamma, relu,

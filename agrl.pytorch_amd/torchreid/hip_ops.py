@@ -567,17 +567,21 @@ def bn_stats(y2d):
     return mean, var
 
 
-def bn_apply(y2d, scale, shift, residual, relu, slope=0.0):
-    """relu: activation on; slope 0 = ReLU, > 0 = LeakyReLU(slope)."""
+def bn_apply(y2d, scale, shift, residual, relu, slope=0.0, want_mask=False):
+    """relu: activation on; slope 0 = ReLU, > 0 = LeakyReLU(slope). -> out, mask: with ``want_mask`` (and relu) the sign bits of
+    the pre-activation, one bit per element (uint8, M*C/8 bytes) -- what ``bn_backward`` needs instead of the output."""
     M, Cc = y2d.shape
     out = torch.empty_like(y2d)
+    mask = torch.empty(((M * Cc + 7) // 8,), dtype=torch.uint8, device=y2d.device) if (want_mask and relu) else None
     with _dev(y2d):
-        call("agrl_bn_apply", ptr(y2d), ptr(scale), ptr(shift), ptr(residual), ptr(out), M, Cc, 1 if relu else 0, float(slope), _stream(y2d))
-    return out
+        call("agrl_bn_apply", ptr(y2d), ptr(scale), ptr(shift), ptr(residual), ptr(out), ptr(mask), M, Cc, 1 if relu else 0, float(slope),
+             _stream(y2d))
+    return out, mask
 
 
-def bn_backward(dout, out, y2d, mean, invstd, gamma, relu, want_dz, slope=0.0):
-    """-> dy (M,C), dz (M,C) or None, dgamma (C), dbeta (C)."""
+def bn_backward(dout, out, y2d, mean, invstd, gamma, relu, want_dz, slope=0.0, mask=None):
+    """-> dy (M,C), dz (M,C) or None, dgamma (C), dbeta (C). With relu either the forward output ``out`` or the sign ``mask``
+    of ``bn_apply``."""
     M, Cc = y2d.shape
     dy = torch.empty_like(y2d)
     dz = torch.empty_like(y2d) if want_dz else None
@@ -585,7 +589,8 @@ def bn_backward(dout, out, y2d, mean, invstd, gamma, relu, want_dz, slope=0.0):
     dbeta = torch.empty((Cc,), dtype=torch.float32, device=y2d.device)
     ws, nbytes = _bn_ws(M, Cc, y2d.device)
     with _dev(y2d):
-        call("agrl_bn_backward", ptr(dout), ptr(out) if relu else None, ptr(y2d), ptr(mean), ptr(invstd), ptr(gamma), 1 if relu else 0,
+        call("agrl_bn_backward", ptr(dout), ptr(out) if (relu and mask is None) else None, ptr(mask) if relu else None, ptr(y2d), ptr(mean),
+             ptr(invstd), ptr(gamma), 1 if relu else 0,
              float(slope), ptr(dy), ptr(dz), ptr(dgamma), ptr(dbeta), M, Cc, ptr(ws), nbytes, _stream(y2d))
     return dy, dz, dgamma, dbeta
 

@@ -181,19 +181,20 @@ class HipBatchNormAct(torch.autograd.Function):
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
         res2 = None if residual is None else residual.contiguous().view(-1, C)
-        out = ops.bn_apply(y2, scale, shift, res2, relu, slope)
-        ctx.save_for_backward(y2, out, mean, invstd, gamma)
+        # with an activation the backward pass needs only the sign of the pre-activation: one bit per element instead of the output
+        out, mask = ops.bn_apply(y2, scale, shift, res2, relu, slope, want_mask=True)
+        ctx.save_for_backward(y2, mask, mean, invstd, gamma)
         ctx.cfg = (bool(relu), residual is not None, tuple(y.shape), float(slope))
         ctx.mark_non_differentiable(mean, var)
         return out.view(y.shape), mean, var
 
     @staticmethod
     def backward(ctx, dout, _dmean, _dvar):
-        y2, out, mean, invstd, gamma = ctx.saved_tensors
+        y2, mask, mean, invstd, gamma = ctx.saved_tensors
         relu, has_res, shape, slope = ctx.cfg
         C = shape[-1]
-        dy, dz, dgamma, dbeta = ops.bn_backward(dout.contiguous().view(-1, C), out, y2, mean, invstd, gamma.detach().contiguous(),
-                                                relu, want_dz=has_res, slope=slope)
+        dy, dz, dgamma, dbeta = ops.bn_backward(dout.contiguous().view(-1, C), None, y2, mean, invstd, gamma.detach().contiguous(),
+                                                relu, want_dz=has_res, slope=slope, mask=mask)
         return dy.view(shape), dgamma, dbeta, (dz.view(shape) if has_res else None), None, None, None
 
 

@@ -327,16 +327,20 @@ int agrl_bn_stats(const float* y, float* mean, float* var, int M, int C, void* w
 
 /* out = act(y * scale[c] + shift[c] (+ residual)): the normalisation with scale = gamma / sqrt(var + eps), shift = beta -
  * mean * scale, the shortcut add and the activation in one pass: relu != 0 -> v > 0 ? v : slope * v (slope 0: the ReLU of
- * vmgn.py:49-64; slope 0.1: the LeakyReLU behind GraphLayer's BatchNorm1d, vmgn.py:169-170). C % 4 == 0. */
-int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, int M, int C,
-                  int relu, float slope, agrl_stream_t stream);
+ * vmgn.py:49-64; slope 0.1: the LeakyReLU behind GraphLayer's BatchNorm1d, vmgn.py:169-170). C % 4 == 0.
+ * mask (optional, used with relu): M*C/8 bytes (rounded up), one bit per element in linear order (bit e & 7 of byte e >> 3),
+ * set where the pre-activation is positive -- all the backward pass needs of the output, at 1/32 of its bytes. */
+int agrl_bn_apply(const float* y, const float* scale, const float* shift, const float* residual, float* out, unsigned char* mask,
+                  int M, int C, int relu, float slope, agrl_stream_t stream);
 
 /* Backward of agrl_bn_apply + batch statistics: dz = relu ? (out > 0 ? dout : slope * dout) : dout; dbeta = sum dz;
  * dgamma = sum dz * xhat (xhat = (y - mean) * invstd); dy = gamma * invstd * (dz - dbeta / M - xhat * dgamma / M).
- * dz (optional) is the gradient that continues into the residual branch. */
-int agrl_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
-                     const float* gamma, int relu, float slope, float* dy, float* dz, float* dgamma, float* dbeta, int M, int C,
-                     void* workspace, size_t workspace_bytes, agrl_stream_t stream);
+ * dz (optional) is the gradient that continues into the residual branch. With relu, "out > 0" comes from ``mask`` (the sign
+ * bits agrl_bn_apply wrote; C % 4 == 0, operands 16-byte aligned) when it is given -- ``out`` may then be NULL -- else from
+ * ``out`` itself. */
+int agrl_bn_backward(const float* dout, const float* out, const unsigned char* mask, const float* y, const float* mean,
+                     const float* invstd, const float* gamma, int relu, float slope, float* dy, float* dz, float* dgamma,
+                     float* dbeta, int M, int C, void* workspace, size_t workspace_bytes, agrl_stream_t stream);
 
 /* T[(tap*C + c)][m] = x[f][oh*stride - pad + r][ow*stride - pad + s][c] (0 outside), tap = r*S + s, m = (f, oh, ow):
  * the channel-major, tap-expanded transpose of x (F,H,W,C) fp32 -> T (R*S*C, ldT) fp32, ldT >= F*OH*OW (columns past the last
