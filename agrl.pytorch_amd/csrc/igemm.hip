@@ -302,6 +302,12 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         }
     } else {
         const bool vec_ok = p.vec_ok != 0;
+        const bool do_stats = p.stats != nullptr;   // workgroup-uniform
+        float st1[FN][4], st2[FN][4];
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st1[a][r] = 0.f; st2[a][r] = 0.f; }
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
             const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
@@ -332,6 +338,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
                     store4<TOUT>(outp + o, v);
+                    if (do_stats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { st1[a][r] += v[r]; st2[a][r] = fmaf(v[r], v[r], st2[a][r]); }
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -343,6 +353,39 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                         }
                     }
                 }
+            }
+        }
+        if (do_stats) {
+            // per-channel sums of this tile's rows: over the 16 pixel lanes of a fragment by shuffles, over the WM wave rows
+            // through the (now idle) staging buffer in wave order, one partial row per 64-row granule of M
+            float* sred = reinterpret_cast<float*>(smem);   // [WM][BN][2]
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float u1 = st1[a][r], u2 = st2[a][r];
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) {
+                        u1 += __shfl_xor(u1, off);
+                        u2 += __shfl_xor(u2, off);
+                    }
+                    if (frow == 0) {
+                        const int col = wn * (BN / 2) + a * 16 + fchunk * 4 + r;
+                        sred[(wm * BN + col) * 2 + 0] = u1;
+                        sred[(wm * BN + col) * 2 + 1] = u2;
+                    }
+                }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+                for (int w_ = 0; w_ < WM; ++w_) {
+                    u1 += sred[(w_ * BN + tid) * 2 + 0];
+                    u2 += sred[(w_ * BN + tid) * 2 + 1];
+                }
+                float* dst = p.stats + (size_t)(m0 >> 6) * 2 * p.N + n0 + tid;
+                dst[0] = u1;
+                dst[p.N] = u2;
             }
         }
     }
@@ -900,7 +943,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     AGRL_CHECK_ARG(R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_conv2d_bn_act: bad filter geometry");
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16 || dtype == AGRL_F32X3, "agrl_conv2d_bn_act: bad dtype %d", dtype);
     IgemmParams p;
-    p.x2 = nullptr; p.K1 = 0;
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
     p.OH = (H + 2 * pad - R) / stride + 1;
@@ -942,12 +985,41 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
 }
 
+// conv without bias / residual / activation in fp32 (exact or split-bf16) whose epilogue also leaves the per-channel sum and sum
+// of squares of every finished tile's rows in ``partial`` ([ceil(M / 64)][2][Cout] floats, zeroed here): the batch statistics
+// of the train-mode BatchNorm behind the conv without a second pass over its output (agrl_bn_stats_from_partials finishes them)
+extern "C" int agrl_conv2d_stats(const float* x, const float* w, float* out, float* partial, size_t partial_bytes, int N, int H, int W,
+                                 int Cin, int Cout, int R, int S, int stride, int pad, int dtype, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && w && out && partial, "agrl_conv2d_stats: null pointer");
+    AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_conv2d_stats: bad shape");
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_F32X3, "agrl_conv2d_stats: dtype must be fp32 (0) or split-bf16 fp32 (2), got %d", dtype);
+    AGRL_CHECK_ARG((Cout % 4) == 0 && (((uintptr_t)out | (uintptr_t)partial) & 15) == 0, "agrl_conv2d_stats: Cout %% 4 == 0, out / partial 16-byte aligned");
+    IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0; p.stats = partial;
+    p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = out;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
+    p.OH = (H + 2 * pad - R) / stride + 1;
+    p.OW = (W + 2 * pad - S) / stride + 1;
+    AGRL_CHECK_ARG(p.OH > 0 && p.OW > 0, "agrl_conv2d_stats: empty output");
+    p.M = N * p.OH * p.OW; p.N = Cout; p.K = R * S * Cin;
+    p.Cin = Cin; p.H = H; p.W = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.ldo = Cout;
+    const size_t need = (size_t)cdiv(p.M, 64) * 2 * Cout * sizeof(float);
+    AGRL_CHECK_ARG(partial_bytes >= need, "agrl_conv2d_stats: partial buffer too small (ceil(M / 64) * 2 * Cout floats)");
+    if (hipMemsetAsync(partial, 0, need, (hipStream_t)stream) != hipSuccess) {   // 128-row tiles fill every other granule row
+        agrl_set_error("agrl_conv2d_stats: hipMemsetAsync failed");
+        return 1;
+    }
+    if (dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_conv2d_stats");
+    return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_conv2d_stats");
+}
+
 extern "C" int agrl_conv1x1_dual_bn_act(const void* x1, const void* x2, const void* w, const float* bias, void* out, int M,
                                        int K1, int K2, int Cout, int relu, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x1 && x2 && w && out, "agrl_conv1x1_dual_bn_act: null pointer");
     AGRL_CHECK_ARG(M > 0 && K1 > 0 && K2 > 0 && Cout > 0, "agrl_conv1x1_dual_bn_act: bad shape");
     IgemmParams p;
-    p.x2 = nullptr; p.K1 = 0;
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x1; p.x2 = x2; p.K1 = K1; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = nullptr; p.out = out;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0; p.dbg = 0; p.vec_ok = 1;
     p.M = M; p.N = Cout; p.K = K1 + K2;
@@ -966,7 +1038,7 @@ extern "C" int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const floa
     AGRL_CHECK_ARG(H * W == 128, "agrl_conv1x1_bn_act_pool: a frame must be exactly 128 pixels (got %dx%d)", H, W);
     AGRL_CHECK_ARG(Cout > 64 && Cout % 8 == 0 && Cin % 64 == 0, "agrl_conv1x1_bn_act_pool: unsupported channel counts");
     IgemmParams p;
-    p.x2 = nullptr; p.K1 = 0;
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = relu; p.ksplit = 1;
     p.OH = H; p.OW = W;
@@ -995,7 +1067,7 @@ extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M,
     AGRL_CHECK_ARG(x && w && y, "agrl_linear_nobias: null pointer");
     AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_linear_nobias: bad dtype %d", in_dtype);
     IgemmParams p;
-    p.x2 = nullptr; p.K1 = 0;
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     p.M = M; p.N = Nout; p.K = K;
@@ -1024,7 +1096,7 @@ extern "C" int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M
     AGRL_CHECK_ARG(x && w && y, "agrl_gemm_nt_splitk: null pointer");
     AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_gemm_nt_splitk: bad dtype %d", in_dtype);
     IgemmParams p;
-    p.x2 = nullptr; p.K1 = 0;
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
     p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     p.M = M; p.N = Nout; p.K = K;
@@ -1064,7 +1136,7 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
     AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && ldd >= n, "agrl_distmat: bad shape m=%d n=%d D=%d ldd=%d", m, n, D, ldd);
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_distmat: bad dtype %d", dtype);
     IgemmParams p;
-    p.x2 = nullptr; p.K1 = 0;
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     if (metric == AGRL_METRIC_EUCLIDEAN) {
         AGRL_CHECK_ARG(qn && gn, "agrl_distmat: euclidean needs the squared row norms");

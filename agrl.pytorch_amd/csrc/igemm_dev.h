@@ -28,6 +28,7 @@ struct IgemmParams {
     int pool_start[16], pool_end[16];  // bins in image rows [start, end)
     float* pool_out;      // fp32 (frames, nparts, N)
     void* pool_out_lp;    // optional bf16 copy
+    float* stats;  // optional (fp32-output, non-LDS epilogue only): per-channel sum / sum of squares of the finished tile's rows, [M / 64 granule][2][N] (train: batch statistics without re-reading the conv output)
     int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
 };
 

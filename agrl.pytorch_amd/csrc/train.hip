@@ -151,9 +151,10 @@ __global__ __launch_bounds__(256) void colreduce_vec_kernel(const float* __restr
 // MODE 0 -> mean, biased variance; MODE 1 -> the two sums themselves (dbeta, dgamma)
 // grid = ceil(C/16) blocks of 16 channels x 16 chunk lanes: a lane adds every 16th partial (loads independent, four in flight),
 // the 16 lane sums are added in lane order by the first 16 threads -- the summation order depends on ``chunks`` only.
-template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __restrict__ partial, int chunks, int C, int M,
-                                                              float* __restrict__ o1, float* __restrict__ o2) {
+template <int MODE, typename TP = double>
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const TP* __restrict__ partial, int chunks, int C, int M,
+                                                              float* __restrict__ o1, float* __restrict__ o2, int kstride) {
+    // chunk k: s1 at partial[k * kstride + c], s2 at partial[k * kstride + C + c] (kstride = 2 C for this file's reductions)
     __shared__ double s_a[16][17], s_b[16][17];
     const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -164,15 +165,15 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const double* __re
             double pa[4], pb[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                pa[u] = partial[((size_t)(k + 16 * u) * 2 + 0) * C + c];
-                pb[u] = partial[((size_t)(k + 16 * u) * 2 + 1) * C + c];
+                pa[u] = (double)partial[(size_t)(k + 16 * u) * kstride + c];
+                pb[u] = (double)partial[(size_t)(k + 16 * u) * kstride + C + c];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { sa += pa[u]; sb += pb[u]; }
         }
         for (; k < chunks; k += 16) {
-            sa += partial[((size_t)k * 2 + 0) * C + c];
-            sb += partial[((size_t)k * 2 + 1) * C + c];
+            sa += (double)partial[(size_t)k * kstride + c];
+            sb += (double)partial[(size_t)k * kstride + C + c];
         }
     }
     s_a[kl][cl] = sa;
@@ -432,8 +433,29 @@ extern "C" int agrl_bn_stats(const float* y, float* mean, float* var, int M, int
     else
         hipLaunchKernelGGL(colreduce_kernel<0>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, nullptr, nullptr, nullptr, nullptr, 0, 0.f, M,
                            C, rpc, (double*)workspace);
-    hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, mean, var);
+    hipLaunchKernelGGL(colreduce_final_kernel<0>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, mean, var, 2 * C);
     AGRL_CHECK_LAUNCH("agrl_bn_stats");
+    return 0;
+}
+
+// mean / biased variance from the per-tile sums agrl_conv2d_stats left ([rows][2][C] floats = a rows x 2C matrix whose column
+// sums are wanted): the vectorised column reduction over the rows (double partials per chunk), then one small final kernel
+extern "C" int agrl_bn_stats_from_partials(const float* partial, int rows, int C, int M, float* mean, float* var, void* workspace,
+                                           size_t workspace_bytes, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(partial && mean && var && workspace && rows > 0 && C > 0 && M > 0, "agrl_bn_stats_from_partials: bad arguments");
+    AGRL_CHECK_ARG((C % 2) == 0 && (((uintptr_t)partial) & 15) == 0, "agrl_bn_stats_from_partials: C must be even, partial 16-byte aligned");
+    AGRL_CHECK_ARG(workspace_bytes >= agrl_bn_workspace(rows, 2 * C) && (((uintptr_t)workspace) & 7) == 0,
+                   "agrl_bn_stats_from_partials: workspace too small (agrl_bn_workspace(rows, 2 * C))");
+    int rpc;
+    const int chunks = reduce_chunks(rows, 2 * C, &rpc);
+    const int lanes = reduce_lanes(2 * C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colreduce_vec_kernel<0>, dim3(cdiv(2 * C / 4, lanes), chunks), dim3(256), 0, st, partial, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, 0, 0.f, rows, 2 * C, rpc, lanes, (double*)workspace);
+    // plane 0 of chunk k holds the 2C column sums [sum | sum of squares]: the usual final reduce with a chunk stride of 4C
+    hipLaunchKernelGGL((colreduce_final_kernel<0, double>), dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, mean, var,
+                       4 * C);
+    AGRL_CHECK_LAUNCH("agrl_bn_stats_from_partials");
     return 0;
 }
 
@@ -471,7 +493,7 @@ extern "C" int agrl_bn_backward(const float* dout, const float* out, const unsig
     else
         hipLaunchKernelGGL(colreduce_kernel<1>, dim3(cdiv(C, 64), chunks), dim3(256), 0, st, y, dout, out, mean, invstd, relu, slope, M, C,
                            rpc, (double*)workspace);
-    hipLaunchKernelGGL(colreduce_final_kernel<1>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, dbeta, dgamma);
+    hipLaunchKernelGGL(colreduce_final_kernel<1>, dim3(cdiv(C, 16)), dim3(256), 0, st, (const double*)workspace, chunks, C, M, dbeta, dgamma, 2 * C);
     const size_t total = (size_t)M * C;
     if (lanes) {
         const size_t total4 = total / 4;

@@ -78,6 +78,8 @@ SIGNATURES = {
     "agrl_triplet_loss": [_p, _p, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p],
     "agrl_bn_workspace": [_i, _i],   # returns size_t
     "agrl_bn_stats": [_p, _p, _p, _i, _i, _p, C.c_size_t, _p],
+    "agrl_conv2d_stats": [_p, _p, _p, _p, C.c_size_t] + [_i] * 10 + [_p],
+    "agrl_bn_stats_from_partials": [_p, _i, _i, _i, _p, _p, _p, C.c_size_t, _p],
     "agrl_bn_apply": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "agrl_bn_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _i, _i, _p, C.c_size_t, _p],
     "agrl_im2col_t": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],

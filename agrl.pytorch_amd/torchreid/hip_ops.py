@@ -567,6 +567,27 @@ def bn_stats(y2d):
     return mean, var
 
 
+def conv_stats(x, w_ohwi, stride, pad):
+    """fp32 NHWC conv (no bias / activation) + the batch statistics of its output: -> y (N,OH,OW,Cout), mean (Cout), var (Cout,
+    biased). The per-tile sums come out of the conv's epilogue; nothing re-reads y."""
+    N, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w_ohwi.shape
+    assert Cin == Cin2 and x.dtype == torch.float32 and w_ohwi.dtype == torch.float32
+    OH, OW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    M = N * OH * OW
+    rows = -(-M // 64)
+    out = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    partial = torch.empty((rows * 2 * Cout,), dtype=torch.float32, device=x.device)
+    mean = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    var = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    with _dev(x):
+        call("agrl_conv2d_stats", ptr(x), ptr(w_ohwi), ptr(out), ptr(partial), partial.numel() * 4, N, H, W, Cin, Cout, R, S, stride, pad,
+             _gemm_code(torch.float32), _stream(x))
+        ws, nbytes = _bn_ws(rows, 2 * Cout, x.device)
+        call("agrl_bn_stats_from_partials", ptr(partial), rows, Cout, M, ptr(mean), ptr(var), ptr(ws), nbytes, _stream(x))
+    return out, mean, var
+
+
 def bn_apply(y2d, scale, shift, residual, relu, slope=0.0, want_mask=False):
     """relu: activation on; slope 0 = ReLU, > 0 = LeakyReLU(slope). -> out, mask: with ``want_mask`` (and relu) the sign bits of
     the pre-activation, one bit per element (uint8, M*C/8 bytes) -- what ``bn_backward`` needs instead of the output."""

@@ -114,6 +114,26 @@ class HipConv2d(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class HipConv2dStats(torch.autograd.Function):
+    """HipConv2d whose forward also returns the batch statistics (mean, biased variance per channel) of its output, taken from
+    the conv kernel's epilogue (agrl_conv2d_stats) instead of a second pass over the output -- for the BatchNorm behind it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (int(stride), int(pad))
+        ctx.split = _split_mode()
+        y, mean, var = ops.conv_stats(x, weight.detach().permute(0, 2, 3, 1).contiguous(), int(stride), int(pad))
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        with ops.f32_split(ctx.split):
+            return HipConv2d._backward(ctx, dy)
+
+
 class HipConvFork(torch.autograd.Function):
     """The two consumers of a Bottleneck's input as ONE node, so that their two data gradients are summed inside a GEMM epilogue
     instead of by autograd's accumulation (an extra read-read-write pass over the block's largest tensor, 16 times per step):
@@ -129,15 +149,18 @@ class HipConvFork(torch.autograd.Function):
         x = x.contiguous()
         ctx.split = _split_mode()
         ctx.stride_d = int(stride_d)
-        y1 = _conv_forward(x, w1, 1, 0)
+        y1, m1, v1 = ops.conv_stats(x, w1.detach().permute(0, 2, 3, 1).contiguous(), 1, 0)
         if wd is None:
             ctx.save_for_backward(x, w1)
-            return y1, x
+            ctx.mark_non_differentiable(m1, v1)
+            return y1, m1, v1, x
         ctx.save_for_backward(x, w1, wd)
-        return y1, _conv_forward(x, wd, ctx.stride_d, 0)
+        sc, md, vd = ops.conv_stats(x, wd.detach().permute(0, 2, 3, 1).contiguous(), ctx.stride_d, 0)
+        ctx.mark_non_differentiable(m1, v1, md, vd)
+        return y1, m1, v1, sc, md, vd
 
     @staticmethod
-    def backward(ctx, dy1, dsc):
+    def backward(ctx, dy1, _m1, _v1, dsc, *_rest):
         with ops.f32_split(ctx.split):
             return HipConvFork._backward(ctx, dy1, dsc)
 
@@ -173,10 +196,13 @@ class HipBatchNormAct(torch.autograd.Function):
     """BatchNorm2d in train mode (+ shortcut add) (+ ReLU) on NHWC fp32: out = act(bn(y) + residual)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, relu, eps, slope=0.0):
+    def forward(ctx, y, gamma, beta, residual, relu, eps, slope=0.0, mean=None, var=None):
         C = y.shape[-1]
         y2 = y.contiguous().view(-1, C)
-        mean, var = ops.bn_stats(y2)
+        if mean is None:
+            mean, var = ops.bn_stats(y2)
+        else:                                   # handed over by the conv in front (HipConv2dStats / HipConvFork)
+            mean, var = mean.detach(), var.detach()
         invstd = torch.rsqrt(var + eps)
         scale = (gamma.detach() * invstd).contiguous()
         shift = (beta.detach() - mean * scale).contiguous()
@@ -195,7 +221,7 @@ class HipBatchNormAct(torch.autograd.Function):
         C = shape[-1]
         dy, dz, dgamma, dbeta = ops.bn_backward(dout.contiguous().view(-1, C), None, y2, mean, invstd, gamma.detach().contiguous(),
                                                 relu, want_dz=has_res, slope=slope, mask=mask)
-        return dy.view(shape), dgamma, dbeta, (dz.view(shape) if has_res else None), None, None, None
+        return dy.view(shape), dgamma, dbeta, (dz.view(shape) if has_res else None), None, None, None, None, None
 
 
 class HipMaxPool(torch.autograd.Function):
@@ -213,12 +239,12 @@ class HipMaxPool(torch.autograd.Function):
         return ops.maxpool3x3s2_backward(dout.contiguous(), idx, ctx.hw[0], ctx.hw[1])
 
 
-def _bn_act(bn, y, residual, relu, slope=0.0):
+def _bn_act(bn, y, residual, relu, slope=0.0, stats=None):
     """nn.BatchNorm{1,2}d(train) semantics around HipBatchNormAct, including the running-statistics update. ``slope`` > 0:
-    LeakyReLU instead of ReLU."""
+    LeakyReLU instead of ReLU. ``stats`` = (mean, biased var) of y when the producing conv already has them."""
     if not bn.training or not bn.track_running_stats:
         raise RuntimeError('the native train path expects BatchNorm layers in train mode with running statistics')
-    out, mean, var = HipBatchNormAct.apply(y, bn.weight, bn.bias, residual, relu, bn.eps, slope)
+    out, mean, var = HipBatchNormAct.apply(y, bn.weight, bn.bias, residual, relu, bn.eps, slope, *(stats or (None, None)))
     with torch.no_grad():
         n = y.numel() // y.shape[-1]
         bn.num_batches_tracked += 1
@@ -232,6 +258,14 @@ def _conv(conv, x):
     return HipConv2d.apply(x, conv.weight, conv.stride[0], conv.padding[0])
 
 
+def _conv_bn(conv, bn, x, residual, relu):
+    """conv -> BatchNorm(train) [+ residual] [-> ReLU]; the statistics come out of the conv's epilogue when its widths allow."""
+    if conv.weight.shape[0] % 4 == 0:
+        y, mean, var = HipConv2dStats.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+        return _bn_act(bn, y, residual, relu, stats=(mean, var))
+    return _bn_act(bn, _conv(conv, x), residual, relu)
+
+
 def bottleneck_train(unit, x):
     """Bottleneck.forward (vmgn.py:45-65) in train mode, NHWC."""
     ds = unit.downsample
@@ -239,14 +273,14 @@ def bottleneck_train(unit, x):
     fork = (x.requires_grad and unit.conv1.stride[0] == 1 and Cin % 32 == 0 and C1 % 32 == 0 and
             (ds is None or (ds[0].weight.shape[0] % 32 == 0 and ds[0].kernel_size == (1, 1))))
     if fork:
-        y1, sc = HipConvFork.apply(x, unit.conv1.weight, None if ds is None else ds[0].weight, 1 if ds is None else ds[0].stride[0])
-        shortcut = sc if ds is None else _bn_act(ds[1], sc, None, False)
-    else:                                                                             # the trunk's first block (x = the pooled stem output needs its gradient too, but keep the plain nodes for odd widths)
-        y1 = _conv(unit.conv1, x)
-        shortcut = x if ds is None else _bn_act(ds[1], _conv(ds[0], x), None, False)
-    y = _bn_act(unit.bn1, y1, None, True)
-    y = _bn_act(unit.bn2, _conv(unit.conv2, y), None, True)
-    return _bn_act(unit.bn3, _conv(unit.conv3, y), shortcut, True)
+        res = HipConvFork.apply(x, unit.conv1.weight, None if ds is None else ds[0].weight, 1 if ds is None else ds[0].stride[0])
+        y = _bn_act(unit.bn1, res[0], None, True, stats=(res[1], res[2]))
+        shortcut = res[3] if ds is None else _bn_act(ds[1], res[3], None, False, stats=(res[4], res[5]))
+    else:                                                                             # odd widths: the plain nodes
+        y = _conv_bn(unit.conv1, unit.bn1, x, None, True)
+        shortcut = x if ds is None else _conv_bn(ds[0], ds[1], x, None, False)
+    y = _conv_bn(unit.conv2, unit.bn2, y, None, True)
+    return _conv_bn(unit.conv3, unit.bn3, y, shortcut, True)
 
 
 def stem_train(model, frames_nchw):
@@ -258,9 +292,9 @@ def stem_train(model, frames_nchw):
     patches, OH, OW = ops.im2col_rows(frames_nchw.detach(), R, S, 2, 3, ld, nchw=True)  # (F*OH*OW, 160), columns (r, s, c)
     # the weight in the patches' column order; its gradient returns through these (tiny) torch ops
     wp = torch.nn.functional.pad(w.permute(0, 2, 3, 1).reshape(Cout, ncol), (0, ld - ncol))
-    y = HipConv2d.apply(patches.view(1, patches.shape[0], 1, ld), wp.view(Cout, ld, 1, 1), 1, 0)
+    y, mean, var = HipConv2dStats.apply(patches.view(1, patches.shape[0], 1, ld), wp.view(Cout, ld, 1, 1), 1, 0)
     y = y.view(frames_nchw.shape[0], OH, OW, Cout)
-    y = _bn_act(model.bn1, y, None, True)
+    y = _bn_act(model.bn1, y, None, True, stats=(mean, var))
     return HipMaxPool.apply(y)
 
 

@@ -325,6 +325,15 @@ size_t agrl_bn_workspace(int M, int C);
 int agrl_bn_stats(const float* y, float* mean, float* var, int M, int C, void* workspace, size_t workspace_bytes,
                   agrl_stream_t stream);
 
+/* The conv in front of a train-mode BatchNorm (nn.Conv2d without bias, vmgn.py:48/52/56/60) in fp32 (dtype 0 exact, 2
+ * split-bf16) whose epilogue also leaves per-channel sum / sum of squares of every finished tile in ``partial``
+ * ([ceil(M/64)][2][Cout] floats, M = N*OH*OW; zeroed by the call), and the reduce that turns them into the batch mean / biased
+ * variance: the statistics of vmgn.py:49/53/57/61 without re-reading the conv output. x NHWC, w OHWI, out NHWC. */
+int agrl_conv2d_stats(const float* x, const float* w, float* out, float* partial, size_t partial_bytes, int N, int H, int W, int Cin,
+                      int Cout, int R, int S, int stride, int pad, int dtype, agrl_stream_t stream);
+int agrl_bn_stats_from_partials(const float* partial, int rows, int C, int M, float* mean, float* var, void* workspace,
+                                size_t workspace_bytes /* agrl_bn_workspace(rows, 2 * C) */, agrl_stream_t stream);
+
 /* out = act(y * scale[c] + shift[c] (+ residual)): the normalisation with scale = gamma / sqrt(var + eps), shift = beta -
  * mean * scale, the shortcut add and the activation in one pass: relu != 0 -> v > 0 ? v : slope * v (slope 0: the ReLU of
  * vmgn.py:49-64; slope 0.1: the LeakyReLU behind GraphLayer's BatchNorm1d, vmgn.py:169-170). C % 4 == 0.

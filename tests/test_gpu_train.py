@@ -88,6 +88,29 @@ def test_conv_wgrad_ragged_shapes(cfg):
         assert torch.equal(dw, dw2), "the slice reduce runs in a fixed order: two runs must agree bitwise"
 
 
+@pytest.mark.parametrize("cfg", [(40, 16, 8, 512, 256, 1, 1, 0), (3, 9, 5, 64, 128, 3, 2, 1), (2, 64, 32, 64, 64, 3, 1, 1), (256, 16, 8, 256, 1024, 1, 1, 0),
+                                 (5, 7, 3, 32, 36, 1, 1, 0)])
+def test_conv_epilogue_statistics(cfg):
+    """agrl_conv2d_stats: the conv output equals agrl_conv2d_bn_act's bitwise, and the batch statistics that come out of its
+    epilogue (per-tile fp32 sums, reduced in double) match a float64 reduction of that output -- 64- and 128-row tiles, ragged
+    pixel counts, channel counts that do not fill a tile."""
+    from torchreid import hip_ops
+    N, H, W, Cin, Cout, R, stride, pad = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn((N, H, W, Cin), generator=g).to(DEV)
+    w = (torch.randn((Cout, R, R, Cin), generator=g) / np.sqrt(Cin * R * R)).to(DEV)
+    for split in (False, True):
+        with hip_ops.f32_split(split):
+            y, mean, var = hip_ops.conv_stats(x, w, stride, pad)
+            y_ref = hip_ops.conv_bn_act(x, w, None, stride, pad, False)
+        assert torch.equal(y, y_ref)
+        y64 = y.double().view(-1, Cout)
+        e_m = ((mean.double() - y64.mean(0)).abs().max() / y64.std(0).mean()).item()
+        e_v = ((var.double() - y64.var(0, unbiased=False)).abs() / y64.var(0, unbiased=False)).max().item()
+        print("conv stats", cfg, "split" if split else "exact", "mean %.1e var %.1e" % (e_m, e_v))
+        assert e_m < 1e-6 and e_v < 1e-5
+
+
 @pytest.mark.parametrize("cfg", [(4, 16, 8, 64, True, True), (3, 9, 5, 128, False, True), (6, 4, 2, 256, True, False), (2, 64, 32, 64, False, False)])
 def test_batchnorm_act_forward_backward(cfg):
     """HipBatchNormAct (batch statistics, shortcut add, ReLU) and the running-statistics update against nn.BatchNorm2d in
@@ -444,7 +467,7 @@ def test_native_step_is_what_runs(monkeypatch):
             "agrl_attn_pool_bnneck", "agrl_attn_pool_backward", "agrl_axpby", "agrl_xent_label_smooth", "agrl_triplet_loss"} <= names
     # ... and no stock-torch arithmetic kernel is left between the input frames and the loss: the autograd graph of the loss
     # consists of the native nodes plus views / gathers / the scalar sums of DeepSupervision
-    native = ("HipConv2d", "HipConvFork", "HipBatchNormAct", "HipMaxPool", "HipPartPool", "HipGraphMatrix", "HipGraphBmm", "HipAxpby",
+    native = ("HipConv2d", "HipConv2dStats", "HipConvFork", "HipBatchNormAct", "HipMaxPool", "HipPartPool", "HipGraphMatrix", "HipGraphBmm", "HipAxpby",
               "HipAttnPool", "HipXent", "_NativeTriplet")
     plumbing = ("View", "Reshape", "Permute", "Transpose", "Gather", "Add", "Div", "Mul", "AccumulateGrad", "Alias", "Unsafe", "Expand",
                 "Squeeze", "Unsqueeze", "Clone", "T", "Select", "Slice", "Copy", "Constant", "AsStrided", "Repeat", "ToCopy", "Contiguous")
