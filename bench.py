@@ -349,7 +349,7 @@ def config4_block(device):
         agg = {}
         for name, s_ev, e_ev, _tag in prof:
             agg[name] = agg.get(name, 0.0) + s_ev.elapsed_time(e_ev)
-        gemm_ms = sum(v for k, v in agg.items() if k in ("agrl_conv2d_bn_act", "agrl_linear_nobias", "agrl_conv_wgrad", "agrl_gemm_nt_splitk"))
+        gemm_ms = sum(v for k, v in agg.items() if k in ("agrl_conv2d_bn_act", "agrl_conv2d_stats", "agrl_linear_nobias", "agrl_conv_wgrad", "agrl_gemm_nt_splitk"))
         out["native_breakdown"] = {"entry_point_ms": {k: round(v, 2) for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:8]},
                                    "launches": len(prof), "gemm_ms": round(gemm_ms, 2), "gemm_tflops": round(fl / gemm_ms / 1e9, 1),
                                    "gemm_frac_of_fp32_mfma_peak": round(fl / gemm_ms / 1e9 / PEAK_TFLOPS["fp32"], 3),
