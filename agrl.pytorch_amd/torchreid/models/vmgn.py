@@ -210,7 +210,10 @@ class GSTA(nn.Module):
             return hip_forward(self, x, adj)
 
         B, S, C, H, W = x.size()
-        if x.is_cuda and self.training and self.hip_train and self.hip_train_tail and x.dtype == torch.float32:
+        if x.is_cuda and self.training and self.hip_train and x.dtype != torch.float32:
+            raise TypeError('the native train step takes float32 frames (the reference trains in fp32), got {}; '
+                            'set model.hip_train = False for the stock-torch module tree'.format(x.dtype))
+        if x.is_cuda and self.training and self.hip_train and self.hip_train_tail:
             # the whole train forward -- trunk, pooling, graph layers, attention pooling, BNNecks, classifiers -- as autograd
             # Functions over C-ABI calls (models/_train_hip.py); the losses have native forms too (torchreid/losses)
             from torchreid.models._train_hip import forward_train
