@@ -552,17 +552,20 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
 // Gram matrices to each other INSIDE the launch:
 //   A  the workgroup loads its f slice (V x 256 fp32, 57 KB at V = 56) into LDS -- it stays there as the residual input of
 //      phase C -- and forms the partial Gram over its 256 channels with v_mfma_f32_16x16x4_f32 (exact fp32), stores it, and
-//      publishes: __syncthreads -> lane 0: agent-scope release fence -> s_waitcnt vmcnt(0) -> relaxed agent atomic add on the
-//      tracklet's counter (cdna_hip_programming.md Guideline 16, counter form; placement-independent);
+//      publishes WITHOUT a fence: the partial goes out with write-through (sc1, relaxed agent-scope atomic) stores, every wave
+//      drains them (s_waitcnt vmcnt(0)), __syncthreads, then lane 0 does a relaxed agent-scope atomic add on the tracklet's
+//      counter; the readers use sc1 loads (L2-served, never this CU's L1) -- the "sc1 both sides" form of
+//      cdna_hip_programming.md Guideline 16, placement-independent;
 //      its h slice (the operand of phase C) is requested into registers BEFORE the wait, so the hand-off latency is covered;
-//   B  lane 0 polls the counter (relaxed, s_sleep) until all NS partials are in, ONE agent-scope acquire fence,
-//      __syncthreads; then every workgroup of the tracklet redundantly sums the NS partials in slice order (deterministic),
+//   B  lane 0 polls the counter (relaxed, s_sleep) until all NS partials are in, __syncthreads (no acquire fence: the
+//      partials are read with sc1 loads); then every workgroup of the tracklet redundantly sums the NS partials in slice order (deterministic),
 //      d -> sim -> row-L1 normalise -> mix with the pose graph, into LDS (one wavefront per graph row);
 //   C  G h for the workgroup's channels (exact-fp32 MFMA, the channel <-> MFMA-row assignment of graph_propagate_stream_kernel)
 //      + BatchNorm + LeakyReLU + residual from the LDS-resident f -> out (+ bf16 copy).
 // All workgroups of a tracklet must be resident together: the host sizes the grid by the occupancy query (83 KB of LDS: one
 // workgroup per CU) and larger batches are walked persistently by `groups` tracklet groups. The spin is bounded (a lost
-// partner would otherwise hang the device): on time-out the workgroup raises the error word and carries on.
+// partner would otherwise hang the device): on time-out the workgroup raises the error word AND writes NaN into every output
+// element it owns for that tracklet, so an incomplete hand-off can never pass as a result.
 template <int PS_NT>  // V = 4 PS_NT exactly, V <= 64
 __global__ __launch_bounds__(256) void graph_message_pass_kernel(
     const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ adj, const float* __restrict__ bn_scale,
@@ -582,6 +585,8 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
     for (int b = group; b < B; b += ngroups) {
         const size_t node0 = (size_t)b * V;
         const int cs = s * 256;
+        float keep_b = keep;
+        int lost = 0;
         // this wave's h operand for phase C and the f slice: ALL requested up front (one latency, not two), h consumed after the hand-off
         const int c0 = cs + wave * 64;
         const int cl = c0 + 4 * kg;
@@ -645,11 +650,12 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > (1 << 22)) {
                         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lost = 1;
                         break;
                     }
                 }
             }
-            __syncthreads();
+            if (__syncthreads_or(lost)) keep_b = __builtin_nanf("");   // poisons keep f + gamma y below
             // Gram = sum of the NS partials in slice order, every element by one thread, all of a thread's loads in flight at once
             // (sc1 loads: served by L2, never by this CU's possibly stale L1) -> LDS; its diagonal = the squared norms
             {
@@ -746,7 +752,7 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
                     for (int j = 0; j < 4; ++j) {
                         float y = fmaf(acc[vf][j][r], scv[j], shv[j]);
                         y = y > 0.f ? y : slope * y;
-                        o[j] = keep * fv[j] + gamma * y;
+                        o[j] = keep_b * fv[j] + gamma * y;
                     }
                     const size_t idx = (node0 + v) * C + cl + 16 * r;
                     *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);

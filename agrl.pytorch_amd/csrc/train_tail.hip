@@ -204,12 +204,16 @@ __global__ __launch_bounds__(256) void xent_rows_kernel(const float* __restrict_
     sz = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     const float lse = m + logf(se);
     const int y = targets[i];
+    // a label outside [0, K) (class count mismatch, un-relabelled pids): the reference's scatter_ raises a device assert
+    // (cross_entropy_loss.py:31); nothing can be raised from here without a host sync, so the row's loss and gradient
+    // become NaN -- the step's loss is NaN and says so -- and z[y] is never read
+    const bool bad = y < 0 || y >= K;
     // -sum_k q_k log p_k = -(1 - eps) (z_y - lse) - (eps / K) (sum_k z_k - K lse)
-    if (tid == 0) row_loss[i] = -(1.f - eps) * (z[y] - lse) - (eps / (float)K) * (sz - (float)K * lse);
+    if (tid == 0) row_loss[i] = bad ? NAN : -(1.f - eps) * (z[y] - lse) - (eps / (float)K) * (sz - (float)K * lse);
     for (int k = tid; k < K; k += 256) {
         const float p = expf(z[k] - lse);
         const float q = (k == y ? 1.f - eps : 0.f) + eps / (float)K;
-        dlogits[(size_t)i * K + k] = (p - q) * inv_n;
+        dlogits[(size_t)i * K + k] = bad ? NAN : (p - q) * inv_n;
     }
 }
 

@@ -1,5 +1,9 @@
-"""Label-smoothed cross entropy (reference: torchreid/losses/cross_entropy_loss.py:8-37). Stock PyTorch:
-the classifier loss is not on the forward-and-match hot path."""
+"""Label-smoothed cross entropy (reference: torchreid/losses/cross_entropy_loss.py:8-37).
+
+CUDA fp32 logits: loss value + logit gradient from ONE native call (``agrl_xent_label_smooth``, row a14 of SURVEY 8a: the
+train step). A label outside [0, num_classes) makes the loss NaN (the reference's ``scatter_`` raises a device assert there; the
+kernel never reads out of bounds). ``hip_native = False`` on the instance (or CPU tensors) selects the stock-torch formulation.
+"""
 from __future__ import absolute_import
 from __future__ import division
 
@@ -16,9 +20,10 @@ class CrossEntropyLabelSmooth(nn.Module):
         self.epsilon = epsilon
         self.use_gpu = use_gpu
         self.logsoftmax = nn.LogSoftmax(dim=1)
+        self.hip_native = True
 
     def forward(self, inputs, targets):
-        if inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 2 and inputs.size(1) == self.num_classes:
+        if self.hip_native and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 2 and inputs.size(1) == self.num_classes:
             # value + gradient from one native call (agrl_xent_label_smooth)
             from torchreid.models._train_hip import HipXent
             return HipXent.apply(inputs, targets.to(inputs.device), self.epsilon)

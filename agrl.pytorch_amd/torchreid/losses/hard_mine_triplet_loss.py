@@ -45,11 +45,12 @@ class TripletLoss(nn.Module):
         self.margin = margin
         self.soft = soft
         self.ranking_loss = nn.MarginRankingLoss(margin=margin)
+        self.hip_native = True   # False: the stock-torch formulation below on CUDA tensors too (bench.py's baseline step)
 
     def mine(self, inputs, targets):
         """Indices (idx_ap, idx_an) of the hardest positive / negative of every anchor."""
         n = inputs.size(0)
-        if inputs.is_cuda:
+        if inputs.is_cuda and self.hip_native:
             from torchreid import hip_ops as ops
             _, _, idx_ap, idx_an = ops.triplet_hard_mine(inputs.detach().float().contiguous(),
                                                          targets.detach().to(torch.int32).contiguous())
@@ -68,7 +69,7 @@ class TripletLoss(nn.Module):
         return idx_ap, idx_an
 
     def forward(self, inputs, targets):
-        if inputs.is_cuda and inputs.dtype == torch.float32:
+        if self.hip_native and inputs.is_cuda and inputs.dtype == torch.float32:
             return _NativeTriplet.apply(inputs, targets, self.margin, self.soft)
         idx_ap, idx_an = self.mine(inputs, targets)
         dist_ap = _pair_dist(inputs, idx_ap)

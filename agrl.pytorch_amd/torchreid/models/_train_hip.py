@@ -340,16 +340,15 @@ class HipPartPool(torch.autograd.Function):
     def forward(ctx, x4_1, x4_2, S, splits):
         F_, h, w, C = x4_2.shape
         x4_2 = x4_2.contiguous()
-        x41 = x4_2 if x4_1 is None else x4_1.contiguous()
-        gsum, nodes, _ = ops.part_pool(x41, x4_2, list(splits), want_lp=False)
-        ctx.cfg = (int(S), h, w, tuple(splits), x4_1 is not None)
+        gsum, nodes, _ = ops.part_pool(x4_1.contiguous(), x4_2, list(splits), want_lp=False)
+        ctx.cfg = (int(S), h, w, tuple(splits))
         g_f = gsum.view(F_ // S, S, C).sum(dim=1) / float(S * h * w)
         return g_f, nodes
 
     @staticmethod
     def backward(ctx, dg, dnodes):
-        S, h, w, splits, two = ctx.cfg
-        dx1, dx2 = ops.part_pool_backward(dg.contiguous() if two else None, dnodes.contiguous(), S, h, w, list(splits))
+        S, h, w, splits = ctx.cfg
+        dx1, dx2 = ops.part_pool_backward(dg.contiguous(), dnodes.contiguous(), S, h, w, list(splits))
         return dx1, dx2, None, None
 
 

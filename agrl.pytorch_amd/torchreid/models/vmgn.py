@@ -9,9 +9,10 @@ Two execution paths, chosen by where the input lives:
 * CUDA tensors, ``model.eval()``  -> the MI355X path: ``_vmgn_hip.hip_forward`` drives the gfx950 kernels of
   libagrl_hip.so (stem, implicit-GEMM convs, part pooling, graph layers, attention tail). There is no
   fallback: a missing library raises.
-* CUDA tensors, ``model.train()`` -> the conv trunk (99 % of the step's arithmetic), forward with batch-statistics
-  BatchNorm and the whole backward, runs on the gfx950 kernels through ``_train_hip`` (autograd Functions whose forward
-  and backward are C-ABI calls); the small tail stays on the module tree below.
+* CUDA tensors, ``model.train()`` -> the WHOLE train forward and backward -- conv trunk with batch-statistics BatchNorm,
+  pooling, graph layers, attention pooling, BNNecks, classifiers -- runs on the gfx950 kernels through ``_train_hip``
+  (autograd Functions whose forward and backward are C-ABI calls). ``hip_train_tail = False`` keeps only the trunk
+  native, ``hip_train = False`` selects the stock-torch module tree below (bench.py's baseline step).
 * CPU tensors (the reference's own CPU-runnable configuration, also what ``compute_model_complexity`` runs
   at start-up) -> the module tree below, evaluated by stock ``torch.nn`` leaf modules so forward hooks, autograd
   and ``nn.DataParallel`` replication behave exactly as they do for the reference.

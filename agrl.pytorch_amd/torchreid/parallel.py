@@ -15,6 +15,7 @@ sharding/merge logic under gloo without a GPU.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -162,6 +163,7 @@ class GradientBuckets(object):
             self.buckets.append((flat, group))
         self._pending = [0] * len(self.buckets)
         self._handles = []
+        self._hit = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self.zero_grad()
 
@@ -171,9 +173,11 @@ class GradientBuckets(object):
             flat.zero_()
             self._pending[i] = len(group)
         self._handles = []
+        self._hit = set()
 
     def _on_grad(self, p):
         i = self._bucket_of[p]
+        self._hit.add(p)
         self._pending[i] -= 1
         if self._pending[i] == 0 and world_size() > 1:
             flat = self.buckets[i][0]
@@ -190,6 +194,21 @@ class GradientBuckets(object):
         for h in self._handles:
             h.wait()
         self._handles = []
+
+    @contextlib.contextmanager
+    def only_touched(self):
+        """Around optimizer.step(): parameters that received NO gradient in this backward (the classifiers of an
+        htri-only step, an unused branch) show ``.grad is None`` -- as they do after optimizer.zero_grad() on the plain
+        path -- so the optimiser skips them instead of applying weight decay / moment updates on a zero gradient. The
+        views into the flat buffers come back afterwards. Every rank runs the same graph, so every rank skips the same."""
+        parked = [(p, p.grad) for p in self.params if p not in self._hit]
+        for p, _ in parked:
+            p.grad = None
+        try:
+            yield
+        finally:
+            for p, g in parked:
+                p.grad = g
 
     def remove(self):
         for h in self._hooks:
@@ -244,9 +263,11 @@ def train_step(model, imgs, adj, pids, criterion_xent, criterion_htri, optimizer
         buckets.zero_grad()
         loss.backward()
         buckets.finish()
+        with buckets.only_touched():
+            optimizer.step()
     else:
         optimizer.zero_grad()
         loss.backward()
         allreduce_gradients(list(model.parameters()))
-    optimizer.step()
+        optimizer.step()
     return float(loss.detach()), float(xent.detach()), float(htri.detach())

@@ -162,3 +162,37 @@ def test_sharded_train_step_equals_replicated_global_step(tmp_path):
         assert set(grads) == set(ref)
         worst = max(((grads[k] - ref[k]).abs().max() / ref[k].abs().max().clamp(min=1e-12)).item() for k in ref)
         assert worst < 1e-3, worst
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_step_skips_parameters_without_gradient_like_the_plain_step():
+    """An htri-only step leaves the classifiers without a gradient: the plain path's optimizer.zero_grad() makes their
+    .grad None and Adam skips them; the bucketed path keeps zero-filled .grad views and must park them around
+    optimizer.step() (GradientBuckets.only_touched) -- otherwise weight decay and the moment updates move those weights."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "agrl.pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+    from torchreid import losses, models, parallel
+    results = []
+    for use_buckets in (False, True):
+        m, x, adj, pids = _train_problem(models, recipe_state_dict, synthetic_clips, synthetic_adj)
+        before = {k: v.clone() for k, v in m.state_dict().items()}
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-2)
+        buckets = parallel.GradientBuckets(m.parameters(), bucket_bytes=8 << 20) if use_buckets else None
+        for _ in range(2):
+            parallel.train_step(m, x, adj, pids, losses.CrossEntropyLabelSmooth(5, use_gpu=False),
+                                losses.TripletLoss(margin=0.3, soft=True), opt, htri_only=True, buckets=buckets)
+        if buckets is not None:
+            for p in m.parameters():  # the views are back after the step
+                assert p.grad is not None or not p.requires_grad
+            buckets.remove()
+        results.append((before, {k: v.clone() for k, v in m.state_dict().items()}))
+    (b0, plain), (b1, bucketed) = results
+    for k in ("global_classifier.weight", "att_classifier.weight"):
+        assert torch.equal(plain[k], b0[k]), k            # untouched by the plain step
+        assert torch.equal(bucketed[k], b1[k]), k         # and by the bucketed one
+    for k in plain:
+        assert torch.allclose(plain[k].float(), bucketed[k].float(), rtol=1e-5, atol=1e-7), k
