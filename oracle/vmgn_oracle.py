@@ -416,6 +416,24 @@ def triplet_hard(x, pids, margin=0.3, soft=True):
     return loss, dist_ap, dist_an, idx_ap, idx_an
 
 
+def xent_label_smooth(logits, targets, epsilon=0.1):
+    """CrossEntropyLabelSmooth.forward, losses/cross_entropy_loss.py:26-37: q = (1 - eps) onehot + eps / K,
+    loss = sum_k mean_i(-q_ik log_softmax(z)_ik)."""
+    n, K = logits.shape
+    log_probs = F.log_softmax(logits, dim=1)
+    q = torch.zeros_like(log_probs).scatter_(1, targets.view(n, 1), 1)
+    q = (1 - epsilon) * q + epsilon / K
+    return (-q * log_probs).mean(0).sum()
+
+
+def deep_supervision(criterion, xs, y):
+    """DeepSupervision, losses/__init__.py:9-20: the mean of the criterion over the output list."""
+    loss = 0.
+    for x in xs:
+        loss = loss + criterion(x, y)
+    return loss / len(xs)
+
+
 # ---- pose adjacency (input contract) -------------------------------------------------------------------------
 
 def pose_adjacency(part_sets, num_split=4, pyramid_part=True):

@@ -257,6 +257,82 @@ def main():
         res["grad_soft" if soft else "grad_margin"] = fx.grad
     save("triplet", pids=pids, meta=np.array([16, 2048, 61]), **res)
 
+    # ---- F13: label-smoothed cross entropy + DeepSupervision (losses/cross_entropy_loss.py:26-37, losses/__init__.py:9-20):
+    # value and logit gradients of the five-output list the consistent loss produces --------------------------------------
+    ref_xent = load("ref_xent", "torchreid/losses/cross_entropy_loss.py")
+    g = torch.Generator().manual_seed(131)
+    n_out, n, K = 5, 16, 702
+    logits = [(3.0 * torch.randn((n, K), generator=g)).requires_grad_(True) for _ in range(n_out)]
+    pids = torch.randint(0, K, (n,), generator=g)
+    res = {}
+    for eps in (0.1, 0.0, 0.3):
+        crit = ref_xent.CrossEntropyLabelSmooth(num_classes=K, epsilon=eps, use_gpu=False)
+        loss = 0.
+        for x in logits:           # DeepSupervision, losses/__init__.py:9-20 (restated here: the package __init__ is not importable)
+            loss += crit(x, pids)
+        loss /= len(logits)
+        for x in logits:
+            x.grad = None
+        loss.backward()
+        tag = "eps%02d" % int(round(eps * 100))
+        res["loss_" + tag] = loss.detach()
+        res["single_" + tag] = crit(logits[0], pids).detach()
+        res["grad0_" + tag] = logits[0].grad.clone()
+    save("xent", logits0=logits[0].detach(), pids=pids, meta=np.array([n_out, n, K, 131]), **res)
+
+    # ---- F14: the reference's own native evaluator (rank_cylib/rank_cy.pyx:154-241, built by oracle/build_ref.py) on the
+    # seeded inputs tests/test_gpu_kernels.py::test_rank_market1501_device regenerates: its outputs as data, so the built
+    # extension itself never has to travel to the GPU box --------------------------------------------------------------
+    from oracle import build_ref
+    build_ref.build(verbose=False)
+    cy = build_ref.load()
+    res = {}
+    for m, n in ((40, 500), (64, 12180)):
+        rng = np.random.RandomState(m + n)
+        d = rng.rand(m, n).astype(np.float32)
+        d[:, 5] = d[:, 3]
+        npid = max(4, n // 40)
+        q_pids, g_pids = rng.randint(0, npid + 2, m), rng.randint(0, npid, n)
+        q_cam, g_cam = rng.randint(0, 6, m), rng.randint(0, 6, n)
+        i64 = [np.ascontiguousarray(a, dtype=np.int64) for a in (q_pids, g_pids, q_cam, g_cam)]
+        cmc_cy, mAP_cy = cy.eval_market1501_cy(d, i64[0], i64[1], i64[2], i64[3], 50)
+        cmc_py, mAP_py = ref_rank.evaluate_rank(d, q_pids, g_pids, q_cam, g_cam, max_rank=50, use_metric_market1501=True, use_cython=False)
+        res["cmc_cy_%dx%d" % (m, n)], res["mAP_cy_%dx%d" % (m, n)] = np.asarray(cmc_cy), np.float64(mAP_cy)
+        res["cmc_py_%dx%d" % (m, n)], res["mAP_py_%dx%d" % (m, n)] = np.asarray(cmc_py), np.float64(mAP_py)
+        res["dist_checksum_%dx%d" % (m, n)] = np.float64(d.astype(np.float64).sum())   # guards the seeded regeneration
+    save("rank_market1501_cy", **res)
+
+    # ---- F15: loss.backward() of the reference's train step (train_vidreid_xent_htri.py:397-411): B = 4 (2 ids x 2), S = 8,
+    # xent + htri with the consistent loss; loss value and the gradients of a few named parameters (slices of the large ones) --
+    ref_trip2 = ref_trip
+    model_b = ref_vmgn.vmgn(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                            pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=True)
+    sd_b = recipe_state_dict(model_b.state_dict(), seed=2)
+    model_b.load_state_dict(sd_b)
+    model_b.train()
+    pids = torch.tensor([0, 0, 1, 1])
+    x, adj = synthetic_clips(4, 8, seed=151, identities=pids.tolist()), synthetic_adj(4, 8, seed=151)
+    torch.manual_seed(1234)
+    outs, feats = model_b(x, adj)
+    crit_x = ref_xent.CrossEntropyLabelSmooth(num_classes=5, use_gpu=False)
+    crit_t = ref_trip2.TripletLoss(margin=0.3, soft=True)
+    lx = sum(crit_x(o, pids) for o in outs) / len(outs)
+    lt = sum(crit_t(f_, pids) for f_ in feats) / len(feats)
+    loss = lx + lt
+    loss.backward()
+    named = dict(model_b.named_parameters())
+    res = {"loss": loss.detach(), "xent": lx.detach(), "htri": lt.detach(), "meta": np.array([4, 8, 151, 1234, 2])}
+    for key, rows in (("conv1.weight", None), ("bn1.weight", None), ("layer1.0.conv1.weight", None), ("layer1.0.bn3.bias", None),
+                      ("layer2.0.downsample.0.weight", 8), ("layer3.5.conv3.weight", 8), ("layer3.5.bn2.weight", None),
+                      ("layer4_1.2.conv3.weight", 4), ("layer4_2.0.conv2.weight", 1), ("layer4_2.2.bn3.weight", None),
+                      ("graph_layers.0.linear.weight", 4), ("graph_layers.1.linear.weight", 4), ("graph_layers.1.bn.weight", None),
+                      ("global_bottleneck.weight", None), ("att_bottleneck.weight", None), ("global_classifier.weight", None),
+                      ("att_classifier.weight", None)):
+        gfull = named[key].grad
+        res["g:" + key] = gfull if rows is None else gfull[:rows]
+        res["n:" + key] = gfull.double().norm()          # norm of the WHOLE gradient tensor
+    save("vmgn_backward_b4s8", **res)
+
     # ---- F7: pose adjacency (dataset_loader.py:218-388) -------------------------------------------------
     rng = np.random.RandomState(71)
     S, width, height = 8, 128, 256

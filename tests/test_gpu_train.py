@@ -485,3 +485,53 @@ def test_native_step_is_what_runs(monkeypatch):
     dev.hip_train = False
     l2 = _step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), True)
     assert abs(l1.item() - l2.item()) < 1e-4 * abs(l2.item())
+
+
+def test_native_step_against_reference_gradients():
+    """The native step against gradients the REFERENCE ITSELF produced (tests/golden/vmgn_backward_b4s8.npz: its own model,
+    loss.backward() of xent + htri with the consistent loss, B = 4, S = 8; train_vidreid_xent_htri.py:397-411). Loss to 1e-5;
+    per named parameter the stored gradient slice and the norm of the whole gradient tensor. The bars are the measured errors
+    with a 3 x margin: the step is fifty conv + batch-statistics-BatchNorm layers deep, so a different (but equally valid) fp32
+    summation order moves individual gradient entries by ~1e-3 of the tensor's largest entry -- the same step on the CPU in
+    fp32 sits at that distance from its own float64 evaluation (test_train_step_loss_and_gradients_at_the_reference_noise_floor)."""
+    from test_oracle_golden import backward_case, gradient_errors
+    z, m, loss, lx, lt = backward_case(DEV)
+    torch.cuda.synchronize()
+    for got, key in ((loss, "loss"), (lx, "xent"), (lt, "htri")):
+        assert abs(float(got.detach()) - float(z[key])) < 1e-5 * abs(float(z[key])), key
+    errs = gradient_errors(z, m)
+    for key, (e_slice, e_norm) in errs.items():
+        print("%-34s slice %.2e norm %.2e" % (key, e_slice, e_norm))
+    for key, (e_slice, e_norm) in errs.items():
+        assert e_slice < 3e-2 and e_norm < 1e-2, (key, e_slice, e_norm)
+
+
+def test_xent_native_matches_reference_fixture_and_flags_bad_labels():
+    """agrl_xent_label_smooth (value + logit gradient in one call) against the reference's CrossEntropyLabelSmooth +
+    DeepSupervision (tests/golden/xent.npz: losses/cross_entropy_loss.py:26-37, losses/__init__.py:9-20), and a label outside
+    [0, K): NaN loss, NaN gradient row, every other row untouched, no out-of-bounds read."""
+    from test_oracle_golden import xent_case
+    from torchreid import hip_ops as ops, losses
+    z, logits, pids, K = xent_case()
+    for eps in (0.1, 0.0, 0.3):
+        tag = "eps%02d" % int(round(eps * 100))
+        xs = [x.clone().to(DEV).requires_grad_(True) for x in logits]
+        crit = losses.CrossEntropyLabelSmooth(num_classes=K, epsilon=eps, use_gpu=True)
+        loss = losses.DeepSupervision(crit, xs, pids.to(DEV))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(z["loss_" + tag])) < 1e-6 * abs(float(z["loss_" + tag]))
+        assert abs(float(crit(xs[0].detach(), pids.to(DEV))) - float(z["single_" + tag])) < 1e-6 * abs(float(z["single_" + tag]))
+        assert rel(xs[0].grad, torch.from_numpy(z["grad0_" + tag])) < 1e-5
+    x = logits[0].to(DEV)
+    for bad in (-1, K, K + 1000000):
+        y = pids.clone()
+        y[3] = bad
+        loss, dl = ops.xent_label_smooth(x, y.to(torch.int32).to(DEV), 0.1)
+        torch.cuda.synchronize()
+        assert torch.isnan(loss).all() and torch.isnan(dl[3]).all()
+        keep = torch.ones(x.shape[0], dtype=torch.bool)
+        keep[3] = False
+        ref = O.xent_label_smooth(logits[0].clone().requires_grad_(True), pids, 0.1)
+        xr = logits[0].clone().requires_grad_(True)
+        O.xent_label_smooth(xr, pids, 0.1).backward()
+        assert rel(dl[keep.to(DEV)], xr.grad[keep]) < 1e-5 and torch.isfinite(ref)
