@@ -19,7 +19,9 @@ Rank 0 prints ONE JSON line: value = whole-job frames/s (all ranks) over EXACTLY
   roofline_*      : conv family, layer-4 pointwise convs, GCN message pass (the WHOLE SURVEY 8(d) unit: sim +
                     normalise + mix + G h + BN + LeakyReLU + residual), distance matrix -- the HBM-bound ones with
                     the read-stream yardstick of this chip at the same byte count beside them
-  accuracy        : Rank-1 / mAP of bf16 vs exact-fp32 on a model-generated 625-identity 1980 x 12180 split
+  accuracy        : Rank-1 / mAP of bf16 and exact fp32 on the 625-identity 1980 x 12180 split of tests/fullsplit.py, both held
+                    against the CPU oracle's committed result for the same split (tests/golden/fullsplit_oracle.npz)
+  modes           : the same step timed in the two precision modes that meet the 1e-3 / bit-exact-ranking bar (fp32, bf16x3)
   config5         : the full-eval distance matrix 1980 x 12180 x 4096 + top-50 + MARS AP/CMC, timed
   cpu_baseline    : the CPU oracle (oracle/vmgn_oracle.py, torch CPU kernels) on this host, B = 32, best thread count
 """
@@ -61,6 +63,9 @@ def parse(argv=None):
     ap.add_argument("--sustain-seconds", type=float, default=2.0)
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="upper bound of the CPU-baseline thread sweep")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--dist-timeout", type=float, default=1800.0, help="--gpus N > 1 self-launch: seconds before the ranks are terminated")
+    ap.add_argument("--no-modes", action="store_true", help="skip the fp32 / bf16x3 precision-mode timings")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph", action="store_true",
                     help="replay the forward from a captured HIP graph (host issue cost 1.2 ms -> 0.08 ms per step; GPU time "
                          "unchanged within 1.5 %%, tools/graph_probe.py)")
@@ -70,23 +75,89 @@ def parse(argv=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: the parent starts one fresh child per rank BEFORE it makes any GPU call (it never does:
 # no torch.cuda.* below this line in the parent) and relays rank 0's JSON line.
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, script=None, poll_s=0.2):
+    """Start one fresh child process per rank, watch ALL of them, relay rank 0's stdout.
+
+    * a child that exits non-zero ends the job: the others are terminated (SIGTERM, then SIGKILL after 5 s) and the
+      launcher returns that code -- a rank blocked in a collective whose partner died would otherwise wait for ever;
+    * ``--dist-timeout`` seconds without completion do the same with code 124;
+    * every rank's stderr tail is printed when the job fails;
+    * on success rank 0's JSON line is checked: ``config.ranks == N`` and, when the children saw at least N devices,
+      ``config.collective_backend == "rccl"`` (a silent gloo fallback on a real multi-GPU node is an error).
+    Children are always fresh processes created before anything here touches the GPU (the parent never does)."""
+    import tempfile
+    script = script or os.path.abspath(__file__)
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    procs = []
+    procs, outs, errs = [], [], []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        outs.append(tempfile.TemporaryFile())
+        errs.append(tempfile.TemporaryFile())
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env, stdout=outs[-1], stderr=errs[-1]))
+
+    def tail(f, nbytes=2000):
+        f.seek(0, os.SEEK_END)
+        size = f.tell()
+        f.seek(max(0, size - nbytes))
+        return f.read().decode(errors="replace")
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    deadline = time.time() + args.dist_timeout
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = (abs(bad[0][1]) or 1), "rank %d exited with code %d" % bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            rc, why = 124, "no completion within --dist-timeout %.0f s" % args.dist_timeout
+            break
+        time.sleep(poll_s)
+    if rc:
+        stop_all()
+        sys.stderr.write("bench.py launcher: %s; remaining ranks terminated\n" % why)
+        for r in range(args.gpus):
+            sys.stderr.write("---- rank %d (exit %s) stderr tail ----\n%s\n" % (r, procs[r].returncode, tail(errs[r])))
+    else:
+        for r in range(1, args.gpus):
+            sys.stderr.write(tail(errs[r], 1 << 20))
+    sys.stderr.write(tail(errs[0], 1 << 20))
+    outs[0].seek(0)
+    text = outs[0].read().decode(errors="replace")
+    sys.stdout.write(text)
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    if rc == 0:
+        lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+        try:
+            cfg = json.loads(lines[-1])["config"]
+            if cfg.get("ranks") != args.gpus:
+                rc, why = 1, "JSON line reports %r ranks, launched %d" % (cfg.get("ranks"), args.gpus)
+            elif cfg.get("devices_visible", 0) >= args.gpus and cfg.get("collective_backend") != "rccl":
+                rc, why = 1, "%d devices visible but the collective backend is %r, not rccl" % (cfg["devices_visible"], cfg.get("collective_backend"))
+        except (IndexError, KeyError, ValueError) as e:
+            rc, why = 1, "no JSON line from rank 0 (%r)" % (e,)
+        if rc:
+            sys.stderr.write("bench.py launcher: %s\n" % why)
+    return rc
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -117,18 +188,60 @@ def synthetic_pose_adjacency(B, S, device, gen):
     return ops.pose_adjacency(poses, detected, height=256.0, num_split=4, pyramid_part=True, threshold=0.1)
 
 
-def cpu_baseline(sd, S, metric, gallery_cpu, budget_s):
-    """The oracle on this host's cores: the same step at the same batch (32 tracklets x S frames, forward + distance
-    matrix against the full gallery), one timed batch per thread count, best reported."""
+def _one_socket_cpus():
+    """Logical CPUs of package 0, one hardware thread per physical core (sysfs topology); None when unreadable."""
+    try:
+        seen, cpus = set(), []
+        for cpu in sorted(os.sched_getaffinity(0)):
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            if int(open(base + "physical_package_id").read()) != 0:
+                continue
+            core = int(open(base + "core_id").read())
+            if core not in seen:
+                seen.add(core)
+                cpus.append(cpu)
+        return cpus or None
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
+def cpu_baseline_child(S, metric, budget_s):
+    """Runs in a FRESH process that never touches the GPU (bench.py --cpu-baseline-only): the oracle on this host's cores,
+    the same step at the same batch (32 tracklets x S frames, forward + distance matrix against the full gallery). The
+    process is pinned to ONE socket, one hardware thread per physical core, before torch starts its thread pool (an
+    unpinned 64- or 128-thread run across both sockets of the GPU host was slower than 32 threads), and glibc is told to
+    keep freed activations (default thresholds hand every large tensor back to the kernel: 3 x slower on this oracle).
+    One timed batch per thread count, best reported with the sweep."""
+    cpus = _one_socket_cpus()
+    pinned = False
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+            pinned = True
+        except OSError:
+            pass
+    try:
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-1, 1 << 30)   # M_TRIM_THRESHOLD
+        libc.mallopt(-3, 1 << 30)   # M_MMAP_THRESHOLD
+    except OSError:
+        pass
     import torch
     from oracle import vmgn_oracle as O
-    from recipe import synthetic_adj, synthetic_clips
+    from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+    from torchreid import models
+    m = models.init_model("vmgn", num_classes=N_IDS, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2,
+                          num_scale=1, pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=False,
+                          num_parts=3, bnneck=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    del m
+    gallery_cpu = torch.randn((GALLERY_ROWS, FEATURE_DIM), generator=torch.Generator().manual_seed(7))
     bs = 32
     x, adj = synthetic_clips(bs, S, seed=123), synthetic_adj(bs, S, seed=123)
     fn = O.cosine if metric == "cosine" else O.euclidean_squared
-    ncpu = os.cpu_count() or 1
-    # widest first: the best width on a many-core host is 32 or more, and the time budget may end the sweep early
-    cands = sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu} | {min(ncpu, 128)}, key=lambda t: (t < 32, t))
+    ncpu = len(os.sched_getaffinity(0))
+    cands = sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu} | {ncpu}, key=lambda t: -t)
     sweep, t_start, frames_total = {}, time.time(), 0
     with torch.no_grad():
         for threads in cands:
@@ -144,88 +257,158 @@ def cpu_baseline(sd, S, metric, gallery_cpu, budget_s):
     best = min(sweep, key=sweep.get)
     return {"value": round(bs * S / sweep[best], 2), "unit": "frames/s", "cores": best, "kind": "port",
             "sweep_frames_per_s": {str(t): round(bs * S / dt, 2) for t, dt in sweep.items()},
-            "host_cpus": ncpu,
+            "host_cpus": os.cpu_count(), "pinned_to_socket0_physical_cores": ncpu if pinned else None,
             "sample": "%d frames per thread count (one batch of %d tracklets x %d frames, fwd+GCN+%s distmat vs %d gallery rows), "
-                      "%d frames in %.1f s overall, oracle/vmgn_oracle.py on torch CPU fp32" %
-                      (bs * S, bs, S, metric, gallery_cpu.size(0), frames_total, time.time() - t_start)}
+                      "%d frames in %.1f s overall, oracle/vmgn_oracle.py on torch CPU fp32, process pinned to one socket" %
+                      (bs * S, bs, S, metric, GALLERY_ROWS, frames_total, time.time() - t_start)}
+
+
+def cpu_baseline(S, metric, budget_s):
+    """Fresh child process (affinity and allocator settings must precede torch's thread pool; the child makes no GPU call)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--seq-len", str(S), "--metric", metric,
+                              "--cpu-seconds", str(budget_s)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             timeout=max(300.0, 8 * budget_s))
+        line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
 def accuracy_block(model, device, S, metric):
-    """Rank-1 / mAP on a model-generated split (SURVEY 8d gallery recipe): 625 synthetic identities (identity-specific
-    smooth pattern + per-frame noise), 12 180 gallery tracklets (5 % junk, pid -1) and 1 980 queries over 6 cameras,
-    embedded by the model itself in bf16 and in exact fp32, distance + MARS ranking on the device for both."""
+    """Rank-1 / mAP on the full-size split of SURVEY 8(d) (tests/fullsplit.py: 625 identities, 1 980 queries, 12 180
+    gallery tracklets with 5 % junk, 6 cameras; inputs are integer hashes, bit-identical on CPU and GPU): embedded by
+    the model in bf16 and in exact fp32, distance + MARS ranking on the device for both, and the fp32 run held against
+    what the CPU ORACLE produced for the same split in the build container (tests/golden/fullsplit_oracle.npz: Rank-1,
+    mAP, the first 51 ranked gallery indices and distances of every query)."""
     import numpy as np
     import torch
+    import fullsplit as FS
     from torchreid import evaluation
+    from torchreid import hip_ops as ops
     from torchreid.models._vmgn_hip import hip_forward
-    rng = np.random.RandomState(0xFF)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(0xFF)
-    low = torch.randn((N_IDS + 1024, 3, 8, 4), device=device, generator=gen)
+    assert S == FS.SEQ_LEN
+    q_pids, q_cams, g_pids, g_cams = FS.labels()
 
-    def pattern(ids):
-        return torch.nn.functional.interpolate(low[ids], size=(256, 128), mode="bilinear", align_corners=False)
+    def make_adj(poses, detected):
+        return ops.pose_adjacency(poses, detected, height=float(FS.HEIGHT), num_split=4, pyramid_part=True, threshold=0.1)
 
-    g_pids = rng.randint(0, N_IDS, GALLERY_ROWS)
-    junk = rng.rand(GALLERY_ROWS) < 0.05
-    g_pids[junk] = -1
-    g_cams = rng.randint(0, 6, GALLERY_ROWS)
-    q_pids = rng.randint(0, N_IDS, QUERY_ROWS)
-    q_cams = rng.randint(0, 6, QUERY_ROWS)
-    for i in range(QUERY_ROWS):  # MARS property the reference relies on (rank.py:203): >= 1 cross-camera match per query
-        if not np.any((g_pids == q_pids[i]) & (g_cams != q_cams[i])):
-            j = rng.randint(0, GALLERY_ROWS)
-            g_pids[j], g_cams[j] = q_pids[i], (q_cams[i] + 1) % 6
-    junk_pat = N_IDS + (np.arange(GALLERY_ROWS) % 1024)
+    def batches(pids, cams, first, bs=64):
+        return FS.batches(pids, cams, first, device, bs, make_adj)
 
-    def batches(pids, cams, seed, bs=64):
-        g = torch.Generator(device=device)
-        g.manual_seed(seed)
-        for i in range(0, len(pids), bs):
-            p = pids[i:i + bs]
-            ids = torch.as_tensor(np.where(p >= 0, p, junk_pat[i:i + len(p)]), device=device)
-            b = len(p)
-            clips = pattern(ids).view(b, 1, 3, 256, 128) + 0.5 * torch.randn((b, S, 3, 256, 128), device=device, generator=g)
-            yield clips, p, cams[i:i + bs], synthetic_pose_adjacency(b, S, device, g)
-
-    # BNNeck calibration, as training would leave it: random-init features share a dominant common component, so the two
-    # BatchNorm1d layers get running statistics of the data (from the exact-fp32 forward of 2048 gallery tracklets)
     prev = model.hip_precision
-    model.hip_precision = "fp32"
-    gf_, af_ = [], []
-    with torch.no_grad():
-        for clips, _, _, adj in batches(g_pids[:2048], g_cams[:2048], 11):
-            _, g_f, a_f = hip_forward(model, clips, adj, return_feats=True)
-            gf_.append(g_f)
-            af_.append(a_f)
-        for bn, f in ((model.global_bottleneck, torch.cat(gf_)), (model.att_bottleneck, torch.cat(af_))):
-            bn.running_mean.copy_(f.mean(0))
-            bn.running_var.copy_(f.var(0, unbiased=False).clamp(min=1e-8))
-            bn.weight.fill_(1.0)
-            bn.bias.zero_()
-    model.invalidate_hip_cache()
-    out = {"ids": N_IDS, "n_query": QUERY_ROWS, "n_gallery": GALLERY_ROWS, "metric": metric, "max_rank": 50}
+    z = FS.load_oracle_fixture()
+    if z is not None:
+        FS.apply_calibration(model, z)   # the oracle's own BNNeck statistics: both sides normalise identically
+        cal = "tests/golden/fullsplit_oracle.npz (oracle features of gallery rows 0..2047)"
+    else:
+        # no fixture: calibrate from the exact-fp32 forward of the same 2048 gallery tracklets
+        model.hip_precision = "fp32"
+        gf_, af_ = [], []
+        with torch.no_grad():
+            for clips, _, _, adj in batches(g_pids[:2048], g_cams[:2048], FS.QUERY_ROWS):
+                _, g_f, a_f = hip_forward(model, clips, adj, return_feats=True)
+                gf_.append(g_f)
+                af_.append(a_f)
+            for bn, f in ((model.global_bottleneck, torch.cat(gf_)), (model.att_bottleneck, torch.cat(af_))):
+                bn.running_mean.copy_(f.mean(0))
+                bn.running_var.copy_(f.var(0, unbiased=False).clamp(min=1e-8))
+                bn.weight.fill_(1.0)
+                bn.bias.zero_()
+        model.invalidate_hip_cache()
+        cal = "this run's fp32 forward (no oracle fixture present)"
+    out = {"ids": FS.N_IDS, "n_query": FS.QUERY_ROWS, "n_gallery": FS.GALLERY_ROWS, "metric": metric, "max_rank": 50,
+           "bnneck_calibration": cal}
     top = {}
     for prec in ("bf16", "fp32"):
         model.hip_precision = prec
         t0 = time.perf_counter()
-        qf, _, _ = evaluation.extract_features(model, batches(q_pids, q_cams, 21), prefetch=False)
-        gf, _, _ = evaluation.extract_features(model, batches(g_pids, g_cams, 22), prefetch=False)
-        cmc, mAP, idx, _ = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, prec, return_topk=True)
+        qf, _, _ = evaluation.extract_features(model, batches(q_pids, q_cams, 0), prefetch=False)
+        gf, _, _ = evaluation.extract_features(model, batches(g_pids, g_cams, FS.QUERY_ROWS), prefetch=False)
+        cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, prec, return_topk=True)
         torch.cuda.synchronize()
         out[prec] = {"rank1": round(float(cmc[0]), 6), "rank5": round(float(cmc[4]), 6), "mAP": round(float(mAP), 6),
                      "seconds": round(time.perf_counter() - t0, 2)}
-        top[prec] = idx
+        top[prec] = (idx, val, qf)
         if prec == "fp32":
             out["_embeddings"] = (qf, gf)
     model.hip_precision = prev
     model.invalidate_hip_cache()
     out["rank1_delta"] = round(out["bf16"]["rank1"] - out["fp32"]["rank1"], 6)
     out["mAP_delta"] = round(out["bf16"]["mAP"] - out["fp32"]["mAP"], 6)
-    out["top1_index_agreement"] = round(float((top["bf16"][:, 0] == top["fp32"][:, 0]).mean()), 6)
-    out["note"] = ("fp32 = the exact-fp32 HIP mode, which tests/test_gpu_model.py holds to the CPU oracle below 1e-3 at this batch "
-                   "size (measured ~3e-7); the CPU oracle itself needs ~1 h for these 113 k frames and is compared at reduced "
-                   "size in tests/test_gpu_eval.py")
+    out["top1_index_agreement"] = round(float((top["bf16"][0][:, 0] == top["fp32"][0][:, 0]).mean()), 6)
+    if z is not None and metric + "_idx" in z.files:
+        o_cmc, o_map = z[metric + "_cmc"], float(z[metric + "_mAP"])
+        emb = top["fp32"][2][:16].cpu().double().numpy()
+        ref = z["q_emb_head"].astype(np.float64)
+        out["oracle"] = {"rank1": round(float(o_cmc[0]), 6), "rank5": round(float(o_cmc[4]), 6), "mAP": round(o_map, 6),
+                         "source": "tests/golden/fullsplit_oracle.npz (oracle/vmgn_oracle.py on the build container's CPU, tests/golden/make_fullsplit.py)"}
+        for prec in ("fp32", "bf16"):
+            c = FS.compare_topk(top[prec][0], top[prec][1], z[metric + "_idx"], z[metric + "_val"])
+            out[prec + "_vs_oracle"] = {"rank1_delta": round(out[prec]["rank1"] - float(o_cmc[0]), 6),
+                                        "mAP_delta": round(out[prec]["mAP"] - o_map, 6),
+                                        "top50_index_agreement": round(c["agreement"], 6), "top1_index_agreement": round(c["top1_agreement"], 6),
+                                        "queries_with_identical_top50": round(c["rows_equal"], 6),
+                                        "max_abs_distance_err": float("%.3g" % c["max_abs_val_err"]),
+                                        "swapped_positions": c["swapped_positions"], "swaps_not_explained_by_a_near_tie": c["unexplained"]}
+        out["fp32_vs_oracle"]["embedding_max_rel_err_first16"] = float("%.3g" % (np.abs(emb - ref).max() / np.abs(ref).max()))
+    else:
+        out["oracle"] = None
+        out["note"] = "tests/golden/fullsplit_oracle.npz absent: fp32 = the exact-fp32 HIP mode only (run tests/golden/make_fullsplit.py in the build container)"
+    return out
+
+
+def modes_block(model, clips, adj, g_shard, metric, steps=3):
+    """The same step (forward + distance matrix of the batch against the resident gallery) in the two precision modes that
+    meet the north-star tolerance (1e-3 relative, ranking indices bit-exact on the test splits): exact fp32 and bf16x3
+    (fp32 tensors, every conv / Linear product as three bf16 MFMAs). ``steps`` timed steps each after one warm-up, plus one
+    instrumented step for the conv family's share of the respective MFMA peak."""
+    import torch
+    from torchreid import _hip
+    from torchreid import hip_ops as ops
+    prev = model.hip_precision
+    B, S = clips.shape[:2]
+    fam = ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block", "agrl_conv1x1_dual_bn_act")
+    out = {}
+    if metric == "cosine":
+        g_op, g_norm = ops.row_l2_normalize(g_shard, True, torch.float32), None
+    else:
+        g_op, g_norm = g_shard, ops.row_sqnorm(g_shard)
+
+    def one():
+        emb = model(clips, adj)
+        if metric == "cosine":
+            return ops.distmat(ops.row_l2_normalize(emb, True, torch.float32), g_op, "cosine")
+        return ops.distmat(emb, g_op, "euclidean", ops.row_sqnorm(emb), g_norm)
+
+    try:
+        for prec in ("fp32", "bf16x3"):
+            model.hip_precision = prec
+            one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            _hip.PROFILE = []
+            one()
+            torch.cuda.synchronize()
+            prof, _hip.PROFILE = _hip.PROFILE, None
+            ms = sum(s_ev.elapsed_time(e_ev) for name, s_ev, e_ev, tag in prof if name in fam)
+            fl = sum(tag["flops"] for name, s_ev, e_ev, tag in prof if name in fam and tag)
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out[prec] = {"ms_per_step": round(1e3 * dt, 3), "frames_per_s": round(B * S / dt, 1), "steps": steps,
+                         "conv_family_tflops": round(tf, 1), "peak_tflops": round(PEAK_TFLOPS[prec], 1),
+                         "conv_family_frac_of_peak": round(tf / PEAK_TFLOPS[prec], 4)}
+    finally:
+        _hip.PROFILE = None
+        model.hip_precision = prev
+    out["note"] = ("fp32: v_mfma_f32_16x16x4_f32, bit-compatible with an fmaf chain; bf16x3: three bf16 MFMAs per product on the high / low "
+                   "halves of fp32 operands (~1e-5 per product). Both hold the whole forward within 1e-3 of the CPU oracle "
+                   "(tests/test_gpu_model.py: 3e-7 / 4e-5); bf16, the mode `value` is quoted in, is at ~2e-3")
     return out
 
 
@@ -375,6 +558,9 @@ def config4_block(device):
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_child(args.seq_len, args.metric, args.cpu_seconds)), flush=True)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, argv))
 
@@ -474,6 +660,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if os.environ.get("AGRL_BENCH_FAULT_RANK") == str(rank):   # tests/test_gpu_configs.py: a rank that dies mid-run
+        os._exit(int(os.environ.get("AGRL_BENCH_FAULT_CODE", "3")))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -524,6 +712,7 @@ def main():
                    "global_batch": B * world, "seq_len": S, "frames_per_step": B * S * world,
                    "gallery_rows_per_gpu": hi - lo, "parallelism": "dp%d" % world, "hip_graph": bool(args.graph),
                    "ranks": world, "collective_backend": ("rccl" if backend == "nccl" else backend),
+                   "devices_visible": torch.cuda.device_count(),
                    "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms]},
     }
     if sustained is not None:
@@ -693,12 +882,21 @@ def main():
         result["kernels"] = kernels
         if world == 1:
             acc = None
+            if not args.no_modes and args.precision == "bf16":
+                try:
+                    result["modes"] = modes_block(model, clips, adj, g_shard, args.metric)
+                except Exception as e:  # noqa: BLE001
+                    result["modes"] = {"error": repr(e)[:300]}
             if not args.no_accuracy:
                 acc = accuracy_block(model, device, S, args.metric)
                 emb = acc.pop("_embeddings", None)
                 result["accuracy"] = acc
                 result["rank1"] = acc["bf16"]["rank1"]
                 result["mAP"] = acc["bf16"]["mAP"]
+                result["dtype_note"] = ("bf16 = the throughput mode BASELINE configs[1] names; its top-1 gallery index agrees with the exact-fp32 "
+                                        "mode for %.4f of the 1980 queries (Rank-1 / mAP deltas in `accuracy`); the fp32 and bf16x3 modes that meet "
+                                        "the 1e-3 / bit-exact-ranking bar are timed in `modes`" % acc["top1_index_agreement"])
+                result["top1_index_agreement_bf16_vs_fp32"] = acc["top1_index_agreement"]
             else:
                 emb = None
             if not args.no_config5:
@@ -708,7 +906,7 @@ def main():
                 torch.cuda.empty_cache()
                 result["config4_train_step"] = config4_block(device)
             if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(sd, S, args.metric, gallery_cpu, args.cpu_seconds)
+                result["cpu_baseline"] = cpu_baseline(S, args.metric, args.cpu_seconds)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

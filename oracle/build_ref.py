@@ -1,13 +1,13 @@
 """Builds the reference's ONLY native component -- the Cython evaluator torchreid/metrics/rank_cylib/rank_cy.pyx -- from
-the sources where they lie under /root/reference into oracle/_ref/ (git-ignored; travels to the GPU box like any
-built artefact). Test infrastructure: used to cross-check oracle.eval_market1501 (tests/test_oracle_golden.py); never
-imported by the product. Recipe = what the reference's own setup.py does (cythonize + one C compile), driven directly:
+the sources where they lie under /root/reference into oracle/_ref/ (git-ignored AND gpurun-ignored: it stays in the build
+container). Test infrastructure: used there to cross-check oracle.eval_market1501 and to capture its outputs on seeded
+inputs as data (tests/golden/rank_market1501_cy.npz, make_golden.py F14) -- what the GPU-side tests compare against; never
+imported by the product, never loaded on the GPU box. Recipe = what the reference's own setup.py does (cythonize + one C compile), driven directly:
 
     cython -3 rank_cy.pyx -o oracle/_ref/rank_cy.c ; gcc -O2 -shared -fPIC $(python-config --includes) -I numpy ...
 
 No reference source is copied into the repository: only the built .so stays under oracle/_ref/ (the generated C file, which
-quotes the .pyx line by line, is deleted after the compile), so nothing that reads like the reference's source travels to the GPU
-box with the snapshot.
+quotes the .pyx line by line, is deleted after the compile), and neither travels to the GPU box.
 """
 import os
 import subprocess
@@ -37,14 +37,14 @@ def build(verbose=True):
     cmd = ["gcc", "-O2", "-shared", "-fPIC", "-w", "-I" + sysconfig.get_paths()["include"], "-I" + np.get_include(),
            "-DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION", c_file, "-o", so]
     subprocess.check_call(cmd)
-    os.remove(c_file)   # the intermediate carries the reference's source text as comments: only the binary is kept (and travels)
+    os.remove(c_file)   # the intermediate carries the reference's source text as comments: only the binary is kept
     if verbose:
         print("built", so)
     return so
 
 
 def load():
-    """Import oracle/_ref/rank_cy if it has been built (here or shipped); None otherwise."""
+    """Import oracle/_ref/rank_cy if it has been built (build container only); None otherwise."""
     import importlib.util
     import glob
     hits = glob.glob(os.path.join(OUT, "rank_cy*.so"))

@@ -111,3 +111,44 @@ def batches(pids, cams, first_tracklet, device, bs, make_adj):
         x = clips(tid, pattern_ids(p, i), device)
         ps, det = poses(tid, device)
         yield x, p, cams[i:i + bs], make_adj(ps, det)
+
+
+def compare_topk(idx, val, ref_idx, ref_val, k=50):
+    """Device top-k lists (m,k) against the oracle's first k+1 positions (m,k+1). Ranking indices are only defined where
+    neighbouring distances differ by more than the two implementations' rounding error, so every position where the indices
+    differ must be EXPLAINED: the device's choice sits in the oracle's list at a distance within ``tol`` of the oracle's
+    entry at that position (a near-tie swap), tol = 2 x (largest distance disagreement at matching positions) + 1e-6.
+    -> dict(agreement, rows_equal, top1_agreement, max_abs_val_err, tol, unexplained, oracle_min_gap)."""
+    idx, val = np.asarray(idx)[:, :k].astype(np.int64), np.asarray(val)[:, :k].astype(np.float64)
+    ref_idx, ref_val = np.asarray(ref_idx).astype(np.int64), np.asarray(ref_val).astype(np.float64)
+    same = idx == ref_idx[:, :k]
+    err = float(np.abs(val - ref_val[:, :k])[same].max()) if same.any() else float("inf")
+    tol = 2.0 * err + 1e-6
+    unexplained = 0
+    rows, cols = np.nonzero(~same)
+    for r, c in zip(rows, cols):
+        pos = np.nonzero(ref_idx[r] == idx[r, c])[0]
+        if len(pos) == 0 or abs(ref_val[r, pos[0]] - ref_val[r, c]) > tol:
+            unexplained += 1
+    return {"agreement": float(same.mean()), "rows_equal": float(same.all(axis=1).mean()), "top1_agreement": float(same[:, 0].mean()),
+            "max_abs_val_err": err, "tol": tol, "swapped_positions": int((~same).sum()), "unexplained": int(unexplained),
+            "oracle_min_gap": float(np.diff(ref_val, axis=1).min())}
+
+
+def load_oracle_fixture():
+    """tests/golden/fullsplit_oracle.npz (made by tests/golden/make_fullsplit.py), or None when it has not been generated."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsplit_oracle.npz")
+    return np.load(path) if os.path.exists(path) else None
+
+
+def apply_calibration(model, z):
+    """Load the fixture's BNNeck statistics into the model's two BatchNorm1d layers (weight 1, bias 0)."""
+    with torch.no_grad():
+        for bn, key in ((model.global_bottleneck, "g"), (model.att_bottleneck, "a")):
+            bn.running_mean.copy_(torch.from_numpy(z["cal_%s_mean" % key]).to(bn.running_mean.device))
+            bn.running_var.copy_(torch.from_numpy(z["cal_%s_var" % key]).to(bn.running_var.device))
+            bn.weight.fill_(1.0)
+            bn.bias.zero_()
+    if hasattr(model, "invalidate_hip_cache"):
+        model.invalidate_hip_cache()

@@ -109,3 +109,24 @@ def test_bench_self_launches_two_ranks():
     assert r["config"]["gallery_rows_per_gpu"] == 6090 and len(r["config"]["per_rank_ms_per_step"]) == 2
     assert r["value"] > 0 and "allgather_us" in r["config"] and r["scaling"] == "weak"
     print("bench --gpus 2 (2 ranks on one GPU, gloo): %.0f frames/s, all-gather %.0f us" % (r["value"], r["config"]["allgather_us"]))
+
+
+def test_bench_launcher_notices_a_rank_that_dies_mid_run():
+    """``python bench.py --gpus 2`` with rank 1 exiting (code 3) right after the warm-up: rank 0 is then blocked in the
+    all-gather; the launcher must terminate it and return non-zero well inside --dist-timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(AGRL_BENCH_FAULT_RANK="1", AGRL_BENCH_FAULT_CODE="3")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+                          "--sustain-seconds", "0", "--profile-steps", "1", "--dist-timeout", "600"], env=env, cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    dt = time.time() - t0
+    err = out.stderr.decode()
+    print("launcher returned %d after %.0f s" % (out.returncode, dt))
+    # (rank 0 may notice the closed connection itself and exit non-zero before the next poll: either rank can be the one named)
+    assert out.returncode != 0, err[-2000:]
+    assert "exited with code" in err and "remaining ranks terminated" in err and dt < 500

@@ -1,0 +1,85 @@
+"""The exact-fp32 HIP pipeline on the FULL-SIZE synthetic MARS split (tests/fullsplit.py: 1 980 x 12 180 tracklets of 8 frames,
+625 identities) against what the CPU oracle produced for the same split in the build container
+(tests/golden/fullsplit_oracle.npz, tests/golden/make_fullsplit.py). Reference dataflow: train_vidreid_xent_htri.py:450-542."""
+import numpy as np
+import pytest
+import torch
+
+import fullsplit as FS
+from recipe import recipe_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_split_inputs_are_bit_identical_on_cpu_and_gpu():
+    """The premise of the fixture: clips, poses and detection flags are integer hashes + exact fp32 steps."""
+    tid = np.array([0, 1, 1979, 1980, 7777, 14159])
+    pat = np.array([3, 624, 17, 625 + 5, 0, 1648])
+    assert torch.equal(FS.clips(tid, pat, "cpu"), FS.clips(tid, pat, DEV).cpu())
+    pc, dc = FS.poses(tid, "cpu")
+    pg, dg = FS.poses(tid, DEV)
+    assert torch.equal(pc, pg.cpu()) and torch.equal(dc, dg.cpu())
+    x = FS.clips(tid, pat, DEV)
+    assert abs(float(x.mean())) < 0.05 and 1.0 < float(x.std()) < 1.3
+
+
+def test_device_adjacency_equals_oracle_adjacency_on_the_split_poses():
+    """agrl_pose_adjacency (what the GPU side feeds the model) == the oracle's generate_graph restatement (what the fixture
+    was made with) on the split's own keypoints."""
+    from oracle import vmgn_oracle as O
+    from torchreid import hip_ops as ops
+    tid = np.arange(2000, 2064)
+    ps, det = FS.poses(tid, DEV)
+    got = ops.pose_adjacency(ps, det, height=float(FS.HEIGHT), num_split=4, pyramid_part=True, threshold=0.1).cpu().numpy()
+    psc, detc = ps.cpu().numpy(), det.cpu().numpy()
+    for b in range(len(tid)):
+        sets = [O.pose_part_sets(psc[b, s] if detc[b, s] else None, float(FS.HEIGHT), 4, 0.1) for s in range(FS.SEQ_LEN)]
+        assert np.array_equal(got[b], O.pose_adjacency(sets, 4, True)), b
+
+
+@pytest.fixture(scope="module")
+def embedded():
+    from torchreid import evaluation, models
+    from torchreid import hip_ops as ops
+    z = FS.load_oracle_fixture()
+    if z is None:
+        pytest.skip("tests/golden/fullsplit_oracle.npz not generated (python tests/golden/make_fullsplit.py, build container)")
+    m = models.init_model("vmgn", num_classes=FS.N_IDS, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=False)
+    m.load_state_dict(recipe_state_dict(m.state_dict(), seed=0))
+    m = m.to(DEV).eval()
+    FS.apply_calibration(m, z)
+    m.hip_precision = "fp32"
+    labels = FS.labels()
+
+    def make_adj(poses, detected):
+        return ops.pose_adjacency(poses, detected, height=float(FS.HEIGHT), num_split=4, pyramid_part=True, threshold=0.1)
+
+    qf, _, _ = evaluation.extract_features(m, FS.batches(labels[0], labels[1], 0, DEV, 64, make_adj), prefetch=False)
+    gf, _, _ = evaluation.extract_features(m, FS.batches(labels[2], labels[3], FS.QUERY_ROWS, DEV, 64, make_adj), prefetch=False)
+    return z, labels, qf, gf
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+def test_fp32_pipeline_at_full_size_against_the_oracle(embedded, metric):
+    from torchreid import evaluation
+    z, (q_pids, q_cams, g_pids, g_cams), qf, gf = embedded
+    ref = z["q_emb_head"].astype(np.float64)
+    e = np.abs(qf[:16].cpu().double().numpy() - ref).max() / np.abs(ref).max()
+    cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, "fp32", return_topk=True)
+    c = FS.compare_topk(idx, val, z[metric + "_idx"], z[metric + "_val"])
+    o_cmc, o_map = z[metric + "_cmc"], float(z[metric + "_mAP"])
+    print("%s: embedding rel err %.2e | Rank-1 %.6f (oracle %.6f) mAP %.6f (oracle %.6f) | top-50 index agreement %.6f, identical rows %.4f, "
+          "distance err %.2e, swapped %d, unexplained %d, oracle min gap %.2e" % (
+              metric, e, cmc[0], o_cmc[0], mAP, o_map, c["agreement"], c["rows_equal"], c["max_abs_val_err"], c["swapped_positions"],
+              c["unexplained"], c["oracle_min_gap"]))
+    assert e < 1e-3                                            # north star: 1e-3 relative fp32
+    scale = float(np.abs(z[metric + "_val"]).max())
+    assert c["max_abs_val_err"] < 1e-3 * scale
+    assert c["unexplained"] == 0                               # every differing index is a swap inside a near-tie
+    assert c["agreement"] > 0.995
+    # Rank-1 / mAP: equal up to what those near-tie swaps can move
+    assert abs(cmc[0] - o_cmc[0]) <= (c["swapped_positions"] + 0.5) / len(q_pids)
+    assert abs(mAP - o_map) < 1e-4
+    assert np.abs(cmc - o_cmc).max() <= (c["swapped_positions"] + 0.5) / len(q_pids)
