@@ -40,16 +40,15 @@ __device__ inline int block_excl_scan(int flag, int* s_w, int& total) {
     return base + within;
 }
 
-__global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict__ dist, int n, int ldd, int k,
-                                                        int kpad, int idx_offset, int32_t* __restrict__ idx_out,
-                                                        float* __restrict__ val_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cand[];  // kpad composites
+// One row by radix select (reads the row 5 x: 4 histogram passes + the collect): any n, k <= 1024, any alignment.
+// s_cand: kpad composites of LDS.
+__device__ void radix_topk_row(const float* __restrict__ row, int n, int k, int kpad, int idx_offset,
+                               int32_t* __restrict__ idx_row, float* __restrict__ val_row, unsigned long long* s_cand) {
     __shared__ int s_hist[256];
     __shared__ int s_w[4];
     __shared__ uint32_t s_prefix;
     __shared__ int s_kth, s_cnt;
     const int tid = threadIdx.x;
-    const float* row = dist + (size_t)blockIdx.x * ldd;
 
     if (tid == 0) {
         s_prefix = 0;
@@ -122,8 +121,108 @@ __global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict_
     }
     for (int i = tid; i < k; i += 256) {
         const unsigned long long c = s_cand[i];
-        idx_out[(size_t)blockIdx.x * k + i] = (int32_t)(uint32_t)(c & 0xffffffffull) + idx_offset;
-        val_out[(size_t)blockIdx.x * k + i] = key_dist((uint32_t)(c >> 32));
+        idx_row[i] = (int32_t)(uint32_t)(c & 0xffffffffull) + idx_offset;
+        val_row[i] = key_dist((uint32_t)(c >> 32));
+    }
+}
+
+__global__ __launch_bounds__(256) void rank_topk_kernel(const float* __restrict__ dist, int n, int ldd, int k,
+                                                        int kpad, int idx_offset, int32_t* __restrict__ idx_out,
+                                                        float* __restrict__ val_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cand_dyn[];  // kpad composites
+    radix_topk_row(dist + (size_t)blockIdx.x * ldd, n, k, kpad, idx_offset, idx_out + (size_t)blockIdx.x * k,
+                   val_out + (size_t)blockIdx.x * k, s_cand_dyn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bandwidth-bound top-k (k <= 128, n <= 1024 NV, 16-byte aligned rows): the row crosses HBM ONCE, as NV 16-byte loads
+// per thread all in flight together, and stays in registers as order-preserving keys.
+//   1. every thread's smallest key -> LDS; tau = the k-th smallest of those 256 minima. They are k distinct elements of
+//      the row, so the row's k-th smallest key is <= tau: tau is an upper bound that needs no histogram;
+//   2. candidates = every key <= tau (for i.i.d. data ~1.1 k of them; any data: >= k), compacted into LDS as
+//      (key << 32 | index) composites;
+//   3. each candidate's rank among the candidates by counting (composites are distinct: the index breaks ties towards the
+//      lower gallery index); ranks < k are the answer, written in place.
+// The result equals the radix kernel's bit for bit (a stable argsort truncated to k, NaN last). Rows whose candidate
+// count exceeds TOPK_CAP (a row of mostly equal values) take the radix path from global memory, same kernel.
+constexpr int TOPK_CAP = 1024;
+
+template <int NV>
+__global__ __launch_bounds__(256) void rank_topk_fast_kernel(const float* __restrict__ dist, int n, int ldd, int k, int kpad,
+                                                             int idx_offset, int32_t* __restrict__ idx_out, float* __restrict__ val_out) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_cand[TOPK_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_min[256];
+    __shared__ uint32_t s_tau;
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const float* row = dist + (size_t)blockIdx.x * ldd;
+    uint32_t key[NV][4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int j0 = (i * 256 + tid) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j0 + 3 < n) {
+            v = *reinterpret_cast<const float4*>(row + j0);
+        } else {
+            if (j0 < n) v.x = row[j0];
+            if (j0 + 1 < n) v.y = row[j0 + 1];
+            if (j0 + 2 < n) v.z = row[j0 + 2];
+        }
+        key[i][0] = j0 < n ? dist_key(v.x) : 0xffffffffu;
+        key[i][1] = j0 + 1 < n ? dist_key(v.y) : 0xffffffffu;
+        key[i][2] = j0 + 2 < n ? dist_key(v.z) : 0xffffffffu;
+        key[i][3] = j0 + 3 < n ? dist_key(v.w) : 0xffffffffu;
+    }
+    uint32_t mine = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mine = key[i][e] < mine ? key[i][e] : mine;
+    s_min[tid] = mine;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    {   // rank of this thread's minimum among the 256 (ties -> lower thread id): the thread of rank k - 1 publishes tau
+        int r = 0;
+#pragma unroll 8
+        for (int u4 = 0; u4 < 64; ++u4) {
+            const uint4 o = *reinterpret_cast<const uint4*>(&s_min[u4 * 4]);
+            const int u = u4 * 4;
+            r += (o.x < mine || (o.x == mine && u < tid)) ? 1 : 0;
+            r += (o.y < mine || (o.y == mine && u + 1 < tid)) ? 1 : 0;
+            r += (o.z < mine || (o.z == mine && u + 2 < tid)) ? 1 : 0;
+            r += (o.w < mine || (o.w == mine && u + 3 < tid)) ? 1 : 0;
+        }
+        if (r == k - 1) s_tau = mine;
+    }
+    __syncthreads();
+    const uint32_t tau = s_tau;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = (i * 256 + tid) * 4 + e;
+            if (j < n && key[i][e] <= tau) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < TOPK_CAP) s_cand[pos] = ((unsigned long long)key[i][e] << 32) | (uint32_t)j;
+            }
+        }
+    __syncthreads();
+    const int C = s_cnt;
+    int32_t* idx_row = idx_out + (size_t)blockIdx.x * k;
+    float* val_row = val_out + (size_t)blockIdx.x * k;
+    if (C > TOPK_CAP) {   // block-uniform: a row dominated by ties at the threshold
+        __syncthreads();
+        radix_topk_row(row, n, k, kpad, idx_offset, idx_row, val_row, s_cand);
+        return;
+    }
+    for (int i = tid; i < C; i += 256) {
+        const unsigned long long c = s_cand[i];
+        int r = 0;
+        for (int j = 0; j < C; ++j) r += s_cand[j] < c ? 1 : 0;
+        if (r < k) {
+            idx_row[r] = (int32_t)(uint32_t)(c & 0xffffffffull) + idx_offset;
+            val_row[r] = key_dist((uint32_t)(c >> 32));
+        }
     }
 }
 
@@ -371,16 +470,74 @@ __global__ __launch_bounds__(256) void rank_market1501_kernel(const float* __res
 
 }  // namespace
 
+static int launch_topk(const float* dist, int m, int n, int ldd, int k, int idx_offset, int32_t* idx, float* val, hipStream_t st) {
+    int kpad = 2;
+    while (kpad < k) kpad <<= 1;
+    const bool aligned = ((uintptr_t)dist % 16 == 0) && (ldd % 4 == 0);
+    static const bool force_radix = getenv("AGRL_TOPK_RADIX") != nullptr;   // A/B switch: the 5-pass radix kernel for every row
+    if (aligned && k <= 128 && n <= 32768 && !force_radix) {
+        const int nv = (n + 1023) / 1024;
+#define AGRL_TOPK_FAST(NV) hipLaunchKernelGGL(rank_topk_fast_kernel<NV>, dim3(m), dim3(256), 0, st, dist, n, ldd, k, kpad, idx_offset, idx, val)
+        if (nv <= 1) AGRL_TOPK_FAST(1);
+        else if (nv <= 2) AGRL_TOPK_FAST(2);
+        else if (nv <= 4) AGRL_TOPK_FAST(4);
+        else if (nv <= 8) AGRL_TOPK_FAST(8);
+        else if (nv <= 12) AGRL_TOPK_FAST(12);
+        else if (nv <= 16) AGRL_TOPK_FAST(16);
+        else if (nv <= 24) AGRL_TOPK_FAST(24);
+        else AGRL_TOPK_FAST(32);
+#undef AGRL_TOPK_FAST
+    } else {
+        hipLaunchKernelGGL(rank_topk_kernel, dim3(m), dim3(256), (size_t)kpad * 8, st, dist, n, ldd, k, kpad, idx_offset, idx, val);
+    }
+    return 0;
+}
+
 extern "C" int agrl_rank_topk(const float* dist, int m, int n, int ldd, int k, int idx_offset, int32_t* idx, float* val,
                               agrl_stream_t stream) {
     AGRL_CHECK_ARG(dist && idx && val, "agrl_rank_topk: null pointer");
     AGRL_CHECK_ARG(m > 0 && n > 0 && ldd >= n, "agrl_rank_topk: bad shape m=%d n=%d ldd=%d", m, n, ldd);
     AGRL_CHECK_ARG(k > 0 && k <= n && k <= 1024, "agrl_rank_topk: need 0 < k <= min(n, 1024), got k=%d n=%d", k, n);
-    int kpad = 2;
-    while (kpad < k) kpad <<= 1;
-    hipLaunchKernelGGL(rank_topk_kernel, dim3(m), dim3(256), (size_t)kpad * 8, (hipStream_t)stream, dist, n, ldd, k,
-                       kpad, idx_offset, idx, val);
+    launch_topk(dist, m, n, ldd, k, idx_offset, idx, val, (hipStream_t)stream);
     AGRL_CHECK_LAUNCH("agrl_rank_topk");
+    return 0;
+}
+
+// Distance matrix + per-row top-k WITHOUT the m x n matrix (agrl_distmat_topk; reference
+// metrics/distance.py:59-89 followed by metrics/rank.py:171-172): the queries are walked in row blocks whose distance rows
+// (block x n fp32) live in a caller-provided workspace that is reused block after block -- small enough to stay in the
+// 256 MB memory-side cache between the GEMM that writes it and the top-k that reads it -- so HBM sees the operands and the
+// (m, k) lists, not 4 m n bytes out and back. Arithmetic and results are those of agrl_distmat + agrl_rank_topk, bit for bit.
+extern "C" size_t agrl_distmat_topk_workspace(int m, int n) {
+    if (m <= 0 || n <= 0) return 0;
+    const int ldd = (n + 3) & ~3;
+    int rows = (int)((size_t)(24u << 20) / ((size_t)ldd * 4));   // ~24 MB of distance rows per block ...
+    rows = rows / 128 * 128;
+    if (rows < 128) rows = 128;                                  // ... at least one row of GEMM tiles
+    if (rows > m) rows = m;
+    return (size_t)rows * ldd * 4;
+}
+
+extern "C" int agrl_distmat_topk(const void* q, const void* g, const float* qn, const float* gn, int m, int n, int D, int metric,
+                                 int dtype, int k, int idx_offset, int32_t* idx, float* val, void* workspace, size_t workspace_bytes,
+                                 void* gemm_workspace, size_t gemm_workspace_bytes, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(q && g && idx && val && workspace, "agrl_distmat_topk: null pointer");
+    AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && k > 0 && k <= n && k <= 1024, "agrl_distmat_topk: bad shape m=%d n=%d D=%d k=%d", m, n, D, k);
+    const int ldd = (n + 3) & ~3;
+    AGRL_CHECK_ARG((uintptr_t)workspace % 16 == 0 && workspace_bytes >= (size_t)ldd * 4,
+                   "agrl_distmat_topk: workspace must be 16-byte aligned and hold at least one distance row (%zu bytes)", (size_t)ldd * 4);
+    int rows = (int)(workspace_bytes / ((size_t)ldd * 4));
+    if (rows > m) rows = m;
+    if (rows >= 128) rows = rows / 128 * 128;
+    const size_t esz = dtype == AGRL_BF16 ? 2 : 4;
+    for (int r0 = 0; r0 < m; r0 += rows) {
+        const int mb = m - r0 < rows ? m - r0 : rows;
+        const int rc = agrl_distmat((const char*)q + (size_t)r0 * D * esz, g, qn ? qn + r0 : nullptr, gn, (float*)workspace, mb, n, D, ldd,
+                                    metric, dtype, gemm_workspace, gemm_workspace_bytes, stream);
+        if (rc != 0) return rc;
+        launch_topk((const float*)workspace, mb, n, ldd, k, idx_offset, idx + (size_t)r0 * k, val + (size_t)r0 * k, (hipStream_t)stream);
+    }
+    AGRL_CHECK_LAUNCH("agrl_distmat_topk");
     return 0;
 }
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "agrl_re_ranking_workspace": [_i, _i, _i],   # returns size_t (restype patched after loading)
     "agrl_re_ranking": [_p, _p, _p, _i, _i, _i, _i, C.c_double, _p, _i, _p, C.c_size_t, _p],
     "agrl_rank_topk": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "agrl_distmat_topk_workspace": [_i, _i],   # returns size_t
+    "agrl_distmat_topk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, C.c_size_t, _p, C.c_size_t, _p],
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],
@@ -124,6 +126,7 @@ def lib():
         h.agrl_bn_workspace.restype = C.c_size_t
         h.agrl_conv_wgrad_workspace.restype = C.c_size_t
         h.agrl_graph_message_pass_workspace.restype = C.c_size_t
+        h.agrl_distmat_topk_workspace.restype = C.c_size_t
         for name in ("agrl_reload_options", "agrl_built_with_ablation"):
             getattr(h, name).argtypes = []
             getattr(h, name).restype = _i

@@ -6,8 +6,8 @@
     model(imgs, adj) per batch            (:469,:499)   same call (the HIP eval forward)
     dense/skipdense clip pooling          (:471-476)    ``pool_clips`` (mean / max over a tracklet's clips)
     features.data.cpu(); torch.cat        (:477-511)    embeddings stay in HBM; RCCL all-gather when sharded
-    compute_distance_matrix on CPU        (:520)        ``agrl_distmat`` against the rank's gallery shard
-    evaluate_rank(use_metric_mars=True)   (:531)        ``agrl_rank_topk`` + candidate merge + ``agrl_rank_mars``
+    compute_distance_matrix on CPU        (:520)        ``agrl_distmat_topk`` against the rank's gallery shard: distance rows of
+    evaluate_rank(use_metric_mars=True)   (:531)        one query block at a time + top-k; candidate merge + ``agrl_rank_mars``
     returns cmc[0], mAP                   (:542)        returns (cmc, mAP) (+ the top-k lists on request)
 
 With ``torch.distributed`` initialised (one process per GPU) the tracklet batches and the gallery rows are sharded
@@ -20,7 +20,7 @@ import torch
 
 from torchreid import hip_ops as ops
 from torchreid import parallel
-from torchreid.metrics.distance import hip_distmat_device
+from torchreid.metrics.distance import hip_distmat_device, hip_distmat_topk_device
 
 
 def pool_clips(features, num_clips, pool="avg"):
@@ -127,7 +127,12 @@ def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosi
         idx, val = topk_fn(dist, max_rank)
         idx = idx.to(torch.int64)
     else:
-        idx, val = parallel.sharded_topk(qf.float().contiguous(), gf.float().contiguous(), lo, max_rank, dist_fn, topk_fn)
+        # distance + top-k fused (agrl_distmat_topk): the (m, n) matrix of the reference's test() is never materialised
+        def match_fn(q, g, k):
+            return hip_distmat_topk_device(q, g, dist_metric, k, precision)
+
+        idx, val = parallel.sharded_topk(qf.float().contiguous(), gf.float().contiguous(), lo, max_rank, dist_fn, topk_fn,
+                                         match_fn=match_fn if qf.is_cuda else None)
     ap, cmc = ops.rank_mars(idx.to(torch.int32).contiguous(), _i32(q_pids, device), _i32(q_camids, device),
                             _i32(g_pids, device), _i32(g_camids, device))
     ap = ap.cpu().numpy()

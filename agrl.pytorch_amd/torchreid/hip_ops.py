@@ -467,6 +467,30 @@ def rank_topk(dist, k, idx_offset=0):
     return idx, val
 
 
+def distmat_topk(q, g, metric, k, qn=None, gn=None, idx_offset=0, workspace_bytes=None):
+    """q (m,D), g (n,D) prepared operands (as for ``distmat``) -> idx int32 (m,k), val fp32 (m,k): the k nearest gallery rows
+    of every query in ascending (distance, index) order, without the (m,n) matrix (distance.py:59-89 + rank.py:171-172).
+    Bit-identical to ``rank_topk(distmat(q, g, ...), k)``."""
+    m, D = q.shape
+    n, D2 = g.shape
+    assert D == D2 and q.dtype == g.dtype
+    code = METRIC_EUCLIDEAN if metric == "euclidean" else METRIC_COSINE
+    nbytes = int(_hip.lib().agrl_distmat_topk_workspace(m, n)) if workspace_bytes is None else int(workspace_bytes)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=q.device)
+    rows = max(1, min(m, nbytes // (4 * (-(-n // 4) * 4))))
+    gws = None
+    if (-(-rows // 64)) * (-(-n // 128)) < 256:   # few output tiles per block: split-K scratch, as in ``distmat``
+        gws = torch.empty((8 * rows * n,), dtype=torch.float32, device=q.device)
+    idx = torch.empty((m, k), dtype=torch.int32, device=q.device)
+    val = torch.empty((m, k), dtype=torch.float32, device=q.device)
+    if _hip.PROFILE is not None:  # SURVEY 8(d): (m+n) D e in, m k 8 out
+        _hip.PROFILE_TAG = {"flops": 2.0 * m * n * D, "bytes": q.element_size() * (m + n) * D + 8.0 * m * k}
+    with _dev(q):
+        _hip.call("agrl_distmat_topk", ptr(q), ptr(g), ptr(qn), ptr(gn), m, n, D, code, dtype_code(q.dtype), int(k), int(idx_offset),
+                  ptr(idx), ptr(val), ptr(ws), ws.numel() * 4, ptr(gws), 0 if gws is None else gws.numel() * 4, _stream(q))
+    return idx, val
+
+
 def rank_mars(topk_idx, q_pids, q_camids, g_pids, g_camids):
     """-> ap fp64 (m), cmc fp32 (m,k). rank.py:160-212."""
     m, k = topk_idx.shape

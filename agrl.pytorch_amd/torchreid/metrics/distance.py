@@ -70,6 +70,23 @@ def hip_distmat_device(q, g, metric, precision='fp32', out=None):
     return ops.distmat(qh, gh, 'cosine', out=out)
 
 
+def hip_distmat_topk_device(q, g, metric, k, precision='fp32'):
+    """Device-resident distance + ranking: q (m,d), g (n,d) fp32 CUDA tensors -> idx int32 (m,k), val fp32 (m,k), the k nearest
+    gallery rows per query in ascending (distance, index) order -- ``rank_topk(hip_distmat_device(q, g), k)`` bit for bit,
+    without the (m,n) matrix (``agrl_distmat_topk``)."""
+    from torchreid import hip_ops as ops
+    lp = precision == 'bf16'
+    dt = torch.bfloat16 if lp else torch.float32
+    km = ops.k_multiple(dt)
+    if metric == 'euclidean':
+        qn, gn = ops.row_sqnorm(q), ops.row_sqnorm(g)
+        if lp or q.size(1) % km:
+            q, g = ops.row_l2_normalize(q, False, dt, km), ops.row_l2_normalize(g, False, dt, km)
+        return ops.distmat_topk(q, g, 'euclidean', k, qn, gn)
+    qh, gh = ops.row_l2_normalize(q, True, dt, km), ops.row_l2_normalize(g, True, dt, km)
+    return ops.distmat_topk(qh, gh, 'cosine', k)
+
+
 def euclidean_squared_distance(input1, input2):
     """||a||^2 + ||b||^2 - 2 a.b  (squared distance: no clamp, no sqrt)."""
     if _use_hip(input1):

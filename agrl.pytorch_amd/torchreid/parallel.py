@@ -77,17 +77,20 @@ def all_gather_ragged_rows(local, counts):
     return torch.cat([gathered[r, : counts[r]] for r in range(world)], dim=0)
 
 
-def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn):
+def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn, match_fn=None):
     """Global top-k of every query against a gallery sharded by rows across ranks.
 
     ``distmat_fn(q, g) -> (m, n_local)`` and ``topk_fn(d, k) -> (idx (m,k') int, val (m,k'))`` (ascending
-    (distance, index), ties towards the lower index) are the per-rank kernels. Returns (idx (m,k) global gallery
-    indices, val (m,k)), identical on every rank and identical to a single-GPU top-k of the full matrix:
-    shards are contiguous and rank-ordered, so 'position in the concatenated candidate list' orders ties exactly
-    like 'global gallery index'."""
-    d_local = distmat_fn(q_all, gallery_shard)
-    k_local = min(k, d_local.size(1))
-    idx, val = topk_fn(d_local, k_local)
+    (distance, index), ties towards the lower index) are the per-rank kernels; ``match_fn(q, g, k) -> (idx, val)``, when
+    given, replaces the pair for the local step (the fused distance + top-k that never writes the (m, n_local) matrix).
+    Returns (idx (m,k) global gallery indices, val (m,k)), identical on every rank and identical to a single-GPU top-k of
+    the full matrix: shards are contiguous and rank-ordered, so 'position in the concatenated candidate list' orders ties
+    exactly like 'global gallery index'."""
+    k_local = min(k, gallery_shard.size(0))
+    if match_fn is not None:
+        idx, val = match_fn(q_all, gallery_shard, k_local)
+    else:
+        idx, val = topk_fn(distmat_fn(q_all, gallery_shard), k_local)
     idx = idx.to(torch.int64) + shard_lo
     world = world_size()
     if world == 1:

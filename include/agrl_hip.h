@@ -276,9 +276,26 @@ int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn,
 /* Per query row: the k smallest distances in ascending (distance, gallery index) order -- i.e.
  * np.argsort(dist[i])[:k] with ties broken towards the lower index -- torchreid/metrics/rank.py:170-172.
  *   dist fp32 (m, n) row stride ldd; idx int32 (m,k) (gallery index + idx_offset); val fp32 (m,k).
- *   NaNs sort last. Requires k <= 1024, k <= n. */
+ *   NaNs sort last. Requires k <= 1024, k <= n. With 16-byte aligned rows (dist and ldd * 4 multiples of 16), k <= 128 and
+ *   n <= 32768 every row crosses HBM exactly once (threshold from the per-thread minima, no histogram passes); other shapes
+ *   take the five-pass radix select. Both give the same lists. */
 int agrl_rank_topk(const float* dist, int m, int n, int ldd, int k, int idx_offset, int32_t* idx,
                    float* val, agrl_stream_t stream);
+
+/* Distance matrix and per-query top-k in one call, WITHOUT materialising the (m, n) matrix: what the reference's
+ * test() does with compute_distance_matrix (torchreid/metrics/distance.py:59-89, train_vidreid_xent_htri.py:520) followed by
+ * np.argsort(distmat[k])[:max_rank] (torchreid/metrics/rank.py:171-172). Operands / qn / gn / metric / dtype as for
+ * agrl_distmat; idx / val / idx_offset / ordering (ascending (distance, gallery index), NaN last) as for agrl_rank_topk, and
+ * the results equal agrl_distmat followed by agrl_rank_topk bit for bit.
+ *   workspace: device scratch for the distance rows of ONE block of queries, 16-byte aligned, at least one row
+ *   (4 * roundup(n, 4) bytes); agrl_distmat_topk_workspace(m, n) returns the recommended size (~24 MB of rows: a block stays in
+ *   the memory-side cache between the GEMM that writes it and the selection that reads it). The buffer is reused block after
+ *   block, so HBM carries the operands and the (m, k) lists instead of 4 m n bytes out and back.
+ *   gemm_workspace: agrl_distmat's optional split-K scratch (may be NULL). */
+size_t agrl_distmat_topk_workspace(int m, int n);
+int agrl_distmat_topk(const void* q, const void* g, const float* qn, const float* gn, int m, int n, int D, int metric,
+                      int dtype, int k, int idx_offset, int32_t* idx, float* val, void* workspace,
+                      size_t workspace_bytes, void* gemm_workspace, size_t gemm_workspace_bytes, agrl_stream_t stream);
 
 /* MARS evaluation of every query from its top-k list: evaluate_mars + Compute_AP,
  * torchreid/metrics/rank.py:160-212.

@@ -41,6 +41,9 @@ def test_config5_full_mars_distmat_and_rank(precision):
         assert torch.equal(torch.gather(dist, 1, idx.long()), val)
         distinct = (tv[:, 1:] != tv[:, :-1]).all(dim=1)            # rows without exact ties: indices must be identical
         assert torch.equal(idx.long()[distinct], ti[distinct])
+        from torchreid.metrics.distance import hip_distmat_topk_device
+        idx_f, val_f = hip_distmat_topk_device(qd, gd, metric, k, precision)    # never writes the 96.5 MB matrix
+        assert torch.equal(idx_f, idx) and torch.equal(val_f, val)
         idx2, val2 = ops.rank_topk(val.contiguous(), k)
         assert torch.equal(val2, val) and torch.equal(idx2.long(), torch.arange(k, device=DEV).expand(m, k))
         # a query's own identity dominates its top ranks (sanity of the whole match)

@@ -703,6 +703,70 @@ def test_rank_topk_exact(shape):
         assert np.array_equal(val[r], d[r][ref], equal_nan=True)
 
 
+@pytest.mark.parametrize("shape", [(9, 12180, 50), (5, 1023, 20), (6, 37, 30), (4, 2049, 128), (3, 30000, 1), (3, 4099, 50), (2, 40000, 50)])
+def test_rank_topk_single_pass_form(shape):
+    """The bandwidth-bound kernel (k <= 128, n <= 32768, aligned rows: the row crosses HBM once, threshold from the per-thread
+    minima) on the cases that exercise its branches -- a row of equal values (candidate overflow -> radix path inside the same
+    launch), NaN / +-inf / -0.0, more NaNs than the row has room after the top k, an n that is not a multiple of 4, rows shorter
+    than k threads' worth of elements -- against the stable argsort (rank.py:171-172), and a row-strided view whose rows are not
+    16-byte aligned (radix kernel) giving the same lists. (2, 40000, 50): n beyond the register form."""
+    from torchreid import hip_ops as ops
+    m, n, k = shape
+    rng = np.random.RandomState(m * n + k)
+    d = rng.randn(m, n).astype(np.float32)
+    d[0] = np.float32(0.5)                       # every value equal: all n are candidates -> overflow path
+    d[1, ::7] = np.nan
+    d[1, 3] = -np.inf
+    d[1, 11 % n] = np.inf
+    if m > 2:
+        d[2, : n // 2] = np.float32(-0.0)
+        d[2, n // 2:] = np.float32(0.0)          # -0.0 == +0.0: pure index order
+    if m > 3:
+        d[3] = np.sort(d[3])                      # sorted row: the k smallest all sit with the first few threads
+    if m > 4:
+        d[4, k // 2:] = np.nan                    # fewer than k finite values
+    dd = torch.from_numpy(d).to(DEV)
+    idx, val = ops.rank_topk(dd, k)
+    wide = torch.zeros((m, n + 3), dtype=torch.float32, device=DEV)
+    wide[:, 1:n + 1] = dd
+    idx_u, val_u = ops.rank_topk(wide[:, 1:n + 1], k)          # base pointer + 4 bytes: not 16-byte aligned
+    torch.cuda.synchronize()
+    idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    for r in range(m):
+        ref = O.stable_topk(d[r], k)
+        assert np.array_equal(idx[r], ref), (r, idx[r][:10], ref[:10])
+        assert np.array_equal(val[r], d[r][ref] + np.float32(0.0), equal_nan=True)   # the kernel reports -0.0 as +0.0
+    assert torch.equal(idx_u.cpu(), torch.from_numpy(idx)) and np.array_equal(val_u.cpu().numpy(), val, equal_nan=True)
+
+
+@pytest.mark.parametrize("cfg", [(700, 3000, 256, "fp32"), (700, 3000, 256, "bf16"), (130, 517, 64, "fp32"), (40, 12180, 4096, "bf16")])
+def test_distmat_topk_equals_distmat_then_topk(cfg):
+    """agrl_distmat_topk (distance rows of one query block at a time in a reused workspace, then the top-k of the block) ==
+    agrl_distmat + agrl_rank_topk bit for bit, for both metrics, for the recommended workspace and for one that forces many
+    blocks; lists in ascending (distance, index) order. distance.py:59-89 + rank.py:171-172."""
+    from torchreid import hip_ops as ops
+    from torchreid.metrics.distance import hip_distmat_device, hip_distmat_topk_device
+    m, n, D, prec = cfg
+    g = torch.Generator().manual_seed(m + n)
+    q, gal = torch.randn((m, D), generator=g).to(DEV), torch.randn((n, D), generator=g).to(DEV)
+    gal[7] = gal[3]                                            # duplicate gallery rows: exact distance ties
+    k = 50
+    for metric in ("cosine", "euclidean"):
+        dist = hip_distmat_device(q, gal, metric, prec)
+        idx0, val0 = ops.rank_topk(dist, k)
+        idx1, val1 = hip_distmat_topk_device(q, gal, metric, k, prec)
+        assert torch.equal(idx0, idx1) and torch.equal(val0, val1), metric
+        assert bool((val1[:, 1:] >= val1[:, :-1]).all())
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    qh, gh = ops.row_l2_normalize(q, True, dt, ops.k_multiple(dt)), ops.row_l2_normalize(gal, True, dt, ops.k_multiple(dt))
+    dist = ops.distmat(qh, gh, "cosine")
+    idx0, val0 = ops.rank_topk(dist, k, idx_offset=1000)
+    idx2, val2 = ops.distmat_topk(qh, gh, "cosine", k, idx_offset=1000, workspace_bytes=130 * 4 * (-(-n // 4) * 4))   # 128-row blocks
+    assert torch.equal(idx0, idx2) and torch.equal(val0, val2)
+    with pytest.raises(Exception):
+        ops.distmat_topk(qh, gh, "cosine", n + 1)
+
+
 def test_rank_mars_bit_exact():
     from torchreid import metrics
     rng = np.random.RandomState(7)

@@ -500,10 +500,10 @@ def test_native_step_against_reference_gradients():
     for got, key in ((loss, "loss"), (lx, "xent"), (lt, "htri")):
         assert abs(float(got.detach()) - float(z[key])) < 1e-5 * abs(float(z[key])), key
     errs = gradient_errors(z, m)
-    for key, (e_slice, e_norm) in errs.items():
-        print("%-34s slice %.2e norm %.2e" % (key, e_slice, e_norm))
-    for key, (e_slice, e_norm) in errs.items():
-        assert e_slice < 3e-2 and e_norm < 1e-2, (key, e_slice, e_norm)
+    for key, (e_slice, e_norm, e_l2) in errs.items():
+        print("%-34s slice max %.2e L2 %.2e | tensor norm %.2e" % (key, e_slice, e_l2, e_norm))
+    for key, (e_slice, e_norm, e_l2) in errs.items():
+        assert e_l2 < 5e-2 and e_norm < 2e-3, (key, e_slice, e_norm, e_l2)
 
 
 def test_xent_native_matches_reference_fixture_and_flags_bad_labels():
