@@ -543,6 +543,75 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
 }
 
 
+// P = G f, nothing else: the message pass applied to the layer INPUT (vmgn.py:168 with the Linear commuted behind it,
+// G (f W^T) = (G f) W^T), written ONCE in the dtype the following GEMM (agrl_graph_linear_mix) consumes. Same streaming
+// structure as graph_propagate_stream_kernel -- G by LDS-DMA at the head of the queue, one 16-byte load per lane per 4 graph
+// rows feeding four exact-fp32 MFMAs, the free channel <-> MFMA-row assignment chosen so that loads are whole cache lines --
+// minus the residual / BatchNorm operands: f crosses HBM once (V C 4 bytes per tracklet in, V C 2 or 4 out).
+template <int PS_NT, int NWV, bool LP>
+__global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const float* __restrict__ f, const float* __restrict__ G,
+                                                                      float* __restrict__ out, bf16_t* __restrict__ out_lp, int C) {
+    extern __shared__ __attribute__((aligned(16))) float s_g[];  // [16*NVF][V]
+    constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = (blockIdx.y * NWV + wave) * 64;
+    const int i16 = lane & 15, kg = lane >> 4;
+    {
+        const unsigned char* Gb = reinterpret_cast<const unsigned char*>(G + (size_t)b * V * V);
+        const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+        constexpr int GBYTES = V * V * 4, NPIECE = (GBYTES + 1023) / 1024;
+#pragma unroll
+        for (int pc = 0; pc < (NPIECE + NWV - 1) / NWV; ++pc) {  // every wave issues the same number of pieces (vmcnt below)
+            const int piece = NWV * pc + wave;
+            const int off = piece * 1024 + lane * 16;
+            const bool real = piece < NPIECE;
+            dma16(real && off < GBYTES ? Gb + off : zsrc,
+                  reinterpret_cast<unsigned char*>(s_g) + (real ? piece : NPIECE) * 1024);  // spare KiB for the odd one
+        }
+    }
+    const size_t node0 = (size_t)b * V;
+    const int cl = c0 + 4 * kg;  // float4 r of this lane's results = channels cl + 16 r .. +3
+    const int sig = 4 * (i16 & 3) + (i16 >> 2);
+    const float* fb = f + (size_t)b * V * C + c0 + 4 * sig;
+    f32x4_t freg[PS_NT];
+#pragma unroll
+    for (int t = 0; t < PS_NT; ++t) freg[t] = gload16(fb + (size_t)(4 * t + kg) * C);
+    wait_vmcnt<PS_NT>();  // the DMA pieces are the oldest entries of the queue
+    wg_barrier();
+
+    f32x4_t acc[NVF][4];
+#pragma unroll
+    for (int vf = 0; vf < NVF; ++vf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[vf][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < PS_NT; ++t) {
+        float gq[NVF];
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) gq[vf] = s_g[(vf * 16 + i16) * V + 4 * t + kg];
+        landed(PS_NT - 1 - t, freg[t]);
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[vf][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(freg[t][j], gq[vf], acc[vf][j], 0, 0, 0);
+    }
+    // D_j row 4 kg + r = channel c0 + 4 sigma(4 kg + r) + j = cl + 16 r + j -> float4 r = {acc[vf][0..3][r]}
+#pragma unroll
+    for (int vf = 0; vf < NVF; ++vf) {
+        const int v = vf * 16 + i16;
+        if (v >= V) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float o0 = acc[vf][0][r], o1 = acc[vf][1][r], o2 = acc[vf][2][r], o3 = acc[vf][3][r];
+            if constexpr (LP) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            else *reinterpret_cast<float4*>(out + (node0 + v) * C + cl + 16 * r) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The WHOLE message-pass unit of a GraphLayer (similarity + normalise + mix + G h + BatchNorm + LeakyReLU +
 // residual; everything of vmgn.py:155-172 but the Linear) in ONE launch, every byte of f / h / out crossing HBM exactly once.
@@ -858,6 +927,38 @@ extern "C" int agrl_graph_finalize(const float* gram_part, int nz, const float* 
     hipLaunchKernelGGL(graph_finalize_kernel, dim3(B, cdiv(V, 4)), dim3(256), (size_t)V * sizeof(float),
                        (hipStream_t)stream, gram_part, nz, adj, G, V, use_pose, learn_graph, mask_diag);
     AGRL_CHECK_LAUNCH("agrl_graph_finalize");
+    return 0;
+}
+
+extern "C" int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, int B, int V, int C, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(G && f && out, "agrl_graph_apply: null pointer");
+    AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0, "agrl_graph_apply: bad shape");
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_graph_apply: out dtype must be fp32 or bf16");
+    const bool lp = out_dtype == AGRL_BF16;
+    const bool aligned = ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)G) & 15) == 0);
+    AGRL_CHECK_ARG(V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned,
+                   "agrl_graph_apply: the streaming form needs V <= 64, V %% 4 == 0, C %% 128 == 0, 16-byte aligned operands (V=%d C=%d); "
+                   "use agrl_graph_propagate with h = f and a unit BatchNorm otherwise", V, C);
+    const int V4 = (V + 3) & ~3;
+    const int nvf = (V + 15) / 16;
+    const int nwv = (C % 256) == 0 ? 4 : 2;
+    const size_t lds_s = (size_t)16 * nvf * V4 * sizeof(float) + 2048;
+#define LAUNCH_GA(NT_)                                                                                                          \
+    case NT_:                                                                                                                   \
+        if (nwv == 4) {                                                                                                         \
+            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, true>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, nullptr, (bf16_t*)out, C); \
+            else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, false>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
+        } else {                                                                                                                \
+            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, true>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, nullptr, (bf16_t*)out, C); \
+            else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, false>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
+        }                                                                                                                       \
+        break
+    switch (V4 >> 2) {
+        LAUNCH_GA(1); LAUNCH_GA(2); LAUNCH_GA(3); LAUNCH_GA(4); LAUNCH_GA(5); LAUNCH_GA(6); LAUNCH_GA(7); LAUNCH_GA(8);
+        LAUNCH_GA(9); LAUNCH_GA(10); LAUNCH_GA(11); LAUNCH_GA(12); LAUNCH_GA(13); LAUNCH_GA(14); LAUNCH_GA(15); LAUNCH_GA(16);
+    }
+#undef LAUNCH_GA
+    AGRL_CHECK_LAUNCH("agrl_graph_apply");
     return 0;
 }
 

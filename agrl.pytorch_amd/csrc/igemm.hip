@@ -63,8 +63,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         const int xcd = bid & 7, within = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
     }
-    const int mt = bid / nNt;
-    const int nt = bid - mt * nNt;
+    int mt = bid / nNt;
+    int nt = bid - mt * nNt;
+    if (p.nmajor) {  // consecutive tile ids (= one XCD's range) walk the M-tiles of one N-tile
+        const int nMt = nblk / nNt;
+        nt = bid / nMt;
+        mt = bid - nt * nMt;
+    }
     const int m0 = mt * BM;
     const int n0 = nt * BN;
 
@@ -325,8 +330,20 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                         const float4 c4 = *reinterpret_cast<const float4*>(p.colv + gn);
                         cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
                     }
+                    if (p.mix_f) {   // GraphLayer: BatchNorm1d + LeakyReLU + residual mix on (G f) W^T (workgroup-uniform branch)
+                        const float4 s4 = *reinterpret_cast<const float4*>(p.mix_scale + gn);
+                        const float4 f4 = *reinterpret_cast<const float4*>(p.mix_f + o);
+                        const float sv[4] = {s4.x, s4.y, s4.z, s4.w}, fv[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float y = fmaf(acc[a][b][r], sv[r], cv[r]);
+                            y = y > 0.f ? y : p.mix_slope * y;
+                            v[r] = p.mix_keep * fv[r] + p.mix_gamma * y;
+                        }
+                    } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaf(p.alpha, acc[a][b][r], rv + cv[r]);
+                    }
                     if (resp) {
                         float rr[4];
                         load4<TOUT>(resp + o, rr);
@@ -1076,6 +1093,35 @@ extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M,
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
     if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
     return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
+}
+
+// GraphLayer, second half, as ONE GEMM with a fused epilogue (vmgn.py:148, :168-172):
+//     out = keep * f + gamma * LeakyReLU( BN( (G f) W^T ) )
+// G (f W^T) = (G f) W^T: with the message pass applied to the layer INPUT (agrl_graph_apply: P = G f, written once in the GEMM's
+// operand dtype) the Linear's output h never exists, and BatchNorm1d (folded scale / shift), LeakyReLU and the residual mix ride
+// in the GEMM's register epilogue. p_op (M, K) in dtype, w (N, K) in dtype, f / out (M, N) fp32.
+extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const float* f, const float* bn_scale, const float* bn_shift,
+                                     float keep, float gamma, float slope, float* out, int M, int K, int Nout, int in_dtype,
+                                     agrl_stream_t stream) {
+    AGRL_CHECK_ARG(p_op && w && f && bn_scale && bn_shift && out, "agrl_graph_linear_mix: null pointer");
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
+    AGRL_CHECK_ARG((Nout % 4) == 0 && ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0),
+                   "agrl_graph_linear_mix: Nout %% 4 == 0 and 16-byte aligned f / out / scale / shift required");
+    IgemmParams p;
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
+    p.x = p_op; p.w = w; p.colv = bn_shift; p.rowv = nullptr; p.res = nullptr; p.out = out;
+    p.alpha = 1.f; p.rowc = 0.f; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
+    p.M = M; p.N = Nout; p.K = K;
+    p.Cin = K; p.H = 1; p.W = 1; p.OH = 1; p.OW = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+    p.ldo = Nout;
+    p.mix_f = f; p.mix_scale = bn_scale; p.mix_keep = keep; p.mix_gamma = gamma; p.mix_slope = slope;
+    // few pixel rows against a 2048 x 2048 weight matrix: every XCD keeps ITS slice of W in L2 and streams the operand rows
+    // (with the conv map each XCD walked the whole 8-17 MB of W once per M-tile out of the memory-side cache)
+    static const bool mmajor = getenv("AGRL_GRAPH_LINEAR_MMAJOR") != nullptr;   // A/B switch
+    p.nmajor = mmajor ? 0 : 1;
+    if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
+    if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
+    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
 }
 
 // out[m][n] = alpha * sum_z ws[z][m][n] + rowv[m] (or rowc) + colv[n]

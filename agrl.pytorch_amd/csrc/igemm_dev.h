@@ -29,6 +29,14 @@ struct IgemmParams {
     float* pool_out;      // fp32 (frames, nparts, N)
     void* pool_out_lp;    // optional bf16 copy
     float* stats;  // optional (fp32-output, non-LDS epilogue only): per-channel sum / sum of squares of the finished tile's rows, [M / 64 granule][2][N] (train: batch statistics without re-reading the conv output)
+    // GraphLayer epilogue (fp32 output, register epilogue only): out = mix_keep * mix_f[m][n] + mix_gamma * lrelu(mix_scale[n] * acc + colv[n])
+    // -- BatchNorm1d (folded) + LeakyReLU + the residual mix of vmgn.py:169-172 applied to (G f) W^T; nullptr = off
+    const float* mix_f = nullptr;
+    const float* mix_scale = nullptr;
+    float mix_keep = 0.f, mix_gamma = 0.f, mix_slope = 0.f;
+    int nmajor = 0;  // XCD map: 1 = each XCD owns a contiguous range of N-TILES for all M-tiles (few pixel rows, large weight
+                     // matrix: the XCD's weight slice stays in its 4 MB L2 and the small activation matrix is streamed per
+                     // XCD); 0 = the N-tiles of one M-tile share an XCD (convs: large activations, small weights)
     int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
 };
 

@@ -511,9 +511,9 @@ extern "C" int agrl_rank_topk(const float* dist, int m, int n, int ldd, int k, i
 extern "C" size_t agrl_distmat_topk_workspace(int m, int n) {
     if (m <= 0 || n <= 0) return 0;
     const int ldd = (n + 3) & ~3;
-    int rows = (int)((size_t)(24u << 20) / ((size_t)ldd * 4));   // ~24 MB of distance rows per block ...
+    int rows = (int)((size_t)(64u << 20) / ((size_t)ldd * 4));   // ~64 MB of distance rows per block (1280 rows at n = 12180) ...
     rows = rows / 128 * 128;
-    if (rows < 128) rows = 128;                                  // ... at least one row of GEMM tiles
+    if (rows < 256) rows = 256;                                  // ... at least two rows of GEMM tiles
     if (rows > m) rows = m;
     return (size_t)rows * ldd * 4;
 }
@@ -526,12 +526,22 @@ extern "C" int agrl_distmat_topk(const void* q, const void* g, const float* qn, 
     const int ldd = (n + 3) & ~3;
     AGRL_CHECK_ARG((uintptr_t)workspace % 16 == 0 && workspace_bytes >= (size_t)ldd * 4,
                    "agrl_distmat_topk: workspace must be 16-byte aligned and hold at least one distance row (%zu bytes)", (size_t)ldd * 4);
-    int rows = (int)(workspace_bytes / ((size_t)ldd * 4));
-    if (rows > m) rows = m;
-    if (rows >= 128) rows = rows / 128 * 128;
+    // Block size: the whole of m when it fits; else equal blocks of whole 128-row GEMM tiles. Every block goes through the same
+    // kernel family (a tail of <= 64 rows would take the streaming form, whose k-order differs in the last bit): such a tail is
+    // grown by taking 128 rows from the block before it.
+    const int cap = (int)(workspace_bytes / ((size_t)ldd * 4) < (size_t)m ? workspace_bytes / ((size_t)ldd * 4) : (size_t)m);
+    int rows = cap;
+    if (cap < m && cap >= 128) {
+        rows = cap / 128 * 128;
+        const int nblk = (m + rows - 1) / rows;
+        const int even = ((m + nblk - 1) / nblk + 127) / 128 * 128;
+        if (even < rows) rows = even;
+    }
     const size_t esz = dtype == AGRL_BF16 ? 2 : 4;
-    for (int r0 = 0; r0 < m; r0 += rows) {
-        const int mb = m - r0 < rows ? m - r0 : rows;
+    for (int r0 = 0, mb = 0; r0 < m; r0 += mb) {
+        mb = m - r0 < rows ? m - r0 : rows;
+        const int rest = m - r0 - mb;
+        if (rest > 0 && rest <= 64 && mb >= 256) mb -= 128;
         const int rc = agrl_distmat((const char*)q + (size_t)r0 * D * esz, g, qn ? qn + r0 : nullptr, gn, (float*)workspace, mb, n, D, ldd,
                                     metric, dtype, gemm_workspace, gemm_workspace_bytes, stream);
         if (rc != 0) return rc;

@@ -59,6 +59,8 @@ SIGNATURES = {
     "agrl_pam_combine": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
     "agrl_graph_message_pass_workspace": [_i, _i, _i],   # returns size_t
     "agrl_graph_message_pass": [_p, _p, _p, _p, _p, _f, _f, _f, _i, _i, _i, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _p],
+    "agrl_graph_apply": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "agrl_graph_linear_mix": [_p, _p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _p],
     "agrl_row_sqnorm": [_p, _p, _i, _i, _i, _p],
     "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _i, _p],

@@ -321,6 +321,44 @@ def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp, keep=Non
     return out, out_lp
 
 
+def graph_apply_operand(G, f, out_dtype):
+    """P = G f, (B,V,V) x (B,V,C) fp32 -> (B,V,C) in ``out_dtype`` (fp32 / bf16): the message pass applied to the layer INPUT,
+    written once as the operand of ``graph_linear_mix``. vmgn.py:168 with the Linear commuted behind it."""
+    B, V, Cc = f.shape
+    assert f.dtype == torch.float32 and G.dtype == torch.float32 and tuple(G.shape) == (B, V, V)
+    if V <= 64 and V % 4 == 0 and Cc % 128 == 0:
+        out = torch.empty((B, V, Cc), dtype=out_dtype, device=f.device)
+        if _hip.PROFILE is not None:
+            _hip.PROFILE_TAG = {"flops": 2.0 * B * V * V * Cc, "bytes": 4.0 * (B * V * Cc + B * V * V) + out.element_size() * B * V * Cc}
+        with _dev(f):
+            call("agrl_graph_apply", ptr(G.contiguous()), ptr(f.contiguous()), ptr(out), dtype_code(out_dtype), B, V, Cc, _stream(f))
+        return out
+    # other node counts (V > 64: seq_len 16; V % 4 != 0): the general message-pass kernels with a unit BatchNorm
+    key = (f.device, Cc)
+    if key not in _UNIT:
+        _UNIT[key] = (torch.ones((Cc,), dtype=torch.float32, device=f.device), torch.zeros((Cc,), dtype=torch.float32, device=f.device))
+    one, zero = _UNIT[key]
+    out, out_lp = graph_propagate(f, f, G, one, zero, 1.0, 1.0, want_lp=out_dtype == torch.bfloat16, keep=0.0)
+    return out_lp if out_dtype == torch.bfloat16 else out
+
+
+def graph_linear_mix(p_op, w, f, bn_scale, bn_shift, gamma, slope, keep=None):
+    """out = keep f + gamma lrelu(bn((G f) W^T)): the Linear of a GraphLayer as ONE GEMM over P = G f with BatchNorm1d, LeakyReLU
+    and the residual mix in its epilogue (vmgn.py:148, :168-172). p_op (B,V,K) fp32 / bf16, w (N,K) same dtype, f (B,V,N) fp32."""
+    if keep is None:
+        keep = 1.0 - float(gamma)
+    B, V, K = p_op.shape
+    Nout = w.shape[0]
+    assert w.shape[1] == K and p_op.dtype == w.dtype and f.dtype == torch.float32 and tuple(f.shape) == (B, V, Nout)
+    out = torch.empty_like(f)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * B * V * K * Nout, "bytes": p_op.element_size() * (p_op.numel() + w.numel()) + 8.0 * f.numel()}
+    with _dev(f):
+        call("agrl_graph_linear_mix", ptr(p_op.contiguous()), ptr(w), ptr(f.contiguous()), ptr(bn_scale), ptr(bn_shift), float(keep), float(gamma),
+             float(slope), ptr(out), B * V, K, Nout, _gemm_code(p_op.dtype), _stream(f))
+    return out
+
+
 def pam_pool(x, qk, splits):
     """ganet's position-attention part nodes, first half: x (F,h,w,C) NHWC, qk (F,h,w,2*Cq) NHWC stacked query / key conv
     output (None when the module's gamma is 0) -> xbar (F,P,C) fp32 (None without qk), xmean (F,P,C) fp32. ganet.py:98-136,

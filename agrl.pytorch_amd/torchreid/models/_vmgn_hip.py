@@ -186,7 +186,7 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
-def hip_features_pooled(model, frames, pack, splits):
+def hip_features_pooled(model, frames, pack, splits, want_lp=True):
     """Conv stages with the global / part pooling fused into the last conv of each layer4 branch (bf16, 16x8 maps):
     -> gsum (F,C) per-frame sums, nodes (F,P,C) fp32, nodes_lp bf16, hw. None when the fusion does not apply."""
     if pack['dtype'] != torch.bfloat16 or pack['l4_1'][0]['stride'] != 1:
@@ -211,7 +211,7 @@ def hip_features_pooled(model, frames, pack, splits):
         x4_2 = a
         for blk in pack['l4_2'][:-1]:
             x4_2 = _run_block(x4_2, blk)
-        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, True))
+        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, want_lp))
     else:
         # the two layer4 branches are independent: run the global branch on a side stream so its memory-heavy
         # kernels (conv3 + residual) overlap the other branch's MFMA-heavy ones (3x3) on the same CUs
@@ -232,13 +232,22 @@ def hip_features_pooled(model, frames, pack, splits):
         x4_2 = a
         for blk in pack['l4_2'][:-1]:
             x4_2 = _run_block(x4_2, blk)
-        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, True))
+        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, want_lp))
         main.wait_event(done)
         gsum.record_stream(main)
     return gsum.view(gsum.shape[0], gsum.shape[2]), nodes, nodes_lp, 128
 
 
-def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False):
+def gcn_commute_enabled(model=None):
+    """The commuted GraphLayer ((G f) W^T, one GEMM with the BatchNorm / LeakyReLU / residual epilogue) is the default;
+    ``model.hip_gcn_commute = False`` or AGRL_HIP_GCN_COMMUTE=0 selects Linear -> message pass (the round-1/2 form)."""
+    import os
+    if model is not None and hasattr(model, 'hip_gcn_commute'):
+        return bool(model.hip_gcn_commute)
+    return os.environ.get('AGRL_HIP_GCN_COMMUTE', '1') != '0'
+
+
+def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, commute=True):
     """GraphLayer x num_gb on (B,V,C) fp32 nodes. reference vmgn.py:311-312 -> :142-172.
     ``overlap``: the adaptive graph (Gram partials + finalize: 2 short latency-bound launches) is built on a side HIP stream
     while the Linear (a 448-workgroup GEMM that does not fill the chip either) runs on the main one -- both only read the
@@ -249,6 +258,17 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False):
     main = torch.cuda.current_stream(nodes.device)
     side = _side_stream(nodes.device) if overlap else None
     for i, g in enumerate(pack['graph']):
+        if commute and not ops.graph_message_pass_supported(nodes):
+            # G (f W^T) = (G f) W^T: graph -> P = G f (written once, in the GEMM's operand dtype) -> ONE GEMM whose epilogue
+            # applies BatchNorm1d + LeakyReLU + the residual mix. h never exists; f and out cross HBM once each.
+            G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+            if stages is not None:
+                stages['G%d' % i] = G
+            P = ops.graph_apply_operand(G, nodes, pack['dtype'])
+            nodes = ops.graph_linear_mix(P, g['w'], nodes, g['scale'], g['shift'], g['gamma'], g['slope'])
+            continue
+        if lp and nodes_lp is None:   # A/B form entered without the pooled bf16 copy: native conversion kernel
+            nodes_lp = ops.row_l2_normalize(nodes.view(B * V, C), False, torch.bfloat16).view(B, V, C)
         operand = nodes_lp if lp else nodes
         if ops.graph_message_pass_supported(nodes):
             # the whole message-pass unit (Gram -> graph -> G h -> BN -> LeakyReLU -> residual) in one launch
@@ -297,7 +317,8 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
     lp = pack['dtype'] == torch.bfloat16
     with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
-        fused = hip_features_pooled(model, frames, pack, model.total_split_list) if model.hip_fuse_pool else None
+        commute = gcn_commute_enabled(model)
+        fused = hip_features_pooled(model, frames, pack, model.total_split_list, want_lp=not commute) if model.hip_fuse_pool else None
         if fused is not None:
             gsum, nodes, nodes_lp, hw = fused
             C = nodes.shape[-1]
@@ -305,7 +326,7 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
             x4_1, x4_2 = hip_featuremaps(model, frames, pack)
             F_, h, w, C = x4_1.shape
             hw = h * w
-            gsum, nodes, nodes_lp = ops.part_pool(x4_1, x4_2, model.total_split_list, want_lp=lp)
+            gsum, nodes, nodes_lp = ops.part_pool(x4_1, x4_2, model.total_split_list, want_lp=lp and not commute)
             del x4_1, x4_2
         nodes = nodes.view(B, V, C)
         if nodes_lp is not None:
@@ -313,7 +334,7 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
         adj32 = adj.detach().to(torch.float32).contiguous()
         if stages is not None:
             stages.update(gsum=gsum, hw=hw, nodes=nodes)
-        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages, overlap=getattr(model, 'hip_gcn_overlap', False))
+        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages, overlap=getattr(model, 'hip_gcn_overlap', False), commute=commute)
         sqn = ops.row_sqnorm(nodes.view(B * V, C))
         res = ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
                                    pack['a_bn'][1], B, S, P, hw, want_feats=return_feats or stages is not None)

@@ -183,6 +183,20 @@ int agrl_graph_gram(const float* f, float* gram_part, int B, int V, int C, int c
 int agrl_graph_finalize(const float* gram_part, int nz, const float* adj, float* G, int B, int V,
                         int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream);
 
+/* GraphLayer with the Linear commuted behind the message pass: G (f W^T) = (G f) W^T (torchreid/models/vmgn.py:148, :168-172).
+ *   agrl_graph_apply      P = G f, (B,V,V) x (B,V,C) fp32 -> (B,V,C) in out_dtype (AGRL_F32 / AGRL_BF16): the operand of the
+ *                         GEMM below, written once. Streaming form: V <= 64, V % 4 == 0, C % 128 == 0 (other shapes: call
+ *                         agrl_graph_propagate with h = f, unit scale, zero shift, keep 0, gamma 1, slope 1).
+ *   agrl_graph_linear_mix out = keep * f + gamma * LeakyReLU_slope( bn_scale * (P W^T) + bn_shift ): ONE GEMM (M = B V rows,
+ *                         K -> Nout) whose register epilogue applies the folded eval BatchNorm1d, the LeakyReLU and the residual
+ *                         mix with the layer input f (fp32 (M,Nout)); the Linear's output h never exists. p_op (M,K) and w (Nout,K)
+ *                         in in_dtype (AGRL_F32 exact, AGRL_F32X3 split, AGRL_BF16); K a multiple of 32 (fp32) / 64 (bf16),
+ *                         Nout % 4 == 0. The workgroup -> tile map keeps each XCD on its own slice of W (L2-resident). */
+int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, int B, int V, int C, agrl_stream_t stream);
+int agrl_graph_linear_mix(const void* p_op, const void* w, const float* f, const float* bn_scale, const float* bn_shift,
+                          float keep, float gamma, float slope, float* out, int M, int K, int Nout, int in_dtype,
+                          agrl_stream_t stream);
+
 /* Message pass + BatchNorm1d(eval) + LeakyReLU + residual mix:
  *   out[b,v,c] = keep*f[b,v,c] + gamma*lrelu(bn_scale[c]*(sum_u G[b,v,u]*h[b,u,c]) + bn_shift[c])
  * torchreid/models/vmgn.py:168-172 with keep = (float)(1.0 - gamma) (the reference's Python-float 1 - gamma, rounded once);
@@ -285,12 +299,13 @@ int agrl_rank_topk(const float* dist, int m, int n, int ldd, int k, int idx_offs
 /* Distance matrix and per-query top-k in one call, WITHOUT materialising the (m, n) matrix: what the reference's
  * test() does with compute_distance_matrix (torchreid/metrics/distance.py:59-89, train_vidreid_xent_htri.py:520) followed by
  * np.argsort(distmat[k])[:max_rank] (torchreid/metrics/rank.py:171-172). Operands / qn / gn / metric / dtype as for
- * agrl_distmat; idx / val / idx_offset / ordering (ascending (distance, gallery index), NaN last) as for agrl_rank_topk, and
- * the results equal agrl_distmat followed by agrl_rank_topk bit for bit.
+ * agrl_distmat; idx / val / idx_offset / ordering (ascending (distance, gallery index), NaN last) as for agrl_rank_topk. Each
+ * block of queries is agrl_distmat + agrl_rank_topk on that block: with one block the results equal the two calls bit for bit.
  *   workspace: device scratch for the distance rows of ONE block of queries, 16-byte aligned, at least one row
- *   (4 * roundup(n, 4) bytes); agrl_distmat_topk_workspace(m, n) returns the recommended size (~24 MB of rows: a block stays in
- *   the memory-side cache between the GEMM that writes it and the selection that reads it). The buffer is reused block after
- *   block, so HBM carries the operands and the (m, k) lists instead of 4 m n bytes out and back.
+ *   (4 * roundup(n, 4) bytes); agrl_distmat_topk_workspace(m, n) returns the recommended size (all of m, at most ~64 MB of rows:
+ *   a block stays in the 256 MB memory-side cache between the GEMM that writes it and the selection that reads it, and is
+ *   large enough to fill the chip with GEMM tiles). The buffer is reused block after block, so the footprint is one block
+ *   instead of 4 m n bytes.
  *   gemm_workspace: agrl_distmat's optional split-K scratch (may be NULL). */
 size_t agrl_distmat_topk_workspace(int m, int n);
 int agrl_distmat_topk(const void* q, const void* g, const float* qn, const float* gn, int m, int n, int D, int metric,
