@@ -240,6 +240,56 @@ __global__ __launch_bounds__(PROP_THREADS) void graph_propagate_kernel(
 }
 
 
+// Any V (the LDS-resident forms stop at V = 128 / V (V + 128) 4 bytes <= 160 KB): grid = (B, C / 128, ceil(V / 16)). A
+// workgroup holds 16 rows of G (16 x V) in LDS and streams h[u][c], u = 0..V-1, from L2 (h is re-read once per 16 output rows).
+constexpr int PROPT_ROWS = 16;
+__global__ __launch_bounds__(PROP_THREADS) void graph_propagate_tiled_kernel(
+    const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
+    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int V, int C) {
+    extern __shared__ __attribute__((aligned(16))) float s_gr[];   // [V][16]: s_gr[u * 16 + k] = G[v0 + k][u]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int c = blockIdx.y * PROP_THREADS + tid;
+    const bool live = c < C;
+    const int cc = live ? c : C - 1;
+    const int v0 = blockIdx.z * PROPT_ROWS;
+    const float* Gb = G + (size_t)b * V * V;
+    for (int e = tid; e < V * PROPT_ROWS; e += PROP_THREADS) {
+        const int k = e / V, u = e - k * V;     // coalesced over u along a graph row
+        s_gr[u * PROPT_ROWS + k] = v0 + k < V ? Gb[(size_t)(v0 + k) * V + u] : 0.f;
+    }
+    __syncthreads();
+    const float* hb = h + (size_t)b * V * C + cc;
+    float acc[PROPT_ROWS];
+#pragma unroll
+    for (int k = 0; k < PROPT_ROWS; ++k) acc[k] = 0.f;
+#pragma unroll 4
+    for (int u = 0; u < V; ++u) {
+        const float hv = hb[(size_t)u * C];
+#pragma unroll
+        for (int k4 = 0; k4 < PROPT_ROWS / 4; ++k4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(&s_gr[u * PROPT_ROWS + 4 * k4]);
+            acc[4 * k4 + 0] = fmaf(g4.x, hv, acc[4 * k4 + 0]);
+            acc[4 * k4 + 1] = fmaf(g4.y, hv, acc[4 * k4 + 1]);
+            acc[4 * k4 + 2] = fmaf(g4.z, hv, acc[4 * k4 + 2]);
+            acc[4 * k4 + 3] = fmaf(g4.w, hv, acc[4 * k4 + 3]);
+        }
+    }
+    const float sc = bn_scale[cc], sh = bn_shift[cc];
+#pragma unroll
+    for (int k = 0; k < PROPT_ROWS; ++k) {
+        const int v = v0 + k;
+        if (v < V && live) {
+            const size_t idx = ((size_t)b * V + v) * C + c;
+            float y = fmaf(acc[k], sc, sh);
+            y = y > 0.f ? y : slope * y;
+            const float o = one_minus_gamma * f[idx] + gamma * y;
+            out[idx] = o;
+            if (out_lp) out_lp[idx] = f32_to_bf16(o);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Propagate, MFMA form (V <= 128). grid = (B, C/128), 256 threads. Per workgroup: D'[c][v] = sum_u H[u][c] G[v][u]
 // for a 128-channel slab, with v_mfma_f32_16x16x4_f32 (exact fp32): A operand = H^T (rows = channels), B operand =
@@ -647,6 +697,7 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
     unsigned char* s_f = s_raw;                          // [VP][ROWB]
     float* s_g = reinterpret_cast<float*>(s_raw + VP * ROWB);   // [VP][V] graph (rows >= V zero)
     float* s_n = s_g + VP * V;                           // [V] squared norms
+    int* s_flag = reinterpret_cast<int*>(s_n + V);       // hand-off time-out flag
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = blockIdx.x % NS, group = blockIdx.x / NS, ngroups = gridDim.x / NS;
@@ -724,7 +775,9 @@ __global__ __launch_bounds__(256) void graph_message_pass_kernel(
                     }
                 }
             }
-            if (__syncthreads_or(lost)) keep_b = __builtin_nanf("");   // poisons keep f + gamma y below
+            if (tid == 0) *s_flag = lost;     // (a slot of the dynamic LDS: a static __shared__ object would push the 160 KB request over the limit)
+            __syncthreads();
+            if (*s_flag) keep_b = __builtin_nanf("");   // poisons keep f + gamma y below
             // Gram = sum of the NS partials in slice order, every element by one thread, all of a thread's loads in flight at once
             // (sc1 loads: served by L2, never by this CU's possibly stale L1) -> LDS; its diagonal = the squared norms
             {
@@ -1021,7 +1074,13 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     const int Vp = (V + PROP_RB - 1) & ~(PROP_RB - 1);
     const bool fixed = false;  // register-resident h (VT > 0) spills: hipcc hoists every LDS graph read; keep h in LDS
     const size_t lds = ((size_t)V * Vp + (fixed ? 0 : (size_t)V * PROP_THREADS)) * sizeof(float);
-    AGRL_CHECK_ARG(lds <= 160 * 1024, "agrl_graph_propagate: V=%d too large", V);
+    if (lds > 160 * 1024) {   // graph + h slab no longer fit the LDS (V > ~125): 16 graph rows per workgroup, h streamed from L2
+        AGRL_CHECK_ARG((size_t)V * PROPT_ROWS * 4 <= 64 * 1024, "agrl_graph_propagate: V=%d too large", V);
+        hipLaunchKernelGGL(graph_propagate_tiled_kernel, dim3(B, cdiv(C, PROP_THREADS), cdiv(V, PROPT_ROWS)), dim3(PROP_THREADS),
+                           (size_t)V * PROPT_ROWS * 4, (hipStream_t)stream, f, h, G, bn_scale, bn_shift, keep, gamma, slope, out, (bf16_t*)out_lp, V, C);
+        AGRL_CHECK_LAUNCH("agrl_graph_propagate");
+        return 0;
+    }
     const float omg = keep;
     const dim3 grid(B, cdiv(C, PROP_THREADS));
     hipStream_t st = (hipStream_t)stream;
@@ -1061,7 +1120,7 @@ extern "C" int agrl_graph_message_pass(const float* f, const float* h, const flo
     AGRL_CHECK_ARG((al & 15) == 0, "agrl_graph_message_pass: operands must be 16-byte aligned");
     const int NS = C / 256;
     const int nvf = (V + 15) / 16, VP = nvf * 16;
-    const size_t lds = (size_t)VP * (256 * 4 + 16) + (size_t)VP * V * 4 + (size_t)V * 4;
+    const size_t lds = (size_t)VP * (256 * 4 + 16) + (size_t)VP * V * 4 + (size_t)V * 4 + 16;
     float* gram_part = (float*)workspace;
     int* counters = (int*)((char*)workspace + (((size_t)B * NS * V * V * sizeof(float) + 15) & ~(size_t)15));
     int* err = counters + B;
@@ -1082,7 +1141,7 @@ extern "C" int agrl_graph_message_pass(const float* f, const float* h, const flo
             (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
             constexpr int V_ = 4 * NT_, VP_ = ((NT_ + 3) / 4) * 16;                                                            \
             int n = 0;                                                                                                         \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, (size_t)VP_ * (256 * 4 + 16) + (size_t)VP_ * V_ * 4 + V_ * 4) != hipSuccess || n < 1) n = 1; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, (size_t)VP_ * (256 * 4 + 16) + (size_t)VP_ * V_ * 4 + V_ * 4 + 16) != hipSuccess || n < 1) n = 1; \
             return n;                                                                                                          \
         }();                                                                                                                   \
         const int per_cu = per_cu_cached;                                                                                      \
