@@ -46,6 +46,9 @@ static AgrlOpts load_opts() {
     o.gcn_split = opt_flag("AGRL_GCN_SPLIT");
     o.stem_wgs = opt_int("AGRL_STEM_WGS");
     o.wgrad_wgs = opt_int("AGRL_WGRAD_WGS");
+    o.wide_nofold = opt_flag("AGRL_IGEMM_WIDE_NOFOLD");
+    o.topk_radix = opt_flag("AGRL_TOPK_RADIX");
+    o.graph_linear_mmajor = opt_flag("AGRL_GRAPH_LINEAR_MMAJOR");
 #ifdef AGRL_ABLATE
     o.igemm_dbg = agrl_opt_set(opt_int("AGRL_IGEMM_DBG")) ? opt_int("AGRL_IGEMM_DBG") : 0;
     o.conv3x3_dbg = agrl_opt_set(opt_int("AGRL_CONV3X3_DBG")) ? opt_int("AGRL_CONV3X3_DBG") : 0;

@@ -1117,8 +1117,7 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
     p.mix_f = f; p.mix_scale = bn_scale; p.mix_keep = keep; p.mix_gamma = gamma; p.mix_slope = slope;
     // few pixel rows against a 2048 x 2048 weight matrix: every XCD keeps ITS slice of W in L2 and streams the operand rows
     // (with the conv map each XCD walked the whole 8-17 MB of W once per M-tile out of the memory-side cache)
-    static const bool mmajor = getenv("AGRL_GRAPH_LINEAR_MMAJOR") != nullptr;   // A/B switch
-    p.nmajor = mmajor ? 0 : 1;
+    p.nmajor = agrl_opts().graph_linear_mmajor ? 0 : 1;   // AGRL_GRAPH_LINEAR_MMAJOR=1: A/B switch
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
     if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
     return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");

@@ -474,7 +474,7 @@ static int launch_topk(const float* dist, int m, int n, int ldd, int k, int idx_
     int kpad = 2;
     while (kpad < k) kpad <<= 1;
     const bool aligned = ((uintptr_t)dist % 16 == 0) && (ldd % 4 == 0);
-    static const bool force_radix = getenv("AGRL_TOPK_RADIX") != nullptr;   // A/B switch: the 5-pass radix kernel for every row
+    const bool force_radix = agrl_opts().topk_radix != 0;   // AGRL_TOPK_RADIX=1 (A/B switch): the 5-pass radix kernel for every row
     if (aligned && k <= 128 && n <= 32768 && !force_radix) {
         const int nv = (n + 1023) / 1024;
 #define AGRL_TOPK_FAST(NV) hipLaunchKernelGGL(rank_topk_fast_kernel<NV>, dim3(m), dim3(256), 0, st, dist, n, ldd, k, kpad, idx_offset, idx, val)
