@@ -127,7 +127,6 @@ struct AgrlOpts {
     int gcn_lds, gcn_valu, gcn_nwv, gcn_split;                                                   // AGRL_GCN_*
     int stem_wgs;
     int wgrad_wgs;   // AGRL_WGRAD_WGS: workgroups the pixel-axis split of agrl_conv_wgrad aims for
-    int wide_nofold;       // AGRL_IGEMM_WIDE_NOFOLD: conv + residual layers with K = 512 keep the residual in registers (round-2 form)
     int topk_radix;        // AGRL_TOPK_RADIX: every top-k through the five-pass radix kernel
     int graph_linear_mmajor;  // AGRL_GRAPH_LINEAR_MMAJOR: conv-style XCD map for agrl_graph_linear_mix
     int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library

@@ -46,7 +46,6 @@ static AgrlOpts load_opts() {
     o.gcn_split = opt_flag("AGRL_GCN_SPLIT");
     o.stem_wgs = opt_int("AGRL_STEM_WGS");
     o.wgrad_wgs = opt_int("AGRL_WGRAD_WGS");
-    o.wide_nofold = opt_flag("AGRL_IGEMM_WIDE_NOFOLD");
     o.topk_radix = opt_flag("AGRL_TOPK_RADIX");
     o.graph_linear_mmajor = opt_flag("AGRL_GRAPH_LINEAR_MMAJOR");
 #ifdef AGRL_ABLATE

@@ -17,8 +17,6 @@
 //     DMA'd into the slots, combined in fp32 in place, rounded once and written out as whole 16-byte chunks
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "igemm_dev.h"
 
 namespace {
@@ -35,16 +33,6 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     // rows (ResNet: inplanes = 2 planes in the first block of layers 2-4), which lets ONE stored offset per piece serve both.
     constexpr bool DUAL = (DBG & 32768) != 0;
     constexpr bool REGEPI = (DBG & 8192) == 0;  // bit 8192: the LDS-staged two-half epilogue (kept for A/B)
-    // FOLD (bit 65536, RES, K = 512 = 8 k-tiles): the residual tile never waits in registers. It arrives through the SAME
-    // LDS-DMA stream as the operands, one 16 KB chunk per k-tile (8 pixel rows of every wave row x the tile's 256 channels)
-    // into a 2 x 16 KB staging area behind the ring, and is ADDED INTO THE ACCUMULATORS one k-tile later -- so when the k-loop
-    // ends the accumulators already hold conv + residual, the epilogue is bias + ReLU + pack + store with no load in front of
-    // it, and (no 64 staging registers any more) the workgroup can be PERSISTENT like the plain form: the next tile's first
-    // k-tile and residual chunk are requested before the stores, which drain under the next tile's matrix work. The sum is
-    // formed in fp32 in a different order (residual first, k-tiles on top): <= 1 ulp of fp32 before the single bf16 rounding.
-    constexpr bool FOLD = (DBG & 65536) != 0;
-    static_assert(!FOLD || (RES && WBN_ == 256 && REGEPI), "FOLD is the residual form of the 256-channel register-epilogue tile");
-    constexpr int RCHUNK = 16384;               // bytes of one residual chunk: 32 pixel rows x 512 B
     constexpr int BM = WBM, BN = WBN_, NW = 8, WM = 4;
     constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
     constexpr int FN = BN / 32;         // 8 channel fragments per wave
@@ -52,7 +40,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     constexpr int AJ = BM / (8 * NW), BJ = BN / (8 * NW);                                  // 4 + 4 DMA pieces per wave
     constexpr int DPT = AJ + BJ;
     constexpr int NS = BN == 128 ? 3 : 2;  // ring slots: the 48 KB k-tiles of the 128-channel tile fit three times
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES + (FOLD ? 2 * RCHUNK : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -129,25 +117,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     };
     setup_tile(xbase + tl);
     unsigned kbyte = 0;  // byte offset of the k-tile being STAGED inside a row
-    // FOLD: piece q = 2 wave + i of residual chunk c covers chunk rows 2q, 2q+1; chunk row rr = 8 wm' + t is pixel
-    // 64 wm' + 8 c + t of the tile (8 rows of every wave row per chunk: every wave folds a little each k-tile). A chunk row is
-    // 512 B = 32 sixteen-byte granules; granule g of chunk row rr is stored at slot g ^ (rr & 15): the 16 lanes a ds_read_b128
-    // serves together (8 pixel rows x 2 neighbouring granules) then hit 16 different 16-byte slots of the 256-byte bank window.
-    auto stage_res_piece = [&](int c, int i) {
-        if constexpr (FOLD) {
-            const int q = wave * 2 + i;
-            const int rr = 2 * q + (lane >> 5);
-            const int g = (lane & 31) ^ (rr & 15);
-            const int gm = m0 + 64 * (rr >> 3) + 8 * c + (rr & 7);
-            const unsigned char* rg = reinterpret_cast<const unsigned char*>(p.res);
-            dma16(gm < p.M ? rg + ((size_t)gm * p.ldo + n0) * 2 + g * 16 : zsrc, smem + NS * BUF_BYTES + (c & 1) * RCHUNK + q * 1024);
-        }
-    };
     auto stage_piece = [&](int buf, int idx) {
-        if (idx >= DPT) {
-            stage_res_piece((int)(kbyte >> 7), idx - DPT);   // chunk number = k-tile number being staged
-            return;
-        }
         if (idx < AJ) {
             unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / NW) * 128;
             if constexpr (DUAL) {
@@ -193,7 +163,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 int slot = cur + s;
                 slot = slot >= NS ? slot - NS : slot;
 #pragma unroll
-                for (int i = 0; i < DPT + (FOLD ? 2 : 0); ++i) stage_piece(slot, i);
+                for (int i = 0; i < DPT; ++i) stage_piece(slot, i);
                 kbyte += 128;
             }
         }
@@ -310,39 +280,11 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         for (int g = 0; g < NG; ++g) {
             if (g + 2 < NG) wfr[(g + 2) % 3] = ldw(g + 2);
             if (g < FM) xfr[1][g] = ldx(1, g);
-            if (do_stage && g < DPT + (FOLD ? 2 : 0)) stage_piece(fill, g);
+            if (do_stage && g < DPT) stage_piece(fill, g);
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 if (!(DBG & 2)) acc[g % FN][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g / FN][b], acc[g % FN][b]);
                 else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g / FN][b].x), "v"(xfr[g / FN][b].w));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (FOLD) {
-            // residual chunk kt (landed with k-tile kt: same wait, same barrier) -> accumulators of pixel fragment b = kt >> 1,
-            // pixel lanes frow >> 3 == (kt & 1); lane layout as in the register epilogue: channels cb + 32 j + {0..7} of a pixel
-            // are acc[2j][b][0..3], acc[2j+1][b][0..3] = the 8 bf16 of one 16-byte granule
-            const unsigned char* sr = smem + NS * BUF_BYTES + (kt & 1) * RCHUNK;
-            auto fold_frag = [&](auto bc) {
-                constexpr int b = decltype(bc)::value;
-                const int rr = 8 * wm + (frow & 7);
-                const bool mine = (frow >> 3) == (kt & 1);
-#pragma unroll
-                for (int j = 0; j < FN / 2; ++j) {
-                    const int g = fchunk + 4 * j + 16 * wn;
-                    uint4 w = *reinterpret_cast<const uint4*>(sr + rr * 512 + ((g ^ (rr & 15)) << 4));
-                    if (!mine) w = make_uint4(0u, 0u, 0u, 0u);
-                    acc[2 * j][b][0] += __uint_as_float(w.x << 16); acc[2 * j][b][1] += __uint_as_float(w.x & 0xffff0000u);
-                    acc[2 * j][b][2] += __uint_as_float(w.y << 16); acc[2 * j][b][3] += __uint_as_float(w.y & 0xffff0000u);
-                    acc[2 * j + 1][b][0] += __uint_as_float(w.z << 16); acc[2 * j + 1][b][1] += __uint_as_float(w.z & 0xffff0000u);
-                    acc[2 * j + 1][b][2] += __uint_as_float(w.w << 16); acc[2 * j + 1][b][3] += __uint_as_float(w.w & 0xffff0000u);
-                }
-            };
-            switch (kt >> 1) {   // wave-uniform
-                case 0: fold_frag(std::integral_constant<int, 0>{}); break;
-                case 1: fold_frag(std::integral_constant<int, 1>{}); break;
-                case 2: fold_frag(std::integral_constant<int, 2>{}); break;
-                default: fold_frag(std::integral_constant<int, 3>{}); break;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -352,7 +294,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     if constexpr (REGEPI) {
         const int em0 = m0, en0 = n0;  // the tile whose results are in the accumulators
         bool has_next = false;
-        if constexpr (!POOL && (!RES || FOLD)) {
+        if constexpr (!POOL && !RES) {
             tl += wstep;
             has_next = tl < xcnt;
             if (has_next) {  // the ring is free (every wave is past the barrier of the last k-tile's predecessor)
@@ -373,7 +315,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         // every residual piece is requested before the first store: loads and stores retire in order on one counter, so a
         // load behind a store would wait for that store's acknowledgement
         uint4 rres[FM][NJ];
-        if (has_res && !FOLD) {
+        if (has_res) {
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 const int gm = min(em0 + wm * (BM / WM) + b * 16 + frow, p.M - 1);
@@ -410,7 +352,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 float v[8];
                 v[0] = acc[2 * j][b][0]; v[1] = acc[2 * j][b][1]; v[2] = acc[2 * j][b][2]; v[3] = acc[2 * j][b][3];
                 v[4] = acc[2 * j + 1][b][0]; v[5] = acc[2 * j + 1][b][1]; v[6] = acc[2 * j + 1][b][2]; v[7] = acc[2 * j + 1][b][3];
-                if (has_res && !FOLD) {
+                if (has_res) {
                     const uint32_t w4[4] = {rres[b][j].x, rres[b][j].y, rres[b][j].z, rres[b][j].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -589,23 +531,15 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
         return 0;
     }
     const int tiles256 = cdiv(p.M, WBM) * (p.N / WBN);
-    // residual folded into the accumulators out of LDS-staged chunks (8 k-tiles = K 512: the conv3 layers of layer 4)
-    const bool fold = res && p.K == 512 && p.dbg == 0 && !opt.wide_nofold;   // AGRL_IGEMM_WIDE_NOFOLD=1: A/B switch
-    const int grid = persist && (!res || fold) && p.pool_nparts == 0 && (p.dbg & (4096 | 8192)) == 0 ? min(tiles256, n_cu) : tiles256;
+    const int grid = persist && !res && p.pool_nparts == 0 && (p.dbg & (4096 | 8192)) == 0 ? min(tiles256, n_cu) : tiles256;
     if (p.pool_nparts > 0) {
-        if (fold) hipLaunchKernelGGL((igemm_wide_kernel<16384 | 65536, 256, true>), dim3(grid), dim3(512), 0, stream, p);
-        else if (res) hipLaunchKernelGGL((igemm_wide_kernel<16384, 256, true>), dim3(grid), dim3(512), 0, stream, p);
+        if (res) hipLaunchKernelGGL((igemm_wide_kernel<16384, 256, true>), dim3(grid), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((igemm_wide_kernel<16384, 256, false>), dim3(grid), dim3(512), 0, stream, p);
         AGRL_CHECK_LAUNCH(who);
         return 0;
     }
     if (p.x2) {  // two-source form (agrl_conv1x1_dual_bn_act): no residual, no pooling, 256-channel tiles
         hipLaunchKernelGGL((igemm_wide_kernel<32768, 256, false>), dim3(grid), dim3(512), 0, stream, p);
-        AGRL_CHECK_LAUNCH(who);
-        return 0;
-    }
-    if (fold) {
-        hipLaunchKernelGGL((igemm_wide_kernel<65536, 256, true>), dim3(grid), dim3(512), 0, stream, p);
         AGRL_CHECK_LAUNCH(who);
         return 0;
     }
