@@ -457,6 +457,11 @@ def config5_block(device, embeddings, metric):
         out[prec] = {"prepare_ms": round(t_prep, 3), "distmat_ms": round(t_mm, 3),
                      "tflops": round(flops / (t_mm * 1e-3) / 1e12, 1), "peak": peak,
                      "frac_of_mfma_peak": round(flops / (t_mm * 1e-3) / 1e12 / peak, 4)}
+        if metric == "cosine":   # distance + top-50 without the 96.5 MB matrix (agrl_distmat_topk: query blocks in a reused workspace)
+            (idx_f, _), t_f = timed(lambda: ops.distmat_topk(qh, gh, "cosine", 50))
+            out[prec]["distmat_topk50_ms"] = round(t_f, 3)
+            idx_s, _ = ops.rank_topk(d, 50)
+            out[prec]["distmat_topk50_equals_separate"] = bool(torch.equal(idx_f, idx_s))
         if prec == "fp32":
             (idx, _), t_topk = timed(lambda: ops.rank_topk(d, 50))
             _, t_mars = timed(lambda: ops.rank_mars(idx, q_pids, q_cams, g_pids, g_cams))
@@ -853,19 +858,89 @@ def main():
             return nbytes / (best * 1e-3) / 1e9
 
         V, Cc, n_layers = S * 7, 2048, 2
-        gcn_names = [n for n in ("agrl_graph_message_pass", "agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_propagate") if n in agg]
-        if gcn_names:
-            ms = sum(agg[n]["ms"] for n in gcn_names)
-            unit_bytes = GCN_UNIT_BYTES(V, Cc) * B            # per launch set (one layer, B tracklets)
-            gbs = unit_bytes * n_layers * nprof / (ms * 1e-3) / 1e9
-            ygbs = yardstick(int(unit_bytes))
-            result["roofline_gcn_message_pass"] = {
-                "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
-                "bytes_per_layer": unit_bytes, "us_per_layer": round(1e3 * ms / (n_layers * nprof), 2),
-                "kernels": {n: round(1e3 * agg[n]["ms"] / agg[n]["launches"], 2) for n in gcn_names},
-                "what": "SURVEY 8(d) message-pass unit (sim + normalise + mix + G h + BN + LeakyReLU + residual; Linear excluded): "
-                        "1.389 MB per tracklet-layer over the time of ALL its kernels (one launch: agrl_graph_message_pass)",
-                "read_stream_yardstick_gbs": round(ygbs, 1), "frac_of_yardstick": round(gbs / ygbs, 4)}
+        esz = 2.0 if lp else 4.0
+
+        def gcn_rooflines(agg_, B_, layers_):
+            """The GraphLayer as it runs (vmgn.py:142-172). Commuted form (default): gram -> finalize -> P = G f -> ONE GEMM
+            with BatchNorm1d + LeakyReLU + residual mix in its epilogue, i.e. SURVEY 8(d)'s "Linear fused in" unit: 2 V C 4 +
+            V^2 4 bytes per tracklet (+ W once), 2 V C^2 + 4 V^2 C flops per tracklet, MFMA-bound; its HBM-bound part (gram +
+            finalize + G f: read f, read adj, write the GEMM operand) is reported against the 8 TB/s roofline and against the
+            chip's own one-pass read rate at that byte count. Round-1/2 form (AGRL_HIP_GCN_COMMUTE=0): the SURVEY's unfused
+            message-pass unit (1.389 MB per tracklet-layer over gram + finalize + propagate)."""
+            names_new = [n for n in ("agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_apply", "agrl_graph_linear_mix") if n in agg_]
+            names_old = [n for n in ("agrl_graph_message_pass", "agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_propagate") if n in agg_]
+            out_ = {}
+            if "agrl_graph_linear_mix" in agg_:
+                ms_all = sum(agg_[n]["ms"] for n in names_new)
+                hbm_names = [n for n in names_new if n != "agrl_graph_linear_mix"]
+                ms_hbm = sum(agg_[n]["ms"] for n in hbm_names)
+                flops = (2.0 * V * Cc * Cc + 4.0 * V * V * Cc) * B_
+                bytes_layer = (2.0 * V * Cc * 4 + V * V * 4) * B_ + Cc * Cc * esz
+                bytes_hbm = (V * Cc * 4 + V * V * 4 + V * Cc * esz) * B_
+                us_layer = 1e3 * ms_all / layers_
+                tf = flops * layers_ / (ms_all * 1e-3) / 1e12
+                gbs = bytes_hbm * layers_ / (ms_hbm * 1e-3) / 1e9
+                ygbs = yardstick(int(bytes_hbm))
+                out_["roofline_gcn_layer"] = {
+                    "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                    "frac": round(tf / PEAK_TFLOPS[args.precision], 4), "tracklets": B_, "us_per_layer": round(us_layer, 2),
+                    "flops_per_layer": flops, "algorithmic_bytes_per_layer": bytes_layer,
+                    "algorithmic_gbs": round(bytes_layer * layers_ / (ms_all * 1e-3) / 1e9, 1),
+                    "kernels_us": {n: round(1e3 * agg_[n]["ms"] / agg_[n]["launches"], 2) for n in names_new},
+                    "what": "whole GraphLayer, Linear fused in (SURVEY 8d: 0.930 MB + 470 MFLOP per tracklet): gram + finalize + G f + "
+                            "(G f) W^T with the BatchNorm / LeakyReLU / residual epilogue"}
+                out_["roofline_gcn_message_pass"] = {
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "tracklets": B_, "bytes_per_layer": bytes_hbm, "us_per_layer": round(1e3 * ms_hbm / layers_, 2),
+                    "kernels": {n: round(1e3 * agg_[n]["ms"] / agg_[n]["launches"], 2) for n in hbm_names},
+                    "what": "HBM-bound part of the commuted GraphLayer: sim + normalise + mix with the pose graph + P = G f "
+                            "(read f, read adj, write the GEMM operand); BatchNorm / LeakyReLU / residual ride in the GEMM's epilogue",
+                    "read_stream_yardstick_gbs": round(ygbs, 1), "frac_of_yardstick": round(gbs / ygbs, 4)}
+            elif names_old:
+                ms = sum(agg_[n]["ms"] for n in names_old)
+                unit_bytes = GCN_UNIT_BYTES(V, Cc) * B_
+                gbs = unit_bytes * layers_ / (ms * 1e-3) / 1e9
+                ygbs = yardstick(int(unit_bytes))
+                out_["roofline_gcn_message_pass"] = {
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "tracklets": B_, "bytes_per_layer": unit_bytes, "us_per_layer": round(1e3 * ms / layers_, 2),
+                    "kernels": {n: round(1e3 * agg_[n]["ms"] / agg_[n]["launches"], 2) for n in names_old},
+                    "what": "SURVEY 8(d) message-pass unit (sim + normalise + mix + G h + BN + LeakyReLU + residual; Linear excluded): "
+                            "1.389 MB per tracklet-layer over the time of ALL its kernels",
+                    "read_stream_yardstick_gbs": round(ygbs, 1), "frac_of_yardstick": round(gbs / ygbs, 4)}
+            return out_
+
+        result.update(gcn_rooflines(agg, B, n_layers * nprof))
+        # the same layers at 256 tracklets per GPU (BASELINE configs[2]'s global batch on ONE GPU): the size at which the
+        # kernels are past their launch / drain floor
+        try:
+            from torchreid.models import _vmgn_hip as eng
+            pack = eng.pack_weights(model, device, args.precision)
+            g256 = torch.Generator(device=device)
+            g256.manual_seed(256)
+            B2 = 256
+            nodes2 = torch.rand((B2, 1, Cc), device=device, generator=g256) + 0.02 * torch.randn((B2, V, Cc), device=device, generator=g256)
+            adj2 = synthetic_pose_adjacency(B2, S, device, g256)
+            nodes2_lp = nodes2.to(torch.bfloat16) if lp else None
+            commute = eng.gcn_commute_enabled(model)
+            for _ in range(2):
+                eng.hip_graph_layers(nodes2, nodes2_lp, adj2, pack, commute=commute)
+            torch.cuda.synchronize()
+            _hip.PROFILE = []
+            for _ in range(5):
+                eng.hip_graph_layers(nodes2, nodes2_lp, adj2, pack, commute=commute)
+            torch.cuda.synchronize()
+            prof2, _hip.PROFILE = _hip.PROFILE, None
+            agg2 = {}
+            for name, s_ev, e_ev, tag in prof2:
+                a2 = agg2.setdefault(name, {"ms": 0.0, "launches": 0})
+                a2["ms"] += s_ev.elapsed_time(e_ev)
+                a2["launches"] += 1
+            result["gcn_at_256_tracklets"] = gcn_rooflines(agg2, B2, n_layers * 5)
+            del nodes2, adj2, nodes2_lp
+        except Exception as e:  # noqa: BLE001
+            _hip.PROFILE = None
+            result["gcn_at_256_tracklets"] = {"error": repr(e)[:300]}
         if "agrl_distmat" in agg and agg["agrl_distmat"]["bytes"]:
             names = [n for n in ("agrl_distmat", "agrl_row_l2_normalize") if n in agg]
             ms_all = sum(agg[n]["ms"] for n in names)
