@@ -413,6 +413,42 @@ static int reduce_chunks(int M, int C, int* rows_per_chunk) {
 
 }  // namespace
 
+// Everything nn.BatchNorm{1,2}d does with the batch statistics besides normalising, in ONE launch (it was eleven tiny torch
+// kernels per BatchNorm layer, ~770 launches per train step): invstd = rsqrt(var + eps), the folded scale = gamma * invstd and
+// shift = beta - mean * scale for agrl_bn_apply, and the running-statistics update of torch.nn.functional.batch_norm --
+// running = (1 - momentum) * running + momentum * {mean, var * n / (n - 1)} -- plus num_batches_tracked += 1.
+__global__ __launch_bounds__(256) void bn_fold_train_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            float momentum, float unbias, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, long long* __restrict__ num_batches,
+                                                            float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ invstd, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && num_batches) num_batches[0] += 1;
+    if (c >= C) return;
+    const float mu = mean[c], v = var[c];
+    const float is = rsqrtf(v + eps);
+    const float sc = gamma[c] * is;
+    invstd[c] = is;
+    scale[c] = sc;
+    shift[c] = beta[c] - mu * sc;
+    if (running_mean) {
+        running_mean[c] = fmaf(momentum, mu, running_mean[c] * (1.f - momentum));
+        running_var[c] = fmaf(momentum, v * unbias, running_var[c] * (1.f - momentum));
+    }
+}
+
+extern "C" int agrl_bn_fold_train(const float* mean, const float* var, const float* gamma, const float* beta, float eps, float momentum,
+                                  long long n, float* running_mean, float* running_var, long long* num_batches_tracked, float* scale,
+                                  float* shift, float* invstd, int C, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(mean && var && gamma && beta && scale && shift && invstd && C > 0 && n > 0, "agrl_bn_fold_train: bad arguments");
+    AGRL_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "agrl_bn_fold_train: running_mean and running_var go together");
+    const float unbias = n > 1 ? (float)((double)n / (double)(n - 1)) : 1.f;
+    hipLaunchKernelGGL(bn_fold_train_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, var, gamma, beta, eps, momentum, unbias,
+                       running_mean, running_var, num_batches_tracked, scale, shift, invstd, C);
+    AGRL_CHECK_LAUNCH("agrl_bn_fold_train");
+    return 0;
+}
+
 extern "C" size_t agrl_bn_workspace(int M, int C) {
     int rpc;
     const int chunks = reduce_chunks(M, C, &rpc);

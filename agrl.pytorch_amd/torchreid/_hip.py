@@ -84,6 +84,7 @@ SIGNATURES = {
     "agrl_bn_stats": [_p, _p, _p, _i, _i, _p, C.c_size_t, _p],
     "agrl_conv2d_stats": [_p, _p, _p, _p, C.c_size_t] + [_i] * 10 + [_p],
     "agrl_bn_stats_from_partials": [_p, _i, _i, _i, _p, _p, _p, C.c_size_t, _p],
+    "agrl_bn_fold_train": [_p, _p, _p, _p, _f, _f, C.c_longlong, _p, _p, _p, _p, _p, _p, _i, _p],
     "agrl_bn_apply": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "agrl_bn_backward": [_p, _p, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _p, _i, _i, _p, C.c_size_t, _p],
     "agrl_im2col_t": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -650,6 +650,19 @@ def conv_stats(x, w_ohwi, stride, pad):
     return out, mean, var
 
 
+def bn_fold_train(mean, var, gamma, beta, eps, momentum, n, running_mean=None, running_var=None, num_batches_tracked=None):
+    """-> scale, shift, invstd (C): the folded BatchNorm of the batch statistics, and -- in the same launch -- the running-statistics
+    update nn.BatchNorm applies in train mode (momentum, unbiased variance, num_batches_tracked += 1). vmgn.py:49-63, :169."""
+    Cc = mean.numel()
+    scale, shift, invstd = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(mean)
+    if num_batches_tracked is not None:
+        assert num_batches_tracked.dtype == torch.int64
+    with _dev(mean):
+        call("agrl_bn_fold_train", ptr(mean), ptr(var), ptr(gamma), ptr(beta), float(eps), float(momentum), int(n), ptr(running_mean),
+             ptr(running_var), ptr(num_batches_tracked), ptr(scale), ptr(shift), ptr(invstd), Cc, _stream(mean))
+    return scale, shift, invstd
+
+
 def bn_apply(y2d, scale, shift, residual, relu, slope=0.0, want_mask=False):
     """relu: activation on; slope 0 = ReLU, > 0 = LeakyReLU(slope). -> out, mask: with ``want_mask`` (and relu) the sign bits of
     the pre-activation, one bit per element (uint8, M*C/8 bytes) -- what ``bn_backward`` needs instead of the output."""

@@ -196,16 +196,17 @@ class HipBatchNormAct(torch.autograd.Function):
     """BatchNorm2d in train mode (+ shortcut add) (+ ReLU) on NHWC fp32: out = act(bn(y) + residual)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, residual, relu, eps, slope=0.0, mean=None, var=None):
+    def forward(ctx, y, gamma, beta, residual, relu, eps, slope=0.0, mean=None, var=None, running=None):
         C = y.shape[-1]
         y2 = y.contiguous().view(-1, C)
         if mean is None:
             mean, var = ops.bn_stats(y2)
         else:                                   # handed over by the conv in front (HipConv2dStats / HipConvFork)
             mean, var = mean.detach(), var.detach()
-        invstd = torch.rsqrt(var + eps)
-        scale = (gamma.detach() * invstd).contiguous()
-        shift = (beta.detach() - mean * scale).contiguous()
+        # folded scale / shift / invstd and the running-statistics update in ONE native launch (was eleven tiny torch kernels)
+        rm, rv, nbt, momentum = running if running is not None else (None, None, None, 0.0)
+        scale, shift, invstd = ops.bn_fold_train(mean, var, gamma.detach().contiguous(), beta.detach().contiguous(), eps, momentum,
+                                                 y2.shape[0], rm, rv, nbt)
         res2 = None if residual is None else residual.contiguous().view(-1, C)
         # with an activation the backward pass needs only the sign of the pre-activation: one bit per element instead of the output
         out, mask = ops.bn_apply(y2, scale, shift, res2, relu, slope, want_mask=True)
@@ -221,7 +222,7 @@ class HipBatchNormAct(torch.autograd.Function):
         C = shape[-1]
         dy, dz, dgamma, dbeta = ops.bn_backward(dout.contiguous().view(-1, C), None, y2, mean, invstd, gamma.detach().contiguous(),
                                                 relu, want_dz=has_res, slope=slope, mask=mask)
-        return dy.view(shape), dgamma, dbeta, (dz.view(shape) if has_res else None), None, None, None, None, None
+        return dy.view(shape), dgamma, dbeta, (dz.view(shape) if has_res else None), None, None, None, None, None, None
 
 
 class HipMaxPool(torch.autograd.Function):
@@ -244,13 +245,13 @@ def _bn_act(bn, y, residual, relu, slope=0.0, stats=None):
     LeakyReLU instead of ReLU. ``stats`` = (mean, biased var) of y when the producing conv already has them."""
     if not bn.training or not bn.track_running_stats:
         raise RuntimeError('the native train path expects BatchNorm layers in train mode with running statistics')
-    out, mean, var = HipBatchNormAct.apply(y, bn.weight, bn.bias, residual, relu, bn.eps, slope, *(stats or (None, None)))
-    with torch.no_grad():
-        n = y.numel() // y.shape[-1]
-        bn.num_batches_tracked += 1
-        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-        bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-        bn.running_var.mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+    if bn.momentum is None:   # cumulative moving average: the factor depends on the counter's value -> one host read (not the reference's setting)
+        m = 1.0 / float(int(bn.num_batches_tracked) + 1)
+    else:
+        m = float(bn.momentum)
+    mean, var = stats or (None, None)
+    out, _, _ = HipBatchNormAct.apply(y, bn.weight, bn.bias, residual, relu, bn.eps, slope, mean, var,
+                                      (bn.running_mean, bn.running_var, bn.num_batches_tracked, m))
     return out
 
 

@@ -366,6 +366,16 @@ int agrl_conv2d_stats(const float* x, const float* w, float* out, float* partial
 int agrl_bn_stats_from_partials(const float* partial, int rows, int C, int M, float* mean, float* var, void* workspace,
                                 size_t workspace_bytes /* agrl_bn_workspace(rows, 2 * C) */, agrl_stream_t stream);
 
+/* What nn.BatchNorm{1,2}d (train mode) does with the batch statistics besides normalising, in one launch
+ * (torch.nn.functional.batch_norm as called at torchreid/models/vmgn.py:49-63, :169 under model.train()):
+ *   invstd = rsqrt(var + eps); scale = gamma * invstd; shift = beta - mean * scale   (the operands of agrl_bn_apply / _backward)
+ *   running_mean = (1 - momentum) running_mean + momentum mean; running_var likewise with the UNBIASED variance var n / (n - 1);
+ *   num_batches_tracked += 1 (int64 scalar). running_* / num_batches_tracked may be NULL (statistics not tracked).
+ * mean, var, gamma, beta, scale, shift, invstd: fp32 (C); n = rows the statistics were taken over. */
+int agrl_bn_fold_train(const float* mean, const float* var, const float* gamma, const float* beta, float eps, float momentum,
+                       long long n, float* running_mean, float* running_var, long long* num_batches_tracked, float* scale,
+                       float* shift, float* invstd, int C, agrl_stream_t stream);
+
 /* out = act(y * scale[c] + shift[c] (+ residual)): the normalisation with scale = gamma / sqrt(var + eps), shift = beta -
  * mean * scale, the shortcut add and the activation in one pass: relu != 0 -> v > 0 ? v : slope * v (slope 0: the ReLU of
  * vmgn.py:49-64; slope 0.1: the LeakyReLU behind GraphLayer's BatchNorm1d, vmgn.py:169-170). C % 4 == 0.
