@@ -953,6 +953,31 @@ def main():
                                           "avg_launch_us": round(1e3 * agg["agrl_distmat"]["ms"] / agg["agrl_distmat"]["launches"], 2),
                                           "achieved_incl_query_normalise": round(gbs_all, 1),
                                           "read_stream_yardstick_gbs": round(ygbs, 1), "frac_of_yardstick": round(gbs / ygbs, 4)}
+            # the same kernel against an 8 x longer gallery (97 440 rows, 798 MB in bf16): at 100 MB a launch is ~6 us of ramp /
+            # drain on top of ~18 us of streaming, so the fraction above is bounded by the SIZE; this one shows the kernel's rate
+            try:
+                if args.metric == "cosine":
+                    rows8 = 8 * GALLERY_ROWS
+                    g8 = g_op.repeat(-(-rows8 // g_op.shape[0]), 1)[:rows8].contiguous()   # bandwidth does not care about the values
+                    q8 = ops.row_l2_normalize(torch.randn((B, FEATURE_DIM), device=device), True, g_op.dtype)
+                    out8 = torch.empty((B, rows8), dtype=torch.float32, device=device)
+                    ts8 = []
+                    for _ in range(4):
+                        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s_ev.record()
+                        for _i in range(4):   # back to back: the host's launch cost hides under the previous launch
+                            ops.distmat(q8, g8, "cosine", out=out8)
+                        e_ev.record()
+                        e_ev.synchronize()
+                        ts8.append(s_ev.elapsed_time(e_ev) / 4.0)
+                    t8 = sorted(ts8[1:])[len(ts8[1:]) // 2]
+                    b8 = g_op.element_size() * (B + rows8) * FEATURE_DIM + 4.0 * B * rows8
+                    result["roofline_distmat_8x_gallery"] = {"bound": "hbm", "achieved": round(b8 / (t8 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                             "frac": round(b8 / (t8 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "gallery_rows": rows8,
+                                                             "bytes_per_launch": b8, "launch_us": round(1e3 * t8, 1)}
+                    del g8, q8, out8
+            except Exception as e:  # noqa: BLE001
+                result["roofline_distmat_8x_gallery"] = {"error": repr(e)[:200]}
         del scratch
         result["kernels"] = kernels
         if world == 1:
