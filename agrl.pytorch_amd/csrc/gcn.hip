@@ -663,230 +663,6 @@ __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const floa
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The WHOLE message-pass unit of a GraphLayer (similarity + normalise + mix + G h + BatchNorm + LeakyReLU +
-// residual; everything of vmgn.py:155-172 but the Linear) in ONE launch, every byte of f / h / out crossing HBM exactly once.
-//
-// grid = (groups * NS), NS = C / 256 workgroups per tracklet, 256 threads = 4 waves, each wave 64 channels. A tracklet's
-// graph needs the Gram matrix over ALL channels before a single output can be formed, so its NS workgroups hand their partial
-// Gram matrices to each other INSIDE the launch:
-//   A  the workgroup loads its f slice (V x 256 fp32, 57 KB at V = 56) into LDS -- it stays there as the residual input of
-//      phase C -- and forms the partial Gram over its 256 channels with v_mfma_f32_16x16x4_f32 (exact fp32), stores it, and
-//      publishes WITHOUT a fence: the partial goes out with write-through (sc1, relaxed agent-scope atomic) stores, every wave
-//      drains them (s_waitcnt vmcnt(0)), __syncthreads, then lane 0 does a relaxed agent-scope atomic add on the tracklet's
-//      counter; the readers use sc1 loads (L2-served, never this CU's L1) -- the "sc1 both sides" form of
-//      cdna_hip_programming.md Guideline 16, placement-independent;
-//      its h slice (the operand of phase C) is requested into registers BEFORE the wait, so the hand-off latency is covered;
-//   B  lane 0 polls the counter (relaxed, s_sleep) until all NS partials are in, __syncthreads (no acquire fence: the
-//      partials are read with sc1 loads); then every workgroup of the tracklet redundantly sums the NS partials in slice order (deterministic),
-//      d -> sim -> row-L1 normalise -> mix with the pose graph, into LDS (one wavefront per graph row);
-//   C  G h for the workgroup's channels (exact-fp32 MFMA, the channel <-> MFMA-row assignment of graph_propagate_stream_kernel)
-//      + BatchNorm + LeakyReLU + residual from the LDS-resident f -> out (+ bf16 copy).
-// All workgroups of a tracklet must be resident together: the host sizes the grid by the occupancy query (83 KB of LDS: one
-// workgroup per CU) and larger batches are walked persistently by `groups` tracklet groups. The spin is bounded (a lost
-// partner would otherwise hang the device): on time-out the workgroup raises the error word AND writes NaN into every output
-// element it owns for that tracklet, so an incomplete hand-off can never pass as a result.
-template <int PS_NT>  // V = 4 PS_NT exactly, V <= 64
-__global__ __launch_bounds__(256) void graph_message_pass_kernel(
-    const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ adj, const float* __restrict__ bn_scale,
-    const float* __restrict__ bn_shift, float keep, float gamma, float slope, int use_pose, int learn_graph, int mask_diag,
-    float* __restrict__ out, bf16_t* __restrict__ out_lp, float* __restrict__ G_out, float* __restrict__ gram_part,
-    int* __restrict__ counters, int* __restrict__ err, int B, int C, int NS) {
-    constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4, VP = NVF * 16;
-    constexpr int ROWB = 256 * 4 + 16;                  // f slice row: 256 channels fp32 + 16 B (conflict-free fragment reads)
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    unsigned char* s_f = s_raw;                          // [VP][ROWB]
-    float* s_g = reinterpret_cast<float*>(s_raw + VP * ROWB);   // [VP][V] graph (rows >= V zero)
-    float* s_n = s_g + VP * V;                           // [V] squared norms
-    int* s_flag = reinterpret_cast<int*>(s_n + V);       // hand-off time-out flag
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s = blockIdx.x % NS, group = blockIdx.x / NS, ngroups = gridDim.x / NS;
-    const int i16 = lane & 15, kg = lane >> 4;
-    for (int b = group; b < B; b += ngroups) {
-        const size_t node0 = (size_t)b * V;
-        const int cs = s * 256;
-        float keep_b = keep;
-        int lost = 0;
-        // this wave's h operand for phase C and the f slice: ALL requested up front (one latency, not two), h consumed after the hand-off
-        const int c0 = cs + wave * 64;
-        const int cl = c0 + 4 * kg;
-        const int sig = 4 * (i16 & 3) + (i16 >> 2);
-        f32x4_t hreg[PS_NT];
-        // ---- A: f slice -> LDS (rows >= V zero)
-        {
-            // all of a thread's loads are issued before its first LDS store (a load -> store loop is a chain of HBM round trips)
-            const float* src = f + node0 * C + cs;
-            constexpr int NLD = VP * 64 / 256;   // float4 per thread: row 4 i + (tid >> 6), float4 column tid & 63
-            float4 v[NLD];
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int r = 4 * i + (tid >> 6);
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r < V) v[i] = *reinterpret_cast<const float4*>(src + (size_t)r * C + (tid & 63) * 4);
-            }
-            {
-                const float* hb = h + node0 * C + c0 + 4 * sig;
-#pragma unroll
-                for (int t = 0; t < PS_NT; ++t) hreg[t] = *reinterpret_cast<const f32x4_t*>(hb + (size_t)(4 * t + kg) * C);
-            }
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) *reinterpret_cast<float4*>(s_f + (4 * i + (tid >> 6)) * ROWB + (tid & 63) * 16) = v[i];
-        }
-        __syncthreads();
-        if (learn_graph) {
-            float* dst = gram_part + ((size_t)b * NS + s) * V * V;
-            const int frow = lane & 15, fch = lane >> 4;
-            for (int fr = wave; fr < NVF * NVF; fr += 4) {
-                const int fi = fr / NVF, fj = fr - fi * NVF;
-                f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-                const unsigned char* pa = s_f + (fi * 16 + frow) * ROWB + fch * 16;
-                const unsigned char* pb = s_f + (fj * 16 + frow) * ROWB + fch * 16;
-#pragma unroll 4
-                for (int ks = 0; ks < 16; ++ks) {
-                    const float4 av = *reinterpret_cast<const float4*>(pa + ks * 64);
-                    const float4 bv = *reinterpret_cast<const float4*>(pb + ks * 64);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-                }
-                const int j = fj * 16 + frow;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = fi * 16 + fch * 4 + r;
-                    // write-through (sc1) stores: the partial is published without a release fence (which would write back the
-                    // XCD's whole dirty L2: ~6.5 us with a fresh 12.5 KB slab per workgroup), read back below with sc1 loads
-                    if (i < V && j < V) __hip_atomic_store(&dst[(size_t)i * V + j], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            // publish this slice's partial (Guideline 16: sc1 payload -> every wave drains its stores -> barrier -> relaxed counter)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __hip_atomic_fetch_add(&counters[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // ---- B: wait for the NS - 1 partners (bounded: a partner that never arrives must not hang the device)
-                int spins = 0;
-                while (__hip_atomic_load(&counters[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < NS) {
-                    __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) {
-                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        lost = 1;
-                        break;
-                    }
-                }
-            }
-            if (tid == 0) *s_flag = lost;     // (a slot of the dynamic LDS: a static __shared__ object would push the 160 KB request over the limit)
-            __syncthreads();
-            if (*s_flag) keep_b = __builtin_nanf("");   // poisons keep f + gamma y below
-            // Gram = sum of the NS partials in slice order, every element by one thread, all of a thread's loads in flight at once
-            // (sc1 loads: served by L2, never by this CU's possibly stale L1) -> LDS; its diagonal = the squared norms
-            {
-                const float* gp = gram_part + (size_t)b * NS * V * V;
-                constexpr int NEL = (V * V + 255) / 256;
-                for (int z0 = 0; z0 < NS; z0 += 8) {
-                    float part[NEL][8];
-#pragma unroll
-                    for (int i = 0; i < NEL; ++i) {
-                        const int e = tid + 256 * i;
-#pragma unroll
-                        for (int z = 0; z < 8; ++z)
-                            part[i][z] = (e < V * V && z0 + z < NS)
-                                             ? __hip_atomic_load(&gp[(size_t)(z0 + z) * V * V + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                    }
-#pragma unroll
-                    for (int i = 0; i < NEL; ++i) {
-                        const int e = tid + 256 * i;
-                        if (e < V * V) {
-                            float acc = z0 ? s_g[e] : 0.f;
-#pragma unroll
-                            for (int z = 0; z < 8; ++z)
-                                if (z0 + z < NS) acc += part[i][z];
-                            s_g[e] = acc;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            for (int j = tid; j < V; j += 256) s_n[j] = s_g[j * V + j];
-            __syncthreads();
-        }
-        // graph rows: one wavefront per row (V <= 64: one column per lane)
-        for (int i = wave; i < VP; i += 4) {
-            float g = 0.f;
-            if (i < V) {
-                float sim = 0.f, av = 0.f;
-                const bool live = lane < V;
-                if (learn_graph && live) {
-                    const float gsum = s_g[i * V + lane];   // rewritten in place below: the wave owns the row
-                    float d2 = (s_n[lane] + s_n[i]) - 2.f * gsum;
-                    d2 = fmaxf(d2, 1e-12f);
-                    sim = 2.f / (expf(sqrtf(d2)) + 1.f);
-                    if (mask_diag && lane == i) sim = 0.f;
-                }
-                if (use_pose && live) {
-                    av = adj[(node0 + i) * V + lane];
-                    if (mask_diag && lane == i) av = 0.f;
-                }
-                const float sden = fmaxf(wave_sum(fabsf(sim)), 1e-12f), aden = fmaxf(wave_sum(fabsf(av)), 1e-12f);
-                if (learn_graph) {
-                    g = sim / sden;
-                    if (use_pose) g = (av / aden + g) / 2.f;
-                } else {
-                    g = av / aden;
-                }
-                if (live && G_out && s == 0) G_out[(node0 + i) * V + lane] = g;
-            }
-            if (lane < V) s_g[i * V + lane] = g;
-        }
-        __syncthreads();
-        // ---- C: G h + BatchNorm + LeakyReLU + residual (f from LDS)
-        {
-            f32x4_t acc[NVF][4];
-#pragma unroll
-            for (int vf = 0; vf < NVF; ++vf)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[vf][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < PS_NT; ++t) {
-                float gq[NVF];
-#pragma unroll
-                for (int vf = 0; vf < NVF; ++vf) gq[vf] = s_g[(vf * 16 + i16) * V + 4 * t + kg];
-#pragma unroll
-                for (int vf = 0; vf < NVF; ++vf)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[vf][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[t][j], gq[vf], acc[vf][j], 0, 0, 0);
-            }
-            // D_j row 4 kg + r = channel cl + 16 r + j -> float4 r = {acc[vf][0..3][r]}
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float4 sc = *reinterpret_cast<const float4*>(bn_scale + cl + 16 * r);
-                const float4 sh = *reinterpret_cast<const float4*>(bn_shift + cl + 16 * r);
-                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-                for (int vf = 0; vf < NVF; ++vf) {
-                    const int v = vf * 16 + i16;
-                    if (v >= V) continue;
-                    const float4 fv4 = *reinterpret_cast<const float4*>(s_f + v * ROWB + (wave * 64 + 4 * kg + 16 * r) * 4);
-                    const float fv[4] = {fv4.x, fv4.y, fv4.z, fv4.w};
-                    float o[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float y = fmaf(acc[vf][j][r], scv[j], shv[j]);
-                        y = y > 0.f ? y : slope * y;
-                        o[j] = keep_b * fv[j] + gamma * y;
-                    }
-                    const size_t idx = (node0 + v) * C + cl + 16 * r;
-                    *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (out_lp) *reinterpret_cast<uint2*>(out_lp + idx) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-                }
-            }
-        }
-        __syncthreads();  // s_f / s_g are rewritten by the next tracklet
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Pose adjacency on the device: generate_graph + adj_graph(method 'same'), torchreid/dataset_loader.py:218-388.
 // One workgroup per tracklet. Per frame and body part (head / body / leg keypoint groups) the confident keypoints'
 // y coordinates are bucketed into horizontal stripes (bisect_right on the stripe borders, clamped), the stripes
@@ -1100,69 +876,6 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     return 0;
 }
 
-
-extern "C" size_t agrl_graph_message_pass_workspace(int B, int V, int C) {
-    const int NS = C / 256;
-    return (size_t)B * NS * V * V * sizeof(float) + ((size_t)B + 1) * sizeof(int) + 256;
-}
-
-extern "C" int agrl_graph_message_pass(const float* f, const float* h, const float* adj, const float* bn_scale,
-                                       const float* bn_shift, float keep, float gamma, float slope, int use_pose,
-                                       int learn_graph, int mask_diag, float* out, void* out_lp, float* G_out, void* workspace,
-                                       size_t workspace_bytes, int B, int V, int C, agrl_stream_t stream) {
-    AGRL_CHECK_ARG(f && h && bn_scale && bn_shift && out && workspace, "agrl_graph_message_pass: null pointer");
-    AGRL_CHECK_ARG(use_pose || learn_graph, "agrl_graph_message_pass: use_pose or learn_graph must be set");
-    AGRL_CHECK_ARG(!use_pose || adj, "agrl_graph_message_pass: use_pose needs adj");
-    AGRL_CHECK_ARG(B > 0 && V > 0 && V <= 64 && (V % 4) == 0 && C >= 256 && (C % 256) == 0,
-                   "agrl_graph_message_pass: built for V <= 64, V %% 4 == 0, C %% 256 == 0 (got V=%d C=%d): use the three-kernel path", V, C);
-    AGRL_CHECK_ARG(workspace_bytes >= agrl_graph_message_pass_workspace(B, V, C), "agrl_graph_message_pass: workspace too small");
-    const uintptr_t al = (uintptr_t)f | (uintptr_t)h | (uintptr_t)out | (uintptr_t)out_lp | (uintptr_t)bn_scale | (uintptr_t)bn_shift | (uintptr_t)workspace;
-    AGRL_CHECK_ARG((al & 15) == 0, "agrl_graph_message_pass: operands must be 16-byte aligned");
-    const int NS = C / 256;
-    const int nvf = (V + 15) / 16, VP = nvf * 16;
-    const size_t lds = (size_t)VP * (256 * 4 + 16) + (size_t)VP * V * 4 + (size_t)V * 4 + 16;
-    float* gram_part = (float*)workspace;
-    int* counters = (int*)((char*)workspace + (((size_t)B * NS * V * V * sizeof(float) + 15) & ~(size_t)15));
-    int* err = counters + B;
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(counters, 0, ((size_t)B + 1) * sizeof(int), st);
-    AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_message_pass: memset failed: %s", hipGetErrorString(e));
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    // per instantiation, once per process: raise the dynamic-LDS limit and ask how many workgroups a CU holds (both are host
-    // calls of several microseconds; the launch path itself is the memset + one launch)
-#define LAUNCH_MP(NT_)                                                                                                         \
-    case NT_: {                                                                                                                \
-        static const int per_cu_cached = [] {                                                                                  \
-            const void* fn = (const void*)graph_message_pass_kernel<NT_>;                                                      \
-            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-            constexpr int V_ = 4 * NT_, VP_ = ((NT_ + 3) / 4) * 16;                                                            \
-            int n = 0;                                                                                                         \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, (size_t)VP_ * (256 * 4 + 16) + (size_t)VP_ * V_ * 4 + V_ * 4 + 16) != hipSuccess || n < 1) n = 1; \
-            return n;                                                                                                          \
-        }();                                                                                                                   \
-        const int per_cu = per_cu_cached;                                                                                      \
-        /* every workgroup of the grid must be resident at once (the in-launch hand-off): whole tracklet groups only, with a */ \
-        /* margin of one workgroup per CU below the occupancy query's answer where it allows more than one                  */ \
-        int slots = n_cu * (per_cu > 1 ? per_cu - 1 : 1);                                                                      \
-        int groups = slots / NS;                                                                                               \
-        if (groups < 1) groups = 1;                                                                                            \
-        if (groups > B) groups = B;                                                                                            \
-        AGRL_CHECK_ARG(groups * NS <= n_cu * per_cu, "agrl_graph_message_pass: C / 256 = %d workgroups per tracklet do not fit the device", NS); \
-        hipLaunchKernelGGL(graph_message_pass_kernel<NT_>, dim3(groups * NS), dim3(256), lds, st, f, h, adj, bn_scale, bn_shift, keep, gamma, \
-                           slope, use_pose, learn_graph, mask_diag, out, (bf16_t*)out_lp, G_out, gram_part, counters, err, B, C, NS); \
-    } break
-    switch (V / 4) {
-        LAUNCH_MP(1); LAUNCH_MP(2); LAUNCH_MP(3); LAUNCH_MP(4); LAUNCH_MP(5); LAUNCH_MP(6); LAUNCH_MP(7); LAUNCH_MP(8);
-        LAUNCH_MP(9); LAUNCH_MP(10); LAUNCH_MP(11); LAUNCH_MP(12); LAUNCH_MP(13); LAUNCH_MP(14); LAUNCH_MP(15); LAUNCH_MP(16);
-    }
-#undef LAUNCH_MP
-    AGRL_CHECK_LAUNCH("agrl_graph_message_pass");
-    return 0;
-}
 
 extern "C" int agrl_pose_adjacency(const float* poses, const unsigned char* detected, float* adj, int B, int S, int num_split,
                                    int pyramid_part, float height, float threshold, agrl_stream_t stream) {

@@ -46,7 +46,6 @@ SIGNATURES = {
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_block": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "agrl_bottleneck_frame": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_conv1x1_dual_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_conv1x1_bn_act_pool": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_linear_nobias": [_p, _p, _p, _i, _i, _i, _i, _p],
@@ -57,8 +56,6 @@ SIGNATURES = {
     "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _i, _p],
     "agrl_pam_pool": [_p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_pam_combine": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
-    "agrl_graph_message_pass_workspace": [_i, _i, _i],   # returns size_t
-    "agrl_graph_message_pass": [_p, _p, _p, _p, _p, _f, _f, _f, _i, _i, _i, _p, _p, _p, _p, C.c_size_t, _i, _i, _i, _p],
     "agrl_graph_apply": [_p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_graph_linear_mix": [_p, _p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _p],
     "agrl_row_sqnorm": [_p, _p, _i, _i, _i, _p],
@@ -128,7 +125,6 @@ def lib():
         h.agrl_re_ranking_workspace.restype = C.c_size_t
         h.agrl_bn_workspace.restype = C.c_size_t
         h.agrl_conv_wgrad_workspace.restype = C.c_size_t
-        h.agrl_graph_message_pass_workspace.restype = C.c_size_t
         h.agrl_distmat_topk_workspace.restype = C.c_size_t
         for name in ("agrl_reload_options", "agrl_built_with_ablation"):
             getattr(h, name).argtypes = []

@@ -229,32 +229,6 @@ def bottleneck_block(z, w2, b2, w3, b3, residual, w1_next, b1_next, shortcut=Non
     return out, zn
 
 
-def bottleneck_frame_supported(x, w1, w2, w3, stride, has_downsample, force=False):
-    """The frame-resident whole-block kernel exists for bf16 identity-shortcut blocks of width 256 on 16 x 8 maps (layer 3).
-    OFF unless AGRL_HIP_FUSE_FRAME=1 (or ``force``): measured 93-103 us per block against 96 us for the three separate launches
-    (every CU is in the same phase at the same time, so the HBM-heavy first / last GEMMs and the on-chip 3x3
-    do not overlap across the chip at one frame per CU)."""
-    if not force and os.environ.get('AGRL_HIP_FUSE_FRAME', '0') != '1':
-        return False
-    return (x.dtype == torch.bfloat16 and not has_downsample and stride == 1 and tuple(x.shape[1:3]) == (16, 8)
-            and tuple(w1.shape) == (256, 1, 1, x.shape[3]) and tuple(w2.shape) == (256, 3, 3, 256)
-            and tuple(w3.shape) == (x.shape[3], 1, 1, 256) and x.shape[3] % 256 == 0)
-
-
-def bottleneck_frame(x, w1, b1, w2, b2, w3, b3):
-    """out = relu(conv3(relu(conv2(relu(conv1(x))))) + x): a whole identity-shortcut Bottleneck in one pass, y1 / y2 LDS-resident.
-    vmgn.py:45-65. x (F,16,8,Cin) bf16 NHWC -> (F,16,8,Cin)."""
-    F_, H, W, Cin = x.shape
-    out = torch.empty_like(x)
-    if _hip.PROFILE is not None:
-        M = F_ * H * W
-        _hip.PROFILE_TAG = {"flops": 2.0 * M * (Cin * 256 + 9 * 256 * 256 + 256 * Cin), "bytes": 2.0 * (2 * x.numel() + w1.numel() + w2.numel() + w3.numel()),
-                            "conv": (3, 1, 256, 256, H, W)}
-    with _dev(x):
-        call("agrl_bottleneck_frame", ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(out), F_, H, W, Cin, 256, _stream(x))
-    return out
-
-
 def linear_nobias(x, w):
     """(M,K) @ (N,K)^T -> fp32 (M,N). vmgn.py:148."""
     M, K = x.shape
@@ -387,38 +361,6 @@ def pam_combine(y, bv, xmean, gamma, want_lp):
     with _dev(xmean):
         call("agrl_pam_combine", ptr(y), ptr(bv), ptr(xmean), float(gamma), ptr(nodes), ptr(nodes_lp), rows, Cc, _stream(xmean))
     return nodes, nodes_lp
-
-
-def graph_message_pass_supported(f, force=False):
-    """The one-launch message pass exists for V <= 64, V % 4 == 0, C % 256 == 0. Measured SLOWER than the three-kernel unit at
-    the bench shape (47-51 us vs 31-34 us per layer, DESIGN.md section 5), so the model only takes it with AGRL_HIP_GCN_FUSED=1;
-    ``force`` is the tests' way in."""
-    B, V, Cc = f.shape
-    return V <= 64 and V % 4 == 0 and Cc % 256 == 0 and (force or os.environ.get('AGRL_HIP_GCN_FUSED', '0') == '1')
-
-
-def graph_message_pass(f, h, adj, bn_scale, bn_shift, gamma, slope, use_pose, learn_graph, want_lp, keep=None, mask_diag=False,
-                       want_graph=False):
-    """The whole message-pass unit of a GraphLayer in one launch: -> out (B,V,C) fp32, out_lp bf16 | None, G (B,V,V) | None.
-    vmgn.py:155-172 (ganet.py:253-283 with mask_diag, keep = 1)."""
-    B, V, Cc = f.shape
-    if keep is None:
-        keep = 1.0 - float(gamma)
-    out = torch.empty_like(f)
-    out_lp = torch.empty((B, V, Cc), dtype=torch.bfloat16, device=f.device) if want_lp else None
-    G = torch.empty((B, V, V), dtype=torch.float32, device=f.device) if want_graph else None
-    nbytes = int(_hip.lib().agrl_graph_message_pass_workspace(B, V, Cc))
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=f.device)
-    if use_pose:
-        assert adj is not None and tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32
-        adj = adj.contiguous()
-    if _hip.PROFILE is not None:  # SURVEY 8(d): read f + read h + read adj + write out
-        _hip.PROFILE_TAG = {"flops": 2.0 * B * V * V * Cc * 2, "bytes": 4.0 * (3 * B * V * Cc + B * V * V)}
-    with _dev(f):
-        call("agrl_graph_message_pass", ptr(f), ptr(h), ptr(adj) if use_pose else None, ptr(bn_scale), ptr(bn_shift), float(keep),
-             float(gamma), float(slope), 1 if use_pose else 0, 1 if learn_graph else 0, 1 if mask_diag else 0, ptr(out), ptr(out_lp),
-             ptr(G), ptr(ws), nbytes, B, V, Cc, _stream(f))
-    return out, out_lp, G
 
 
 def clip_pool(feats, num_clips, mode="avg"):

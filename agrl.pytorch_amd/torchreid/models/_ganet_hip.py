@@ -109,13 +109,6 @@ def hip_forward_ganet(model, x, adj, stages=None):
                 continue
             operand = nodes_lp if lp else cur
             h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
-            if ops.graph_message_pass_supported(cur):
-                nxt, nodes_lp, G = ops.graph_message_pass(cur, h, adj32, g['scale'], g['shift'], gamma_g, g['slope'], g['use_pose'],
-                                                          g['learn_graph'], want_lp=lp, keep=1.0, mask_diag=True, want_graph=stages is not None)
-                if stages is not None:
-                    stages.setdefault('G', []).append(G)
-                outs.append(nxt)
-                continue
             G = ops.graph_matrix(cur, adj32, g['use_pose'], g['learn_graph'], mask_diag=True)
             if stages is not None:
                 stages.setdefault('G', []).append(G)

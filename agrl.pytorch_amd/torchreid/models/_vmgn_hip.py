@@ -113,10 +113,6 @@ def _run_trunk(a, blocks, fuse_tail=True):
     z = None  # conv1 output of the current block, when the previous block's tail already computed it
     for i, blk in enumerate(blocks):
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
-        if z is None and fuse_tail and ops.bottleneck_frame_supported(a, blk['c1'][0], blk['c2'][0], blk['c3'][0], blk['stride'], blk['ds'] is not None):
-            # layer 3 identity blocks on 16 x 8 maps: the whole Bottleneck in one pass, one frame per workgroup (ops.bottleneck_frame)
-            a = ops.bottleneck_frame(a, blk['c1'][0], blk['c1'][1], blk['c2'][0], blk['c2'][1], blk['c3'][0], blk['c3'][1])
-            continue
         y = z if z is not None else ops.conv_bn_act(a, blk['c1'][0], blk['c1'][1], 1, 0, True)
         if fuse_tail and nxt is not None:
             # layer 1: 3x3 + conv3 (+ shortcut) + next conv1 in ONE pass over 8 x 8 pixel tiles (ops.bottleneck_block)
@@ -258,7 +254,7 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, com
     main = torch.cuda.current_stream(nodes.device)
     side = _side_stream(nodes.device) if overlap else None
     for i, g in enumerate(pack['graph']):
-        if commute and not ops.graph_message_pass_supported(nodes):
+        if commute:
             # G (f W^T) = (G f) W^T: graph -> P = G f (written once, in the GEMM's operand dtype) -> ONE GEMM whose epilogue
             # applies BatchNorm1d + LeakyReLU + the residual mix. h never exists; f and out cross HBM once each.
             G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
@@ -270,14 +266,6 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, com
         if lp and nodes_lp is None:   # A/B form entered without the pooled bf16 copy: native conversion kernel
             nodes_lp = ops.row_l2_normalize(nodes.view(B * V, C), False, torch.bfloat16).view(B, V, C)
         operand = nodes_lp if lp else nodes
-        if ops.graph_message_pass_supported(nodes):
-            # the whole message-pass unit (Gram -> graph -> G h -> BN -> LeakyReLU -> residual) in one launch
-            h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
-            nodes, nodes_lp, G = ops.graph_message_pass(nodes, h, adj, g['scale'], g['shift'], g['gamma'], g['slope'], g['use_pose'],
-                                                        g['learn_graph'], want_lp=lp and i + 1 < n_layers, want_graph=stages is not None)
-            if stages is not None:
-                stages['G%d' % i] = G
-            continue
         if side is not None:
             ready = torch.cuda.Event()
             ready.record(main)

@@ -126,15 +126,6 @@ int agrl_bottleneck_block(const void* z, const void* w2, const float* b2, const 
                           void* out, const void* w1_next, const float* b1_next, void* z_next, int F, int H, int W,
                           int Cmid, int Cout, int Cnext, agrl_stream_t stream);
 
-/* A whole identity-shortcut Bottleneck on 16 x 8 maps (layer 3 of the 256 x 128 configuration) in ONE pass, one frame per
- * workgroup (bf16; torchreid/models/vmgn.py:45-65 with the three BatchNorms folded):
- *   y1 = relu(x @ w1^T + b1); y2 = relu(conv3x3(y1, w2, pad 1) + b2); out = relu(y2 @ w3^T + b3 + x)
- * x, out (F,16,8,Cin); w1 (Cmid,Cin); w2 (Cmid,3,3,Cmid) OHWI; w3 (Cin,Cmid); biases fp32. y1 / y2 never leave the CU (the
- * frame border is the 3x3 conv's zero padding, so a frame needs no halo), x is read from HBM once and out written once.
- * Built for Cmid = 256, Cin a multiple of 256; other shapes are rejected (the caller runs the three convs separately). */
-int agrl_bottleneck_frame(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3,
-                          const float* b3, void* out, int F, int H, int W, int Cin, int Cmid, agrl_stream_t stream);
-
 /* y = x @ w^T (no bias): x (M,K) in_dtype, w (Nout,K) in_dtype, y (M,Nout) fp32.
  * Replaces GraphLayer's nn.Linear(2048,2048,bias=False), torchreid/models/vmgn.py:148. */
 int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
@@ -206,22 +197,6 @@ int agrl_graph_linear_mix(const void* p_op, const void* w, const float* f, const
 int agrl_graph_propagate(const float* f, const float* h, const float* G, const float* bn_scale,
                          const float* bn_shift, float keep, float gamma, float slope, float* out, void* out_lp,
                          int B, int V, int C, agrl_stream_t stream);
-
-/* The whole message-pass unit of a GraphLayer in ONE launch (everything of torchreid/models/vmgn.py:155-172 but the Linear:
- * Gram -> similarity -> row-L1 normalise -> mix with the pose graph -> G h -> BatchNorm1d(eval) -> LeakyReLU -> residual mix;
- * ganet.py:253-283 with mask_diag = 1, keep = 1): f, h and out cross HBM exactly once. The C / 256 workgroups of a tracklet
- * exchange their partial Gram matrices inside the launch (agent-scope release / acquire through `workspace`), so the entry
- * point sizes the grid to what is resident at once and walks larger batches persistently. Same arithmetic and summation
- * order as agrl_graph_gram (slices of 256 channels) + agrl_graph_finalize + agrl_graph_propagate.
- *   f, h fp32 (B,V,C); adj fp32 (B,V,V) or NULL; out fp32 (B,V,C); out_lp NULL or bf16 copy; G_out NULL or fp32 (B,V,V);
- *   workspace >= agrl_graph_message_pass_workspace(B, V, C) bytes of device memory (zeroed counters are set up inside).
- * Built for V <= 64, V % 4 == 0, C % 256 == 0 (the MARS / PRID clip lengths); other shapes are rejected and the caller uses the
- * three entry points above. */
-size_t agrl_graph_message_pass_workspace(int B, int V, int C);
-int agrl_graph_message_pass(const float* f, const float* h, const float* adj, const float* bn_scale, const float* bn_shift,
-                            float keep, float gamma, float slope, int use_pose, int learn_graph, int mask_diag, float* out,
-                            void* out_lp, float* G_out, void* workspace, size_t workspace_bytes, int B, int V, int C,
-                            agrl_stream_t stream);
 
 /* ---- position-attention part nodes (sibling model ganet) ---------------------------------------------- */
 

@@ -262,40 +262,6 @@ def test_conv_wide_tile_strided(case, tile, monkeypatch):
     assert torch.equal(wide, narrow)
 
 
-@pytest.mark.parametrize("case", [(256, 1024), (3, 1024), (300, 1024), (5, 512), (2, 256)])
-def test_bottleneck_frame_resident(case, monkeypatch):
-    """agrl_bottleneck_frame: a whole identity-shortcut Bottleneck on 16 x 8 frames in one pass (y1 / y2 LDS-resident, three
-    weight matrices streamed) against the fp32 reference with the same bf16 roundings of y1 / y2 as the three separate
-    launches, and against those launches themselves; full layer-3 size (256 frames: one per CU), more frames than CUs (the
-    persistent walk), the frame borders (= the 3x3 conv's zero padding) included by construction."""
-    from torchreid import hip_ops as ops
-    Fr, Cin = case
-    g = torch.Generator().manual_seed(Fr + Cin)
-    x = torch.randn((Fr, Cin, 16, 8), generator=g).relu().bfloat16().float()
-    w1 = (torch.randn((256, Cin, 1, 1), generator=g) / np.sqrt(Cin)).bfloat16().float()
-    w2 = (torch.randn((256, 256, 3, 3), generator=g) / np.sqrt(9 * 256)).bfloat16().float()
-    w3 = (0.5 * torch.randn((Cin, 256, 1, 1), generator=g) / np.sqrt(256)).bfloat16().float()
-    b1, b2, b3 = (0.3 * torch.randn((c,), generator=g) for c in (256, 256, Cin))
-    y1 = F.relu(F.conv2d(x, w1, bias=b1)).bfloat16().float()
-    y2 = F.relu(F.conv2d(y1, w2, bias=b2, padding=1)).bfloat16().float()
-    ref = F.relu(F.conv2d(y2, w3, bias=b3) + x)
-    ohwi = lambda w: w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
-    xd = nhwc(x, torch.bfloat16)
-    args = (xd, ohwi(w1), b1.to(DEV), ohwi(w2), b2.to(DEV), ohwi(w3), b3.to(DEV))
-    assert ops.bottleneck_frame_supported(xd, args[1], args[3], args[5], 1, False, force=True)
-    out = ops.bottleneck_frame(*args)
-    a = ops.conv_bn_act(xd, args[1], args[2], 1, 0, True)
-    a = ops.conv_bn_act(a, args[3], args[4], 1, 1, True)
-    sep = ops.conv_bn_act(a, args[5], args[6], 1, 0, True, residual=xd)
-    again = ops.bottleneck_frame(*args)
-    torch.cuda.synchronize()
-    e, es = rel_err(out.float().permute(0, 3, 1, 2), ref), rel_err(sep.float().permute(0, 3, 1, 2), ref)
-    mism = (out != sep).float().mean().item()
-    print("frame-resident bottleneck", case, "rel err %.3e (three launches %.3e), %.4f %% of the outputs differ from the three launches" % (e, es, 100 * mism))
-    assert e < 6e-3 and torch.equal(out, again)
-    assert rel_err(out.float(), sep.float()) < 1e-2
-
-
 DUAL_CASES = [(256, 16, 8, 1024, 512, 2048), (3, 16, 8, 1024, 512, 2048), (90, 16, 8, 128, 64, 512), (81, 16, 8, 512, 256, 256)]
 
 
@@ -616,48 +582,6 @@ def test_pam_pool(shape, dtype):
     print("pam_pool", shape, dtype, "rel err %.3e (gamma = 0 form %.3e)" % (e, e0))
     assert e < (2e-2 if dtype == torch.bfloat16 else 1e-4) and e0 < 1e-5
     assert torch.equal(xmean, xmean0) and rel_err(nodes_lp.float(), nodes) < 5e-3
-
-
-@pytest.mark.parametrize("cfg", [(3, 56, 2048, True, True, False), (3, 28, 2048, True, False, False), (2, 20, 1024, False, True, False),
-                                 (40, 56, 2048, True, True, False), (3, 64, 512, True, True, False), (3, 56, 2048, True, True, True),
-                                 (300, 8, 256, True, True, False)])
-def test_graph_message_pass_one_launch(cfg):
-    """agrl_graph_message_pass: the whole message-pass unit in ONE launch (the tracklet's C / 256 workgroups exchange their
-    partial Gram matrices inside the launch) against the oracle and against the three-kernel path: a few tracklets, more
-    tracklet groups than the device holds at once (B = 40, 300: the persistent walk), pose-only / learned-only graphs, V = 64
-    (full fragments), and ganet's diagonal-masked form with keep = 1; run twice (the in-launch hand-off must not depend on
-    stale counters) and bitwise repeatable."""
-    from torchreid import hip_ops as ops
-    from recipe import synthetic_adj
-    B, V, C, use_pose, learn_graph, masked = cfg
-    g = torch.Generator().manual_seed(B + V + C)
-    base = torch.rand((B, 1, C), generator=g)
-    f = base + 0.02 * torch.randn((B, V, C), generator=g)
-    adj = synthetic_adj(B, V // 7, seed=V) if V % 7 == 0 else (torch.rand((B, V, V), generator=g) > 0.5).float()
-    W = torch.randn((C, C), generator=g) * 0.02
-    sd = {"gl.linear.weight": W, "gl.bn.weight": 0.8 + 0.4 * torch.rand(C, generator=g), "gl.bn.bias": 0.1 * torch.randn(C, generator=g),
-          "gl.bn.running_mean": 0.1 * torch.randn(C, generator=g), "gl.bn.running_var": 0.5 + torch.rand(C, generator=g)}
-    if masked:
-        ref = O.ganet_graph_layer(f, adj, sd, "gl", use_pose, learn_graph, gamma=0.1)
-        keep = 1.0
-    else:
-        ref = O.graph_layer(f, adj, sd, "gl", use_pose, learn_graph)
-        keep = None
-    fd, adjd = f.to(DEV), adj.to(DEV)
-    h = ops.linear_nobias(fd.view(B * V, C), W.to(DEV)).view(B, V, C)
-    scale = (sd["gl.bn.weight"] / torch.sqrt(sd["gl.bn.running_var"] + 1e-5)).to(DEV)
-    shift = (sd["gl.bn.bias"] - sd["gl.bn.running_mean"] * scale.cpu()).to(DEV)
-    assert ops.graph_message_pass_supported(fd, force=True)
-    out, out_lp, G = ops.graph_message_pass(fd, h, adjd, scale, shift, 0.1, 0.1, use_pose, learn_graph, want_lp=True, keep=keep,
-                                            mask_diag=masked, want_graph=True)
-    out2, _, _ = ops.graph_message_pass(fd, h, adjd, scale, shift, 0.1, 0.1, use_pose, learn_graph, want_lp=False, keep=keep, mask_diag=masked)
-    G3 = ops.graph_matrix(fd, adjd, use_pose, learn_graph, mask_diag=masked)
-    out3, _ = ops.graph_propagate(fd, h, G3, scale, shift, 0.1, 0.1, want_lp=False, keep=keep)
-    torch.cuda.synchronize()
-    e_ref, e3, eG = rel_err(out, ref), rel_err(out, out3), rel_err(G, G3)
-    print("one-launch message pass", cfg, "vs oracle %.2e | vs three kernels: out %.2e G %.2e" % (e_ref, e3, eG))
-    assert torch.equal(out, out2)
-    assert e_ref < 1e-3 and e3 < 1e-5 and eG < 1e-3 and rel_err(out_lp.float(), out) < 5e-3
 
 
 def test_attention_tail():
