@@ -663,6 +663,150 @@ __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const floa
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Graph + P = G f of ONE TRACKLET PER WORKGROUP (many tracklets per GPU: B >= 128, so that one workgroup per tracklet fills
+// the chip): the whole HBM-bound part of the commuted GraphLayer in one launch, no Gram partials and no G round trip.
+//   1  Gram: wave w streams channels [w C/4, (w+1) C/4) of the tracklet's V rows straight into exact-fp32 MFMAs (lane = row
+//      i16 of a 16-row fragment, k-group kg: one 16-byte load per fragment and 16 channels feeds four k-steps of the ten
+//      fragment pairs I <= J); the four wave partials meet in LDS and are added in wave order (deterministic);
+//   2  graph: d2 -> sim -> row-L1 normalise -> mix with the pose graph (graph_finalize_kernel's arithmetic), into LDS;
+//   3  P = G f: the streaming message pass of graph_apply_stream_kernel over the tracklet's channels, 64 per wave and step --
+//      f comes a second time, out of the memory-side cache (458 KB per tracklet, just read).
+// f crosses HBM once per tracklet (V C 4 bytes), P leaves once. The Gram is summed in a different order than the
+// slice-partial form (4 wave partials of C/4 channels, not 16 slices of 128): the graph agrees to fp32 roundoff.
+template <int PS_NT, bool LP>
+__global__ __launch_bounds__(256) void graph_tracklet_kernel(const float* __restrict__ f, const float* __restrict__ adj,
+                                                             float* __restrict__ G_out, float* __restrict__ out, bf16_t* __restrict__ out_lp,
+                                                             int C, int use_pose, int learn_graph, int mask_diag) {
+    constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4, VP = NVF * 16, NPAIR = NVF * (NVF + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    float* s_part = s_mem;                       // [4 waves][NPAIR][64 lanes][4]  (phase 1 -> 2)
+    float* s_gram = s_part + 4 * NPAIR * 256;    // [VP][VP + 1]
+    float* s_G = s_gram + VP * (VP + 1);         // [VP][V]   rows >= V zero
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kg = lane >> 4;
+    const size_t node0 = (size_t)b * V;
+    // ---- 1: Gram partial of this wave's channel quarter
+    if (learn_graph) {
+        f32x4_t acc[NPAIR];
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int cq = C >> 2;
+        const float* base[NVF];
+#pragma unroll
+        for (int I = 0; I < NVF; ++I) base[I] = f + (node0 + min(16 * I + i16, V - 1)) * C + wave * cq + 4 * kg;   // rows >= V: a copy, never used
+        float4 cur[NVF], nxt[NVF];
+#pragma unroll
+        for (int I = 0; I < NVF; ++I) cur[I] = *reinterpret_cast<const float4*>(base[I]);
+        for (int c = 0; c < cq; c += 16) {
+            const int cn = c + 16 < cq ? c + 16 : c;
+#pragma unroll
+            for (int I = 0; I < NVF; ++I) nxt[I] = *reinterpret_cast<const float4*>(base[I] + cn);
+            int q = 0;
+#pragma unroll
+            for (int I = 0; I < NVF; ++I)
+#pragma unroll
+                for (int J = I; J < NVF; ++J, ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].x, cur[J].x, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].y, cur[J].y, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].z, cur[J].z, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].w, cur[J].w, acc[q], 0, 0, 0);
+                }
+#pragma unroll
+            for (int I = 0; I < NVF; ++I) cur[I] = nxt[I];
+        }
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) *reinterpret_cast<f32x4_t*>(s_part + ((wave * NPAIR + q) * 64 + lane) * 4) = acc[q];
+    }
+    __syncthreads();
+    if (learn_graph) {
+        // D of pair (I, J): element r of lane l = Gram[16 I + 4 (l >> 4) + r][16 J + (l & 15)]; thread t adds the four wave
+        // partials of (lane t & 63, r = t >> 6) in wave order and writes both mirror images
+        int q = 0;
+#pragma unroll
+        for (int I = 0; I < NVF; ++I)
+#pragma unroll
+            for (int J = I; J < NVF; ++J, ++q) {
+                const int l = tid & 63, r = tid >> 6;
+                float g = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) g += s_part[((w * NPAIR + q) * 64 + l) * 4 + r];
+                const int row = 16 * I + 4 * (l >> 4) + r, col = 16 * J + (l & 15);
+                s_gram[row * (VP + 1) + col] = g;
+                if (I != J) s_gram[col * (VP + 1) + row] = g;
+            }
+    }
+    __syncthreads();
+    // ---- 2: the graph, one wavefront per row (V <= 64: one column per lane) -- graph_finalize_kernel's arithmetic
+    for (int i = wave; i < VP; i += 4) {
+        float g = 0.f;
+        if (i < V) {
+            const bool live = lane < V;
+            float sim = 0.f, av = 0.f;
+            if (learn_graph && live) {
+                float d2 = (s_gram[lane * (VP + 1) + lane] + s_gram[i * (VP + 1) + i]) - 2.f * s_gram[i * (VP + 1) + lane];
+                d2 = fmaxf(d2, 1e-12f);
+                sim = 2.f / (expf(sqrtf(d2)) + 1.f);
+                if (mask_diag && lane == i) sim = 0.f;
+            }
+            if (use_pose && live) {
+                av = adj[(node0 + i) * V + lane];
+                if (mask_diag && lane == i) av = 0.f;
+            }
+            const float sden = fmaxf(wave_sum(fabsf(sim)), 1e-12f), aden = fmaxf(wave_sum(fabsf(av)), 1e-12f);
+            if (learn_graph) {
+                g = sim / sden;
+                if (use_pose) g = (av / aden + g) / 2.f;
+            } else {
+                g = av / aden;
+            }
+            if (live && G_out) G_out[(node0 + i) * V + lane] = g;
+        }
+        if (lane < V) s_G[i * V + lane] = i < V ? g : 0.f;
+    }
+    __syncthreads();
+    // ---- 3: P = G f, 64 channels per wave and step (the lane <-> channel assignment of graph_apply_stream_kernel)
+    const int sig = 4 * (i16 & 3) + (i16 >> 2);
+    for (int c0 = wave * 64; c0 < C; c0 += 256) {
+        const float* fb = f + node0 * C + c0 + 4 * sig;
+        float4 freg[PS_NT];
+#pragma unroll
+        for (int t = 0; t < PS_NT; ++t) freg[t] = *reinterpret_cast<const float4*>(fb + (size_t)(4 * t + kg) * C);
+        f32x4_t acc[NVF][4];
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[vf][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < PS_NT; ++t) {
+            float gq[NVF];
+#pragma unroll
+            for (int vf = 0; vf < NVF; ++vf) gq[vf] = s_G[(vf * 16 + i16) * V + 4 * t + kg];
+#pragma unroll
+            for (int vf = 0; vf < NVF; ++vf) {
+                acc[vf][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(freg[t].x, gq[vf], acc[vf][0], 0, 0, 0);
+                acc[vf][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(freg[t].y, gq[vf], acc[vf][1], 0, 0, 0);
+                acc[vf][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(freg[t].z, gq[vf], acc[vf][2], 0, 0, 0);
+                acc[vf][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(freg[t].w, gq[vf], acc[vf][3], 0, 0, 0);
+            }
+        }
+        const int cl = c0 + 4 * kg;   // D_j row 4 kg + r = channel c0 + 4 sigma(4 kg + r) + j = cl + 16 r + j
+#pragma unroll
+        for (int vf = 0; vf < NVF; ++vf) {
+            const int v = vf * 16 + i16;
+            if (v >= V) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float o0 = acc[vf][0][r], o1 = acc[vf][1][r], o2 = acc[vf][2][r], o3 = acc[vf][3][r];
+                if constexpr (LP) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                else *reinterpret_cast<float4*>(out + (node0 + v) * C + cl + 16 * r) = make_float4(o0, o1, o2, o3);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Pose adjacency on the device: generate_graph + adj_graph(method 'same'), torchreid/dataset_loader.py:218-388.
 // One workgroup per tracklet. Per frame and body part (head / body / leg keypoint groups) the confident keypoints'
 // y coordinates are bucketed into horizontal stripes (bisect_right on the stripe borders, clamped), the stripes
@@ -788,6 +932,34 @@ extern "C" int agrl_graph_apply(const float* G, const float* f, void* out, int o
     }
 #undef LAUNCH_GA
     AGRL_CHECK_LAUNCH("agrl_graph_apply");
+    return 0;
+}
+
+extern "C" int agrl_graph_tracklet_operand(const float* f, const float* adj, float* G_out, void* out, int out_dtype, int B, int V, int C,
+                                           int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(f && out && (use_pose || learn_graph) && (!use_pose || adj), "agrl_graph_tracklet_operand: bad arguments");
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_graph_tracklet_operand: out dtype must be fp32 or bf16");
+    AGRL_CHECK_ARG(B > 0 && V > 0 && V <= 64 && (V % 4) == 0 && C >= 256 && (C % 256) == 0 && ((((uintptr_t)f | (uintptr_t)out) & 15) == 0),
+                   "agrl_graph_tracklet_operand: built for V <= 64, V %% 4 == 0, C %% 256 == 0, 16-byte aligned f / out (V=%d C=%d)", V, C);
+    const int nvf = (V + 15) / 16, VP = nvf * 16, npair = nvf * (nvf + 1) / 2;
+    const size_t lds = ((size_t)4 * npair * 256 + (size_t)VP * (VP + 1) + (size_t)VP * V) * sizeof(float);
+    const bool lp = out_dtype == AGRL_BF16;
+#define LAUNCH_GT(NT_)                                                                                                          \
+    case NT_: {                                                                                                                 \
+        if (lds > 64 * 1024) {                                                                                                  \
+            if (lp) (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            else (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
+        }                                                                                                                       \
+        if (lp) hipLaunchKernelGGL((graph_tracklet_kernel<NT_, true>), dim3(B), dim3(256), lds, (hipStream_t)stream, f, adj, G_out, nullptr, (bf16_t*)out, C, use_pose, learn_graph, mask_diag); \
+        else hipLaunchKernelGGL((graph_tracklet_kernel<NT_, false>), dim3(B), dim3(256), lds, (hipStream_t)stream, f, adj, G_out, (float*)out, nullptr, C, use_pose, learn_graph, mask_diag);   \
+    } break
+    (void)hipGetLastError();
+    switch (V / 4) {
+        LAUNCH_GT(1); LAUNCH_GT(2); LAUNCH_GT(3); LAUNCH_GT(4); LAUNCH_GT(5); LAUNCH_GT(6); LAUNCH_GT(7); LAUNCH_GT(8);
+        LAUNCH_GT(9); LAUNCH_GT(10); LAUNCH_GT(11); LAUNCH_GT(12); LAUNCH_GT(13); LAUNCH_GT(14); LAUNCH_GT(15); LAUNCH_GT(16);
+    }
+#undef LAUNCH_GT
+    AGRL_CHECK_LAUNCH("agrl_graph_tracklet_operand");
     return 0;
 }
 

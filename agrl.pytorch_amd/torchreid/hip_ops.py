@@ -316,6 +316,33 @@ def graph_apply_operand(G, f, out_dtype):
     return out_lp if out_dtype == torch.bfloat16 else out
 
 
+TRACKLET_FORM_MIN_B = int(os.environ.get('AGRL_HIP_GCN_TRACKLET_MIN_B', '128'))
+
+
+def graph_tracklet_operand_supported(f):
+    """One workgroup per tracklet needs enough tracklets to fill the chip (B >= 128 by default) and the streaming shapes."""
+    B, V, Cc = f.shape
+    return B >= TRACKLET_FORM_MIN_B and V <= 64 and V % 4 == 0 and Cc % 256 == 0
+
+
+def graph_tracklet_operand(f, adj, use_pose, learn_graph, out_dtype, want_graph=False, mask_diag=False):
+    """graph_matrix + graph_apply_operand in one launch, one workgroup per tracklet: -> P = G f (B,V,C) in ``out_dtype``, G (B,V,V) or
+    None. vmgn.py:114-120, :155-168."""
+    B, V, Cc = f.shape
+    assert f.dtype == torch.float32
+    P = torch.empty((B, V, Cc), dtype=out_dtype, device=f.device)
+    G = torch.empty((B, V, V), dtype=torch.float32, device=f.device) if want_graph else None
+    if use_pose:
+        assert adj is not None and tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32
+        adj = adj.contiguous()
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 4.0 * B * V * V * Cc, "bytes": 4.0 * (B * V * Cc + B * V * V) + P.element_size() * B * V * Cc}
+    with _dev(f):
+        call("agrl_graph_tracklet_operand", ptr(f.contiguous()), ptr(adj) if use_pose else None, ptr(G), ptr(P), dtype_code(out_dtype), B, V, Cc,
+             1 if use_pose else 0, 1 if learn_graph else 0, 1 if mask_diag else 0, _stream(f))
+    return P, G
+
+
 def graph_linear_mix(p_op, w, f, bn_scale, bn_shift, gamma, slope, keep=None):
     """out = keep f + gamma lrelu(bn((G f) W^T)): the Linear of a GraphLayer as ONE GEMM over P = G f with BatchNorm1d, LeakyReLU
     and the residual mix in its epilogue (vmgn.py:148, :168-172). p_op (B,V,K) fp32 / bf16, w (N,K) same dtype, f (B,V,N) fp32."""

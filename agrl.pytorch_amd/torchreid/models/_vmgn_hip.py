@@ -257,10 +257,13 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, com
         if commute:
             # G (f W^T) = (G f) W^T: graph -> P = G f (written once, in the GEMM's operand dtype) -> ONE GEMM whose epilogue
             # applies BatchNorm1d + LeakyReLU + the residual mix. h never exists; f and out cross HBM once each.
-            G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+            if ops.graph_tracklet_operand_supported(nodes):   # many tracklets per GPU: one workgroup per tracklet, one launch
+                P, G = ops.graph_tracklet_operand(nodes, adj, g['use_pose'], g['learn_graph'], pack['dtype'], want_graph=stages is not None)
+            else:
+                G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+                P = ops.graph_apply_operand(G, nodes, pack['dtype'])
             if stages is not None:
                 stages['G%d' % i] = G
-            P = ops.graph_apply_operand(G, nodes, pack['dtype'])
             nodes = ops.graph_linear_mix(P, g['w'], nodes, g['scale'], g['shift'], g['gamma'], g['slope'])
             continue
         if lp and nodes_lp is None:   # A/B form entered without the pooled bf16 copy: native conversion kernel

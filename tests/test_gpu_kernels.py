@@ -546,6 +546,35 @@ def test_graph_layer_commuted(shape, mode):
     assert errs["bf16"][0] < 1e-2
 
 
+@pytest.mark.parametrize("cfg", [(5, 56, 2048, True, True, False), (300, 28, 512, True, True, False), (3, 64, 256, False, True, False),
+                                 (4, 20, 1024, True, False, False), (6, 56, 512, True, True, True)])
+def test_graph_tracklet_operand(cfg):
+    """agrl_graph_tracklet_operand (Gram -> graph -> P = G f, one workgroup per tracklet, one launch: the form the model takes at
+    >= 128 tracklets per GPU) against the three-launch form gram + finalize + apply and against the fp64 oracle: graph to fp32
+    roundoff (the Gram is summed in another order), P in fp32 and bf16; more tracklets than CUs, V = 64 (full fragments), V = 20,
+    pose-only / learned-only graphs, ganet's masked diagonal; bitwise repeatable."""
+    from torchreid import hip_ops as ops
+    from recipe import synthetic_adj
+    B, V, C, use_pose, learn_graph, masked = cfg
+    g = torch.Generator().manual_seed(B + V + C)
+    f = torch.rand((B, 1, C), generator=g) + 0.02 * torch.randn((B, V, C), generator=g)
+    adj = synthetic_adj(B, V // 7, seed=V) if V % 7 == 0 else (torch.rand((B, V, V), generator=g) > 0.5).float()
+    fd, adjd = f.to(DEV), adj.to(DEV)
+    G3 = ops.graph_matrix(fd, adjd, use_pose, learn_graph, mask_diag=masked)
+    P3 = ops.graph_apply_operand(G3, fd, torch.float32)
+    P, G = ops.graph_tracklet_operand(fd, adjd, use_pose, learn_graph, torch.float32, want_graph=True, mask_diag=masked)
+    P2, _ = ops.graph_tracklet_operand(fd, adjd, use_pose, learn_graph, torch.float32, mask_diag=masked)
+    Plp, _ = ops.graph_tracklet_operand(fd, adjd, use_pose, learn_graph, torch.bfloat16, mask_diag=masked)
+    torch.cuda.synchronize()
+    if not masked:
+        G64 = O.graph_matrix(f.double(), adj.double(), use_pose, learn_graph)
+        assert rel_err(G, G64) < 5e-4 and rel_err(P, torch.bmm(G64, f.double())) < 1e-5
+    eG, eP = rel_err(G, G3), rel_err(P, P3)
+    print("tracklet form", cfg, "G vs three-launch form %.2e, P %.2e" % (eG, eP))
+    assert eG < (5e-4 if learn_graph else 1e-7) and eP < 1e-5
+    assert torch.equal(P, P2) and rel_err(Plp.float(), P) < 5e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(5, 16, 8, 256, 32, [4, 2, 1]), (3, 12, 8, 512, 64, [4, 2, 1]), (2, 16, 8, 128, 32, [2]), (2, 6, 4, 64, 32, [4])])
 def test_pam_pool(shape, dtype):

@@ -31,13 +31,19 @@ def new():
     return ops.graph_linear_mix(P, w, f, sc, sh, 0.1, 0.1)
 
 
+def tracklet():
+    P, _ = ops.graph_tracklet_operand(f, adj, True, True, dt)
+    return ops.graph_linear_mix(P, w, f, sc, sh, 0.1, 0.1)
+
+
 with ops.f32_split(prec == "bf16x3"):
     a, b = old(), new()
+    print("tracklet form vs three-launch form: %.2e" % ((tracklet() - b).abs().max() / b.abs().max()).item())
     torch.cuda.synchronize()
     print("max rel difference between the two orders: %.2e" % ((a - b).abs().max() / a.abs().max()).item())
-    times = {"Linear -> message pass": [], "(G f) W^T, fused epilogue": []}
+    times = {"Linear -> message pass": [], "(G f) W^T, fused epilogue": [], "(G f) W^T, graph + G f per tracklet": []}
     for rnd in range(10):
-        for name, fn in (("Linear -> message pass", old), ("(G f) W^T, fused epilogue", new)):
+        for name, fn in (("Linear -> message pass", old), ("(G f) W^T, fused epilogue", new), ("(G f) W^T, graph + G f per tracklet", tracklet)):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(20):
@@ -48,4 +54,4 @@ with ops.f32_split(prec == "bf16x3"):
                 times[name].append(s.elapsed_time(e) * 50)
 for k, v in times.items():
     t = statistics.median(v)
-    print("B=%d V=%d C=%d %s  %-28s %7.1f us per layer  %6.1f TFLOP/s of the Linear's %.1f GFLOP" % (B, V, C, prec, k, t, 2.0 * B * V * C * C / t / 1e6, 2.0 * B * V * C * C / 1e9))
+    print("B=%d V=%d C=%d %s  %-38s %7.1f us per layer  %6.1f TFLOP/s of the Linear's %.1f GFLOP" % (B, V, C, prec, k, t, 2.0 * B * V * C * C / t / 1e6, 2.0 * B * V * C * C / 1e9))
