@@ -673,73 +673,83 @@ __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const floa
 //      f comes a second time, out of the memory-side cache (458 KB per tracklet, just read).
 // f crosses HBM once per tracklet (V C 4 bytes), P leaves once. The Gram is summed in a different order than the
 // slice-partial form (4 wave partials of C/4 channels, not 16 slices of 128): the graph agrees to fp32 roundoff.
+constexpr int GT_WAVES = 8;   // two waves per SIMD: one wave's exact-fp32 MFMA chain covers the other's memory latency
 template <int PS_NT, bool LP>
-__global__ __launch_bounds__(256) void graph_tracklet_kernel(const float* __restrict__ f, const float* __restrict__ adj,
-                                                             float* __restrict__ G_out, float* __restrict__ out, bf16_t* __restrict__ out_lp,
-                                                             int C, int use_pose, int learn_graph, int mask_diag) {
-    constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4, VP = NVF * 16, NPAIR = NVF * (NVF + 1) / 2;
+__global__ __launch_bounds__(64 * GT_WAVES) void graph_tracklet_kernel(const float* __restrict__ f, const float* __restrict__ adj,
+                                                                       float* __restrict__ G_out, float* __restrict__ out, bf16_t* __restrict__ out_lp,
+                                                                       int C, int use_pose, int learn_graph, int mask_diag) {
+    constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4, VP = NVF * 16, NPAIR = NVF * (NVF + 1) / 2, NT = 64 * GT_WAVES;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
-    float* s_part = s_mem;                       // [4 waves][NPAIR][64 lanes][4]  (phase 1 -> 2)
-    float* s_gram = s_part + 4 * NPAIR * 256;    // [VP][VP + 1]
-    float* s_G = s_gram + VP * (VP + 1);         // [VP][V]   rows >= V zero
+    float* s_part = s_mem;                              // [GT_WAVES][NPAIR][64 lanes][4]  (phase 1 -> 2)
+    float* s_gram = s_part + GT_WAVES * NPAIR * 256;    // [VP][VP + 1]
+    float* s_G = s_gram + VP * (VP + 1);                // [VP][V]   rows >= V zero
     const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kg = lane >> 4;
     const size_t node0 = (size_t)b * V;
-    // ---- 1: Gram partial of this wave's channel quarter
+    // ---- 1: Gram partial of this wave's channel slice (C / GT_WAVES channels), loads two 16-channel steps ahead
     if (learn_graph) {
         f32x4_t acc[NPAIR];
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) acc[q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const int cq = C >> 2;
+        const int cq = C / GT_WAVES;
         const float* base[NVF];
 #pragma unroll
         for (int I = 0; I < NVF; ++I) base[I] = f + (node0 + min(16 * I + i16, V - 1)) * C + wave * cq + 4 * kg;   // rows >= V: a copy, never used
-        float4 cur[NVF], nxt[NVF];
+        float4 cur[NVF], nx1[NVF], nx2[NVF];
 #pragma unroll
-        for (int I = 0; I < NVF; ++I) cur[I] = *reinterpret_cast<const float4*>(base[I]);
+        for (int I = 0; I < NVF; ++I) {
+            cur[I] = *reinterpret_cast<const float4*>(base[I]);
+            nx1[I] = *reinterpret_cast<const float4*>(base[I] + (16 < cq ? 16 : 0));
+        }
         for (int c = 0; c < cq; c += 16) {
-            const int cn = c + 16 < cq ? c + 16 : c;
+            const int c2 = c + 32 < cq ? c + 32 : c;
 #pragma unroll
-            for (int I = 0; I < NVF; ++I) nxt[I] = *reinterpret_cast<const float4*>(base[I] + cn);
-            int q = 0;
+            for (int I = 0; I < NVF; ++I) nx2[I] = *reinterpret_cast<const float4*>(base[I] + c2);
+            // k-step outermost: consecutive MFMAs go to different accumulators (a dependent v_mfma_f32_16x16x4_f32 waits 40
+            // cycles, an independent one issues after 32)
 #pragma unroll
-            for (int I = 0; I < NVF; ++I)
+            for (int e = 0; e < 4; ++e) {
+                int q = 0;
 #pragma unroll
-                for (int J = I; J < NVF; ++J, ++q) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].x, cur[J].x, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].y, cur[J].y, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].z, cur[J].z, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[I].w, cur[J].w, acc[q], 0, 0, 0);
-                }
+                for (int I = 0; I < NVF; ++I)
 #pragma unroll
-            for (int I = 0; I < NVF; ++I) cur[I] = nxt[I];
+                    for (int J = I; J < NVF; ++J, ++q) {
+                        const float a = e == 0 ? cur[I].x : e == 1 ? cur[I].y : e == 2 ? cur[I].z : cur[I].w;
+                        const float bb = e == 0 ? cur[J].x : e == 1 ? cur[J].y : e == 2 ? cur[J].z : cur[J].w;
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[q], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int I = 0; I < NVF; ++I) {
+                cur[I] = nx1[I];
+                nx1[I] = nx2[I];
+            }
         }
 #pragma unroll
         for (int q = 0; q < NPAIR; ++q) *reinterpret_cast<f32x4_t*>(s_part + ((wave * NPAIR + q) * 64 + lane) * 4) = acc[q];
     }
     __syncthreads();
     if (learn_graph) {
-        // D of pair (I, J): element r of lane l = Gram[16 I + 4 (l >> 4) + r][16 J + (l & 15)]; thread t adds the four wave
-        // partials of (lane t & 63, r = t >> 6) in wave order and writes both mirror images
-        int q = 0;
+        // D of pair (I, J): element r of lane l = Gram[16 I + 4 (l >> 4) + r][16 J + (l & 15)]; a thread adds the wave partials
+        // of its (pair, lane, r) in wave order and writes both mirror images
+        for (int e = tid; e < NPAIR * 256; e += NT) {
+            const int q = e >> 8, l = e & 63, r = (e >> 6) & 3;
+            float g = 0.f;
 #pragma unroll
-        for (int I = 0; I < NVF; ++I)
-#pragma unroll
-            for (int J = I; J < NVF; ++J, ++q) {
-                const int l = tid & 63, r = tid >> 6;
-                float g = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) g += s_part[((w * NPAIR + q) * 64 + l) * 4 + r];
-                const int row = 16 * I + 4 * (l >> 4) + r, col = 16 * J + (l & 15);
-                s_gram[row * (VP + 1) + col] = g;
-                if (I != J) s_gram[col * (VP + 1) + row] = g;
-            }
+            for (int w = 0; w < GT_WAVES; ++w) g += s_part[((w * NPAIR + q) * 64 + l) * 4 + r];
+            int I = 0, rem = q;   // q -> (I, J), I <= J, row-major over the upper triangle
+            while (rem >= NVF - I) { rem -= NVF - I; ++I; }
+            const int J = I + rem;
+            const int row = 16 * I + 4 * (l >> 4) + r, col = 16 * J + (l & 15);
+            s_gram[row * (VP + 1) + col] = g;
+            if (I != J) s_gram[col * (VP + 1) + row] = g;
+        }
     }
     __syncthreads();
     // ---- 2: the graph, one wavefront per row (V <= 64: one column per lane) -- graph_finalize_kernel's arithmetic
-    for (int i = wave; i < VP; i += 4) {
+    for (int i = wave; i < VP; i += GT_WAVES) {
         float g = 0.f;
         if (i < V) {
             const bool live = lane < V;
@@ -766,13 +776,20 @@ __global__ __launch_bounds__(256) void graph_tracklet_kernel(const float* __rest
         if (lane < V) s_G[i * V + lane] = i < V ? g : 0.f;
     }
     __syncthreads();
-    // ---- 3: P = G f, 64 channels per wave and step (the lane <-> channel assignment of graph_apply_stream_kernel)
+    // ---- 3: P = G f, 64 channels per wave and step (the lane <-> channel assignment of graph_apply_stream_kernel); the next
+    // step's rows are requested before this step's MFMAs
     const int sig = 4 * (i16 & 3) + (i16 >> 2);
-    for (int c0 = wave * 64; c0 < C; c0 += 256) {
-        const float* fb = f + node0 * C + c0 + 4 * sig;
-        float4 freg[PS_NT];
+    const float* fb = f + node0 * C + 4 * sig + (size_t)kg * C;
+    float4 freg[PS_NT], fnext[PS_NT];
+    int c0 = wave * 64;
+    if (c0 < C) {
 #pragma unroll
-        for (int t = 0; t < PS_NT; ++t) freg[t] = *reinterpret_cast<const float4*>(fb + (size_t)(4 * t + kg) * C);
+        for (int t = 0; t < PS_NT; ++t) freg[t] = *reinterpret_cast<const float4*>(fb + c0 + (size_t)(4 * t) * C);
+    }
+    for (; c0 < C; c0 += 64 * GT_WAVES) {
+        const int cn = c0 + 64 * GT_WAVES < C ? c0 + 64 * GT_WAVES : c0;
+#pragma unroll
+        for (int t = 0; t < PS_NT; ++t) fnext[t] = *reinterpret_cast<const float4*>(fb + cn + (size_t)(4 * t) * C);
         f32x4_t acc[NVF][4];
 #pragma unroll
         for (int vf = 0; vf < NVF; ++vf)
@@ -803,6 +820,8 @@ __global__ __launch_bounds__(256) void graph_tracklet_kernel(const float* __rest
                 else *reinterpret_cast<float4*>(out + (node0 + v) * C + cl + 16 * r) = make_float4(o0, o1, o2, o3);
             }
         }
+#pragma unroll
+        for (int t = 0; t < PS_NT; ++t) freg[t] = fnext[t];
     }
 }
 
@@ -939,10 +958,10 @@ extern "C" int agrl_graph_tracklet_operand(const float* f, const float* adj, flo
                                            int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream) {
     AGRL_CHECK_ARG(f && out && (use_pose || learn_graph) && (!use_pose || adj), "agrl_graph_tracklet_operand: bad arguments");
     AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_graph_tracklet_operand: out dtype must be fp32 or bf16");
-    AGRL_CHECK_ARG(B > 0 && V > 0 && V <= 64 && (V % 4) == 0 && C >= 256 && (C % 256) == 0 && ((((uintptr_t)f | (uintptr_t)out) & 15) == 0),
-                   "agrl_graph_tracklet_operand: built for V <= 64, V %% 4 == 0, C %% 256 == 0, 16-byte aligned f / out (V=%d C=%d)", V, C);
+    AGRL_CHECK_ARG(B > 0 && V > 0 && V <= 64 && (V % 4) == 0 && C >= 512 && (C % 512) == 0 && ((((uintptr_t)f | (uintptr_t)out) & 15) == 0),
+                   "agrl_graph_tracklet_operand: built for V <= 64, V %% 4 == 0, C %% 512 == 0, 16-byte aligned f / out (V=%d C=%d)", V, C);
     const int nvf = (V + 15) / 16, VP = nvf * 16, npair = nvf * (nvf + 1) / 2;
-    const size_t lds = ((size_t)4 * npair * 256 + (size_t)VP * (VP + 1) + (size_t)VP * V) * sizeof(float);
+    const size_t lds = ((size_t)GT_WAVES * npair * 256 + (size_t)VP * (VP + 1) + (size_t)VP * V) * sizeof(float);
     const bool lp = out_dtype == AGRL_BF16;
 #define LAUNCH_GT(NT_)                                                                                                          \
     case NT_: {                                                                                                                 \
@@ -950,8 +969,8 @@ extern "C" int agrl_graph_tracklet_operand(const float* f, const float* adj, flo
             if (lp) (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             else (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
         }                                                                                                                       \
-        if (lp) hipLaunchKernelGGL((graph_tracklet_kernel<NT_, true>), dim3(B), dim3(256), lds, (hipStream_t)stream, f, adj, G_out, nullptr, (bf16_t*)out, C, use_pose, learn_graph, mask_diag); \
-        else hipLaunchKernelGGL((graph_tracklet_kernel<NT_, false>), dim3(B), dim3(256), lds, (hipStream_t)stream, f, adj, G_out, (float*)out, nullptr, C, use_pose, learn_graph, mask_diag);   \
+        if (lp) hipLaunchKernelGGL((graph_tracklet_kernel<NT_, true>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj, G_out, nullptr, (bf16_t*)out, C, use_pose, learn_graph, mask_diag); \
+        else hipLaunchKernelGGL((graph_tracklet_kernel<NT_, false>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj, G_out, (float*)out, nullptr, C, use_pose, learn_graph, mask_diag);   \
     } break
     (void)hipGetLastError();
     switch (V / 4) {

@@ -185,9 +185,9 @@ int agrl_graph_finalize(const float* gram_part, int nz, const float* adj, float*
  *                         Nout % 4 == 0. The workgroup -> tile map keeps each XCD on its own slice of W (L2-resident). */
 int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, int B, int V, int C, agrl_stream_t stream);
 /* agrl_graph_gram + agrl_graph_finalize + agrl_graph_apply for MANY tracklets per GPU, one workgroup per tracklet (use it when
- * B >= ~128, so that B workgroups fill the chip): Gram (exact fp32 MFMA) -> similarity -> row-L1 normalise -> mix with the pose
+ * B >= ~224, so that B workgroups fill the 256 CUs): Gram (exact fp32 MFMA) -> similarity -> row-L1 normalise -> mix with the pose
  * graph -> P = G f in out_dtype, in ONE launch; f crosses HBM once, no Gram partials, G leaves only if G_out != NULL
- * (torchreid/models/vmgn.py:114-120, :155-168). V <= 64, V % 4 == 0, C % 256 == 0. The Gram is summed as four wave partials of C / 4
+ * (torchreid/models/vmgn.py:114-120, :155-168). V <= 64, V % 4 == 0, C % 512 == 0. The Gram is summed as eight wave partials of C / 8
  * channels (the slice-partial form: sixteen of 128): the graph agrees with agrl_graph_finalize's to fp32 roundoff, not bitwise. */
 int agrl_graph_tracklet_operand(const float* f, const float* adj, float* G_out, void* out, int out_dtype, int B, int V, int C,
                                 int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream);
