@@ -798,7 +798,7 @@ def main():
         # HBM traffic per launch: NOT measured in this run -- PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command, tools/collect_profiles.sh) are committed under profiles/ and quoted with their source
         traffic = fam_traffic = traffic_src = None
-        for tname in ("traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:

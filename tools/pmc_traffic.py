@@ -5,7 +5,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB (x1024); on gfx950 FETCH_SIZE counts 128-byte
 coalesced reads (MI355X_MICROARCH.md, HBM section) -> the read side is doubled."""
 import csv, json, sys, collections
 fetch_csv, write_csv, steps, prec = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r02.json"
+out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r03.json"
 def load(path, counter):
     per = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(path)):
@@ -25,7 +25,7 @@ launches = fi[1]
 fetch_b = fi[0] * 1024 * 2.0   # gfx950 correction for wide coalesced reads
 write_b = wi[0] * 1024
 extra = {}
-for k in ("graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel"):
+for k in ("graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "graph_apply_stream_kernel", "graph_tracklet_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel", "rank_topk_fast_kernel"):
     for kk in f:
         if k in kk and not (k == "conv3x3_wide_kernel" and kk != k):
             extra[k] = {"fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
