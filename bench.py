@@ -867,7 +867,7 @@ def main():
             finalize + G f: read f, read adj, write the GEMM operand) is reported against the 8 TB/s roofline and against the
             chip's own one-pass read rate at that byte count. Round-1/2 form (AGRL_HIP_GCN_COMMUTE=0): the SURVEY's unfused
             message-pass unit (1.389 MB per tracklet-layer over gram + finalize + propagate)."""
-            names_new = [n for n in ("agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_apply", "agrl_graph_linear_mix") if n in agg_]
+            names_new = [n for n in ("agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_apply", "agrl_graph_tracklet_operand", "agrl_graph_linear_mix") if n in agg_]
             names_old = [n for n in ("agrl_graph_message_pass", "agrl_graph_gram", "agrl_graph_finalize", "agrl_graph_propagate") if n in agg_]
             out_ = {}
             if "agrl_graph_linear_mix" in agg_:

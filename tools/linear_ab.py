@@ -20,7 +20,9 @@ flp = f.bfloat16()
 w = (torch.randn((C, C), device=dev) * 0.01).bfloat16()
 w32 = w.float()
 adj = (torch.rand((B, V, V), device=dev) > 0.5).float()
-CASES = [("linear bf16 1792x2048x2048", lambda: ops.linear_nobias(flp.view(B * V, C), w), 2.0 * B * V * C * C),
+sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
+CASES = [("graph_linear_mix bf16 1792x2048x2048", lambda: ops.graph_linear_mix(flp, w, f, sc, sh, 0.1, 0.1), 2.0 * B * V * C * C),
+         ("linear bf16 1792x2048x2048", lambda: ops.linear_nobias(flp.view(B * V, C), w), 2.0 * B * V * C * C),
          ("linear fp32 1792x2048x2048", lambda: ops.linear_nobias(f.view(B * V, C), w32), 2.0 * B * V * C * C),
          ("graph_matrix (gram + finalize)", lambda: ops.graph_matrix(f, adj, True, True), 2.0 * B * V * V * C)]
 for label, fn, flops in CASES:

@@ -5,11 +5,11 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/pmcfull_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $out/a -o a --output-format csv -- python3 tools/conv_one.py "$@" > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_MISC -d $out/b -o b --output-format csv -- python3 tools/conv_one.py "$@" > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/c -o c --output-format csv -- python3 tools/conv_one.py "$@" > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/d -o d --output-format csv -- python3 tools/conv_one.py "$@" > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $out/e -o e --output-format csv -- python3 tools/conv_one.py "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $out/a -o a --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_MISC -d $out/b -o b --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/c -o c --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/d -o d --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $out/e -o e --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
 python3 - $out "$tag" "$*" > gpurun_out/pmc_$tag.txt <<'PY'
 import csv, sys, glob, collections
 out, tag, args = sys.argv[1], sys.argv[2], sys.argv[3]
