@@ -96,8 +96,16 @@ __device__ inline float zsum(const float* p, int nz, int zstride) {
 // Finalize. grid = (B, ceil(V/4)), 256 threads: one wavefront per graph row, so B*V/4 workgroups are in
 // flight and every row's loads are independent (the first version, one workgroup per tracklet walking its
 // rows, was latency-bound at ~70 us).
+// adjacency entry (i, j) of tracklet b from the fp32 (B,V,V) tensor of the reference's loader or from the bit-packed form
+// (B, V, ceil(V/32)) uint32 words, bit j & 31 of word j >> 5 of row i (agrl_pose_adjacency_bits / agrl_adjacency_pack)
+__device__ inline float adj_at(const float* __restrict__ adj, const uint32_t* __restrict__ bits, size_t row, int V, int j) {
+    if (bits) return (float)((bits[row * ((V + 31) >> 5) + (j >> 5)] >> (j & 31)) & 1u);
+    return adj[row * V + j];
+}
+
 __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __restrict__ gram_part, int nz,
-                                                             const float* __restrict__ adj, float* __restrict__ G,
+                                                             const float* __restrict__ adj, const uint32_t* __restrict__ adj_bits,
+                                                             float* __restrict__ G,
                                                              int V, int use_pose, int learn_graph, int mask_diag) {
     extern __shared__ __attribute__((aligned(16))) float s_n[];  // V squared norms (Gram diagonal)
     const int b = blockIdx.x;
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void graph_finalize_kernel(const float* __rest
                 ssum += fabsf(sim[q]);
             }
             if (use_pose) {
-                av[q] = adj[((size_t)b * V + i) * V + j];
+                av[q] = adj_at(adj, adj_bits, (size_t)b * V + i, V, j);
                 if (mask_diag && j == i) av[q] = 0.f;
                 asum += fabsf(av[q]);
             }
@@ -676,7 +684,7 @@ __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const floa
 constexpr int GT_WAVES = 8;   // two waves per SIMD: one wave's exact-fp32 MFMA chain covers the other's memory latency
 template <int PS_NT, bool LP>
 __global__ __launch_bounds__(64 * GT_WAVES) void graph_tracklet_kernel(const float* __restrict__ f, const float* __restrict__ adj,
-                                                                       float* __restrict__ G_out, float* __restrict__ out, bf16_t* __restrict__ out_lp,
+                                                                       const uint32_t* __restrict__ adj_bits, float* __restrict__ G_out, float* __restrict__ out, bf16_t* __restrict__ out_lp,
                                                                        int C, int use_pose, int learn_graph, int mask_diag) {
     constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4, VP = NVF * 16, NPAIR = NVF * (NVF + 1) / 2, NT = 64 * GT_WAVES;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
@@ -761,7 +769,7 @@ __global__ __launch_bounds__(64 * GT_WAVES) void graph_tracklet_kernel(const flo
                 if (mask_diag && lane == i) sim = 0.f;
             }
             if (use_pose && live) {
-                av = adj[(node0 + i) * V + lane];
+                av = adj_at(adj, adj_bits, node0 + i, V, lane);
                 if (mask_diag && lane == i) av = 0.f;
             }
             const float sden = fmaxf(wave_sum(fabsf(sim)), 1e-12f), aden = fmaxf(wave_sum(fabsf(av)), 1e-12f);
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(64 * GT_WAVES) void graph_tracklet_kernel(const flo
 // (frame, part). adj[i][j] = 1 iff i != j and some part marks both nodes. Borders are evaluated in fp64 exactly as
 // numpy's arange(0, height + 1, height / num_split) does.
 __global__ __launch_bounds__(256) void pose_adjacency_kernel(const float* __restrict__ poses, const unsigned char* __restrict__ detected,
-                                                             float* __restrict__ adj, int S, int num_split, int levels,
+                                                             float* __restrict__ adj, uint32_t* __restrict__ adj_bits, int S, int num_split, int levels,
                                                              int pyramid, int P, double height, float threshold) {
     __shared__ unsigned s_mask[3 * 64];  // [frame][part] node bitmask (P <= 31), S <= 64
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -875,9 +883,7 @@ __global__ __launch_bounds__(256) void pose_adjacency_kernel(const float* __rest
         s_mask[tid] = mask;
     }
     __syncthreads();
-    float* ab = adj + (size_t)b * V * V;
-    for (int e = tid; e < V * V; e += 256) {
-        const int i = e / V, j = e - i * V;
+    auto edge = [&](int i, int j) {
         const int ti = i / P, pi = i - ti * P, tj = j / P, pj = j - tj * P;
         bool on = false;
         if (i != j) {
@@ -885,7 +891,42 @@ __global__ __launch_bounds__(256) void pose_adjacency_kernel(const float* __rest
             for (int part = 0; part < 3; ++part)
                 on = on || (((s_mask[ti * 3 + part] >> pi) & 1u) && ((s_mask[tj * 3 + part] >> pj) & 1u));
         }
-        ab[e] = on ? 1.f : 0.f;
+        return on;
+    };
+    if (adj) {
+        float* ab = adj + (size_t)b * V * V;
+        for (int e = tid; e < V * V; e += 256) {
+            const int i = e / V, j = e - i * V;
+            ab[e] = edge(i, j) ? 1.f : 0.f;
+        }
+    }
+    if (adj_bits) {   // bit j & 31 of word j >> 5 of row i: 56 x 56 nodes = 448 bytes instead of 12.5 KB
+        const int W = (V + 31) >> 5;
+        uint32_t* bb = adj_bits + (size_t)b * V * W;
+        for (int e = tid; e < V * W; e += 256) {
+            const int i = e / W, w = e - i * W;
+            uint32_t word = 0;
+            for (int q = 0; q < 32; ++q) {
+                const int j = 32 * w + q;
+                if (j < V && edge(i, j)) word |= 1u << q;
+            }
+            bb[e] = word;
+        }
+    }
+}
+
+// fp32 {0, 1} adjacency (B,V,V) (what the reference's loader produces, dataset_loader.py:345-388) -> the bit-packed form
+__global__ __launch_bounds__(256) void adjacency_pack_kernel(const float* __restrict__ adj, uint32_t* __restrict__ bits, int V, size_t total_words) {
+    const int W = (V + 31) >> 5;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total_words; e += (size_t)gridDim.x * 256) {
+        const size_t row = e / W;
+        const int w = (int)(e - row * W);
+        uint32_t word = 0;
+        for (int q = 0; q < 32; ++q) {
+            const int j = 32 * w + q;
+            if (j < V && adj[row * V + j] != 0.f) word |= 1u << q;
+        }
+        bits[e] = word;
     }
 }
 
@@ -917,8 +958,21 @@ extern "C" int agrl_graph_finalize(const float* gram_part, int nz, const float* 
     AGRL_CHECK_ARG(!learn_graph || (gram_part && nz > 0), "agrl_graph_finalize: learn_graph needs the Gram partials");
     AGRL_CHECK_ARG(V <= 256, "agrl_graph_finalize: V=%d > 256 not supported", V);
     hipLaunchKernelGGL(graph_finalize_kernel, dim3(B, cdiv(V, 4)), dim3(256), (size_t)V * sizeof(float),
-                       (hipStream_t)stream, gram_part, nz, adj, G, V, use_pose, learn_graph, mask_diag);
+                       (hipStream_t)stream, gram_part, nz, adj, (const uint32_t*)nullptr, G, V, use_pose, learn_graph, mask_diag);
     AGRL_CHECK_LAUNCH("agrl_graph_finalize");
+    return 0;
+}
+
+extern "C" int agrl_graph_finalize_bits(const float* gram_part, int nz, const uint32_t* adj_bits, float* G, int B, int V,
+                                        int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(G && B > 0 && V > 0, "agrl_graph_finalize_bits: bad arguments");
+    AGRL_CHECK_ARG(use_pose || learn_graph, "agrl_graph_finalize_bits: use_pose or learn_graph must be set");
+    AGRL_CHECK_ARG(!use_pose || adj_bits, "agrl_graph_finalize_bits: use_pose needs the packed adjacency");
+    AGRL_CHECK_ARG(!learn_graph || (gram_part && nz > 0), "agrl_graph_finalize_bits: learn_graph needs the Gram partials");
+    AGRL_CHECK_ARG(V <= 256, "agrl_graph_finalize_bits: V=%d > 256 not supported", V);
+    hipLaunchKernelGGL(graph_finalize_kernel, dim3(B, cdiv(V, 4)), dim3(256), (size_t)V * sizeof(float),
+                       (hipStream_t)stream, gram_part, nz, (const float*)nullptr, adj_bits, G, V, use_pose, learn_graph, mask_diag);
+    AGRL_CHECK_LAUNCH("agrl_graph_finalize_bits");
     return 0;
 }
 
@@ -954,8 +1008,10 @@ extern "C" int agrl_graph_apply(const float* G, const float* f, void* out, int o
     return 0;
 }
 
-extern "C" int agrl_graph_tracklet_operand(const float* f, const float* adj, float* G_out, void* out, int out_dtype, int B, int V, int C,
-                                           int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream) {
+extern "C" int agrl_graph_tracklet_operand(const float* f, const void* adj, int adj_packed, float* G_out, void* out, int out_dtype, int B, int V,
+                                           int C, int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream) {
+    const float* adj_f = adj_packed ? nullptr : (const float*)adj;
+    const uint32_t* adj_b = adj_packed ? (const uint32_t*)adj : nullptr;
     AGRL_CHECK_ARG(f && out && (use_pose || learn_graph) && (!use_pose || adj), "agrl_graph_tracklet_operand: bad arguments");
     AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_graph_tracklet_operand: out dtype must be fp32 or bf16");
     AGRL_CHECK_ARG(B > 0 && V > 0 && V <= 64 && (V % 4) == 0 && C >= 512 && (C % 512) == 0 && ((((uintptr_t)f | (uintptr_t)out) & 15) == 0),
@@ -969,8 +1025,8 @@ extern "C" int agrl_graph_tracklet_operand(const float* f, const float* adj, flo
             if (lp) (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             else (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
         }                                                                                                                       \
-        if (lp) hipLaunchKernelGGL((graph_tracklet_kernel<NT_, true>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj, G_out, nullptr, (bf16_t*)out, C, use_pose, learn_graph, mask_diag); \
-        else hipLaunchKernelGGL((graph_tracklet_kernel<NT_, false>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj, G_out, (float*)out, nullptr, C, use_pose, learn_graph, mask_diag);   \
+        if (lp) hipLaunchKernelGGL((graph_tracklet_kernel<NT_, true>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj_f, adj_b, G_out, nullptr, (bf16_t*)out, C, use_pose, learn_graph, mask_diag); \
+        else hipLaunchKernelGGL((graph_tracklet_kernel<NT_, false>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj_f, adj_b, G_out, (float*)out, nullptr, C, use_pose, learn_graph, mask_diag);   \
     } break
     (void)hipGetLastError();
     switch (V / 4) {
@@ -1077,8 +1133,32 @@ extern "C" int agrl_pose_adjacency(const float* poses, const unsigned char* dete
     int levels = 0;
     while ((1 << levels) < num_split) ++levels;
     const int P = pyramid_part ? 2 * num_split - 1 : num_split;
-    hipLaunchKernelGGL(pose_adjacency_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, poses, detected, adj, S, num_split, levels,
-                       pyramid_part ? 1 : 0, P, (double)height, threshold);
+    hipLaunchKernelGGL(pose_adjacency_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, poses, detected, adj, (uint32_t*)nullptr, S, num_split,
+                       levels, pyramid_part ? 1 : 0, P, (double)height, threshold);
     AGRL_CHECK_LAUNCH("agrl_pose_adjacency");
+    return 0;
+}
+
+extern "C" int agrl_pose_adjacency_bits(const float* poses, const unsigned char* detected, uint32_t* adj_bits, int B, int S, int num_split,
+                                        int pyramid_part, float height, float threshold, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(poses && detected && adj_bits, "agrl_pose_adjacency_bits: null pointer");
+    AGRL_CHECK_ARG(B > 0 && S > 0 && S <= 64, "agrl_pose_adjacency_bits: 1 <= S <= 64 frames (got %d)", S);
+    AGRL_CHECK_ARG(num_split >= 1 && num_split <= 16 && (num_split & (num_split - 1)) == 0,
+                   "agrl_pose_adjacency_bits: num_split must be a power of two <= 16 (got %d)", num_split);
+    int levels = 0;
+    while ((1 << levels) < num_split) ++levels;
+    const int P = pyramid_part ? 2 * num_split - 1 : num_split;
+    hipLaunchKernelGGL(pose_adjacency_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, poses, detected, (float*)nullptr, adj_bits, S, num_split,
+                       levels, pyramid_part ? 1 : 0, P, (double)height, threshold);
+    AGRL_CHECK_LAUNCH("agrl_pose_adjacency_bits");
+    return 0;
+}
+
+extern "C" int agrl_adjacency_pack(const float* adj, uint32_t* adj_bits, int B, int V, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(adj && adj_bits && B > 0 && V > 0, "agrl_adjacency_pack: bad arguments");
+    const size_t total = (size_t)B * V * ((V + 31) >> 5);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adjacency_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, adj, adj_bits, V, total);
+    AGRL_CHECK_LAUNCH("agrl_adjacency_pack");
     return 0;
 }

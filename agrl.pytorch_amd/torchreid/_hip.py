@@ -57,7 +57,10 @@ SIGNATURES = {
     "agrl_pam_pool": [_p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_pam_combine": [_p, _p, _p, _f, _p, _p, _i, _i, _p],
     "agrl_graph_apply": [_p, _p, _p, _i, _i, _i, _i, _p],
-    "agrl_graph_tracklet_operand": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_graph_tracklet_operand": [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_graph_finalize_bits": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "agrl_pose_adjacency_bits": [_p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _p],
+    "agrl_adjacency_pack": [_p, _p, _i, _i, _p],
     "agrl_graph_linear_mix": [_p, _p, _p, _p, _p, _f, _f, _f, _p, _i, _i, _i, _i, _p],
     "agrl_row_sqnorm": [_p, _p, _i, _i, _i, _p],
     "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -271,12 +271,45 @@ def graph_matrix(f, adj, use_pose, learn_graph, mask_diag=False):
             nz = Cc // GRAM_CSLICE
             gram = torch.empty((B, nz, V, V), dtype=torch.float32, device=f.device)
             call("agrl_graph_gram", ptr(f), ptr(gram), B, V, Cc, GRAM_CSLICE, _stream(f))
+        if use_pose and adjacency_is_packed(adj):
+            assert tuple(adj.shape) == (B, V, (V + 31) // 32)
+            call("agrl_graph_finalize_bits", ptr(gram), nz, ptr(adj.contiguous()), ptr(G), B, V, 1, 1 if learn_graph else 0,
+                 1 if mask_diag else 0, _stream(f))
+            return G
         if use_pose:
             assert adj is not None and tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32
             adj = adj.contiguous()
         call("agrl_graph_finalize", ptr(gram), nz, ptr(adj) if use_pose else None, ptr(G), B, V,
              1 if use_pose else 0, 1 if learn_graph else 0, 1 if mask_diag else 0, _stream(f))
     return G
+
+
+def adjacency_is_packed(adj):
+    """The bit-packed adjacency is an int32 tensor (B, V, ceil(V/32)); the reference's form is fp32 (B, V, V)."""
+    return adj is not None and adj.dtype == torch.int32
+
+
+def adjacency_pack(adj):
+    """fp32 {0,1} adjacency (B,V,V) on the device -> bit-packed int32 (B, V, ceil(V/32)): bit j & 31 of word j >> 5 of row i."""
+    B, V, V2 = adj.shape
+    assert V == V2 and adj.dtype == torch.float32
+    bits = torch.empty((B, V, (V + 31) // 32), dtype=torch.int32, device=adj.device)
+    with _dev(adj):
+        call("agrl_adjacency_pack", ptr(adj.contiguous()), ptr(bits), B, V, _stream(adj))
+    return bits
+
+
+def adjacency_pack_host(adj):
+    """The same packing on the HOST (numpy): what a loader does before the upload -- 448 bytes per 56-node tracklet cross PCIe
+    instead of 12.5 KB. adj: CPU tensor / array (B,V,V) -> CPU int32 tensor (B, V, ceil(V/32))."""
+    import numpy as np
+    a = np.asarray(adj.detach().cpu() if hasattr(adj, "detach") else adj) != 0
+    B, V, _ = a.shape
+    W = (V + 31) // 32
+    pad = np.zeros((B, V, W * 32), dtype=bool)
+    pad[:, :, :V] = a
+    words = (pad.reshape(B, V, W, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=3).astype(np.uint32)
+    return torch.from_numpy(words.view(np.int32).copy())
 
 
 def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp, keep=None):
@@ -332,14 +365,15 @@ def graph_tracklet_operand(f, adj, use_pose, learn_graph, out_dtype, want_graph=
     assert f.dtype == torch.float32
     P = torch.empty((B, V, Cc), dtype=out_dtype, device=f.device)
     G = torch.empty((B, V, V), dtype=torch.float32, device=f.device) if want_graph else None
+    packed = use_pose and adjacency_is_packed(adj)
     if use_pose:
-        assert adj is not None and tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32
+        assert adj is not None and (tuple(adj.shape) == (B, V, (V + 31) // 32) if packed else (tuple(adj.shape) == (B, V, V) and adj.dtype == torch.float32))
         adj = adj.contiguous()
     if _hip.PROFILE is not None:
         _hip.PROFILE_TAG = {"flops": 4.0 * B * V * V * Cc, "bytes": 4.0 * (B * V * Cc + B * V * V) + P.element_size() * B * V * Cc}
     with _dev(f):
-        call("agrl_graph_tracklet_operand", ptr(f.contiguous()), ptr(adj) if use_pose else None, ptr(G), ptr(P), dtype_code(out_dtype), B, V, Cc,
-             1 if use_pose else 0, 1 if learn_graph else 0, 1 if mask_diag else 0, _stream(f))
+        call("agrl_graph_tracklet_operand", ptr(f.contiguous()), ptr(adj) if use_pose else None, 1 if packed else 0, ptr(G), ptr(P),
+             dtype_code(out_dtype), B, V, Cc, 1 if use_pose else 0, 1 if learn_graph else 0, 1 if mask_diag else 0, _stream(f))
     return P, G
 
 
@@ -512,14 +546,22 @@ def rank_mars(topk_idx, q_pids, q_camids, g_pids, g_camids):
     return ap, cmc
 
 
-def pose_adjacency(poses, detected, height, num_split=4, pyramid_part=True, threshold=0.1):
-    """AlphaPose keypoints (B,S,18,3) fp32 + per-frame detection flags (B,S) -> adjacency (B,V,V) fp32 on the device.
-    dataset_loader.py:218-388 (generate_graph + adj_graph)."""
+def pose_adjacency(poses, detected, height, num_split=4, pyramid_part=True, threshold=0.1, packed=False):
+    """AlphaPose keypoints (B,S,18,3) fp32 + per-frame detection flags (B,S) -> adjacency (B,V,V) fp32 on the device, or with
+    ``packed`` the bit-packed int32 (B, V, ceil(V/32)) form the graph kernels also take. dataset_loader.py:218-388
+    (generate_graph + adj_graph)."""
     B, S = poses.shape[:2]
     assert poses.dtype == torch.float32 and tuple(poses.shape[2:]) == (18, 3)
     det = detected.to(torch.uint8).contiguous()
     assert tuple(det.shape) == (B, S)
     P = 2 * num_split - 1 if pyramid_part else num_split
+    if packed:
+        V = S * P
+        bits = torch.empty((B, V, (V + 31) // 32), dtype=torch.int32, device=poses.device)
+        with _dev(poses):
+            call("agrl_pose_adjacency_bits", ptr(poses.contiguous()), ptr(det), ptr(bits), B, S, int(num_split), 1 if pyramid_part else 0,
+                 float(height), float(threshold), _stream(poses))
+        return bits
     adj = torch.empty((B, S * P, S * P), dtype=torch.float32, device=poses.device)
     with _dev(poses):
         call("agrl_pose_adjacency", ptr(poses.contiguous()), ptr(det), ptr(adj), B, S, int(num_split), 1 if pyramid_part else 0,

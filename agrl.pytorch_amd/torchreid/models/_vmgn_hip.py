@@ -302,8 +302,10 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
     B, S, Cc, H, W = x.shape
     P = model.total_split
     V = S * P
-    if tuple(adj.shape) != (B, V, V):
-        raise ValueError('adj must be {} for S={} and {} parts, got {}'.format((B, V, V), S, P, tuple(adj.shape)))
+    packed_adj = ops.adjacency_is_packed(adj)   # int32 (B, V, ceil(V/32)): the bit-packed graph (hip_ops.adjacency_pack*)
+    if tuple(adj.shape) != ((B, V, (V + 31) // 32) if packed_adj else (B, V, V)):
+        raise ValueError('adj must be {} (fp32) or {} (bit-packed int32) for S={} and {} parts, got {}'.format(
+            (B, V, V), (B, V, (V + 31) // 32), S, P, tuple(adj.shape)))
     pack = pack_weights(model, x.device, model.hip_precision)
     lp = pack['dtype'] == torch.bfloat16
     with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
@@ -322,7 +324,7 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
         nodes = nodes.view(B, V, C)
         if nodes_lp is not None:
             nodes_lp = nodes_lp.view(B, V, C)
-        adj32 = adj.detach().to(torch.float32).contiguous()
+        adj32 = adj.detach().contiguous() if packed_adj else adj.detach().to(torch.float32).contiguous()
         if stages is not None:
             stages.update(gsum=gsum, hw=hw, nodes=nodes)
         nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages, overlap=getattr(model, 'hip_gcn_overlap', False), commute=commute)

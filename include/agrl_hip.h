@@ -140,6 +140,11 @@ int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int
  *   adj fp32 (B, S*P, S*P), values {0,1}, symmetric, zero diagonal: the layout GSTA.forward consumes (vmgn.py:292). */
 int agrl_pose_adjacency(const float* poses, const unsigned char* detected, float* adj, int B, int S,
                         int num_split, int pyramid_part, float height, float threshold, agrl_stream_t stream);
+/* The same graph written bit-packed (layout: agrl_graph_finalize_bits), and the packing of an fp32 {0, 1} adjacency that
+ * came from the reference's loader (torchreid/dataset_loader.py:218-388). */
+int agrl_pose_adjacency_bits(const float* poses, const unsigned char* detected, uint32_t* adj_bits, int B, int S, int num_split,
+                             int pyramid_part, float height, float threshold, agrl_stream_t stream);
+int agrl_adjacency_pack(const float* adj, uint32_t* adj_bits, int B, int V, agrl_stream_t stream);
 
 /* ---- pooling ------------------------------------------------------------------------------- */
 
@@ -173,6 +178,12 @@ int agrl_graph_gram(const float* f, float* gram_part, int B, int V, int C, int c
  *   G   fp32 (B,V,V) */
 int agrl_graph_finalize(const float* gram_part, int nz, const float* adj, float* G, int B, int V,
                         int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream);
+/* agrl_graph_finalize with the pose adjacency in the bit-packed form of agrl_pose_adjacency_bits / agrl_adjacency_pack:
+ * (B, V, ceil(V / 32)) uint32 words, bit (j & 31) of word (j >> 5) of row i = adj[i][j] (the {0, 1} graph of
+ * torchreid/dataset_loader.py:345-388 at 1/32 of the bytes: 448 B instead of 12.5 KB per 56-node tracklet). Same arithmetic,
+ * bitwise the same G. */
+int agrl_graph_finalize_bits(const float* gram_part, int nz, const uint32_t* adj_bits, float* G, int B, int V, int use_pose,
+                             int learn_graph, int mask_diag, agrl_stream_t stream);
 
 /* GraphLayer with the Linear commuted behind the message pass: G (f W^T) = (G f) W^T (torchreid/models/vmgn.py:148, :168-172).
  *   agrl_graph_apply      P = G f, (B,V,V) x (B,V,C) fp32 -> (B,V,C) in out_dtype (AGRL_F32 / AGRL_BF16): the operand of the
@@ -187,10 +198,11 @@ int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, i
 /* agrl_graph_gram + agrl_graph_finalize + agrl_graph_apply for MANY tracklets per GPU, one workgroup per tracklet (use it when
  * B >= ~224, so that B workgroups fill the 256 CUs): Gram (exact fp32 MFMA) -> similarity -> row-L1 normalise -> mix with the pose
  * graph -> P = G f in out_dtype, in ONE launch; f crosses HBM once, no Gram partials, G leaves only if G_out != NULL
- * (torchreid/models/vmgn.py:114-120, :155-168). V <= 64, V % 4 == 0, C % 512 == 0. The Gram is summed as eight wave partials of C / 8
+ * (torchreid/models/vmgn.py:114-120, :155-168). adj: fp32 (B,V,V), or with adj_packed != 0 the bit-packed form of
+ * agrl_pose_adjacency_bits. V <= 64, V % 4 == 0, C % 512 == 0. The Gram is summed as eight wave partials of C / 8
  * channels (the slice-partial form: sixteen of 128): the graph agrees with agrl_graph_finalize's to fp32 roundoff, not bitwise. */
-int agrl_graph_tracklet_operand(const float* f, const float* adj, float* G_out, void* out, int out_dtype, int B, int V, int C,
-                                int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream);
+int agrl_graph_tracklet_operand(const float* f, const void* adj, int adj_packed, float* G_out, void* out, int out_dtype, int B,
+                                int V, int C, int use_pose, int learn_graph, int mask_diag, agrl_stream_t stream);
 int agrl_graph_linear_mix(const void* p_op, const void* w, const float* f, const float* bn_scale, const float* bn_shift,
                           float keep, float gamma, float slope, float* out, int M, int K, int Nout, int in_dtype,
                           agrl_stream_t stream);

@@ -917,6 +917,39 @@ def test_pose_adjacency_device():
             assert np.array_equal(got[b], O.pose_adjacency(sets, ns, pyr)), (B, S, H, ns, pyr, b)
 
 
+def test_bit_packed_adjacency():
+    """The pose graph at 1/32 of the bytes (56 x 56 nodes = 448 B instead of 12.5 KB): agrl_pose_adjacency_bits
+    == the bits of agrl_pose_adjacency; agrl_adjacency_pack (device) == adjacency_pack_host (numpy, what a loader does before the
+    upload); agrl_graph_finalize_bits and the tracklet form give BITWISE the graph of the fp32 adjacency; V = 56 (two words per
+    row), 28 (one), 112 (four, the seq_len-16 graph), 20 (V % 32 != 0 in the last word)."""
+    from torchreid import hip_ops as ops
+    rng = np.random.RandomState(3)
+    for B, S, ns, pyr in ((5, 8, 4, True), (3, 4, 4, True), (2, 16, 4, True), (4, 5, 4, False)):
+        H = 256.0
+        poses = np.stack([rng.rand(B, S, 18) * 128, rng.rand(B, S, 18) * (H + 8) - 4, rng.rand(B, S, 18) * 0.5], axis=-1).astype(np.float32)
+        det = rng.rand(B, S) > 0.15
+        pd, dd = torch.from_numpy(poses).to(DEV), torch.from_numpy(det).to(DEV)
+        adj = ops.pose_adjacency(pd, dd, H, ns, pyr)
+        bits = ops.pose_adjacency(pd, dd, H, ns, pyr, packed=True)
+        V = adj.shape[1]
+        assert bits.dtype == torch.int32 and tuple(bits.shape) == (B, V, (V + 31) // 32)
+        assert torch.equal(bits, ops.adjacency_pack(adj)) and torch.equal(bits.cpu(), ops.adjacency_pack_host(adj.cpu()))
+        # unpack on the host and compare element by element
+        w = bits.cpu().numpy().view(np.uint32)
+        un = ((w[:, :, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(B, V, -1)[:, :, :V].astype(np.float32)
+        assert np.array_equal(un, adj.cpu().numpy())
+        C = 512
+        f = (torch.rand((B, 1, C)) + 0.02 * torch.randn((B, V, C))).to(DEV)
+        for use_pose, learn in ((True, True), (True, False)):
+            G32 = ops.graph_matrix(f, adj, use_pose, learn)
+            Gb = ops.graph_matrix(f, bits, use_pose, learn)
+            assert torch.equal(G32, Gb)
+            if V <= 64 and V % 4 == 0:
+                P32, Gt32 = ops.graph_tracklet_operand(f, adj, use_pose, learn, torch.float32, want_graph=True)
+                Pb, Gtb = ops.graph_tracklet_operand(f, bits, use_pose, learn, torch.float32, want_graph=True)
+                assert torch.equal(P32, Pb) and torch.equal(Gt32, Gtb)
+
+
 def test_re_ranking_device():
     """agrl_re_ranking vs the reference (golden fixture) and vs the oracle on a larger random problem; the ranking it
     induces (what evaluate_rank consumes) must be identical."""

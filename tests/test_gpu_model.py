@@ -245,6 +245,24 @@ def test_bad_adj_shape_raises():
         m(synthetic_clips(1, 4).to(DEV), torch.ones(1, 20, 20, device=DEV))
 
 
+def test_model_takes_the_bit_packed_adjacency():
+    """model(x, adj) with adj as the bit-packed int32 (B, V, ceil(V/32)) tensor (packed on the host as a loader would, 448 B per
+    tracklet over PCIe instead of 12.5 KB) == the same call with the reference's fp32 (B, V, V) adjacency, bitwise; a packed
+    tensor of the wrong shape raises."""
+    from torchreid import hip_ops as ops
+    m, _ = build()
+    m = m.to(DEV)
+    m.hip_precision = "fp32"
+    x, adj = synthetic_clips(3, 8, seed=21), synthetic_adj(3, 8, seed=21)
+    ref = m(x.to(DEV), adj.to(DEV))
+    bits = ops.adjacency_pack_host(adj)
+    assert bits.dtype == torch.int32 and tuple(bits.shape) == (3, 56, 2) and bits.numel() * 4 * 28 == adj.numel() * 4
+    got = m(x.to(DEV), bits.to(DEV))
+    assert torch.equal(ref, got)
+    with pytest.raises(ValueError):
+        m(x.to(DEV), bits[:, :, :1].contiguous().to(DEV))
+
+
 def test_throughput_probe():
     """Not an assertion on speed: prints a first timing of the full forward at the BASELINE config-2 shape."""
     m, _ = build()
