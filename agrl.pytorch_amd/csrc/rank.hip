@@ -226,6 +226,34 @@ __global__ __launch_bounds__(256) void rank_topk_fast_kernel(const float* __rest
     }
 }
 
+// Full stable argsort of every row (the cuhk03 protocol walks the WHOLE ranking, torchreid/metrics/rank.py:45-47): one
+// workgroup per row, (key << 32 | index) composites in LDS, bitonic sort. Composites are distinct, so the order is the stable
+// one (ties -> lower gallery index, NaN last) whatever the sorting network does. n <= 16384 (128 KB of composites).
+__global__ __launch_bounds__(1024) void rank_argsort_kernel(const float* __restrict__ dist, int n, int ldd, int npad,
+                                                            int32_t* __restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_c[];
+    const int tid = threadIdx.x;
+    const float* row = dist + (size_t)blockIdx.x * ldd;
+    for (int i = tid; i < npad; i += 1024) s_c[i] = i < n ? (((unsigned long long)dist_key(row[i]) << 32) | (uint32_t)i) : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= npad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (npad >> 1); i += 1024) {
+                const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = s_c[lo], b = s_c[hi];
+                if ((a > b) == up) {
+                    s_c[lo] = b;
+                    s_c[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += 1024) idx_out[(size_t)blockIdx.x * n + i] = (int32_t)(uint32_t)(s_c[i] & 0xffffffffull);
+}
+
 // grid = m queries. Block-reduce ngood over the whole gallery, then lane 0 replays Compute_AP in fp64
 // with the reference's operation order, so ap is bit-identical to the Python floats.
 __global__ __launch_bounds__(256) void rank_mars_kernel(const int32_t* __restrict__ topk, const int32_t* __restrict__ q_pids,
@@ -548,6 +576,21 @@ extern "C" int agrl_distmat_topk(const void* q, const void* g, const float* qn, 
         launch_topk((const float*)workspace, mb, n, ldd, k, idx_offset, idx + (size_t)r0 * k, val + (size_t)r0 * k, (hipStream_t)stream);
     }
     AGRL_CHECK_LAUNCH("agrl_distmat_topk");
+    return 0;
+}
+
+extern "C" int agrl_rank_argsort(const float* dist, int m, int n, int ldd, int32_t* idx, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(dist && idx && m > 0 && n > 0 && ldd >= n, "agrl_rank_argsort: bad arguments");
+    AGRL_CHECK_ARG(n <= 16384, "agrl_rank_argsort: n=%d > 16384 (one row of composites must fit the LDS)", n);
+    int npad = 2;
+    while (npad < n) npad <<= 1;
+    const size_t lds = (size_t)npad * 8;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)rank_argsort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        AGRL_CHECK_ARG(e == hipSuccess, "agrl_rank_argsort: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(rank_argsort_kernel, dim3(m), dim3(1024), lds, (hipStream_t)stream, dist, n, ldd, npad, idx);
+    AGRL_CHECK_LAUNCH("agrl_rank_argsort");
     return 0;
 }
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     "agrl_rank_topk": [_p, _i, _i, _i, _i, _i, _p, _p, _p],
     "agrl_distmat_topk_workspace": [_i, _i],   # returns size_t
     "agrl_distmat_topk": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, C.c_size_t, _p, C.c_size_t, _p],
+    "agrl_rank_argsort": [_p, _i, _i, _i, _p, _p],
     "agrl_rank_mars": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "agrl_rank_market1501": [_p, _i, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p],
     "agrl_triplet_hard_mine": [_p, _p, _i, _i, _p, _p, _p, _p, _p],

@@ -532,6 +532,19 @@ def distmat_topk(q, g, metric, k, qn=None, gn=None, idx_offset=0, workspace_byte
     return idx, val
 
 
+RANK_ARGSORT_MAX_N = 16384
+
+
+def rank_argsort(dist):
+    """dist (m,n) fp32, n <= 16384 -> int32 (m,n): the stable ascending order of every row (NaN last). rank.py:45-47."""
+    m, n = dist.shape
+    assert dist.dtype == torch.float32 and dist.stride(1) == 1 and n <= RANK_ARGSORT_MAX_N
+    idx = torch.empty((m, n), dtype=torch.int32, device=dist.device)
+    with _dev(dist):
+        _hip.call("agrl_rank_argsort", dist.data_ptr(), m, n, dist.stride(0), ptr(idx), _stream(dist))
+    return idx
+
+
 def rank_mars(topk_idx, q_pids, q_camids, g_pids, g_camids):
     """-> ap fp64 (m), cmc fp32 (m,k). rank.py:160-212."""
     m, k = topk_idx.shape

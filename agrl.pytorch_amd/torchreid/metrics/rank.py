@@ -234,7 +234,10 @@ def evaluate_cuhk03(distmat, q_pids, g_pids, q_camids, g_camids, max_rank, num_r
             return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
 
         ap, _, dvalid = ops.rank_market1501(d, i32(q_pids), i32(q_camids), i32(g_pids), i32(g_camids), min(max_rank, num_g))
-        order = torch.sort(d, dim=1, stable=True)[1].cpu().numpy()
+        if num_g <= ops.RANK_ARGSORT_MAX_N:
+            order = ops.rank_argsort(d).cpu().numpy().astype(np.int64)      # native full-row stable order (agrl_rank_argsort)
+        else:                                                                # a row of composites no longer fits the LDS
+            order = torch.sort(d, dim=1, stable=True)[1].cpu().numpy()
         cmcs, valid = _cuhk03_trials(order, q_pids, g_pids, q_camids, g_camids, max_rank, num_repeats)
         assert cmcs is not None, 'Error: all query identities do not appear in gallery'
         dvalid = dvalid.cpu().numpy()

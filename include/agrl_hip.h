@@ -306,6 +306,10 @@ int agrl_distmat_topk(const void* q, const void* g, const float* qn, const float
                       int dtype, int k, int idx_offset, int32_t* idx, float* val, void* workspace,
                       size_t workspace_bytes, void* gemm_workspace, size_t gemm_workspace_bytes, agrl_stream_t stream);
 
+/* np.argsort(distmat, axis=1) of the WHOLE row in the stable order (ties -> lower gallery index, NaN last): what the cuhk03
+ * protocol walks, torchreid/metrics/rank.py:45-47. dist fp32 (m, n) row stride ldd; idx int32 (m, n). n <= 16384. */
+int agrl_rank_argsort(const float* dist, int m, int n, int ldd, int32_t* idx, agrl_stream_t stream);
+
 /* MARS evaluation of every query from its top-k list: evaluate_mars + Compute_AP,
  * torchreid/metrics/rank.py:160-212.
  *   topk_idx int32 (m,k) global gallery indices (ascending distance); q_pids,q_camids int32 (m);

@@ -825,6 +825,23 @@ def test_rank_market1501_device(shape):
         assert np.allclose(zc["cmc_cy_%dx%d" % (m, n)], cmc2, atol=1e-6) and abs(float(zc["mAP_cy_%dx%d" % (m, n)]) - mAP2) < 1e-6
 
 
+@pytest.mark.parametrize("shape", [(7, 900), (3, 12180), (5, 16384), (4, 1), (6, 33)])
+def test_rank_argsort_full_rows(shape):
+    """agrl_rank_argsort == np.argsort(kind='stable') of the whole row (rank.py:45-47), with exact ties, NaN, +-inf, -0.0."""
+    from torchreid import hip_ops as ops
+    m, n = shape
+    rng = np.random.RandomState(m + n)
+    d = rng.randn(m, n).astype(np.float32)
+    d[0, ::3] = np.float32(0.25)
+    if n > 8:
+        d[1, 5], d[1, 7], d[1, 2] = np.nan, -np.inf, np.inf
+        d[2, : n // 2] = np.float32(-0.0)
+        d[2, n // 2:] = np.float32(0.0)
+    idx = ops.rank_argsort(torch.from_numpy(d).to(DEV)).cpu().numpy()
+    ref = np.argsort(d, axis=1, kind="stable")
+    assert np.array_equal(idx, ref)
+
+
 def test_rank_cuhk03_device():
     """evaluate_rank(use_metric_cuhk03=True) with the ranking and the AP from the device: equal to the reference's python
     evaluator (golden, seeded np.random) and to the oracle on a case with exact distance ties; a device-resident
