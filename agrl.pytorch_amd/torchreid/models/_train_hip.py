@@ -506,3 +506,48 @@ def forward_train(model, x, adj):
                 b = bottleneck_train(unit, b)
             maps.append(b)
         return tail_train(model, maps[0], maps[1], adj, B, S)
+
+
+def forward_train_gsta(model, x, adj):
+    """The single-branch sibling ``gsta`` under model.train() on the GPU (reference gsta.py:273-322): the same native nodes as
+    vmgn's step -- conv trunk with batch-statistics BatchNorm, part pooling, graph layers, attention pooling, BNNeck, classifier --
+    and its consistent loss (one random frame dropped per tracklet, drawn from numpy's global RNG like the reference)."""
+    import numpy as np
+    B, S, C, H, W = x.shape
+    prec = getattr(model, 'hip_train_precision', 'fp32')
+    if prec not in ('fp32', 'bf16x3'):
+        raise ValueError("hip_train_precision must be 'fp32' or 'bf16x3', got {!r}".format(prec))
+    with ops.f32_split(prec == 'bf16x3'):
+        a = stem_train(model, x.view(B * S, C, H, W))
+        for stage in (model.layer1, model.layer2, model.layer3, model.layer4):
+            for unit in stage:
+                a = bottleneck_train(unit, a)
+        P = model.total_split
+        # the part nodes only (gsta has no global branch): the pooling node takes the map for both of its inputs, the unused
+        # global feature contributes a zero gradient
+        _, nodes = HipPartPool.apply(a, a, S, tuple(model.total_split_list))
+        Cf = nodes.shape[-1]
+        f = nodes.view(B, S * P, Cf)
+        adj = adj.detach().to(torch.float32).contiguous()
+        for layer in model.graph_layers:
+            f = graph_layer_train(layer, f, adj)
+        f = f.view(B, S, P, Cf)
+        f_g = HipAttnPool.apply(f)
+        bn = _bn_act(model.bottleneck, f_g, None, False)
+        sy = sf_g = None
+        if model.consistent_loss:
+            keep = []
+            for _ in range(B):
+                idx = list(range(S))
+                idx.remove(np.random.randint(S))
+                keep.append(idx)
+            keep = torch.LongTensor(keep).to(f.device)
+            sf = torch.gather(f, dim=1, index=keep.view(B, S - 1, 1, 1).repeat(1, 1, P, Cf))
+            sf_g = HipAttnPool.apply(sf)
+            sy = linear_train(_bn_act(model.bottleneck, sf_g, None, False), model.classifier.weight)
+        y = linear_train(bn, model.classifier.weight)
+    if model.loss == {'xent'}:
+        return [y, sy] if model.consistent_loss else y
+    if model.loss == {'xent', 'htri'}:
+        return ([y, sy], [f_g, sf_g]) if model.consistent_loss else (y, f_g)
+    raise KeyError('Unsupported loss: {}'.format(model.loss))

@@ -61,6 +61,8 @@ class GSTASingle(nn.Module):
         self.hip_static_weights = False
         self.hip_fuse_pool = os.environ.get('AGRL_HIP_FUSE_POOL', '1') != '0'
         self.hip_fuse_tail = os.environ.get('AGRL_HIP_FUSE_TAIL', '1') != '0'
+        self.hip_train = os.environ.get('AGRL_HIP_TRAIN', '1') != '0'   # train-mode forward + backward on the HIP kernels
+        self.hip_train_precision = os.environ.get('AGRL_HIP_TRAIN_PRECISION', 'fp32')
         self._hip_packs = {}
 
     def _init_params(self):
@@ -86,6 +88,12 @@ class GSTASingle(nn.Module):
         if x.is_cuda and not self.training:
             from torchreid.models._vmgn_hip import hip_forward_gsta
             return hip_forward_gsta(self, x, adj)
+        if x.is_cuda and self.training and self.hip_train:
+            if x.dtype != torch.float32:
+                raise TypeError('the native train step takes float32 frames, got {}; set model.hip_train = False for the '
+                                'stock-torch module tree'.format(x.dtype))
+            from torchreid.models._train_hip import forward_train_gsta
+            return forward_train_gsta(self, x, adj)
         B, S, C, H, W = x.size()
         fm = self.featuremaps(x.view(B * S, C, H, W))
         c = fm.size(1)

@@ -537,3 +537,50 @@ def test_xent_native_matches_reference_fixture_and_flags_bad_labels():
         xr = logits[0].clone().requires_grad_(True)
         O.xent_label_smooth(xr, pids, 0.1).backward()
         assert rel(dl[keep.to(DEV)], xr.grad[keep]) < 1e-5 and torch.isfinite(ref)
+
+
+@pytest.mark.parametrize("consistent", [False, True])
+def test_gsta_native_train_step_matches_cpu_module(consistent):
+    """The sibling ``gsta`` (one layer4 branch, one BNNeck; reference gsta.py:273-322) in train mode: the native step (same
+    autograd nodes as vmgn's) against the stock-torch module tree on the CPU -- outputs, loss, gradient norms -- incl. its
+    consistent loss (one frame dropped per tracklet from numpy's global RNG)."""
+    from recipe import recipe_state_dict, synthetic_adj, synthetic_clips
+    from torchreid import losses, models
+    kw = dict(num_classes=5, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1, pyramid_part=True,
+              use_pose=True, learn_graph=True, consistent_loss=consistent, pretrained=False)
+    ref = models.init_model("gsta", **kw)
+    sd = recipe_state_dict(ref.state_dict(), seed=5)
+    ref.load_state_dict(sd)
+    dev = models.init_model("gsta", **kw)
+    dev.load_state_dict(sd)
+    dev = dev.to(DEV)
+    pids = torch.tensor([0, 0, 1, 1])
+    x, adj = synthetic_clips(4, 6, H=128, W=64, seed=17, identities=pids.tolist()), synthetic_adj(4, 6, seed=17)
+    htri = losses.TripletLoss(margin=0.3, soft=True)
+
+    def step(model, x_, adj_, y_, ce):
+        model.train()
+        np.random.seed(77)
+        outs, feats = model(x_, adj_)
+        outs, feats = (outs, feats) if isinstance(outs, (list, tuple)) else ([outs], [feats])
+        loss = losses.DeepSupervision(ce, outs, y_) + losses.DeepSupervision(htri, feats, y_)
+        loss.backward()
+        grads = {k: p.grad.detach().double().cpu() for k, p in model.named_parameters() if p.grad is not None}
+        return loss.item(), [o.detach().double().cpu() for o in outs], grads
+
+    l_ref, o_ref, g_ref = step(ref, x, adj, pids, losses.CrossEntropyLabelSmooth(num_classes=5, use_gpu=False))
+    l_dev, o_dev, g_dev = step(dev, x.to(DEV), adj.to(DEV), pids.to(DEV), losses.CrossEntropyLabelSmooth(num_classes=5, use_gpu=True))
+    assert len(o_ref) == len(o_dev) == (2 if consistent else 1) and set(g_ref) == set(g_dev)
+    for a, b in zip(o_dev, o_ref):
+        assert rel(a, b) < 1e-3
+    assert abs(l_ref - l_dev) < 1e-4 * abs(l_ref)
+    gn_ref = torch.sqrt(sum((g ** 2).sum() for g in g_ref.values())).item()
+    gn_dev = torch.sqrt(sum((g ** 2).sum() for g in g_dev.values())).item()
+    print("gsta train step (consistent=%s): loss cpu %.6f gpu %.6f | grad norm cpu %.4e gpu %.4e" % (consistent, l_ref, l_dev, gn_ref, gn_dev))
+    assert abs(gn_ref - gn_dev) < 2e-2 * gn_ref
+    for k in ("classifier.weight", "bottleneck.weight", "graph_layers.1.linear.weight"):
+        assert rel(g_dev[k], g_ref[k]) < 5e-2, k
+    # running statistics moved like nn.BatchNorm's
+    for k in ("bn1.running_mean", "layer4.2.bn3.running_var", "bottleneck.running_mean", "bottleneck.num_batches_tracked"):
+        a, b = dev.state_dict()[k].double().cpu(), ref.state_dict()[k].double()
+        assert rel(a, b) < 1e-3 if b.abs().max() > 0 else torch.equal(a, b), k
