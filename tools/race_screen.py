@@ -120,6 +120,32 @@ for _ in range(REPS):
     bad += int(not torch.equal(ops.distmat(q, g, "cosine"), d0))
 total += bad
 print("%-28s %d / %d runs differ from the first run" % ("propagate + distmat", bad, 2 * REPS))
+# round-3 kernels: GraphLayer in the commuted form (graph, G f, GEMM with the fused epilogue), its one-workgroup-per-tracklet
+# form at 256 tracklets, the single-pass top-k (LDS atomics + in-launch radix fallback) and the full-row argsort
+adj = (torch.rand((32, 56, 56), device=dev) > 0.5).float()
+wl = (torch.randn((2048, 2048), device=dev) * 0.02).bfloat16()
+def commuted(ff, aa):
+    Gm = ops.graph_matrix(ff, aa, True, True)
+    P = ops.graph_apply_operand(Gm, ff, torch.bfloat16)
+    return ops.graph_linear_mix(P, wl, ff, sc, sh, 0.1, 0.1)
+c0 = commuted(f, adj).clone()
+f256 = torch.rand((256, 1, 2048), device=dev) + 0.02 * torch.randn((256, 56, 2048), device=dev)
+adj256 = (torch.rand((256, 56, 56), device=dev) > 0.5).float()
+t0 = [t.clone() for t in ops.graph_tracklet_operand(f256, adj256, True, True, torch.bfloat16, want_graph=True)]
+dk = torch.randn((1980, 12180), device=dev)
+dk[5] = 0.25   # a row of equal values: the radix path inside the single-pass launch
+k0 = [t.clone() for t in ops.rank_topk(dk, 50)]
+a0 = ops.rank_argsort(dk[:64]).clone()
+bad = 0
+for _ in range(REPS):
+    bad += int(not torch.equal(commuted(f, adj), c0))
+    t1 = ops.graph_tracklet_operand(f256, adj256, True, True, torch.bfloat16, want_graph=True)
+    bad += int(not (torch.equal(t1[0], t0[0]) and torch.equal(t1[1], t0[1])))
+    k1 = ops.rank_topk(dk, 50)
+    bad += int(not (torch.equal(k1[0], k0[0]) and torch.equal(k1[1], k0[1])))
+    bad += int(not torch.equal(ops.rank_argsort(dk[:64]), a0))
+total += bad
+print("%-28s %d / %d runs differ from the first run" % ("gcn commuted / tracklet / top-k / argsort", bad, 4 * REPS))
 torch.cuda.synchronize()
 print("RACE SCREEN", "CLEAN" if total == 0 else "FAILED (%d)" % total)
 sys.exit(1 if total else 0)
