@@ -493,12 +493,13 @@ def config4_block(device):
     htri = losses.TripletLoss(margin=0.3, soft=True)
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
     out = {"tracklets": B, "seq_len": S, "frames": B * S, "dtype": "fp32", "classes": ncls,
-           "gflop_per_step": round(3 * 11.93 * B * S, 1)}
+           "gflop_per_step": round(3 * 11.93 * B * S, 1), "timing": "median of 5 steps after one warm-up step, per variant"}
 
-    def run(native, steps=3, precision="fp32"):
+    def run(native, steps=5, precision="fp32"):
         m.load_state_dict(sd0)
         m.hip_train = native
         m.hip_train_precision = precision
+        ce.hip_native = htri.hip_native = native   # the stock-torch baseline step uses the stock-torch losses too
         m.train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=5e-4)
         ts, loss = [], None
@@ -514,13 +515,14 @@ def config4_block(device):
             torch.cuda.synchronize()
             if i:
                 ts.append(time.perf_counter() - t0)
-        return min(ts), float(loss.detach())
+        return sorted(ts)[len(ts) // 2], float(loss.detach())   # median of ``steps`` timed steps (one untimed warm-up step before)
     try:
         t_nat, l_nat = run(True)
         t_x3, l_x3 = run(True, precision="bf16x3")
         t_ref, l_ref = run(False)
     except RuntimeError as e:  # noqa: BLE001  (out of memory on a small device)
         return {"error": str(e)[:200]}
+    ce.hip_native = htri.hip_native = True
     fl = 3 * 11.93e9 * B * S
     # where the native step's time goes: HIP events around every C-ABI call of one more step (exact fp32)
     try:

@@ -25,6 +25,8 @@ SHAPES = [  # N, H, W, Cin, Cout, R, stride, res
     (256, 16, 8, 1024, 512, 1, 1, False),
     (256, 32, 16, 512, 256, 1, 1, False),
     (256, 32, 16, 512, 128, 1, 1, False),
+    (256, 32, 16, 256, 256, 3, 2, False),   # 17: the stride-2 3x3 of layer 3's first block
+    (256, 64, 32, 128, 128, 3, 2, False),   # 18: the stride-2 3x3 of layer 2's first block
 ]
 args = sys.argv[1:]
 if "--shapes" in args:
@@ -58,5 +60,5 @@ for (N, H, W, Cin, Cout, R, stride, res) in SHAPES:
             torch.cuda.synchronize()
             if rnd:
                 times[name].append(s.elapsed_time(e) * 1000 / REPS)
-    fl = 2.0 * N * H * W * Cout * R * R * Cin
+    fl = 2.0 * N * (H // stride) * (W // stride) * Cout * R * R * Cin
     print("%-38s " % str((H, W, Cin, Cout, R, res)) + " ".join("%7.1fus %4.0fTF" % (statistics.median(times[n]), fl / statistics.median(times[n]) / 1e6) for n, _ in variants))
