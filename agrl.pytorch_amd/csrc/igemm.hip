@@ -1107,6 +1107,9 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
     AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
     AGRL_CHECK_ARG((Nout % 4) == 0 && ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0),
                    "agrl_graph_linear_mix: Nout %% 4 == 0 and 16-byte aligned f / out / scale / shift required");
+    // bf16 operands: the kernel shaped for this problem (graph_gemm.hip); AGRL_GRAPH_LINEAR_IGEMM=1 keeps the generic one (A/B)
+    if (in_dtype == AGRL_BF16 && !agrl_opts().graph_linear_igemm && graph_gemm_applicable(M, K, Nout))
+        return launch_graph_gemm(p_op, w, f, bn_scale, bn_shift, keep, gamma, slope, out, M, K, Nout, (hipStream_t)stream);
     IgemmParams p;
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = p_op; p.w = w; p.colv = bn_shift; p.rowv = nullptr; p.res = nullptr; p.out = out;

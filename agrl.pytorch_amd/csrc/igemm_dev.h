@@ -175,6 +175,11 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
 bool distmat_stream_applicable(const IgemmParams& p, int elem_size);
 int launch_distmat_stream(const IgemmParams& p, int dtype, hipStream_t stream);
 
+// GraphLayer Linear with the BatchNorm / LeakyReLU / residual-mix epilogue, bf16 operands (graph_gemm.hip)
+bool graph_gemm_applicable(int M, int K, int Nout);
+int launch_graph_gemm(const void* p_op, const void* w, const float* f, const float* bn_scale, const float* bn_shift, float keep,
+                      float gamma, float slope, float* out, int M, int K, int Nout, hipStream_t stream);
+
 // two-block 3x3 kernel (conv3x3_wide.hip)
 int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream);
 int launch_conv3x3_c64(const IgemmParams& p, hipStream_t stream);
