@@ -20,15 +20,21 @@ namespace {
 constexpr int GRAM_CS = 128;
 constexpr int GRAM_ROWB = GRAM_CS * 4 + 16;
 
-__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, float* __restrict__ gram_part, int V,
-                                                   int C, int nz) {
+// PAIR: partials of A B^T for two node matrices (the message pass's d loss / d G = dmsg h^T per tracklet) -- the second
+// matrix is staged behind the first
+template <bool PAIR>
+__global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, const float* __restrict__ f2,
+                                                   float* __restrict__ gram_part, int V, int C, int nz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_f[];
     const int b = blockIdx.x, z = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Vp = (V + 15) & ~15;
     const int nf = Vp >> 4;
     // stage: thread -> float4 (tid&31) of row (tid>>5) + 8*i
-    const float* src = f + (size_t)b * V * C + (size_t)z * GRAM_CS;
+#pragma unroll
+    for (int which = 0; which < (PAIR ? 2 : 1); ++which) {
+    const float* src = (which ? f2 : f) + (size_t)b * V * C + (size_t)z * GRAM_CS;
+    unsigned char* s_dst = s_f + which * Vp * GRAM_ROWB;
     // all of a thread's loads are issued before the first LDS store (a load -> store loop is a chain of HBM round trips)
     for (int r0 = tid >> 5; r0 < Vp; r0 += 64) {
         float4 v[8];
@@ -41,8 +47,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, 
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = r0 + 8 * i;
-            if (r < Vp) *reinterpret_cast<float4*>(s_f + r * GRAM_ROWB + (tid & 31) * 16) = v[i];
+            if (r < Vp) *reinterpret_cast<float4*>(s_dst + r * GRAM_ROWB + (tid & 31) * 16) = v[i];
         }
+    }
     }
     __syncthreads();
     const int frow = lane & 15, fch = lane >> 4;
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ f, 
         const int fi = fr / nf, fj = fr - fi * nf;
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const unsigned char* pa = s_f + (fi * 16 + frow) * GRAM_ROWB + fch * 16;
-        const unsigned char* pb = s_f + (fj * 16 + frow) * GRAM_ROWB + fch * 16;
+        const unsigned char* pb = s_f + (PAIR ? Vp * GRAM_ROWB : 0) + (fj * 16 + frow) * GRAM_ROWB + fch * 16;
         // all sixteen operand reads of the fragment pair first, then the 32 MFMAs (one read -> wait -> MFMA per k-step is
         // a chain of LDS round trips)
         float4 av[GRAM_CS / 16], bv[GRAM_CS / 16];
@@ -681,6 +688,14 @@ __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const floa
 //      f comes a second time, out of the memory-side cache (458 KB per tracklet, just read).
 // f crosses HBM once per tracklet (V C 4 bytes), P leaves once. The Gram is summed in a different order than the
 // slice-partial form (4 wave partials of C/4 channels, not 16 slices of 128): the graph agrees to fp32 roundoff.
+// out[b][e] = sum over the nz slice partials, z ascending
+__global__ __launch_bounds__(256) void gram_sum_kernel(const float* __restrict__ part, int nz, float* __restrict__ out, int vv, size_t total) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const size_t b = e / vv;
+    out[e] = zsum(part + b * nz * vv + (e - b * vv), nz, vv);
+}
+
 constexpr int GT_WAVES = 8;   // two waves per SIMD: one wave's exact-fp32 MFMA chain covers the other's memory latency
 template <int PS_NT, bool LP>
 __global__ __launch_bounds__(64 * GT_WAVES) void graph_tracklet_kernel(const float* __restrict__ f, const float* __restrict__ adj,
@@ -942,11 +957,30 @@ extern "C" int agrl_graph_gram(const float* f, float* gram_part, int B, int V, i
     AGRL_CHECK_ARG(lds <= 160 * 1024, "agrl_graph_gram: V=%d too large", V);
     const int nz = C / GRAM_CS;
     if (lds > 64 * 1024) {  // V >= 125 (e.g. seq_len 20 x 7 parts): above the default dynamic-LDS limit of a launch
-        hipError_t e = hipFuncSetAttribute((const void*)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)gram_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_gram: cannot raise dynamic LDS: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(gram_kernel, dim3(B, nz), dim3(256), lds, (hipStream_t)stream, f, gram_part, V, C, nz);
+    hipLaunchKernelGGL(gram_kernel<false>, dim3(B, nz), dim3(256), lds, (hipStream_t)stream, f, (const float*)nullptr, gram_part, V, C, nz);
     AGRL_CHECK_LAUNCH("agrl_graph_gram");
+    return 0;
+}
+
+extern "C" int agrl_graph_pair_product(const float* a, const float* b, float* part, float* out, int B, int V, int C, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(a && b && part && out, "agrl_graph_pair_product: null pointer");
+    AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0 && C % GRAM_CS == 0, "agrl_graph_pair_product: bad shape (C must be a multiple of %d)", GRAM_CS);
+    const int Vp = (V + 15) & ~15;
+    const size_t lds = (size_t)2 * Vp * GRAM_ROWB;
+    AGRL_CHECK_ARG(lds <= 160 * 1024, "agrl_graph_pair_product: V=%d too large (two V x 128 slices must fit the LDS)", V);
+    const int nz = C / GRAM_CS;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gram_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_pair_product: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(gram_kernel<true>, dim3(B, nz), dim3(256), lds, (hipStream_t)stream, a, b, part, V, C, nz);
+    AGRL_CHECK_LAUNCH("agrl_graph_pair_product");
+    const size_t total = (size_t)B * V * V;
+    hipLaunchKernelGGL(gram_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part, nz, out, V * V, total);
+    AGRL_CHECK_LAUNCH("agrl_graph_pair_product(sum)");
     return 0;
 }
 

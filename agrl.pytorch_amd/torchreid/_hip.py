@@ -52,6 +52,7 @@ SIGNATURES = {
     "agrl_part_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_clip_pool": [_p, _p, _i, _i, _i, _i, _p],
     "agrl_graph_gram": [_p, _p, _i, _i, _i, _i, _p],
+    "agrl_graph_pair_product": [_p, _p, _p, _p, _i, _i, _i, _p],
     "agrl_graph_finalize": [_p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_graph_propagate": [_p, _p, _p, _p, _p, _f, _f, _f, _p, _p, _i, _i, _i, _p],
     "agrl_pam_pool": [_p, _p, _p, _p, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],

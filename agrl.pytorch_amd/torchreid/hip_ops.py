@@ -851,6 +851,20 @@ def graph_gram(f):
     return gram
 
 
+PAIR_PRODUCT_MAX_V = 144
+
+
+def graph_pair_product(a, b):
+    """a, b (B,V,C) fp32 -> (B,V,V) with out[t] = a[t] b[t]^T (d loss / d G of the message pass, vmgn.py:168)."""
+    B, V, Cc = a.shape
+    assert a.shape == b.shape and a.dtype == b.dtype == torch.float32 and Cc % GRAM_CSLICE == 0 and V <= PAIR_PRODUCT_MAX_V
+    part = torch.empty((B, Cc // GRAM_CSLICE, V, V), dtype=torch.float32, device=a.device)
+    out = torch.empty((B, V, V), dtype=torch.float32, device=a.device)
+    with _dev(a):
+        call("agrl_graph_pair_product", ptr(a.contiguous()), ptr(b.contiguous()), ptr(part), ptr(out), B, V, Cc, _stream(a))
+    return out
+
+
 def graph_finalize(gram, adj, B, V, use_pose, learn_graph, mask_diag=False):
     G = torch.empty((B, V, V), dtype=torch.float32, device=(gram if gram is not None else adj).device)
     nz = gram.shape[1] if gram is not None else 0

@@ -391,10 +391,12 @@ class HipGraphBmm(torch.autograd.Function):
         dmsg = dmsg.contiguous()
         B, V, C = h.shape
         dh = ops.graph_apply(G.transpose(1, 2).contiguous(), dmsg)
-        # dG[b] = dmsg[b] h[b]^T: one GEMM over all (B V) rows, its diagonal V x V blocks are the answer (B is a train batch)
-        full = ops.linear_nobias(dmsg.view(B * V, C), h.view(B * V, C)).view(B, V, B, V)
-        idx = torch.arange(B, device=h.device)
-        dG = full[idx, :, idx, :].contiguous()
+        if V <= ops.PAIR_PRODUCT_MAX_V and C % ops.GRAM_CSLICE == 0:
+            dG = ops.graph_pair_product(dmsg, h)  # dG[b] = dmsg[b] h[b]^T per tracklet
+        else:  # longer clips (V > 144): one GEMM over all (B V) rows, its diagonal V x V blocks are the answer
+            full = ops.linear_nobias(dmsg.view(B * V, C), h.view(B * V, C)).view(B, V, B, V)
+            idx = torch.arange(B, device=h.device)
+            dG = full[idx, :, idx, :].contiguous()
         return dG, dh
 
 

@@ -449,6 +449,12 @@ int agrl_attn_pool_backward(const float* nodes, const float* datt, float* dnodes
 int agrl_graph_matrix_backward(const float* gram_part, int nz, const float* dG, float* M, int B, int V, int use_pose,
                                int mask_diag, agrl_stream_t stream);
 
+/* Per-tracklet product out[b] = a[b] b[b]^T of two node matrices, fp32 (B,V,C) each -> fp32 (B,V,V): the gradient of the
+ * message pass msg = G h (vmgn.py:168) w.r.t. the graph, d loss / d G[b] = dmsg[b] h[b]^T. Exact fp32 MFMA over 128-channel
+ * slices (the agrl_graph_gram kernel with two operands), slice partials summed in slice order. part: workspace of
+ * B * (C/128) * V * V floats. C % 128 == 0, V <= 144 (two V x 128 fp32 slices in LDS). */
+int agrl_graph_pair_product(const float* a, const float* b, float* part, float* out, int B, int V, int C, agrl_stream_t stream);
+
 /* CrossEntropyLabelSmooth (torchreid/losses/cross_entropy_loss.py:26-37), value and gradient in one call:
  * loss (1) = (-q * log_softmax(logits)).mean(0).sum(), q = (1 - eps) onehot + eps / K; dlogits (n,K) = (softmax - q) / n.
  * logits fp32 (n,K); targets int32 (n); row_loss: scratch fp32 (n). */

@@ -584,3 +584,25 @@ def test_gsta_native_train_step_matches_cpu_module(consistent):
     for k in ("bn1.running_mean", "layer4.2.bn3.running_var", "bottleneck.running_mean", "bottleneck.num_batches_tracked"):
         a, b = dev.state_dict()[k].double().cpu(), ref.state_dict()[k].double()
         assert rel(a, b) < 1e-3 if b.abs().max() > 0 else torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("B,V,C", [(16, 112, 2048), (3, 28, 256), (2, 144, 128), (5, 7, 384)])
+def test_graph_pair_product_is_the_bmm_gradient(B, V, C):
+    """agrl_graph_pair_product = d loss / d G of msg = bmm(G, h) (vmgn.py:168): dmsg[b] h[b]^T per tracklet, against
+    float64 and against autograd; and the autograd function routes through it."""
+    from torchreid import hip_ops as ops
+    from torchreid.models._train_hip import HipGraphBmm
+    g = torch.Generator().manual_seed(B * 1000 + V)
+    dmsg = torch.randn((B, V, C), generator=g)
+    h = torch.randn((B, V, C), generator=g)
+    G = torch.rand((B, V, V), generator=g)
+    ref = torch.bmm(dmsg.double(), h.double().transpose(1, 2))
+    out = ops.graph_pair_product(dmsg.to(DEV), h.to(DEV))
+    err = ((out.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 2e-6, err
+    Gd, hd = G.to(DEV).requires_grad_(True), h.to(DEV).requires_grad_(True)
+    HipGraphBmm.apply(Gd, hd).backward(dmsg.to(DEV))
+    Gc, hc = G.double().requires_grad_(True), h.double().requires_grad_(True)
+    torch.bmm(Gc, hc).backward(dmsg.double())
+    assert ((Gd.grad.double().cpu() - Gc.grad).abs().max() / Gc.grad.abs().max()).item() < 2e-6
+    assert ((hd.grad.double().cpu() - hc.grad).abs().max() / hc.grad.abs().max()).item() < 2e-6
