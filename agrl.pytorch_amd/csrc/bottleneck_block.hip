@@ -239,7 +239,7 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
             for (int st = 0; st < 18; ++st) {
                 if (st + 2 < 18) ld0(st + 2, (st + 2) % 3);
 #pragma unroll
-                for (int a = 0; a < 2; ++a) acc0[a] = Frag<bf16_t>::mma(wq[st % 3][a], xq[st % 3], acc0[a]);
+                for (int a = 0; a < 2; ++a) acc0[a] = Frag<lp16_t>::mma(wq[st % 3][a], xq[st % 3], acc0[a]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int prow = wm * 16 + q;  // tile pixel (row-major) of this lane's MFMA column
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
                 const int c = wn * 32 + a * 16 + fc * 4;
                 float v[4] = {fmaxf(acc0[a][0] + b2v[a].x, 0.f), fmaxf(acc0[a][1] + b2v[a].y, 0.f),
                               fmaxf(acc0[a][2] + b2v[a].z, 0.f), fmaxf(acc0[a][3] + b2v[a].w, 0.f)};
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(s_y + prow * 128 + (((c >> 3) ^ ((prow >> 1) & 7)) << 4) + ((c & 4) << 1)), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(s_y + prow * 128 + (((c >> 3) ^ ((prow >> 1) & 7)) << 4) + ((c & 4) << 1)), v);
             }
         }
         if constexpr (CAT) {  // the x tile is an operand of GEMM 1: it must have landed (it is older than the patch prefetch)
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<bf16_t>::mma(w3f[a][kk], xf[b], acc[a][b]);
+                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<lp16_t>::mma(w3f[a][kk], xf[b], acc[a][b]);
         }
         if constexpr (CAT) {
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc[a][b] = Frag<bf16_t>::mma(wsf[a][kk], xf[b], acc[a][b]);
+                    for (int b = 0; b < 2; ++b) acc[a][b] = Frag<lp16_t>::mma(wsf[a][kk], xf[b], acc[a][b]);
             }
         } else {
             if (has_next) wait_vmcnt<PJ>();  // the residual pieces are older than the patch prefetch
@@ -312,15 +312,15 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
                 unsigned char* cell = s_r + px * 512 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
                 float rr[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (!CAT) {
-                    rr[0] = __uint_as_float(rcell[b][a].x << 16); rr[1] = __uint_as_float(rcell[b][a].x & 0xffff0000u);
-                    rr[2] = __uint_as_float(rcell[b][a].y << 16); rr[3] = __uint_as_float(rcell[b][a].y & 0xffff0000u);
+                    unpack_lp16x2(rcell[b][a].x, rr[0], rr[1]);
+                    unpack_lp16x2(rcell[b][a].y, rr[2], rr[3]);
                 }
                 float v[4];
                 v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
                 v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
                 v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
                 v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(cell), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
             }
         }
         wg_barrier();  // out tile complete
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
 #pragma unroll
                 for (int a = 0; a < NA2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc2[a][b] = Frag<bf16_t>::mma(w1f[a][ks], x2[ks % 3][b], acc2[a][b]);
+                    for (int b = 0; b < 2; ++b) acc2[a][b] = Frag<lp16_t>::mma(w1f[a][ks], x2[ks % 3][b], acc2[a][b]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
                 v[1] = fmaxf(acc2[a][b][1] + b1v[a].y, 0.f);
                 v[2] = fmaxf(acc2[a][b][2] + b1v[a].z, 0.f);
                 v[3] = fmaxf(acc2[a][b][3] + b1v[a].w, 0.f);
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(sz + px * (CN * 2) + (((c >> 3) ^ (px & (CN / 8 - 1))) << 4) + ((c & 4) << 1)), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(sz + px * (CN * 2) + (((c >> 3) ^ (px & (CN / 8 - 1))) << 4) + ((c & 4) << 1)), v);
             }
         }
         wg_barrier();  // z' tile complete (CN == 64: and every read of the out tile done)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<lp16_t>::mma(wf[a], xf[b], acc[a][b]);
         }
         // bias + residual (in place) + ReLU -> bf16 out tile
 #pragma unroll
@@ -153,13 +153,13 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
                 const int c = wn4 * 64 + a * 16 + fchunk * 4;
                 unsigned char* cell = sr + px * 512 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
                 float rr[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (!CAT) load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
+                if constexpr (!CAT) load4<lp16_t>(reinterpret_cast<const lp16_t*>(cell), rr);
                 float v[4];
                 v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
                 v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
                 v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
                 v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(cell), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
             }
         }
         wg_barrier();  // out tile complete
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
             for (int b = 0; b < 2; ++b) {
                 const int px = wm2 * 32 + b * 16 + frow;
                 const uint4 xf = *reinterpret_cast<const uint4*>(sr + px * 512 + (((ks * 4 + fchunk) ^ (px & 31)) << 4));
-                acc2[b] = Frag<bf16_t>::mma(wf, xf, acc2[b]);
+                acc2[b] = Frag<lp16_t>::mma(wf, xf, acc2[b]);
             }
         }
         // z tile -> the y2 slot of this tile (every wave finished reading it before the barrier above)
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
             v[1] = fmaxf(acc2[b][1] + b1v.y, 0.f);
             v[2] = fmaxf(acc2[b][2] + b1v.z, 0.f);
             v[3] = fmaxf(acc2[b][3] + b1v.w, 0.f);
-            store4<bf16_t>(reinterpret_cast<bf16_t*>(sz + px * 128 + (((c >> 3) ^ (px & 7)) << 4) + ((c & 4) << 1)), v);
+            store4<lp16_t>(reinterpret_cast<lp16_t*>(sz + px * 128 + (((c >> 3) ^ (px & 7)) << 4) + ((c & 4) << 1)), v);
         }
         wg_barrier();  // z tile complete; every read of the out tile done
         {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParam
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+                for (int b = 0; b < 2; ++b) acc[a][b] = Frag<lp16_t>::mma(wf[a], xf[b], acc[a][b]);
         }
         if (has_next) wait_vmcnt<1>();  // the residual pieces are older than the y2 prefetch
         else wait_vmcnt<0>();
@@ -313,13 +313,13 @@ __global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParam
                 const int c = wn4 * 64 + a * 16 + fchunk * 4;
                 unsigned char* cell = sr + px * 512 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
                 float rr[4];
-                load4<bf16_t>(reinterpret_cast<const bf16_t*>(cell), rr);
+                load4<lp16_t>(reinterpret_cast<const lp16_t*>(cell), rr);
                 float v[4];
                 v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
                 v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
                 v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
                 v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(cell), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
             }
         }
         wg_barrier();  // out tile complete
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParam
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc2[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc2[a][b]);
+                for (int b = 0; b < 2; ++b) acc2[a][b] = Frag<lp16_t>::mma(wf[a], xf[b], acc2[a][b]);
         }
         wg_barrier();  // every read of the out tile (drain + GEMM 2) is done: stage z over it, 256-byte rows
 #pragma unroll
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParam
                 v[1] = fmaxf(acc2[a][b][1] + b1v[a].y, 0.f);
                 v[2] = fmaxf(acc2[a][b][2] + b1v[a].z, 0.f);
                 v[3] = fmaxf(acc2[a][b][3] + b1v[a].w, 0.f);
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(sr + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(sr + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
             }
         }
         wg_barrier();
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = Frag<bf16_t>::mma(w3f[2 * ah + a][kk], xp[kk & 1][b], acc[a][b]);
+                    for (int b = 0; b < 4; ++b) acc[a][b] = Frag<lp16_t>::mma(w3f[2 * ah + a][kk], xp[kk & 1][b], acc[a][b]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             float bv[2][4];
@@ -525,12 +525,13 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
                 for (int a = 0; a < 2; ++a) {
                     const int c = wave * 64 + (2 * ah + a) * 16 + fchunk * 4;
                     unsigned char* cell = sr + px * 1024 + (((c >> 3) ^ (px & 31)) << 4) + ((c & 4) << 1);
-                    const float rr[4] = {__uint_as_float(rcell[b][a].x << 16), __uint_as_float(rcell[b][a].x & 0xffff0000u),
-                                         __uint_as_float(rcell[b][a].y << 16), __uint_as_float(rcell[b][a].y & 0xffff0000u)};
+                    float rr[4];
+                    unpack_lp16x2(rcell[b][a].x, rr[0], rr[1]);
+                    unpack_lp16x2(rcell[b][a].y, rr[2], rr[3]);
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[a][b][r] + bv[a][r] + rr[r], 0.f);
-                    store4<bf16_t>(reinterpret_cast<bf16_t*>(cell), v);
+                    store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
                 }
             }
         }
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
                 for (int b = 0; b < 4; ++b) xq[(ks + 1) & 1][b] = ld2(ks + 1, b);
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc2[b] = Frag<bf16_t>::mma(w1f[ks], xq[ks & 1][b], acc2[b]);
+            for (int b = 0; b < 4; ++b) acc2[b] = Frag<lp16_t>::mma(w1f[ks], xq[ks & 1][b], acc2[b]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // z tile (64 px x 128 ch, 256-byte rows, chunk c at c ^ (row & 15)) over this tile's y2 slot
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc2[b][r] + lane_bias(b1l, fchunk * 4 + r), 0.f);
-            store4<bf16_t>(reinterpret_cast<bf16_t*>(sz + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
+            store4<lp16_t>(reinterpret_cast<lp16_t*>(sz + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
         }
         wg_barrier();  // z tile complete; every read of the out tile done
 #pragma unroll

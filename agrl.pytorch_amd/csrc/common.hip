@@ -13,6 +13,8 @@ void agrl_set_error(const char* fmt, ...) {
 extern "C" int agrl_version(void) { return 100; }
 extern "C" const char* agrl_last_error(void) { return g_err; }
 
+extern "C" int agrl_lp16_is_f16(void) { return kLpF16 ? 1 : 0; }
+
 // ---- tuning switches (agrl_common.h) ----------------------------------------------------------------------------------
 #include <stdlib.h>
 

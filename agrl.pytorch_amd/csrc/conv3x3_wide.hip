@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
                 if (g < FM) xfr[1][g] = ldx(1, g);
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
-                    if (!(DBG & 2)) acc[g & 3][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g >> 2][b], acc[g & 3][b]);
+                    if (!(DBG & 2)) acc[g & 3][b] = Frag<lp16_t>::mma(wfr[g % 3], xfr[g >> 2][b], acc[g & 3][b]);
                     else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g >> 2][b].x), "v"(xfr[g >> 2][b].w));
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            store4<bf16_t>(reinterpret_cast<bf16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
+            store4<lp16_t>(reinterpret_cast<lp16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
         }
     }
     wg_barrier();
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
 #pragma unroll
                 for (int a = 0; a < FN; ++a)
 #pragma unroll
-                    for (int b = 0; b < FM; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+                    for (int b = 0; b < FM; ++b) acc[a][b] = Frag<lp16_t>::mma(wf[a], xf[b], acc[a][b]);
             }
         }
         // bias + ReLU -> bf16 out tile (128-byte rows, chunk c at c ^ (row & 7)); the previous block's stores read it
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(s_o + prow * 128 + (((c >> 3) ^ (prow & 7)) << 4) + ((c & 4) << 1)), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(s_o + prow * 128 + (((c >> 3) ^ (prow & 7)) << 4) + ((c & 4) << 1)), v);
             }
         }
         wg_barrier();

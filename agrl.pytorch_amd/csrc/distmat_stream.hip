@@ -213,11 +213,9 @@ __global__ __launch_bounds__(512) void distmat_regq_kernel(const IgemmParams p) 
 #pragma unroll
                 for (int s = 0; s < NS; ++s) asm volatile("" : "+v"(qreg[q][s]));
         }
-        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, ring[i % RD]);
+        const f32x4_t a = ring[i % RD];
 #pragma unroll
-        for (int q = 0; q < QF; ++q)
-            acc[i / NS][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(bf16x8_t, qreg[q][i % NS]),
-                                                                     acc[i / NS][q], 0, 0, 0);
+        for (int q = 0; q < QF; ++q) acc[i / NS][q] = mfma_lp16_16x16x32(a, qreg[q][i % NS], acc[i / NS][q]);
         if (i + RD < NL) {
             // (the register allocator orders the refill behind the MFMAs that read the old value)
             ring[i % RD] = ds_gload16(grow[(i + RD) / NS] + ((i + RD) % NS) * 64);
@@ -305,5 +303,5 @@ int launch_distmat_stream(const IgemmParams& p_in, int dtype, hipStream_t stream
         if (p.K == 1024) REGQ(4);
 #undef REGQ
     }
-    return launch_stream<bf16_t>(p, stream);
+    return launch_stream<lp16_t>(p, stream);
 }

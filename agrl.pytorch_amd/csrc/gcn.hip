@@ -180,7 +180,7 @@ template <int VT>  // VT > 0: compile-time V, h in registers; VT == 0: generic, 
 __global__ __launch_bounds__(PROP_THREADS) void graph_propagate_kernel(
     const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
-    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int Vrt, int C) {
+    float slope, float* __restrict__ out, lp16_t* __restrict__ out_lp, int Vrt, int C) {
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
     const int V = VT > 0 ? VT : Vrt;
     const int Vp = (V + PROP_RB - 1) & ~(PROP_RB - 1);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(PROP_THREADS) void graph_propagate_kernel(
                 const float o = one_minus_gamma * fv[k] + gamma * y;
                 const size_t idx = ((size_t)b * V + v) * C + c;
                 out[idx] = o;
-                if (out_lp) out_lp[idx] = f32_to_bf16(o);
+                if (out_lp) out_lp[idx] = f32_to_lp16(o);
             }
         }
     }
@@ -261,7 +261,7 @@ constexpr int PROPT_ROWS = 16;
 __global__ __launch_bounds__(PROP_THREADS) void graph_propagate_tiled_kernel(
     const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
-    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int V, int C) {
+    float slope, float* __restrict__ out, lp16_t* __restrict__ out_lp, int V, int C) {
     extern __shared__ __attribute__((aligned(16))) float s_gr[];   // [V][16]: s_gr[u * 16 + k] = G[v0 + k][u]
     const int b = blockIdx.x, tid = threadIdx.x;
     const int c = blockIdx.y * PROP_THREADS + tid;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(PROP_THREADS) void graph_propagate_tiled_kernel(
             y = y > 0.f ? y : slope * y;
             const float o = one_minus_gamma * f[idx] + gamma * y;
             out[idx] = o;
-            if (out_lp) out_lp[idx] = f32_to_bf16(o);
+            if (out_lp) out_lp[idx] = f32_to_lp16(o);
         }
     }
 }
@@ -321,7 +321,7 @@ template <int NVF>
 __global__ __launch_bounds__(256) void graph_propagate_mfma_kernel(
     const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
-    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int V, int C) {
+    float slope, float* __restrict__ out, lp16_t* __restrict__ out_lp, int V, int C) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const int V4 = (V + 3) & ~3;
     constexpr int VP = NVF * 16;
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void graph_propagate_mfma_kernel(
                 *reinterpret_cast<float4*>(out + idx) = make_float4(o[0], o[1], o[2], o[3]);
                 if (out_lp) {
                     uint2 pk;
-                    pk.x = pack_bf16x2(o[0], o[1]);
-                    pk.y = pack_bf16x2(o[2], o[3]);
+                    pk.x = pack_lp16x2(o[0], o[1]);
+                    pk.y = pack_lp16x2(o[2], o[3]);
                     *reinterpret_cast<uint2*>(out_lp + idx) = pk;
                 }
             }
@@ -514,7 +514,7 @@ template <int PS_NT, int NWV>  // V = 4 PS_NT exactly; NWV waves (64 channels ea
 __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
     const float* __restrict__ f, const float* __restrict__ h, const float* __restrict__ G,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float one_minus_gamma, float gamma,
-    float slope, float* __restrict__ out, bf16_t* __restrict__ out_lp, int C) {
+    float slope, float* __restrict__ out, lp16_t* __restrict__ out_lp, int C) {
     extern __shared__ __attribute__((aligned(16))) float s_g[];  // [16*NVF][V]
     constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4;
     const int b = blockIdx.x;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
         const int v = vf * 16 + i16;
         if (v >= V) continue;
         float* op = out + (node0 + v) * C + cl;
-        bf16_t* lp = out_lp ? out_lp + (node0 + v) * C + cl : nullptr;
+        lp16_t* lp = out_lp ? out_lp + (node0 + v) * C + cl : nullptr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float o[4];
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
                 o[j] = one_minus_gamma * fin[vf][r][j] + gamma * y;
             }
             *reinterpret_cast<float4*>(op + 16 * r) = make_float4(o[0], o[1], o[2], o[3]);
-            if (lp) *reinterpret_cast<uint2*>(lp + 16 * r) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            if (lp) *reinterpret_cast<uint2*>(lp + 16 * r) = make_uint2(pack_lp16x2(o[0], o[1]), pack_lp16x2(o[2], o[3]));
         }
     }
 }
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
 // minus the residual / BatchNorm operands: f crosses HBM once (V C 4 bytes per tracklet in, V C 2 or 4 out).
 template <int PS_NT, int NWV, bool LP>
 __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const float* __restrict__ f, const float* __restrict__ G,
-                                                                      float* __restrict__ out, bf16_t* __restrict__ out_lp, int C) {
+                                                                      float* __restrict__ out, lp16_t* __restrict__ out_lp, int C) {
     extern __shared__ __attribute__((aligned(16))) float s_g[];  // [16*NVF][V]
     constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4;
     const int b = blockIdx.x;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const floa
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float o0 = acc[vf][0][r], o1 = acc[vf][1][r], o2 = acc[vf][2][r], o3 = acc[vf][3][r];
-            if constexpr (LP) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            if constexpr (LP) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_lp16x2(o0, o1), pack_lp16x2(o2, o3));
             else *reinterpret_cast<float4*>(out + (node0 + v) * C + cl + 16 * r) = make_float4(o0, o1, o2, o3);
         }
     }
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void gram_sum_kernel(const float* __restrict__
 constexpr int GT_WAVES = 8;   // two waves per SIMD: one wave's exact-fp32 MFMA chain covers the other's memory latency
 template <int PS_NT, bool LP>
 __global__ __launch_bounds__(64 * GT_WAVES) void graph_tracklet_kernel(const float* __restrict__ f, const float* __restrict__ adj,
-                                                                       const uint32_t* __restrict__ adj_bits, float* __restrict__ G_out, float* __restrict__ out, bf16_t* __restrict__ out_lp,
+                                                                       const uint32_t* __restrict__ adj_bits, float* __restrict__ G_out, float* __restrict__ out, lp16_t* __restrict__ out_lp,
                                                                        int C, int use_pose, int learn_graph, int mask_diag) {
     constexpr int V = 4 * PS_NT, NVF = (PS_NT + 3) / 4, VP = NVF * 16, NPAIR = NVF * (NVF + 1) / 2, NT = 64 * GT_WAVES;
     extern __shared__ __attribute__((aligned(16))) float s_mem[];
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64 * GT_WAVES) void graph_tracklet_kernel(const flo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float o0 = acc[vf][0][r], o1 = acc[vf][1][r], o2 = acc[vf][2][r], o3 = acc[vf][3][r];
-                if constexpr (LP) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                if constexpr (LP) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_lp16x2(o0, o1), pack_lp16x2(o2, o3));
                 else *reinterpret_cast<float4*>(out + (node0 + v) * C + cl + 16 * r) = make_float4(o0, o1, o2, o3);
             }
         }
@@ -1013,8 +1013,8 @@ extern "C" int agrl_graph_finalize_bits(const float* gram_part, int nz, const ui
 extern "C" int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, int B, int V, int C, agrl_stream_t stream) {
     AGRL_CHECK_ARG(G && f && out, "agrl_graph_apply: null pointer");
     AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0, "agrl_graph_apply: bad shape");
-    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_graph_apply: out dtype must be fp32 or bf16");
-    const bool lp = out_dtype == AGRL_BF16;
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_LP16, "agrl_graph_apply: out dtype must be fp32 or bf16");
+    const bool lp = out_dtype == AGRL_LP16;
     const bool aligned = ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)G) & 15) == 0);
     AGRL_CHECK_ARG(V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned,
                    "agrl_graph_apply: the streaming form needs V <= 64, V %% 4 == 0, C %% 128 == 0, 16-byte aligned operands (V=%d C=%d); "
@@ -1026,10 +1026,10 @@ extern "C" int agrl_graph_apply(const float* G, const float* f, void* out, int o
 #define LAUNCH_GA(NT_)                                                                                                          \
     case NT_:                                                                                                                   \
         if (nwv == 4) {                                                                                                         \
-            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, true>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, nullptr, (bf16_t*)out, C); \
+            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, true>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, nullptr, (lp16_t*)out, C); \
             else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, false>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
         } else {                                                                                                                \
-            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, true>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, nullptr, (bf16_t*)out, C); \
+            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, true>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, nullptr, (lp16_t*)out, C); \
             else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, false>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
         }                                                                                                                       \
         break
@@ -1047,19 +1047,19 @@ extern "C" int agrl_graph_tracklet_operand(const float* f, const void* adj, int 
     const float* adj_f = adj_packed ? nullptr : (const float*)adj;
     const uint32_t* adj_b = adj_packed ? (const uint32_t*)adj : nullptr;
     AGRL_CHECK_ARG(f && out && (use_pose || learn_graph) && (!use_pose || adj), "agrl_graph_tracklet_operand: bad arguments");
-    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_graph_tracklet_operand: out dtype must be fp32 or bf16");
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_LP16, "agrl_graph_tracklet_operand: out dtype must be fp32 or bf16");
     AGRL_CHECK_ARG(B > 0 && V > 0 && V <= 64 && (V % 4) == 0 && C >= 512 && (C % 512) == 0 && ((((uintptr_t)f | (uintptr_t)out) & 15) == 0),
                    "agrl_graph_tracklet_operand: built for V <= 64, V %% 4 == 0, C %% 512 == 0, 16-byte aligned f / out (V=%d C=%d)", V, C);
     const int nvf = (V + 15) / 16, VP = nvf * 16, npair = nvf * (nvf + 1) / 2;
     const size_t lds = ((size_t)GT_WAVES * npair * 256 + (size_t)VP * (VP + 1) + (size_t)VP * V) * sizeof(float);
-    const bool lp = out_dtype == AGRL_BF16;
+    const bool lp = out_dtype == AGRL_LP16;
 #define LAUNCH_GT(NT_)                                                                                                          \
     case NT_: {                                                                                                                 \
         if (lds > 64 * 1024) {                                                                                                  \
             if (lp) (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             else (void)hipFuncSetAttribute((const void*)graph_tracklet_kernel<NT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   \
         }                                                                                                                       \
-        if (lp) hipLaunchKernelGGL((graph_tracklet_kernel<NT_, true>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj_f, adj_b, G_out, nullptr, (bf16_t*)out, C, use_pose, learn_graph, mask_diag); \
+        if (lp) hipLaunchKernelGGL((graph_tracklet_kernel<NT_, true>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj_f, adj_b, G_out, nullptr, (lp16_t*)out, C, use_pose, learn_graph, mask_diag); \
         else hipLaunchKernelGGL((graph_tracklet_kernel<NT_, false>), dim3(B), dim3(64 * GT_WAVES), lds, (hipStream_t)stream, f, adj_f, adj_b, G_out, (float*)out, nullptr, C, use_pose, learn_graph, mask_diag);   \
     } break
     (void)hipGetLastError();
@@ -1093,11 +1093,11 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
         if (nwv == 4)                                                                                                 \
             hipLaunchKernelGGL((graph_propagate_stream_kernel<NT_, 4>), dim3(B, C / 256), dim3(256), lds_s,           \
                                (hipStream_t)stream, f, h, G, bn_scale, bn_shift, omg_m, gamma, slope, out,            \
-                               (bf16_t*)out_lp, C);                                                                   \
+                               (lp16_t*)out_lp, C);                                                                   \
         else                                                                                                          \
             hipLaunchKernelGGL((graph_propagate_stream_kernel<NT_, 2>), dim3(B, C / 128), dim3(128), lds_s,           \
                                (hipStream_t)stream, f, h, G, bn_scale, bn_shift, omg_m, gamma, slope, out,            \
-                               (bf16_t*)out_lp, C);                                                                   \
+                               (lp16_t*)out_lp, C);                                                                   \
         break
         switch (V4 >> 2) {
             LAUNCH_PS(1); LAUNCH_PS(2); LAUNCH_PS(3); LAUNCH_PS(4); LAUNCH_PS(5); LAUNCH_PS(6); LAUNCH_PS(7); LAUNCH_PS(8);
@@ -1115,7 +1115,7 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
         const dim3 grid_m(B, C / 128);
         if (nvf == 4) {
             hipLaunchKernelGGL(graph_propagate_mfma_kernel<4>, grid_m, dim3(256), lds_m, (hipStream_t)stream, f, h, G,
-                               bn_scale, bn_shift, omg_m, gamma, slope, out, (bf16_t*)out_lp, V, C);
+                               bn_scale, bn_shift, omg_m, gamma, slope, out, (lp16_t*)out_lp, V, C);
         } else {
             if (lds_m > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute((const void*)graph_propagate_mfma_kernel<8>,
@@ -1123,7 +1123,7 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
                 AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_propagate: cannot raise dynamic LDS: %s", hipGetErrorString(e));
             }
             hipLaunchKernelGGL(graph_propagate_mfma_kernel<8>, grid_m, dim3(256), lds_m, (hipStream_t)stream, f, h, G,
-                               bn_scale, bn_shift, omg_m, gamma, slope, out, (bf16_t*)out_lp, V, C);
+                               bn_scale, bn_shift, omg_m, gamma, slope, out, (lp16_t*)out_lp, V, C);
         }
         AGRL_CHECK_LAUNCH("agrl_graph_propagate");
         return 0;
@@ -1134,7 +1134,7 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     if (lds > 160 * 1024) {   // graph + h slab no longer fit the LDS (V > ~125): 16 graph rows per workgroup, h streamed from L2
         AGRL_CHECK_ARG((size_t)V * PROPT_ROWS * 4 <= 64 * 1024, "agrl_graph_propagate: V=%d too large", V);
         hipLaunchKernelGGL(graph_propagate_tiled_kernel, dim3(B, cdiv(C, PROP_THREADS), cdiv(V, PROPT_ROWS)), dim3(PROP_THREADS),
-                           (size_t)V * PROPT_ROWS * 4, (hipStream_t)stream, f, h, G, bn_scale, bn_shift, keep, gamma, slope, out, (bf16_t*)out_lp, V, C);
+                           (size_t)V * PROPT_ROWS * 4, (hipStream_t)stream, f, h, G, bn_scale, bn_shift, keep, gamma, slope, out, (lp16_t*)out_lp, V, C);
         AGRL_CHECK_LAUNCH("agrl_graph_propagate");
         return 0;
     }
@@ -1149,7 +1149,7 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
             AGRL_CHECK_ARG(e == hipSuccess, "agrl_graph_propagate: cannot raise dynamic LDS: %s", hipGetErrorString(e)); \
         }                                                                                                            \
         hipLaunchKernelGGL(graph_propagate_kernel<VT>, grid, dim3(PROP_THREADS), lds, st, f, h, G, bn_scale, bn_shift, \
-                           omg, gamma, slope, out, (bf16_t*)out_lp, V, C);                                           \
+                           omg, gamma, slope, out, (lp16_t*)out_lp, V, C);                                           \
     } while (0)
     LAUNCH_PROP(0);
 #undef LAUNCH_PROP

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512) void graph_linear_kernel(const GraphGemmParams
         for (int a = 0; a < 4; ++a) {
             if (do_stage) stage_piece(fill, a);  // one piece of the k-tile three ahead rides with each group of MFMAs
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+            for (int b = 0; b < 4; ++b) acc[a][b] = Frag<lp16_t>::mma(wf[a], xf[b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (do_stage) kbyte += 128;

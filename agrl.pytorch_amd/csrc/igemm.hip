@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(p.alpha, acc[a][b][r], rv + cv[r]);
                 if (resp) {
                     float rr[4];
-                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), rr);
+                    load4<lp16_t>(reinterpret_cast<const lp16_t*>(slot), rr);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += rr[r];
                 }
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(slot), v);
             }
         }
         __syncthreads();
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                     v[3] = fmaf(p.alpha, acc[a][b][3], p.rowc + cv.w);
                     if (has_res) {
                         float rr[4];
-                        load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), rr);
+                        load4<lp16_t>(reinterpret_cast<const lp16_t*>(slot), rr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += rr[r];
                     }
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                     }
-                    store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+                    store4<lp16_t>(reinterpret_cast<lp16_t*>(slot), v);
                 }
             }
         }
@@ -633,8 +633,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                 const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    part8[2 * j] += __uint_as_float(w4[j] << 16);
-                    part8[2 * j + 1] += __uint_as_float(w4[j] & 0xffff0000u);
+                    float lo, hi;
+                    unpack_lp16x2(w4[j], lo, hi);
+                    part8[2 * j] += lo;
+                    part8[2 * j + 1] += hi;
                 }
             }
             wg_barrier();  // everybody holds its partial: the tile image may be overwritten
@@ -662,11 +664,11 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                 *reinterpret_cast<float4*>(p.pool_out + o + 4) = hi4;
                 if (p.pool_out_lp) {
                     uint4 pk;
-                    pk.x = pack_bf16x2(lo4.x, lo4.y);
-                    pk.y = pack_bf16x2(lo4.z, lo4.w);
-                    pk.z = pack_bf16x2(hi4.x, hi4.y);
-                    pk.w = pack_bf16x2(hi4.z, hi4.w);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.pool_out_lp) + o) = pk;
+                    pk.x = pack_lp16x2(lo4.x, lo4.y);
+                    pk.y = pack_lp16x2(lo4.z, lo4.w);
+                    pk.z = pack_lp16x2(hi4.x, hi4.y);
+                    pk.w = pack_lp16x2(hi4.z, hi4.w);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<lp16_t*>(p.pool_out_lp) + o) = pk;
                 }
             }
         }
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const IgemmParams p)
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+                for (int b = 0; b < FM; ++b) acc[a][b] = Frag<lp16_t>::mma(wf[a], xf[b], acc[a][b]);
         }
         tap = ntap;
         slab = nsl;
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const IgemmParams p)
                 v[r] = acc[a][b][r] + cvr[a][r];
                 if (p.relu) v[r] = fmaxf(v[r], 0.f);
             }
-            store4<bf16_t>(reinterpret_cast<bf16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
+            store4<lp16_t>(reinterpret_cast<lp16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
         }
     }
     wg_barrier();
@@ -958,7 +960,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     AGRL_CHECK_ARG(x && w && out, "agrl_conv2d_bn_act: null pointer");
     AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "agrl_conv2d_bn_act: bad shape");
     AGRL_CHECK_ARG(R > 0 && S > 0 && stride > 0 && pad >= 0, "agrl_conv2d_bn_act: bad filter geometry");
-    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16 || dtype == AGRL_F32X3, "agrl_conv2d_bn_act: bad dtype %d", dtype);
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_LP16 || dtype == AGRL_F32X3, "agrl_conv2d_bn_act: bad dtype %d", dtype);
     IgemmParams p;
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
@@ -999,7 +1001,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
         AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 patch)");
         return 0;
     }
-    return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
+    return launch_igemm<lp16_t, lp16_t>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
 }
 
 // conv without bias / residual / activation in fp32 (exact or split-bf16) whose epilogue also leaves the per-channel sum and sum
@@ -1076,13 +1078,13 @@ extern "C" int agrl_conv1x1_bn_act_pool(const void* x, const void* w, const floa
     p.pool_nparts = P; p.pool_mean = mean; p.pool_store_out = out != nullptr; p.pool_w = W;
     p.pool_out = pool_out; p.pool_out_lp = pool_out_lp;
     if (!out) p.out = pool_out;  // never dereferenced as activations; keeps the alignment checks meaningful
-    return launch_igemm<bf16_t, bf16_t>(p, (hipStream_t)stream, "agrl_conv1x1_bn_act_pool");
+    return launch_igemm<lp16_t, lp16_t>(p, (hipStream_t)stream, "agrl_conv1x1_bn_act_pool");
 }
 
 extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M, int K, int Nout,
                                   int in_dtype, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && w && y, "agrl_linear_nobias: null pointer");
-    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_linear_nobias: bad dtype %d", in_dtype);
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3, "agrl_linear_nobias: bad dtype %d", in_dtype);
     IgemmParams p;
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
@@ -1092,7 +1094,7 @@ extern "C" int agrl_linear_nobias(const void* x, const void* w, float* y, int M,
     p.ldo = Nout;
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
     if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
-    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
+    return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_linear_nobias");
 }
 
 // GraphLayer, second half, as ONE GEMM with a fused epilogue (vmgn.py:148, :168-172):
@@ -1104,11 +1106,11 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
                                      float keep, float gamma, float slope, float* out, int M, int K, int Nout, int in_dtype,
                                      agrl_stream_t stream) {
     AGRL_CHECK_ARG(p_op && w && f && bn_scale && bn_shift && out, "agrl_graph_linear_mix: null pointer");
-    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
     AGRL_CHECK_ARG((Nout % 4) == 0 && ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0),
                    "agrl_graph_linear_mix: Nout %% 4 == 0 and 16-byte aligned f / out / scale / shift required");
     // bf16 operands: the kernel shaped for this problem (graph_gemm.hip); AGRL_GRAPH_LINEAR_IGEMM=1 keeps the generic one (A/B)
-    if (in_dtype == AGRL_BF16 && !agrl_opts().graph_linear_igemm && graph_gemm_applicable(M, K, Nout))
+    if (in_dtype == AGRL_LP16 && !agrl_opts().graph_linear_igemm && graph_gemm_applicable(M, K, Nout))
         return launch_graph_gemm(p_op, w, f, bn_scale, bn_shift, keep, gamma, slope, out, M, K, Nout, (hipStream_t)stream);
     IgemmParams p;
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
@@ -1123,7 +1125,7 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
     p.nmajor = agrl_opts().graph_linear_mmajor ? 0 : 1;   // AGRL_GRAPH_LINEAR_MMAJOR=1: A/B switch
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
     if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
-    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
+    return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
 }
 
 // out[m][n] = alpha * sum_z ws[z][m][n] + rowv[m] (or rowc) + colv[n]
@@ -1142,7 +1144,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 extern "C" int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M, int K, int Nout, int in_dtype, void* workspace,
                                    size_t workspace_bytes, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && w && y, "agrl_gemm_nt_splitk: null pointer");
-    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_BF16 || in_dtype == AGRL_F32X3, "agrl_gemm_nt_splitk: bad dtype %d", in_dtype);
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3, "agrl_gemm_nt_splitk: bad dtype %d", in_dtype);
     IgemmParams p;
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w; p.colv = nullptr; p.rowv = nullptr; p.res = nullptr; p.out = y;
@@ -1152,7 +1154,7 @@ extern "C" int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M
     p.ldo = Nout;
     // weight gradients: a handful of output tiles and a K axis of 10^4..10^6 pixels -> K slices over workgroups until the
     // chip is covered twice, fp32 partials in the caller's workspace, summed in slice order (deterministic)
-    const int bke = in_dtype == AGRL_BF16 ? 64 : 32;
+    const int bke = in_dtype == AGRL_LP16 ? 64 : 32;
     AGRL_CHECK_ARG(K % bke == 0, "agrl_gemm_nt_splitk: K=%d must be a multiple of %d", K, bke);
     const int nk = K / bke;
     const int tiles = cdiv(M, 64) * cdiv(Nout, Nout <= 64 ? 64 : 128);
@@ -1164,7 +1166,7 @@ extern "C" int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M
         int rc;
         if (in_dtype == AGRL_F32) rc = launch_igemm<float, float>(ps, (hipStream_t)stream, "agrl_gemm_nt_splitk");
         else if (in_dtype == AGRL_F32X3) rc = launch_igemm<f32s_t, float>(ps, (hipStream_t)stream, "agrl_gemm_nt_splitk");
-        else rc = launch_igemm<bf16_t, float>(ps, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+        else rc = launch_igemm<lp16_t, float>(ps, (hipStream_t)stream, "agrl_gemm_nt_splitk");
         if (rc) return rc;
         const size_t total = (size_t)M * Nout;
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -1175,14 +1177,14 @@ extern "C" int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M
     }
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
     if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
-    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
+    return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
 }
 
 extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist, int m, int n, int D,
                             int ldd, int metric, int dtype, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
     AGRL_CHECK_ARG(q && g && dist, "agrl_distmat: null pointer");
     AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && ldd >= n, "agrl_distmat: bad shape m=%d n=%d D=%d ldd=%d", m, n, D, ldd);
-    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_distmat: bad dtype %d", dtype);
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_LP16, "agrl_distmat: bad dtype %d", dtype);
     IgemmParams p;
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
@@ -1212,7 +1214,7 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
         IgemmParams ps = p;
         ps.out = workspace; ps.ldo = n; ps.alpha = 1.f; ps.rowv = nullptr; ps.colv = nullptr; ps.rowc = 0.f; ps.ksplit = ks;
         int rc = dtype == AGRL_F32 ? launch_igemm<float, float>(ps, (hipStream_t)stream, "agrl_distmat")
-                                   : launch_igemm<bf16_t, float>(ps, (hipStream_t)stream, "agrl_distmat");
+                                   : launch_igemm<lp16_t, float>(ps, (hipStream_t)stream, "agrl_distmat");
         if (rc) return rc;
         const size_t total = (size_t)m * n;
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -1222,5 +1224,5 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
         return 0;
     }
     if (dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_distmat");
-    return launch_igemm<bf16_t, float>(p, (hipStream_t)stream, "agrl_distmat");
+    return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_distmat");
 }

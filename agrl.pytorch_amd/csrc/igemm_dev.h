@@ -44,13 +44,9 @@ template <typename T>
 struct Frag;
 
 template <>
-struct Frag<bf16_t> {
-    // one 16-byte chunk = 8 bf16 = a quarter of the 32-deep k-step of v_mfma_f32_16x16x32_bf16
-    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
-        bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
-        bf16x8_t bv = __builtin_bit_cast(bf16x8_t, b);
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
-    }
+struct Frag<lp16_t> {
+    // one 16-byte chunk = 8 elements = a quarter of the 32-deep k-step of v_mfma_f32_16x16x32_f16 / _bf16
+    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) { return mfma_lp16_16x16x32(a, b, c); }
 };
 
 template <>
@@ -102,10 +98,10 @@ __device__ inline void store4<float>(float* p, const float v[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 template <>
-__device__ inline void store4<bf16_t>(bf16_t* p, const float v[4]) {
+__device__ inline void store4<lp16_t>(lp16_t* p, const float v[4]) {
     uint2 u;
-    u.x = pack_bf16x2(v[0], v[1]);
-    u.y = pack_bf16x2(v[2], v[3]);
+    u.x = pack_lp16x2(v[0], v[1]);
+    u.y = pack_lp16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = u;
 }
 template <typename TOUT>
@@ -116,10 +112,10 @@ __device__ inline void load4<float>(const float* p, float v[4]) {
     v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
 }
 template <>
-__device__ inline void load4<bf16_t>(const bf16_t* p, float v[4]) {
+__device__ inline void load4<lp16_t>(const lp16_t* p, float v[4]) {
     uint2 u = *reinterpret_cast<const uint2*>(p);
-    v[0] = bf16_to_f32((bf16_t)(u.x & 0xffff)); v[1] = bf16_to_f32((bf16_t)(u.x >> 16));
-    v[2] = bf16_to_f32((bf16_t)(u.y & 0xffff)); v[3] = bf16_to_f32((bf16_t)(u.y >> 16));
+    unpack_lp16x2(u.x, v[0], v[1]);
+    unpack_lp16x2(u.y, v[2], v[3]);
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;

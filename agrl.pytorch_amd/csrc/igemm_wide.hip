@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 #pragma unroll
                 for (int a = 0; a < FN; ++a)
 #pragma unroll
-                    for (int b = 0; b < FM; ++b) acc[a][b] = Frag<bf16_t>::mma(wf[a], xf[b], acc[a][b]);
+                    for (int b = 0; b < FM; ++b) acc[a][b] = Frag<lp16_t>::mma(wf[a], xf[b], acc[a][b]);
                 __builtin_amdgcn_s_setprio(0);
                 if (kk == 1 && wn == 0) wait_vmcnt<0>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
             if (do_stage && g < DPT) stage_piece(fill, g);
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
-                if (!(DBG & 2)) acc[g % FN][b] = Frag<bf16_t>::mma(wfr[g % 3], xfr[g / FN][b], acc[g % FN][b]);
+                if (!(DBG & 2)) acc[g % FN][b] = Frag<lp16_t>::mma(wfr[g % 3], xfr[g / FN][b], acc[g % FN][b]);
                 else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g / FN][b].x), "v"(xfr[g / FN][b].w));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -309,8 +309,8 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         // cb + 32 j + {0..7} (cb = n0 + 128 wn + 8 f) in acc[2j][b], acc[2j+1][b]: residual in / result out as one
         // 16-byte access per (b, j); the four lanes of a pixel cover 64 contiguous bytes per instruction.
         const int cb = en0 + wn * (BN / 2) + 8 * fchunk;
-        const bf16_t* __restrict__ resp = reinterpret_cast<const bf16_t*>(p.res);
-        bf16_t* __restrict__ outp = reinterpret_cast<bf16_t*>(p.out);
+        const lp16_t* __restrict__ resp = reinterpret_cast<const lp16_t*>(p.res);
+        lp16_t* __restrict__ outp = reinterpret_cast<lp16_t*>(p.out);
         constexpr int NJ = FN / 2;  // 16-byte pieces (8 channels) per lane and pixel fragment
         // every residual piece is requested before the first store: loads and stores retire in order on one counter, so a
         // load behind a store would wait for that store's acknowledgement
@@ -356,23 +356,27 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                     const uint32_t w4[4] = {rres[b][j].x, rres[b][j].y, rres[b][j].z, rres[b][j].w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += __uint_as_float(w4[e] << 16);
-                        v[2 * e + 1] += __uint_as_float(w4[e] & 0xffff0000u);
+                        float lo, hi;
+                        unpack_lp16x2(w4[e], lo, hi);
+                        v[2 * e] += lo;
+                        v[2 * e + 1] += hi;
                     }
                 }
                 if (p.relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                const uint4 pk = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                const uint4 pk = make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
                 if (gm < p.M && (!POOL || p.pool_store_out) && (!(DBG & 1) || p.relu == 12345)) *reinterpret_cast<uint4*>(outp + (size_t)gm * p.ldo + cb + 32 * j) = pk;
                 if constexpr (POOL) {  // pool the bf16-rounded activations (what a separate pooling pass would read)
                     const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
                     const float live = gm < p.M ? 1.f : 0.f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        psum[b >> 1][j][2 * e] += live * __uint_as_float(w4[e] << 16);
-                        psum[b >> 1][j][2 * e + 1] += live * __uint_as_float(w4[e] & 0xffff0000u);
+                        float lo, hi;
+                        unpack_lp16x2(w4[e], lo, hi);
+                        psum[b >> 1][j][2 * e] += live * lo;
+                        psum[b >> 1][j][2 * e + 1] += live * hi;
                     }
                 }
             }
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 if (p.pool_mean) t *= 1.f / (float)((q1 - q0) * 32);
                 const size_t oi = ((size_t)frame * P + part) * p.N + en0 + c;
                 p.pool_out[oi] = t;
-                if (p.pool_out_lp) reinterpret_cast<bf16_t*>(p.pool_out_lp)[oi] = f32_to_bf16(t);
+                if (p.pool_out_lp) reinterpret_cast<lp16_t*>(p.pool_out_lp)[oi] = f32_to_lp16(t);
             }
         }
         if (!has_next) return;
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 v[3] = acc[a][b][3] + cv.w;
                 if (has_res) {
                     float rr[4];
-                    load4<bf16_t>(reinterpret_cast<const bf16_t*>(slot), rr);
+                    load4<lp16_t>(reinterpret_cast<const lp16_t*>(slot), rr);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += rr[r];
                 }
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
-                store4<bf16_t>(reinterpret_cast<bf16_t*>(slot), v);
+                store4<lp16_t>(reinterpret_cast<lp16_t*>(slot), v);
             }
         }
     };

@@ -29,7 +29,7 @@ __device__ inline float ldf(const T* p);
 template <>
 __device__ inline float ldf<float>(const float* p) { return *p; }
 template <>
-__device__ inline float ldf<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+__device__ inline float ldf<lp16_t>(const lp16_t* p) { return lp16_to_f32(*p); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void pam_pool_kernel(const T* __restrict__ x, const T* __restrict__ qk, float* __restrict__ xbar,
@@ -124,13 +124,13 @@ __global__ __launch_bounds__(256) void pam_pool_kernel(const T* __restrict__ x, 
 // nodes = gamma * (y + bv) + 2 * xmean (y = Wv xbar), + optional bf16 copy (operand of the next Linear)
 __global__ __launch_bounds__(256) void pam_combine_kernel(const float* __restrict__ y, const float* __restrict__ bv,
                                                           const float* __restrict__ xmean, float gamma, float* __restrict__ nodes,
-                                                          bf16_t* __restrict__ nodes_lp, size_t total, int C) {
+                                                          lp16_t* __restrict__ nodes_lp, size_t total, int C) {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int c = (int)(e % C);
         float v = 2.f * xmean[e];
         if (y) v = fmaf(gamma, y[e] + bv[c], v);
         nodes[e] = v;
-        if (nodes_lp) nodes_lp[e] = f32_to_bf16(v);
+        if (nodes_lp) nodes_lp[e] = f32_to_lp16(v);
     }
 }
 
@@ -141,7 +141,7 @@ extern "C" int agrl_pam_pool(const void* x, const void* qk, float* xbar, float* 
     AGRL_CHECK_ARG(x && xmean && splits, "agrl_pam_pool: null pointer");
     AGRL_CHECK_ARG((qk == nullptr) == (xbar == nullptr), "agrl_pam_pool: qk and xbar go together (both NULL when the module's gamma is 0)");
     AGRL_CHECK_ARG(F > 0 && h > 0 && w > 0 && C > 0 && n_splits > 0, "agrl_pam_pool: bad shape");
-    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_pam_pool: bad dtype %d", dtype);
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_LP16, "agrl_pam_pool: bad dtype %d", dtype);
     AGRL_CHECK_ARG(!qk || (Cq > 0 && Cq % PAM_CH == 0), "agrl_pam_pool: Cq=%d must be a multiple of %d", Cq, PAM_CH);
     PamBins bins;
     int P = 0;
@@ -167,9 +167,9 @@ extern "C" int agrl_pam_pool(const void* x, const void* qk, float* xbar, float* 
         hipLaunchKernelGGL(pam_pool_kernel<float>, dim3(F, P), dim3(256), lds, st, (const float*)x, (const float*)qk, xbar, xmean,
                            h, w, C, Cq, bins, att);
     } else {
-        hipError_t e = hipFuncSetAttribute((const void*)pam_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)pam_pool_kernel<lp16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         AGRL_CHECK_ARG(e == hipSuccess, "agrl_pam_pool: cannot raise dynamic LDS: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(pam_pool_kernel<bf16_t>, dim3(F, P), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)qk, xbar, xmean,
+        hipLaunchKernelGGL(pam_pool_kernel<lp16_t>, dim3(F, P), dim3(256), lds, st, (const lp16_t*)x, (const lp16_t*)qk, xbar, xmean,
                            h, w, C, Cq, bins, att);
     }
     AGRL_CHECK_LAUNCH("agrl_pam_pool");
@@ -183,7 +183,7 @@ extern "C" int agrl_pam_combine(const float* y, const float* bv, const float* xm
     const size_t total = (size_t)rows * C;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pam_combine_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bv, xmean, gamma, nodes,
-                       (bf16_t*)nodes_lp, total, C);
+                       (lp16_t*)nodes_lp, total, C);
     AGRL_CHECK_LAUNCH("agrl_pam_combine");
     return 0;
 }

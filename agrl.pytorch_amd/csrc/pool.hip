@@ -23,13 +23,12 @@ __device__ inline void load_vec<float>(const float* p, float v[4]) {
     v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
 }
 template <>
-__device__ inline void load_vec<bf16_t>(const bf16_t* p, float v[8]) {
+__device__ inline void load_vec<lp16_t>(const lp16_t* p, float v[8]) {
     const uint4 u = *reinterpret_cast<const uint4*>(p);
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __uint_as_float(w[i] << 16);
-        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        unpack_lp16x2(w[i], v[2 * i], v[2 * i + 1]);
     }
 }
 
@@ -38,7 +37,7 @@ __device__ inline void load_vec<bf16_t>(const bf16_t* p, float v[8]) {
 template <typename T, int NP>
 __global__ __launch_bounds__(256) void part_pool_kernel(const T* __restrict__ x41, const T* __restrict__ x42,
                                                         float* __restrict__ gsum, float* __restrict__ nodes,
-                                                        bf16_t* __restrict__ nodes_lp, int h, int w, int C,
+                                                        lp16_t* __restrict__ nodes_lp, int h, int w, int C,
                                                         PartBins bins) {
     constexpr int VEC = DT<T>::epc;
     const int frame = blockIdx.x;
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(256) void part_pool_kernel(const T* __restrict__ x4
                     for (int j = 0; j < VEC; ++j) {
                         const float m = acc[q][j] * inv;
                         dst[j] = m;
-                        if (nodes_lp) nodes_lp[((size_t)frame * P + q) * C + c + j] = f32_to_bf16(m);
+                        if (nodes_lp) nodes_lp[((size_t)frame * P + q) * C + c + j] = f32_to_lp16(m);
                     }
                 }
             }
@@ -264,7 +263,7 @@ extern "C" int agrl_part_pool(const void* x4_1, const void* x4_2, float* gsum, f
                               agrl_stream_t stream) {
     AGRL_CHECK_ARG(x4_1 && x4_2 && gsum && nodes && splits, "agrl_part_pool: null pointer");
     AGRL_CHECK_ARG(F > 0 && h > 0 && w > 0 && C > 0 && n_splits > 0, "agrl_part_pool: bad shape");
-    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_part_pool: bad dtype %d", dtype);
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_LP16, "agrl_part_pool: bad dtype %d", dtype);
     PartBins bins;
     int P = 0;
     for (int i = 0; i < n_splits; ++i) {
@@ -285,11 +284,11 @@ extern "C" int agrl_part_pool(const void* x4_1, const void* x4_2, float* gsum, f
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_PP(T, NP)                                                                                         \
     hipLaunchKernelGGL((part_pool_kernel<T, NP>), grid, dim3(threads), 0, st, (const T*)x4_1, (const T*)x4_2, gsum, \
-                       nodes, (bf16_t*)nodes_lp, h, w, C, bins)
+                       nodes, (lp16_t*)nodes_lp, h, w, C, bins)
     if (dtype == AGRL_F32) {
         if (P <= 8) LAUNCH_PP(float, 8); else LAUNCH_PP(float, 16);
     } else {
-        if (P <= 8) LAUNCH_PP(bf16_t, 8); else LAUNCH_PP(bf16_t, 16);
+        if (P <= 8) LAUNCH_PP(lp16_t, 8); else LAUNCH_PP(lp16_t, 16);
     }
 #undef LAUNCH_PP
     AGRL_CHECK_LAUNCH("agrl_part_pool");
@@ -298,13 +297,13 @@ extern "C" int agrl_part_pool(const void* x4_1, const void* x4_2, float* gsum, f
 
 extern "C" int agrl_row_sqnorm(const void* x, float* sqn, int R, int C, int dtype, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && sqn && R > 0 && C > 0, "agrl_row_sqnorm: bad arguments");
-    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_BF16, "agrl_row_sqnorm: bad dtype %d", dtype);
+    AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_LP16, "agrl_row_sqnorm: bad dtype %d", dtype);
     if (dtype == AGRL_F32)
         hipLaunchKernelGGL(row_sqnorm_kernel<float>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, sqn, R, C);
     else
-        hipLaunchKernelGGL(row_sqnorm_kernel<bf16_t>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, sqn, R, C);
+        hipLaunchKernelGGL(row_sqnorm_kernel<lp16_t>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const lp16_t*)x, sqn, R, C);
     AGRL_CHECK_LAUNCH("agrl_row_sqnorm");
     return 0;
 }
@@ -312,13 +311,13 @@ extern "C" int agrl_row_sqnorm(const void* x, float* sqn, int R, int C, int dtyp
 extern "C" int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int ldy, int normalize, int out_dtype,
                                      agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && y && R > 0 && C > 0 && ldy >= C, "agrl_row_l2_normalize: bad arguments");
-    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_row_l2_normalize: bad dtype %d", out_dtype);
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_LP16, "agrl_row_l2_normalize: bad dtype %d", out_dtype);
     if (out_dtype == AGRL_F32)
         hipLaunchKernelGGL(row_normalize_kernel<float>, dim3(R), dim3(256), 0, (hipStream_t)stream, x,
                            (float*)y, R, C, ldy, normalize);
     else
-        hipLaunchKernelGGL(row_normalize_kernel<bf16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, x,
-                           (bf16_t*)y, R, C, ldy, normalize);
+        hipLaunchKernelGGL(row_normalize_kernel<lp16_t>, dim3(R), dim3(256), 0, (hipStream_t)stream, x,
+                           (lp16_t*)y, R, C, ldy, normalize);
     AGRL_CHECK_LAUNCH("agrl_row_l2_normalize");
     return 0;
 }

@@ -565,7 +565,7 @@ extern "C" int agrl_distmat_topk(const void* q, const void* g, const float* qn, 
         const int even = ((m + nblk - 1) / nblk + 127) / 128 * 128;
         if (even < rows) rows = even;
     }
-    const size_t esz = dtype == AGRL_BF16 ? 2 : 4;
+    const size_t esz = dtype == AGRL_LP16 ? 2 : 4;
     for (int r0 = 0, mb = 0; r0 < m; r0 += mb) {
         mb = m - r0 < rows ? m - r0 : rows;
         const int rest = m - r0 - mb;

@@ -124,7 +124,7 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool(const float* x, const float* w, co
                                               int N, int H, int W, int out_dtype, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && w && bias && out, "agrl_stem: null pointer");
     AGRL_CHECK_ARG(N > 0 && H >= 7 && W >= 7, "agrl_stem: bad shape N=%d H=%d W=%d", N, H, W);
-    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_BF16, "agrl_stem: bad dtype %d", out_dtype);
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_LP16, "agrl_stem: bad dtype %d", out_dtype);
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
     const int tiles_h = cdiv(PH, PT_H), tiles_w = cdiv(PW, PT_W);
@@ -134,8 +134,8 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool(const float* x, const float* w, co
         hipLaunchKernelGGL(stem_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, w, bias,
                            (float*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w);
     else
-        hipLaunchKernelGGL(stem_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                           (bf16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w);
+        hipLaunchKernelGGL(stem_kernel<lp16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                           (lp16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w);
     AGRL_CHECK_LAUNCH("agrl_stem");
     return 0;
 }

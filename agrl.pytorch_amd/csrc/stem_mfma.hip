@@ -43,7 +43,7 @@ constexpr int CT_BYTES = (NPOS + 3) * 128;
 constexpr int REGION_BYTES = CT_BYTES > PATCH_BYTES ? CT_BYTES : PATCH_BYTES;
 
 __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
-                                                        const float* __restrict__ bias, bf16_t* __restrict__ out, int H,
+                                                        const float* __restrict__ bias, lp16_t* __restrict__ out, int H,
                                                         int W, int CH, int CW, int PH, int PW, int tiles_w, int tiles_hw,
                                                         int ntiles) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[REGION_BYTES + W_BYTES + 256];
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
             const int e = tid + NTH * i;
             if (e < IT * PWP) {
                 uint2 u;
-                u.x = pack_bf16x2(pv[i][0], pv[i][1]);
-                u.y = (uint32_t)f32_to_bf16(pv[i][2]);
+                u.x = pack_lp16x2(pv[i][0], pv[i][1]);
+                u.y = (uint32_t)f32_to_lp16(pv[i][2]);
                 *reinterpret_cast<uint2*>(s_patch + e * 8) = u;
             }
         }
@@ -138,8 +138,7 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
             for (int i = 0; i < FPW; ++i)
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    acc[i][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[a]),
-                                                                        __builtin_bit_cast(bf16x8_t, xf[i]), acc[i][a], 0, 0, 0);
+                    acc[i][a] = mfma_lp16_16x16x32(wf[a], xf[i], acc[i][a]);
         }
         __syncthreads();  // every wave is done with the patch: the conv tile may overlay it
         int fr = frow, gg = g, tq = tid;
@@ -171,8 +170,8 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
                     const float v0 = fmaxf(acc[i][a][0] + bv.x, 0.f), v1 = fmaxf(acc[i][a][1] + bv.y, 0.f);
                     const float v2 = fmaxf(acc[i][a][2] + bv.z, 0.f), v3 = fmaxf(acc[i][a][3] + bv.w, 0.f);
                     uint2 u;
-                    u.x = pack_bf16x2(v0, v1);
-                    u.y = pack_bf16x2(v2, v3);
+                    u.x = pack_lp16x2(v0, v1);
+                    u.y = pack_lp16x2(v2, v3);
                     if (!in[i]) u = make_uint2(0u, 0u);
                     *reinterpret_cast<uint2*>(s_ct + rowo[i] + (((ch >> 3) ^ swz[i]) << 4) + ((ch & 4) << 1)) = u;
                 }
@@ -211,23 +210,23 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
 }
 }  // namespace
 
-extern "C" int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w_packed, const float* bias, void* out,
+extern "C" int agrl_stem_conv_bn_relu_maxpool_lp16(const float* x, const void* w_packed, const float* bias, void* out,
                                                    int N, int H, int W, agrl_stream_t stream) {
-    AGRL_CHECK_ARG(x && w_packed && bias && out, "agrl_stem_bf16: null pointer");
-    AGRL_CHECK_ARG(N > 0 && H >= 7 && W >= 7, "agrl_stem_bf16: bad shape N=%d H=%d W=%d", N, H, W);
+    AGRL_CHECK_ARG(x && w_packed && bias && out, "agrl_stem_lp16: null pointer");
+    AGRL_CHECK_ARG(N > 0 && H >= 7 && W >= 7, "agrl_stem_lp16: bad shape N=%d H=%d W=%d", N, H, W);
     AGRL_CHECK_ARG((((uintptr_t)w_packed) & 15) == 0 && (((uintptr_t)bias) & 15) == 0 && (((uintptr_t)out) & 15) == 0,
-                   "agrl_stem_bf16: misaligned pointer");
+                   "agrl_stem_lp16: misaligned pointer");
     const int CH = (H + 6 - 7) / 2 + 1, CW = (W + 6 - 7) / 2 + 1;
     const int PH = (CH + 2 - 3) / 2 + 1, PW = (CW + 2 - 3) / 2 + 1;
     const int tiles_h = cdiv(PH, PT), tiles_w = cdiv(PW, PT);
     const long long grid = (long long)N * tiles_h * tiles_w;
-    AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_bf16: grid too large");
+    AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_lp16: grid too large");
     int wgs = 512;  // two persistent workgroups per CU (67 KB of LDS each)
     if (agrl_opt_set(agrl_opts().stem_wgs) && agrl_opts().stem_wgs > 0) wgs = agrl_opts().stem_wgs;
     const unsigned launch = (unsigned)(grid < wgs ? grid : wgs);
     hipLaunchKernelGGL(stem_mfma_kernel, dim3(launch), dim3(NTH), 0, (hipStream_t)stream, x,
-                       (const unsigned char*)w_packed, bias, (bf16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w,
+                       (const unsigned char*)w_packed, bias, (lp16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w,
                        (int)grid);
-    AGRL_CHECK_LAUNCH("agrl_stem_bf16");
+    AGRL_CHECK_LAUNCH("agrl_stem_lp16");
     return 0;
 }

@@ -16,14 +16,22 @@ import threading
 import torch
 
 F32 = 0
-BF16 = 1
+LP16 = 1   # the library's 16-bit storage type: fp16 (libagrl_hip.so) or bfloat16 (libagrl_hip_bf16.so)
 F32X3 = 2  # fp32 tensors, split-bf16 MFMA arithmetic (include/agrl_hip.h)
 METRIC_EUCLIDEAN = 0
 METRIC_COSINE = 1
 
+# The 16-bit type is a property of the LIBRARY (the same sources built twice, include/agrl_hip.h): AGRL_HIP_LP16 = fp16
+# (default: 8 x smaller rounding error at the same MFMA rate, the path's outputs stay within the north star's 1e-3 of the
+# fp32 oracle) or bf16. It is fixed for the process when this module is imported.
+LP_NAME = os.environ.get("AGRL_HIP_LP16", "fp16")
+if LP_NAME not in ("fp16", "bf16"):
+    raise ValueError("AGRL_HIP_LP16 must be fp16 or bf16, not %r" % LP_NAME)
+LP_DTYPE = torch.float16 if LP_NAME == "fp16" else torch.bfloat16
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(
-    "AGRL_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "lib", "libagrl_hip.so"))
+    "AGRL_HIP_LIB", os.path.normpath(os.path.join(_HERE, "..", "lib", "libagrl_hip.so" if LP_NAME == "fp16" else "libagrl_hip_bf16.so"))
 )
 
 
@@ -42,7 +50,7 @@ _f = C.c_float
 # name -> argtypes; must list every function include/agrl_hip.h declares (tests/test_cabi.py checks)
 SIGNATURES = {
     "agrl_stem_conv_bn_relu_maxpool": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "agrl_stem_conv_bn_relu_maxpool_bf16": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "agrl_stem_conv_bn_relu_maxpool_lp16": [_p, _p, _p, _p, _i, _i, _i, _p],
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_block": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -132,11 +140,14 @@ def lib():
         h.agrl_bn_workspace.restype = C.c_size_t
         h.agrl_conv_wgrad_workspace.restype = C.c_size_t
         h.agrl_distmat_topk_workspace.restype = C.c_size_t
-        for name in ("agrl_reload_options", "agrl_built_with_ablation"):
+        for name in ("agrl_reload_options", "agrl_built_with_ablation", "agrl_lp16_is_f16"):
             getattr(h, name).argtypes = []
             getattr(h, name).restype = _i
         h.agrl_version.restype = _i
         h.agrl_last_error.restype = C.c_char_p
+        if bool(h.agrl_lp16_is_f16()) != (LP_NAME == "fp16"):
+            raise HipLibraryError("%s stores 16-bit data as %s but AGRL_HIP_LP16 asks for %s" % (
+                LIB_PATH, "fp16" if h.agrl_lp16_is_f16() else "bf16", LP_NAME))
         _lib = h
     return _lib
 
@@ -177,9 +188,9 @@ def ptr(t):
 def dtype_code(dt):
     if dt == torch.float32:
         return F32
-    if dt == torch.bfloat16:
-        return BF16
-    raise TypeError("unsupported dtype %s (float32 / bfloat16 only)" % dt)
+    if dt == LP_DTYPE:
+        return LP16
+    raise TypeError("unsupported dtype %s (float32 / %s only: the loaded library's 16-bit type is %s)" % (dt, LP_DTYPE, LP_NAME))
 
 
 # Optional launch timing: set ``PROFILE`` to a list and every entry-point call appends

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import BF16, F32, METRIC_COSINE, METRIC_EUCLIDEAN, call, dtype_code, ptr
+from ._hip import F32, LP16, LP_DTYPE, LP_NAME, METRIC_COSINE, METRIC_EUCLIDEAN, call, dtype_code, ptr
 
 
 import contextlib
@@ -60,28 +60,47 @@ def stem(x_nchw, w_ohwi, bias, out_dtype):
     return out
 
 
-def pack_stem_weights_bf16(w_ohwi):
+PRECISIONS = ('fp32', LP_NAME, 'bf16x3')
+
+
+def check_precision(precision, allowed=PRECISIONS, what="hip_precision"):
+    """'fp32' exact-fp32 MFMA | LP_NAME ('fp16' or 'bf16': the loaded library's 16-bit storage type, fp32 accumulation) |
+    'bf16x3' fp32 tensors, split-bf16 products. Asking for the OTHER 16-bit type is an error, not a silent substitution."""
+    if precision in allowed:
+        return precision
+    if precision in ('fp16', 'bf16'):
+        raise ValueError("%s %r: the loaded library stores 16-bit data as %s (set AGRL_HIP_LP16=%s before importing torchreid to load "
+                         "the other build)" % (what, precision, LP_NAME, precision))
+    raise ValueError("%s must be one of %s, got %r" % (what, ", ".join(repr(a) for a in allowed), precision))
+
+
+def is_lp16(precision):
+    """True for the 16-bit mode (validates the name)."""
+    return check_precision(precision, PRECISIONS, "precision") == LP_NAME
+
+
+def pack_stem_weights_lp16(w_ohwi):
     """(64,7,7,3) fp32 OHWI (BN folded) -> (64,240) bf16: per filter row 8 taps x 4 channels, zero padded; 480-byte rows
     (30 sixteen-byte slots: the stride that makes the kernel's weight-fragment reads bank-conflict free)."""
     assert tuple(w_ohwi.shape) == (64, 7, 7, 3)
     w = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=w_ohwi.device)
     w[:, :, :7, :3] = w_ohwi.float()
-    packed = torch.zeros((64, 240), dtype=torch.bfloat16, device=w_ohwi.device)
-    packed[:, :224] = w.view(64, 224).to(torch.bfloat16)
+    packed = torch.zeros((64, 240), dtype=LP_DTYPE, device=w_ohwi.device)
+    packed[:, :224] = w.view(64, 224).to(LP_DTYPE)
     return packed.contiguous()
 
 
-def stem_bf16(x_nchw, w_packed, bias):
-    """bf16-MFMA stem: (N,3,H,W) fp32 NCHW -> (N,PH,PW,64) bf16 NHWC. vmgn.py:281-284."""
+def stem_lp16(x_nchw, w_packed, bias):
+    """16-bit-MFMA stem: (N,3,H,W) fp32 NCHW -> (N,PH,PW,64) NHWC in the library's 16-bit type (LP_DTYPE). vmgn.py:281-284."""
     assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.size(1) == 3
-    assert w_packed.dtype == torch.bfloat16 and tuple(w_packed.shape) == (64, 240)
+    assert w_packed.dtype == LP_DTYPE and tuple(w_packed.shape) == (64, 240)
     x_nchw = x_nchw.contiguous()
     N, _, H, W = x_nchw.shape
     CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
-    out = torch.empty((N, PH, PW, 64), dtype=torch.bfloat16, device=x_nchw.device)
+    out = torch.empty((N, PH, PW, 64), dtype=LP_DTYPE, device=x_nchw.device)
     with _dev(x_nchw):
-        call("agrl_stem_conv_bn_relu_maxpool_bf16", ptr(x_nchw), ptr(w_packed), ptr(bias), ptr(out), N, H, W,
+        call("agrl_stem_conv_bn_relu_maxpool_lp16", ptr(x_nchw), ptr(w_packed), ptr(bias), ptr(out), N, H, W,
              _stream(x_nchw))
     return out
 
@@ -109,7 +128,7 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
 def conv1x1_dual_supported(x1, x2, w_cat):
     """The two-source pointwise GEMM exists for bf16, K1 == 2 K2, K1 % 64 == 0, Cout % 256 == 0 (layer-4 first blocks)."""
     K1, K2 = x1.shape[-1], x2.shape[-1]
-    return (x1.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and K1 == 2 * K2 and K1 % 64 == 0
+    return (x1.dtype == LP_DTYPE and x2.dtype == LP_DTYPE and K1 == 2 * K2 and K1 % 64 == 0
             and w_cat.shape[0] % 256 == 0 and x1.shape[:-1] == x2.shape[:-1] and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0')
 
 
@@ -136,10 +155,10 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
     is never written. -> pooled fp32 (F, P, Cout) [, bf16 copy]. vmgn.py:45-65 + :298-308."""
     N, H, W, Cin = x.shape
     Cout = w_ohwi.shape[0]
-    assert x.dtype == torch.bfloat16 and tuple(w_ohwi.shape[1:3]) == (1, 1) and H * W == 128
+    assert x.dtype == LP_DTYPE and tuple(w_ohwi.shape[1:3]) == (1, 1) and H * W == 128
     P = int(sum(splits))
     pooled = torch.empty((N, P, Cout), dtype=torch.float32, device=x.device)
-    pooled_lp = torch.empty((N, P, Cout), dtype=torch.bfloat16, device=x.device) if want_lp else None
+    pooled_lp = torch.empty((N, P, Cout), dtype=LP_DTYPE, device=x.device) if want_lp else None
     arr = (C.c_int * len(splits))(*[int(s) for s in splits])
     if _hip.PROFILE is not None:
         _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * Cout * Cin,
@@ -153,10 +172,10 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
 def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
     """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 and layer-2 shapes in bf16. ``shortcut_conv`` =
     (weight, stride) of the block's downsample conv when the residual is to be computed in the same pass."""
-    if (y2.dtype == torch.bfloat16 and tuple(w3.shape) == (512, 1, 1, 128) and tuple(w1_next.shape) == (128, 1, 1, 512)
+    if (y2.dtype == LP_DTYPE and tuple(w3.shape) == (512, 1, 1, 128) and tuple(w1_next.shape) == (128, 1, 1, 512)
             and shortcut_conv is None and os.environ.get('AGRL_HIP_FUSE_TAIL_L2', '1') != '0'):
         return True  # layer-2 form (weights resident in registers)
-    ok = (y2.dtype == torch.bfloat16 and tuple(w3.shape) == (256, 1, 1, 64)
+    ok = (y2.dtype == LP_DTYPE and tuple(w3.shape) == (256, 1, 1, 64)
           and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)))
     if shortcut_conv is not None:
         ok = ok and tuple(shortcut_conv[0].shape) == (256, 1, 1, 64) and shortcut_conv[1] == 1 and w1_next.shape[0] == 64
@@ -169,7 +188,7 @@ def bottleneck_tail(y2, w3, b3, residual, w1_next, b1_next, shortcut=None):
     vmgn.py:57-64 (block i) + :48-50 (block i+1). -> out (N,H,W,256), z (N,H,W,64 | 128) bf16 NHWC."""
     N, H, W, Cmid = y2.shape
     Cout, Cnext = w3.shape[0], w1_next.shape[0]
-    assert y2.dtype == torch.bfloat16 and (residual is None) != (shortcut is None)
+    assert y2.dtype == LP_DTYPE and (residual is None) != (shortcut is None)
     xs = ws = bs = None
     Cshort = 0
     if shortcut is not None:
@@ -196,7 +215,7 @@ def bottleneck_block_supported(z, w2, stride, w3, w1_next, shortcut_conv=None):
     8 x 8-divisible maps). ``shortcut_conv`` as in bottleneck_tail_supported."""
     if os.environ.get('AGRL_HIP_FUSE_BLOCK', '1') == '0':
         return False
-    ok = (z.dtype == torch.bfloat16 and stride == 1 and tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64)
+    ok = (z.dtype == LP_DTYPE and stride == 1 and tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64)
           and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)) and z.shape[1] % 8 == 0 and z.shape[2] % 8 == 0)
     if shortcut_conv is not None:
         ok = ok and tuple(shortcut_conv[0].shape) == (256, 1, 1, 64) and shortcut_conv[1] == 1 and w1_next.shape[0] == 64
@@ -209,7 +228,7 @@ def bottleneck_block(z, w2, b2, w3, b3, residual, w1_next, b1_next, shortcut=Non
     downsample conv. vmgn.py:52-64 (block i) + :48-50 (block i+1). -> out (N,H,W,256), z_next (N,H,W,64 | 128)."""
     N, H, W, Cmid = z.shape
     Cout, Cnext = w3.shape[0], w1_next.shape[0]
-    assert z.dtype == torch.bfloat16 and (residual is None) != (shortcut is None)
+    assert z.dtype == LP_DTYPE and (residual is None) != (shortcut is None)
     xs = ws = bs = None
     if shortcut is not None:
         xs, ws, bs = shortcut
@@ -249,7 +268,7 @@ def part_pool(x4_1, x4_2, splits, want_lp):
     P = int(sum(splits))
     gsum = torch.empty((F_, Cc), dtype=torch.float32, device=x4_1.device)
     nodes = torch.empty((F_, P, Cc), dtype=torch.float32, device=x4_1.device)
-    nodes_lp = torch.empty((F_, P, Cc), dtype=torch.bfloat16, device=x4_1.device) if want_lp else None
+    nodes_lp = torch.empty((F_, P, Cc), dtype=LP_DTYPE, device=x4_1.device) if want_lp else None
     arr = (C.c_int * len(splits))(*[int(s) for s in splits])
     with _dev(x4_1):
         call("agrl_part_pool", ptr(x4_1), ptr(x4_2), ptr(gsum), ptr(nodes), ptr(nodes_lp), F_, h, w, Cc, arr,
@@ -319,7 +338,7 @@ def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp, keep=Non
         keep = 1.0 - float(gamma)
     B, V, Cc = f.shape
     out = torch.empty_like(f)
-    out_lp = torch.empty((B, V, Cc), dtype=torch.bfloat16, device=f.device) if want_lp else None
+    out_lp = torch.empty((B, V, Cc), dtype=LP_DTYPE, device=f.device) if want_lp else None
     if _hip.PROFILE is not None:  # read f + read h + read G(adj-sized) + write out
         _hip.PROFILE_TAG = {"flops": 2.0 * B * V * V * Cc, "bytes": 4.0 * (3 * B * V * Cc + B * V * V)}
     with _dev(f):
@@ -345,8 +364,8 @@ def graph_apply_operand(G, f, out_dtype):
     if key not in _UNIT:
         _UNIT[key] = (torch.ones((Cc,), dtype=torch.float32, device=f.device), torch.zeros((Cc,), dtype=torch.float32, device=f.device))
     one, zero = _UNIT[key]
-    out, out_lp = graph_propagate(f, f, G, one, zero, 1.0, 1.0, want_lp=out_dtype == torch.bfloat16, keep=0.0)
-    return out_lp if out_dtype == torch.bfloat16 else out
+    out, out_lp = graph_propagate(f, f, G, one, zero, 1.0, 1.0, want_lp=out_dtype == LP_DTYPE, keep=0.0)
+    return out_lp if out_dtype == LP_DTYPE else out
 
 
 TRACKLET_FORM_MIN_B = int(os.environ.get('AGRL_HIP_GCN_TRACKLET_MIN_B', '224'))
@@ -417,7 +436,7 @@ def pam_pool(x, qk, splits):
 def pam_combine(y, bv, xmean, gamma, want_lp):
     """nodes = gamma (y + bv) + 2 xmean (y = Wv xbar), ganet.py:394-399 -> nodes fp32 like xmean [, bf16 copy]."""
     nodes = torch.empty_like(xmean)
-    nodes_lp = torch.empty(xmean.shape, dtype=torch.bfloat16, device=xmean.device) if want_lp else None
+    nodes_lp = torch.empty(xmean.shape, dtype=LP_DTYPE, device=xmean.device) if want_lp else None
     rows, Cc = xmean.numel() // xmean.shape[-1], xmean.shape[-1]
     with _dev(xmean):
         call("agrl_pam_combine", ptr(y), ptr(bv), ptr(xmean), float(gamma), ptr(nodes), ptr(nodes_lp), rows, Cc, _stream(xmean))
@@ -459,7 +478,7 @@ def attn_pool_bnneck(nodes, sqn, gsum, g_scale, g_shift, a_scale, a_shift, B, S,
 
 def k_multiple(dtype):
     """K granularity of the GEMM kernel: one 128-byte k-tile."""
-    return 64 if dtype == torch.bfloat16 else 32
+    return 64 if dtype == LP_DTYPE else 32
 
 
 def row_l2_normalize(x, normalize, out_dtype, pad_to=1):

@@ -17,7 +17,8 @@ import os
 import torch
 from torch.nn import functional as F
 
-# 'fp32' = exact-fp32 MFMA (parity mode); 'bf16' = bf16 operands, fp32 accumulation (throughput mode)
+# 'fp32' = exact-fp32 MFMA (parity mode); 'fp16' (or 'bf16' with the bf16 build of the library: hip_ops.LP_NAME) = 16-bit
+# operands, fp32 accumulation (throughput mode)
 HIP_PRECISION = os.environ.get('AGRL_HIP_PRECISION', 'fp32')
 
 
@@ -58,8 +59,8 @@ def _hip_distmat(input1, input2, metric):
 def hip_distmat_device(q, g, metric, precision='fp32', out=None):
     """Device-resident form: q (m,d), g (n,d) fp32 CUDA tensors -> fp32 (m,n) on the same device."""
     from torchreid import hip_ops as ops
-    lp = precision == 'bf16'
-    dt = torch.bfloat16 if lp else torch.float32
+    lp = ops.is_lp16(precision)
+    dt = ops.LP_DTYPE if lp else torch.float32
     km = ops.k_multiple(dt)
     if metric == 'euclidean':
         qn, gn = ops.row_sqnorm(q), ops.row_sqnorm(g)
@@ -75,8 +76,8 @@ def hip_distmat_topk_device(q, g, metric, k, precision='fp32'):
     gallery rows per query in ascending (distance, index) order -- ``rank_topk(hip_distmat_device(q, g), k)`` bit for bit,
     without the (m,n) matrix (``agrl_distmat_topk``)."""
     from torchreid import hip_ops as ops
-    lp = precision == 'bf16'
-    dt = torch.bfloat16 if lp else torch.float32
+    lp = ops.is_lp16(precision)
+    dt = ops.LP_DTYPE if lp else torch.float32
     km = ops.k_multiple(dt)
     if metric == 'euclidean':
         qn, gn = ops.row_sqnorm(q), ops.row_sqnorm(g)

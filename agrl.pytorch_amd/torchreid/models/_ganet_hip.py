@@ -23,8 +23,7 @@ from torchreid.models._vmgn_hip import (_PRECISIONS, _fingerprint, _fold_bn1d, _
 
 
 def pack_weights(model, device, precision):
-    if precision not in _PRECISIONS:
-        raise ValueError("hip_precision must be 'fp32', 'bf16' or 'bf16x3', got {!r}".format(precision))
+    ops.check_precision(precision)
     key = (device.index if device.index is not None else torch.cuda.current_device(), precision)
     cached = model._hip_packs.get(key)
     if cached is not None and (model.hip_static_weights or cached['fingerprint'] == _fingerprint(model)):
@@ -40,7 +39,7 @@ def pack_weights(model, device, precision):
         pack = {
             'dtype': dtype,
             'stem': (stem_w, stem_b),
-            'stem_lp': ops.pack_stem_weights_bf16(stem_w) if dtype == torch.bfloat16 else None,
+            'stem_lp': ops.pack_stem_weights_lp16(stem_w) if dtype == ops.LP_DTYPE else None,
             'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype),
             'l4': _pack_stage(model.layer4, dtype),
             # stacked query / key conv as one OHWI weight (2*Cq, 1, 1, C) + bias; value conv as a Linear weight (C, C) + bias
@@ -74,11 +73,11 @@ def hip_forward_ganet(model, x, adj, stages=None):
     if tuple(adj.shape) != (B, V, V):
         raise ValueError('adj must be {} for S={} and {} parts, got {}'.format((B, V, V), S, P, tuple(adj.shape)))
     pack = pack_weights(model, x.device, model.hip_precision)
-    lp = pack['dtype'] == torch.bfloat16
+    lp = pack['dtype'] == ops.LP_DTYPE
     splits = list(model.total_split_list)
     with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
-        a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+        a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
         a = _run_trunk(a, pack['trunk'], model.hip_fuse_tail)
         for blk in pack['l4']:
             a = _run_block(a, blk)

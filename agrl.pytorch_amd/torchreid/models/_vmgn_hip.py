@@ -20,7 +20,7 @@ from torchreid import hip_ops as ops
 from torchreid import _hip
 
 # 'bf16x3': fp32 tensors and layouts of the parity mode, conv / Linear products as three bf16 MFMAs (hip_ops.f32_split)
-_PRECISIONS = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'bf16x3': torch.float32}
+_PRECISIONS = {'fp32': torch.float32, ops.LP_NAME: ops.LP_DTYPE, 'bf16x3': torch.float32}   # ops.LP_NAME: 'fp16' (default build) or 'bf16'
 
 
 def _fold_conv_bn(conv, bn, dtype):
@@ -51,7 +51,7 @@ def _pack_stage(stage, dtype):
         if unit.downsample is not None:
             blk['ds'] = _fold_conv_bn(unit.downsample[0], unit.downsample[1], dtype)
             blk['ds_stride'] = unit.downsample[0].stride[0]
-            if dtype == torch.bfloat16 and blk['ds_stride'] == 1 and blk['stride'] == 1:
+            if dtype == ops.LP_DTYPE and blk['ds_stride'] == 1 and blk['stride'] == 1:
                 # conv3 + downsample as ONE GEMM over the concatenated K axis (ops.conv1x1_dual): [w_ds | w3], b_ds + b3
                 cout = blk['c3'][0].shape[0]
                 blk['dual'] = (torch.cat([blk['ds'][0].view(cout, -1), blk['c3'][0].view(cout, -1)], dim=1).contiguous(),
@@ -66,8 +66,7 @@ def _fingerprint(model):
 
 def pack_weights(model, device, precision):
     """BN-fold + re-layout every weight of the eval forward for ``device``; cached on the model."""
-    if precision not in _PRECISIONS:
-        raise ValueError("hip_precision must be 'fp32', 'bf16' or 'bf16x3', got {!r}".format(precision))
+    ops.check_precision(precision)
     key = (device.index if device.index is not None else torch.cuda.current_device(), precision)
     cached = model._hip_packs.get(key)
     if cached is not None and (model.hip_static_weights or cached['fingerprint'] == _fingerprint(model)):
@@ -81,7 +80,7 @@ def pack_weights(model, device, precision):
         pack = {
             'dtype': dtype,
             'stem': (stem_w, stem_b),
-            'stem_lp': ops.pack_stem_weights_bf16(stem_w) if dtype == torch.bfloat16 else None,
+            'stem_lp': ops.pack_stem_weights_lp16(stem_w) if dtype == ops.LP_DTYPE else None,
             'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype),
             'graph': [],
         }
@@ -159,7 +158,7 @@ def _run_block(x, blk, pool=None):
 def hip_featuremaps(model, frames, pack):
     """(F,3,H,W) fp32 NCHW -> x4_1, x4_2 NHWC (F,h,w,2048). reference vmgn.py:280-290."""
     if pack['stem_lp'] is not None:
-        a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1])
+        a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1])
     else:
         a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
     a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))
@@ -185,7 +184,7 @@ def _side_stream(device):
 def hip_features_pooled(model, frames, pack, splits, want_lp=True):
     """Conv stages with the global / part pooling fused into the last conv of each layer4 branch (bf16, 16x8 maps):
     -> gsum (F,C) per-frame sums, nodes (F,P,C) fp32, nodes_lp bf16, hw. None when the fusion does not apply."""
-    if pack['dtype'] != torch.bfloat16 or pack['l4_1'][0]['stride'] != 1:
+    if pack['dtype'] != ops.LP_DTYPE or pack['l4_1'][0]['stride'] != 1:
         return None
     # applicability is decided from the input size BEFORE anything is launched (a late bail-out would make the caller
     # recompute stem + trunk): the fused epilogue needs 16 x 8 = 128-pixel layer-4 maps, i.e. frames of 256 x 128
@@ -195,7 +194,7 @@ def hip_features_pooled(model, frames, pack, splits, want_lp=True):
         h4, w4 = (h4 + 1) // 2, (w4 + 1) // 2
     if (h4, w4) != (16, 8):
         return None
-    a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1])
+    a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1])
     a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))
     assert a.shape[1] == 16 and a.shape[2] == 8
     splits = list(splits)
@@ -248,7 +247,7 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, com
     ``overlap``: the adaptive graph (Gram partials + finalize: 2 short latency-bound launches) is built on a side HIP stream
     while the Linear (a 448-workgroup GEMM that does not fill the chip either) runs on the main one -- both only read the
     layer's input nodes; the message pass joins them."""
-    lp = pack['dtype'] == torch.bfloat16
+    lp = pack['dtype'] == ops.LP_DTYPE
     B, V, C = nodes.shape
     n_layers = len(pack['graph'])
     main = torch.cuda.current_stream(nodes.device)
@@ -267,7 +266,7 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, com
             nodes = ops.graph_linear_mix(P, g['w'], nodes, g['scale'], g['shift'], g['gamma'], g['slope'])
             continue
         if lp and nodes_lp is None:   # A/B form entered without the pooled bf16 copy: native conversion kernel
-            nodes_lp = ops.row_l2_normalize(nodes.view(B * V, C), False, torch.bfloat16).view(B, V, C)
+            nodes_lp = ops.row_l2_normalize(nodes.view(B * V, C), False, ops.LP_DTYPE).view(B, V, C)
         operand = nodes_lp if lp else nodes
         if side is not None:
             ready = torch.cuda.Event()
@@ -307,7 +306,7 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
         raise ValueError('adj must be {} (fp32) or {} (bit-packed int32) for S={} and {} parts, got {}'.format(
             (B, V, V), (B, V, (V + 31) // 32), S, P, tuple(adj.shape)))
     pack = pack_weights(model, x.device, model.hip_precision)
-    lp = pack['dtype'] == torch.bfloat16
+    lp = pack['dtype'] == ops.LP_DTYPE
     with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
         commute = gcn_commute_enabled(model)
@@ -350,11 +349,11 @@ def hip_forward_gsta(model, x, adj):
     if tuple(adj.shape) != (B, V, V):
         raise ValueError('adj must be {} for S={} and {} parts, got {}'.format((B, V, V), S, P, tuple(adj.shape)))
     pack = pack_weights(model, x.device, model.hip_precision)
-    lp = pack['dtype'] == torch.bfloat16
+    lp = pack['dtype'] == ops.LP_DTYPE
     splits = list(model.total_split_list)
     with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
-        a = ops.stem_bf16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+        a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
         a = _run_trunk(a, pack['trunk'], model.hip_fuse_tail)
         hw = (a.shape[1] // pack['l4'][0]['stride']) * (a.shape[2] // pack['l4'][0]['stride'])
         if lp and model.hip_fuse_pool and a.shape[1] * a.shape[2] == 128 and pack['l4'][0]['stride'] == 1:

@@ -11,8 +11,11 @@
  *     agrl_last_error() returns a thread-local message for the last non-zero return
  *   - activations are NHWC ("pixel-major"): x[n][h][w][c]; conv weights are OHWI:
  *     w[cout][r][s][cin] with eval-mode BatchNorm already folded in (scale into w, shift into bias)
- *   - dtype codes: AGRL_F32 = 0 (exact-fp32 MFMA, the parity mode), AGRL_BF16 = 1 (bf16 MFMA with
- *     fp32 accumulation, the throughput mode), AGRL_F32X3 = 2 (fp32 tensors, each product formed as three bf16 MFMAs
+ *   - dtype codes: AGRL_F32 = 0 (exact-fp32 MFMA, the parity mode), AGRL_LP16 = 1 (the library's 16-bit storage type
+ *     with fp32 accumulation in the MFMA, the throughput mode: IEEE fp16 in lib/libagrl_hip.so, bfloat16 in
+ *     lib/libagrl_hip_bf16.so -- the same sources built with -DAGRL_LP_F16=1 / 0; agrl_lp16_is_f16() tells which one is
+ *     loaded; fp16 is the default because its rounding error keeps the path inside the 1e-3 the north star allows and
+ *     the activations stay far below 65504), AGRL_F32X3 = 2 (fp32 tensors, each product formed as three bf16 MFMAs
  *     on the high / low halves of the operands: x = xh + xl, x w ~ xh wh + xh wl + xl wh, fp32 accumulation; ~1e-5
  *     relative instead of bit-exact fp32, 2-3 x the exact mode's rate; accepted by agrl_conv2d_bn_act and
  *     agrl_linear_nobias)
@@ -31,7 +34,8 @@ extern "C" {
 #endif
 
 #define AGRL_F32 0
-#define AGRL_BF16 1
+#define AGRL_LP16 1
+#define AGRL_BF16 AGRL_LP16 /* historical name of the same code */
 #define AGRL_F32X3 2
 
 #define AGRL_METRIC_EUCLIDEAN 0 /* squared euclidean, torchreid/metrics/distance.py:59-73 */
@@ -42,6 +46,9 @@ typedef void* agrl_stream_t; /* hipStream_t */
 /* library version (major*10000 + minor*100 + patch) and last error of the calling thread */
 int agrl_version(void);
 const char* agrl_last_error(void);
+
+/* 1 when the library's 16-bit storage type (dtype code AGRL_LP16) is IEEE fp16, 0 when it is bfloat16. */
+int agrl_lp16_is_f16(void);
 
 /* Tuning switches (AGRL_IGEMM_*, AGRL_CONV3X3_*, AGRL_GCN_*, AGRL_DISTMAT_*) are read from the environment
  * once, when the library is loaded; agrl_reload_options() re-reads them (the A/B tools and the kernel tests flip them inside
@@ -64,7 +71,7 @@ int agrl_stem_conv_bn_relu_maxpool(const float* x, const float* w, const float* 
  * bf16 (64, 240): row o = [r=0..6][s=0..7][c=0..3] (i.e. 7 x 32 values, zero where s == 7 or c == 3,
  * value w[o][r][s][c] * bn_scale[o] elsewhere) followed by 16 zeros (480-byte rows: the stride that keeps the kernel's
  * LDS weight reads bank-conflict free); out is bf16 NHWC (N, PH, PW, 64). */
-int agrl_stem_conv_bn_relu_maxpool_bf16(const float* x, const void* w_packed, const float* bias,
+int agrl_stem_conv_bn_relu_maxpool_lp16(const float* x, const void* w_packed, const float* bias,
                                         void* out, int N, int H, int W, agrl_stream_t stream);
 
 /* Implicit-GEMM convolution (1x1 or 3x3, stride 1|2) + folded BN + optional residual + optional

@@ -3,10 +3,13 @@ conventions, error behaviour, import side effects, C-ABI exports."""
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+from lp16 import LP16, LP_DTYPE
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -148,13 +151,43 @@ def test_cabi_library_exports_every_declared_symbol():
     lib = _hip.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert set(_hip.SIGNATURES) == declared - {"agrl_version", "agrl_last_error", "agrl_reload_options", "agrl_built_with_ablation"}
+    assert set(_hip.SIGNATURES) == declared - {"agrl_version", "agrl_last_error", "agrl_reload_options", "agrl_built_with_ablation", "agrl_lp16_is_f16"}
     assert lib.agrl_version() >= 100
     assert lib.agrl_built_with_ablation() == 0   # the shipped library has no switch that removes work from a kernel
     assert lib.agrl_reload_options() == 0
     # argument validation happens before any launch, so it is checkable without a GPU
     assert lib.agrl_distmat(None, None, None, None, None, 1, 1, 64, 1, 0, 0, None, 0, None) != 0
     assert b"null pointer" in lib.agrl_last_error()
+    assert bool(lib.agrl_lp16_is_f16()) == (_hip.LP_NAME == "fp16")
+
+
+def test_both_16_bit_builds_of_the_library_export_the_same_abi():
+    """The same sources are built twice (csrc/Makefile): libagrl_hip.so stores 16-bit data as fp16, libagrl_hip_bf16.so as
+    bfloat16. Both export every declared symbol and say which one they are; asking for one and loading the other is an error."""
+    import ctypes
+    from torchreid import _hip
+    header = open(os.path.join(ROOT, "include", "agrl_hip.h")).read()
+    declared = set(re.findall(r"\b(agrl_[a-z0-9_]+)\s*\(", header))
+    libdir = os.path.join(ROOT, "agrl.pytorch_amd", "lib")
+    for name, is_f16 in (("libagrl_hip.so", 1), ("libagrl_hip_bf16.so", 0)):
+        path = os.path.join(libdir, name)
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "agrl.pytorch_amd", "csrc"), "-j8"])
+        h = ctypes.CDLL(path)
+        for sym in declared:
+            assert hasattr(h, sym), (name, sym)
+        assert h.agrl_lp16_is_f16() == is_f16, name
+    other = "bf16" if _hip.LP_NAME == "fp16" else "fp16"
+    code = ("import os, sys; sys.path[:0] = [%r, %r]; os.environ['AGRL_HIP_LP16'] = %r; os.environ['AGRL_HIP_LIB'] = %r\n"
+            "from torchreid import _hip\n"
+            "try:\n    _hip.lib(); print('loaded')\nexcept _hip.HipLibraryError as e:\n    print('refused:', e)\n"
+            % (ROOT, os.path.join(ROOT, "agrl.pytorch_amd"), other, _hip.LIB_PATH))
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300).stdout.decode()
+    assert "refused" in out and "stores 16-bit data as" in out, out
+    from torchreid import hip_ops as ops
+    with pytest.raises(ValueError, match="AGRL_HIP_LP16"):
+        ops.check_precision(other)
+    assert ops.check_precision(_hip.LP_NAME) == _hip.LP_NAME and not ops.is_lp16("bf16x3") and ops.is_lp16(_hip.LP_NAME)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -263,7 +296,7 @@ def test_host_side_helpers_without_gpu():
     from torchreid.evaluation import pool_clips
     assert ops._gemm_code(torch.float32) == _hip.F32
     with ops.f32_split():
-        assert ops._gemm_code(torch.float32) == _hip.F32X3 and ops._gemm_code(torch.bfloat16) == _hip.BF16
+        assert ops._gemm_code(torch.float32) == _hip.F32X3 and ops._gemm_code(LP_DTYPE) == _hip.LP16
         with ops.f32_split(False):
             assert ops._gemm_code(torch.float32) == _hip.F32
         assert ops._gemm_code(torch.float32) == _hip.F32X3

@@ -8,13 +8,15 @@ import numpy as np
 import pytest
 import torch
 
+from lp16 import LP16, LP_DTYPE
+
 from oracle import vmgn_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LP16])
 def test_config5_full_mars_distmat_and_rank(precision):
     from torchreid import hip_ops as ops
     from torchreid.metrics.distance import hip_distmat_device

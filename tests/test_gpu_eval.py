@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from lp16 import LP16, LP_DTYPE
+
 from oracle import vmgn_oracle as O
 from recipe import calibrate_bnneck, recipe_state_dict, synthetic_adj, synthetic_clips
 
@@ -101,10 +103,10 @@ def test_fp32_pipeline_matches_oracle_rank1_map_and_indices(world, metric):
     assert abs(cmc[0] - ref["cmc"][0]) < 1e-9 and abs(mAP - ref["mAP"]) < 1e-6
 
 
-def test_bf16_pipeline_keeps_rank1_and_map(world):
+def test_16_bit_pipeline_keeps_rank1_and_map(world):
     from torchreid import evaluation
     m = world["model"]
-    m.hip_precision = "bf16"
+    m.hip_precision = LP16
     q_pids, q_cams, g_pids, g_cams = world["split"]
     ref = world["ref"]["cosine"]
 
@@ -112,10 +114,10 @@ def test_bf16_pipeline_keeps_rank1_and_map(world):
         return batches(p, c, s)
 
     r1, mAP = evaluation.evaluate(m, loader(q_pids, q_cams, 100), loader(g_pids, g_cams, 500), "cosine")
-    print("bf16: Rank-1 %.3f mAP %.4f (oracle %.3f %.4f)" % (r1, mAP, ref["cmc"][0], ref["mAP"]))
+    print("%s: Rank-1 %.3f mAP %.4f (oracle %.3f %.4f)" % (LP16, r1, mAP, ref["cmc"][0], ref["mAP"]))
     m.hip_precision = "fp32"
     assert abs(r1 - ref["cmc"][0]) <= 1.0 / N_ID + 1e-9
-    assert abs(mAP - ref["mAP"]) < 0.03
+    assert abs(mAP - ref["mAP"]) < (0.005 if LP16 == "fp16" else 0.03)
 
 
 def test_dense_clip_pooling_path(world):

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 import torch
+
+from lp16 import LP16, LP_DTYPE
 import torch.nn.functional as F
 
 from oracle import vmgn_oracle as O
@@ -16,7 +18,7 @@ from torchreid import _hip
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+TOL = {torch.float32: 2e-5, LP_DTYPE: 2e-2}
 
 
 def rel_err(got, ref):
@@ -43,7 +45,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, LP_DTYPE])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_bn_act(case, dtype):
     from torchreid import hip_ops as ops
@@ -53,14 +55,14 @@ def test_conv_bn_act(case, dtype):
     w = torch.randn((Cout, Cin, R, R), generator=g) / np.sqrt(Cin * R * R)
     b = torch.randn((Cout,), generator=g)
     pad = R // 2
-    if dtype == torch.bfloat16:  # the kernel sees bf16-rounded operands; so does the reference
-        x, w = x.bfloat16().float(), w.bfloat16().float()
+    if dtype == LP_DTYPE:  # the kernel sees bf16-rounded operands; so does the reference
+        x, w = x.to(LP_DTYPE).float(), w.to(LP_DTYPE).float()
     ref = F.conv2d(x, w, bias=b, stride=stride, padding=pad)
     res = None
     if use_res:
         res = torch.randn(ref.shape, generator=g)
-        if dtype == torch.bfloat16:
-            res = res.bfloat16().float()
+        if dtype == LP_DTYPE:
+            res = res.to(LP_DTYPE).float()
         ref = ref + res
     if relu:
         ref = F.relu(ref)
@@ -91,18 +93,18 @@ def test_conv_wide_tile(case, tile, monkeypatch):
     from torchreid import hip_ops as ops
     N, H, W, Cin, Cout, use_res, relu = case
     g = torch.Generator().manual_seed(sum(case[:5]))
-    x = (torch.randn((N, Cin, H, W), generator=g)).bfloat16().float()
-    w = (torch.randn((Cout, Cin, 1, 1), generator=g) / np.sqrt(Cin)).bfloat16().float()
+    x = (torch.randn((N, Cin, H, W), generator=g)).to(LP_DTYPE).float()
+    w = (torch.randn((Cout, Cin, 1, 1), generator=g) / np.sqrt(Cin)).to(LP_DTYPE).float()
     b = torch.randn((Cout,), generator=g)
     ref = F.conv2d(x, w, bias=b)
     res = None
     if use_res:
-        res = torch.randn(ref.shape, generator=g).bfloat16().float()
+        res = torch.randn(ref.shape, generator=g).to(LP_DTYPE).float()
         ref = ref + res
     if relu:
         ref = F.relu(ref)
-    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 1, 0, relu)
-    kw = dict(residual=None if res is None else nhwc(res, torch.bfloat16))
+    args = (nhwc(x, LP_DTYPE), w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), b.to(DEV), 1, 0, relu)
+    kw = dict(residual=None if res is None else nhwc(res, LP_DTYPE))
     if tile == "2" and Cout % 256:
         pytest.skip("256-channel tiles need Cout % 256 == 0")
     monkeypatch.setenv("AGRL_IGEMM_WIDE", tile)
@@ -127,16 +129,16 @@ def test_bottleneck_tail(shape, cnext):
     from torchreid import hip_ops as ops
     N, H, W = shape
     g = torch.Generator().manual_seed(N * H)
-    y2 = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
-    res = torch.randn((N, 256, H, W), generator=g).bfloat16().float()
-    w3 = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
-    w1 = (torch.randn((cnext, 256, 1, 1), generator=g) / 16).bfloat16().float()
+    y2 = torch.randn((N, 64, H, W), generator=g).to(LP_DTYPE).float()
+    res = torch.randn((N, 256, H, W), generator=g).to(LP_DTYPE).float()
+    w3 = (torch.randn((256, 64, 1, 1), generator=g) / 8).to(LP_DTYPE).float()
+    w1 = (torch.randn((cnext, 256, 1, 1), generator=g) / 16).to(LP_DTYPE).float()
     b3, b1 = torch.randn(256, generator=g), torch.randn(cnext, generator=g)
     out_ref = F.relu(F.conv2d(y2, w3, bias=b3) + res)
-    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
-    dy2, dres = nhwc(y2, torch.bfloat16), nhwc(res, torch.bfloat16)
-    dw3 = w3.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
-    dw1 = w1.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    z_ref = F.relu(F.conv2d(out_ref.to(LP_DTYPE).float(), w1, bias=b1))
+    dy2, dres = nhwc(y2, LP_DTYPE), nhwc(res, LP_DTYPE)
+    dw3 = w3.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    dw1 = w1.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
     assert ops.bottleneck_tail_supported(dy2, dw3, dw1)
     out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
     out2 = ops.conv_bn_act(dy2, dw3, b3.to(DEV), 1, 0, True, residual=dres)
@@ -149,13 +151,13 @@ def test_bottleneck_tail(shape, cnext):
     if cnext != 64:
         return
     # first-block form: the shortcut is the block's 1x1 downsample conv of x0, computed in the same pass
-    x0 = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
-    ws = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
+    x0 = torch.randn((N, 64, H, W), generator=g).to(LP_DTYPE).float()
+    ws = (torch.randn((256, 64, 1, 1), generator=g) / 8).to(LP_DTYPE).float()
     bs = torch.randn(256, generator=g)
     out_ref = F.relu(F.conv2d(y2, w3, bias=b3) + F.conv2d(x0, ws, bias=bs))
-    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
+    z_ref = F.relu(F.conv2d(out_ref.to(LP_DTYPE).float(), w1, bias=b1))
     out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), None, dw1, b1.to(DEV),
-                                 shortcut=(nhwc(x0, torch.bfloat16), ws.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), bs.to(DEV)))
+                                 shortcut=(nhwc(x0, LP_DTYPE), ws.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), bs.to(DEV)))
     torch.cuda.synchronize()
     e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(z.float().permute(0, 3, 1, 2), z_ref)
     print("bottleneck tail + downsample", shape, "out %.3e z %.3e" % (e1, e2))
@@ -171,17 +173,17 @@ def test_bottleneck_block(shape, cnext, monkeypatch):
     from torchreid import hip_ops as ops
     N, H, W = shape
     g = torch.Generator().manual_seed(N * H + cnext)
-    z = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
-    res = torch.randn((N, 256, H, W), generator=g).bfloat16().float()
-    w2 = (torch.randn((64, 64, 3, 3), generator=g) / 24).bfloat16().float()
-    w3 = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
-    w1 = (torch.randn((cnext, 256, 1, 1), generator=g) / 16).bfloat16().float()
+    z = torch.randn((N, 64, H, W), generator=g).to(LP_DTYPE).float()
+    res = torch.randn((N, 256, H, W), generator=g).to(LP_DTYPE).float()
+    w2 = (torch.randn((64, 64, 3, 3), generator=g) / 24).to(LP_DTYPE).float()
+    w3 = (torch.randn((256, 64, 1, 1), generator=g) / 8).to(LP_DTYPE).float()
+    w1 = (torch.randn((cnext, 256, 1, 1), generator=g) / 16).to(LP_DTYPE).float()
     b2, b3, b1 = torch.randn(64, generator=g), torch.randn(256, generator=g), torch.randn(cnext, generator=g)
-    y2_ref = F.relu(F.conv2d(z, w2, bias=b2, padding=1)).bfloat16().float()
+    y2_ref = F.relu(F.conv2d(z, w2, bias=b2, padding=1)).to(LP_DTYPE).float()
     out_ref = F.relu(F.conv2d(y2_ref, w3, bias=b3) + res)
-    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
-    dz, dres = nhwc(z, torch.bfloat16), nhwc(res, torch.bfloat16)
-    ohwi = lambda w: w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    z_ref = F.relu(F.conv2d(out_ref.to(LP_DTYPE).float(), w1, bias=b1))
+    dz, dres = nhwc(z, LP_DTYPE), nhwc(res, LP_DTYPE)
+    ohwi = lambda w: w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
     dw2, dw3, dw1 = ohwi(w2), ohwi(w3), ohwi(w1)
     assert ops.bottleneck_block_supported(dz, dw2, 1, dw3, dw1)
     out, zn = ops.bottleneck_block(dz, dw2, b2.to(DEV), dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
@@ -195,14 +197,14 @@ def test_bottleneck_block(shape, cnext, monkeypatch):
     assert torch.equal(out, out2) and torch.equal(zn, z2)
     if cnext != 64:
         return
-    x0 = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
-    ws = (torch.randn((256, 64, 1, 1), generator=g) / 8).bfloat16().float()
+    x0 = torch.randn((N, 64, H, W), generator=g).to(LP_DTYPE).float()
+    ws = (torch.randn((256, 64, 1, 1), generator=g) / 8).to(LP_DTYPE).float()
     bs = torch.randn(256, generator=g)
     out_ref = F.relu(F.conv2d(y2_ref, w3, bias=b3) + F.conv2d(x0, ws, bias=bs))
-    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
+    z_ref = F.relu(F.conv2d(out_ref.to(LP_DTYPE).float(), w1, bias=b1))
     out, zn = ops.bottleneck_block(dz, dw2, b2.to(DEV), dw3, b3.to(DEV), None, dw1, b1.to(DEV),
-                                   shortcut=(nhwc(x0, torch.bfloat16), ohwi(ws), bs.to(DEV)))
-    out3, z3 = ops.bottleneck_tail(y2s, dw3, b3.to(DEV), None, dw1, b1.to(DEV), shortcut=(nhwc(x0, torch.bfloat16), ohwi(ws), bs.to(DEV)))
+                                   shortcut=(nhwc(x0, LP_DTYPE), ohwi(ws), bs.to(DEV)))
+    out3, z3 = ops.bottleneck_tail(y2s, dw3, b3.to(DEV), None, dw1, b1.to(DEV), shortcut=(nhwc(x0, LP_DTYPE), ohwi(ws), bs.to(DEV)))
     torch.cuda.synchronize()
     e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(zn.float().permute(0, 3, 1, 2), z_ref)
     print("bottleneck block + downsample", shape, "out %.3e z %.3e" % (e1, e2))
@@ -218,16 +220,16 @@ def test_bottleneck_tail_layer2(shape):
     from torchreid import hip_ops as ops
     N, H, W = shape
     g = torch.Generator().manual_seed(N * H + 7)
-    y2 = torch.randn((N, 128, H, W), generator=g).bfloat16().float()
-    res = torch.randn((N, 512, H, W), generator=g).bfloat16().float()
-    w3 = (torch.randn((512, 128, 1, 1), generator=g) / 11).bfloat16().float()
-    w1 = (torch.randn((128, 512, 1, 1), generator=g) / 22).bfloat16().float()
+    y2 = torch.randn((N, 128, H, W), generator=g).to(LP_DTYPE).float()
+    res = torch.randn((N, 512, H, W), generator=g).to(LP_DTYPE).float()
+    w3 = (torch.randn((512, 128, 1, 1), generator=g) / 11).to(LP_DTYPE).float()
+    w1 = (torch.randn((128, 512, 1, 1), generator=g) / 22).to(LP_DTYPE).float()
     b3, b1 = torch.randn(512, generator=g), torch.randn(128, generator=g)
     out_ref = F.relu(F.conv2d(y2, w3, bias=b3) + res)
-    z_ref = F.relu(F.conv2d(out_ref.bfloat16().float(), w1, bias=b1))
-    dy2, dres = nhwc(y2, torch.bfloat16), nhwc(res, torch.bfloat16)
-    dw3 = w3.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
-    dw1 = w1.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    z_ref = F.relu(F.conv2d(out_ref.to(LP_DTYPE).float(), w1, bias=b1))
+    dy2, dres = nhwc(y2, LP_DTYPE), nhwc(res, LP_DTYPE)
+    dw3 = w3.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    dw1 = w1.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
     assert ops.bottleneck_tail_supported(dy2, dw3, dw1)
     out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
     out2 = ops.conv_bn_act(dy2, dw3, b3.to(DEV), 1, 0, True, residual=dres)
@@ -246,11 +248,11 @@ def test_conv_wide_tile_strided(case, tile, monkeypatch):
     from torchreid import hip_ops as ops
     N, H, W, Cin, Cout = case
     g = torch.Generator().manual_seed(sum(case))
-    x = torch.randn((N, Cin, H, W), generator=g).bfloat16().float()
-    w = (torch.randn((Cout, Cin, 1, 1), generator=g) / np.sqrt(Cin)).bfloat16().float()
+    x = torch.randn((N, Cin, H, W), generator=g).to(LP_DTYPE).float()
+    w = (torch.randn((Cout, Cin, 1, 1), generator=g) / np.sqrt(Cin)).to(LP_DTYPE).float()
     b = torch.randn((Cout,), generator=g)
     ref = F.conv2d(x, w, bias=b, stride=2)
-    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 2, 0, False)
+    args = (nhwc(x, LP_DTYPE), w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), b.to(DEV), 2, 0, False)
     monkeypatch.setenv("AGRL_IGEMM_WIDE", tile)
     _hip.reload_options()
     wide = ops.conv_bn_act(*args)
@@ -274,18 +276,18 @@ def test_conv1x1_dual_source(case):
     from torchreid import hip_ops as ops
     N, H, W, K1, K2, Cout = case
     g = torch.Generator().manual_seed(sum(case))
-    x = torch.randn((N, K1, H, W), generator=g).bfloat16().float()
-    y2 = torch.randn((N, K2, H, W), generator=g).relu().bfloat16().float()
-    wd = (torch.randn((Cout, K1, 1, 1), generator=g) / np.sqrt(K1)).bfloat16().float()
-    w3 = (torch.randn((Cout, K2, 1, 1), generator=g) / np.sqrt(K2)).bfloat16().float()
+    x = torch.randn((N, K1, H, W), generator=g).to(LP_DTYPE).float()
+    y2 = torch.randn((N, K2, H, W), generator=g).relu().to(LP_DTYPE).float()
+    wd = (torch.randn((Cout, K1, 1, 1), generator=g) / np.sqrt(K1)).to(LP_DTYPE).float()
+    w3 = (torch.randn((Cout, K2, 1, 1), generator=g) / np.sqrt(K2)).to(LP_DTYPE).float()
     bd, b3 = torch.randn((Cout,), generator=g), torch.randn((Cout,), generator=g)
     ref = F.relu(F.conv2d(x, wd, bias=bd) + F.conv2d(y2, w3, bias=b3))
-    xd, yd = nhwc(x, torch.bfloat16), nhwc(y2, torch.bfloat16)
-    wcat = torch.cat([wd.view(Cout, K1), w3.view(Cout, K2)], dim=1).bfloat16().to(DEV).contiguous()
+    xd, yd = nhwc(x, LP_DTYPE), nhwc(y2, LP_DTYPE)
+    wcat = torch.cat([wd.view(Cout, K1), w3.view(Cout, K2)], dim=1).to(LP_DTYPE).to(DEV).contiguous()
     assert ops.conv1x1_dual_supported(xd, yd, wcat)
     out = ops.conv1x1_dual(xd, yd, wcat, (bd + b3).to(DEV), True)
-    sc = ops.conv_bn_act(xd, wd.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), bd.to(DEV), 1, 0, False)
-    sep = ops.conv_bn_act(yd, w3.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b3.to(DEV), 1, 0, True, residual=sc)
+    sc = ops.conv_bn_act(xd, wd.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), bd.to(DEV), 1, 0, False)
+    sep = ops.conv_bn_act(yd, w3.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), b3.to(DEV), 1, 0, True, residual=sc)
     again = ops.conv1x1_dual(xd, yd, wcat, (bd + b3).to(DEV), True)
     torch.cuda.synchronize()
     e, es = rel_err(out.float().permute(0, 3, 1, 2), ref), rel_err(sep.float().permute(0, 3, 1, 2), ref)
@@ -304,10 +306,10 @@ def test_conv1x1_pool_fused(cfg, path, monkeypatch):
     from torchreid import hip_ops as ops
     N, Cin, Cout, splits, mean = cfg
     g = torch.Generator().manual_seed(N + Cin)
-    x = torch.randn((N, 16, 8, Cin), generator=g).bfloat16().to(DEV)
-    w = (torch.randn((Cout, 1, 1, Cin), generator=g) / np.sqrt(Cin)).bfloat16().to(DEV)
+    x = torch.randn((N, 16, 8, Cin), generator=g).to(LP_DTYPE).to(DEV)
+    w = (torch.randn((Cout, 1, 1, Cin), generator=g) / np.sqrt(Cin)).to(LP_DTYPE).to(DEV)
     b = torch.randn((Cout,), generator=g).to(DEV)
-    res = torch.randn((N, 16, 8, Cout), generator=g).bfloat16().to(DEV)
+    res = torch.randn((N, 16, 8, Cout), generator=g).to(LP_DTYPE).to(DEV)
     monkeypatch.setenv("AGRL_POOL_PERSIST", "1" if path == "persistent" else "0")
     _hip.reload_options()
     if path == "wide":
@@ -338,13 +340,13 @@ def test_conv3x3_c64_resident_weights(case, monkeypatch):
     from torchreid import hip_ops as ops
     N, H, W, relu = case
     g = torch.Generator().manual_seed(N * H + W)
-    x = torch.randn((N, 64, H, W), generator=g).bfloat16().float()
-    w = (torch.randn((64, 64, 3, 3), generator=g) / 24).bfloat16().float()
+    x = torch.randn((N, 64, H, W), generator=g).to(LP_DTYPE).float()
+    w = (torch.randn((64, 64, 3, 3), generator=g) / 24).to(LP_DTYPE).float()
     b = torch.randn((64,), generator=g)
     ref = F.conv2d(x, w, bias=b, padding=1)
     if relu:
         ref = F.relu(ref)
-    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 1, 1, relu)
+    args = (nhwc(x, LP_DTYPE), w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), b.to(DEV), 1, 1, relu)
     monkeypatch.setenv("AGRL_CONV3X3_C64", "1")
     _hip.reload_options()
     fast = ops.conv_bn_act(*args)
@@ -370,13 +372,13 @@ def test_conv3x3_wide_tile(case, monkeypatch):
     from torchreid import hip_ops as ops
     N, H, W, Cin, Cout, relu = case
     g = torch.Generator().manual_seed(sum(case[:5]))
-    x = torch.randn((N, Cin, H, W), generator=g).bfloat16().float()
-    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / np.sqrt(9 * Cin)).bfloat16().float()
+    x = torch.randn((N, Cin, H, W), generator=g).to(LP_DTYPE).float()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / np.sqrt(9 * Cin)).to(LP_DTYPE).float()
     b = torch.randn((Cout,), generator=g)
     ref = F.conv2d(x, w, bias=b, padding=1)
     if relu:
         ref = F.relu(ref)
-    args = (nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV), b.to(DEV), 1, 1, relu)
+    args = (nhwc(x, LP_DTYPE), w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), b.to(DEV), 1, 1, relu)
     monkeypatch.setenv("AGRL_CONV3X3_WIDE", "1")
     _hip.reload_options()
     wide = ops.conv_bn_act(*args)
@@ -390,7 +392,7 @@ def test_conv3x3_wide_tile(case, monkeypatch):
     assert torch.equal(wide, narrow)  # same k order per output -> identical bf16 results
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, LP_DTYPE])
 @pytest.mark.parametrize("shape", [(2, 256, 128), (3, 64, 48), (1, 37, 29)])
 def test_stem(shape, dtype):
     from torchreid import hip_ops as ops
@@ -416,16 +418,16 @@ def test_stem_bf16_mfma(shape):
     w = torch.randn((64, 3, 7, 7), generator=g) * 0.1
     b = torch.randn((64,), generator=g) * 0.1
     # the kernel rounds pixels and weights to bf16 and accumulates in fp32: so does the reference here
-    ref = F.max_pool2d(F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), bias=b, stride=2, padding=3)), 3, 2, 1)
-    wpk = ops.pack_stem_weights_bf16(w.permute(0, 2, 3, 1).contiguous().to(DEV))
-    out = ops.stem_bf16(x.to(DEV), wpk, b.to(DEV))
+    ref = F.max_pool2d(F.relu(F.conv2d(x.to(LP_DTYPE).float(), w.to(LP_DTYPE).float(), bias=b, stride=2, padding=3)), 3, 2, 1)
+    wpk = ops.pack_stem_weights_lp16(w.permute(0, 2, 3, 1).contiguous().to(DEV))
+    out = ops.stem_lp16(x.to(DEV), wpk, b.to(DEV))
     torch.cuda.synchronize()
     e = rel_err(out.float().permute(0, 3, 1, 2), ref)
     print("stem bf16 mfma", shape, "rel err %.3e" % e)
     assert e < 5e-3  # one bf16 rounding of the output
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, LP_DTYPE])
 @pytest.mark.parametrize("cfg", [(2, 4, 16, 8, 2048, [4, 2, 1]), (1, 3, 14, 7, 512, [4, 2, 1]), (2, 2, 16, 8, 256, [8, 4, 2, 1]), (1, 2, 16, 8, 256, [4])])
 def test_part_pool(cfg, dtype):
     from torchreid import hip_ops as ops
@@ -433,8 +435,8 @@ def test_part_pool(cfg, dtype):
     g = torch.Generator().manual_seed(11)
     x41 = torch.rand((B * S, C, h, w), generator=g)
     x42 = torch.rand((B * S, C, h, w), generator=g)
-    if dtype == torch.bfloat16:
-        x41, x42 = x41.bfloat16().float(), x42.bfloat16().float()
+    if dtype == LP_DTYPE:
+        x41, x42 = x41.to(LP_DTYPE).float(), x42.to(LP_DTYPE).float()
     gsum, nodes, nodes_lp = ops.part_pool(nhwc(x41, dtype), nhwc(x42, dtype), splits, want_lp=True)
     torch.cuda.synchronize()
     ref_nodes = O.part_nodes(x42, B, S, splits)
@@ -532,7 +534,7 @@ def test_graph_layer_commuted(shape, mode):
     fd, adjd = f.to(DEV), adj.to(DEV)
     G = ops.graph_matrix(fd, adjd, use_pose, learn_graph)
     errs = {}
-    for name, dt, split in (("fp32", torch.float32, False), ("bf16x3", torch.float32, True), ("bf16", torch.bfloat16, False)):
+    for name, dt, split in (("fp32", torch.float32, False), ("bf16x3", torch.float32, True), (LP16, LP_DTYPE, False)):
         with ops.f32_split(split):
             P = ops.graph_apply_operand(G, fd, dt)
             out = ops.graph_linear_mix(P, sd["gl.linear.weight"].to(dt).to(DEV), fd, scale, shift, 0.1, 0.1)
@@ -543,7 +545,7 @@ def test_graph_layer_commuted(shape, mode):
     print("commuted graph layer", shape, mode, {k: "%.2e / msg %.2e" % v for k, v in errs.items()})
     assert errs["fp32"][0] < 1e-5 and errs["fp32"][1] < 2e-4
     assert errs["bf16x3"][0] < 2e-4
-    assert errs["bf16"][0] < 1e-2
+    assert errs[LP16][0] < 1e-2
 
 
 @pytest.mark.parametrize("cfg", [(5, 56, 2048, True, True, False), (300, 28, 512, True, True, False), (3, 64, 512, False, True, False),
@@ -564,7 +566,7 @@ def test_graph_tracklet_operand(cfg):
     P3 = ops.graph_apply_operand(G3, fd, torch.float32)
     P, G = ops.graph_tracklet_operand(fd, adjd, use_pose, learn_graph, torch.float32, want_graph=True, mask_diag=masked)
     P2, _ = ops.graph_tracklet_operand(fd, adjd, use_pose, learn_graph, torch.float32, mask_diag=masked)
-    Plp, _ = ops.graph_tracklet_operand(fd, adjd, use_pose, learn_graph, torch.bfloat16, mask_diag=masked)
+    Plp, _ = ops.graph_tracklet_operand(fd, adjd, use_pose, learn_graph, LP_DTYPE, mask_diag=masked)
     torch.cuda.synchronize()
     if not masked:
         G64 = O.graph_matrix(f.double(), adj.double(), use_pose, learn_graph)
@@ -575,7 +577,7 @@ def test_graph_tracklet_operand(cfg):
     assert torch.equal(P, P2) and rel_err(Plp.float(), P) < 5e-3
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, LP_DTYPE])
 @pytest.mark.parametrize("shape", [(5, 16, 8, 256, 32, [4, 2, 1]), (3, 12, 8, 512, 64, [4, 2, 1]), (2, 16, 8, 128, 32, [2]), (2, 6, 4, 64, 32, [4])])
 def test_pam_pool(shape, dtype):
     """agrl_pam_pool + the folded value conv (one Linear on the attention-weighted slice mean) + agrl_pam_combine against
@@ -589,10 +591,10 @@ def test_pam_pool(shape, dtype):
           "pam.key_conv.weight": 0.3 * torch.randn((Cq, C, 1, 1), generator=g) / np.sqrt(C) * 4, "pam.key_conv.bias": 0.1 * torch.randn(Cq, generator=g),
           "pam.value_conv.weight": torch.randn((C, C, 1, 1), generator=g) / np.sqrt(C), "pam.value_conv.bias": 0.1 * torch.randn(C, generator=g),
           "pam.gamma": torch.tensor([0.7])}
-    if dtype == torch.bfloat16:   # the same rounded operands on both sides
-        x = x.bfloat16().float()
+    if dtype == LP_DTYPE:   # the same rounded operands on both sides
+        x = x.to(LP_DTYPE).float()
         for k in ("pam.query_conv.weight", "pam.key_conv.weight", "pam.value_conv.weight"):
-            sd[k] = sd[k].bfloat16().float()
+            sd[k] = sd[k].to(LP_DTYPE).float()
     ref = O.ganet_nodes(x, {k.replace("pam.", "pam_layer."): v for k, v in sd.items()}, Fr, 1, splits).view(Fr, sum(splits), C)
     xd = nhwc(x, dtype)
     qk_w = torch.cat([sd["pam.query_conv.weight"], sd["pam.key_conv.weight"]], 0).permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
@@ -609,7 +611,7 @@ def test_pam_pool(shape, dtype):
     sd0["pam_layer.gamma"] = torch.zeros(1)
     e0 = rel_err(nodes0, O.ganet_nodes(x, sd0, Fr, 1, splits).view(Fr, sum(splits), C))
     print("pam_pool", shape, dtype, "rel err %.3e (gamma = 0 form %.3e)" % (e, e0))
-    assert e < (2e-2 if dtype == torch.bfloat16 else 1e-4) and e0 < 1e-5
+    assert e < (2e-2 if dtype == LP_DTYPE else 1e-4) and e0 < 1e-5
     assert torch.equal(xmean, xmean0) and rel_err(nodes_lp.float(), nodes) < 5e-3
 
 
@@ -654,7 +656,7 @@ def test_distmat(shape, metric):
     gal = torch.randn((n, D), generator=g)
     ref = O.euclidean_squared(q.double(), gal.double()) if metric == "euclidean" else O.cosine(q.double(), gal.double())
     got = hip_distmat_device(q.to(DEV), gal.to(DEV), metric, "fp32")
-    got_lp = hip_distmat_device(q.to(DEV), gal.to(DEV), metric, "bf16")
+    got_lp = hip_distmat_device(q.to(DEV), gal.to(DEV), metric, LP16)
     torch.cuda.synchronize()
     e, elp = rel_err(got, ref), rel_err(got_lp, ref)
     print("distmat", shape, metric, "fp32 %.3e bf16 %.3e" % (e, elp))
@@ -732,7 +734,7 @@ def test_rank_topk_single_pass_form(shape):
     assert torch.equal(idx_u.cpu(), torch.from_numpy(idx)) and np.array_equal(val_u.cpu().numpy(), val, equal_nan=True)
 
 
-@pytest.mark.parametrize("cfg", [(700, 3000, 256, "fp32"), (700, 3000, 256, "bf16"), (130, 517, 64, "fp32"), (40, 12180, 4096, "bf16")])
+@pytest.mark.parametrize("cfg", [(700, 3000, 256, "fp32"), (700, 3000, 256, LP16), (130, 517, 64, "fp32"), (40, 12180, 4096, LP16)])
 def test_distmat_topk_equals_distmat_then_topk(cfg):
     """agrl_distmat_topk (distance rows of one query block at a time in a reused workspace, then the top-k of the block) ==
     agrl_distmat + agrl_rank_topk bit for bit when the queries fit one block (the recommended workspace here), same lists
@@ -751,7 +753,7 @@ def test_distmat_topk_equals_distmat_then_topk(cfg):
         idx1, val1 = hip_distmat_topk_device(q, gal, metric, k, prec)
         assert torch.equal(idx0, idx1) and torch.equal(val0, val1), metric
         assert bool((val1[:, 1:] >= val1[:, :-1]).all())
-    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    dt = LP_DTYPE if prec == LP16 else torch.float32
     qh, gh = ops.row_l2_normalize(q, True, dt, ops.k_multiple(dt)), ops.row_l2_normalize(gal, True, dt, ops.k_multiple(dt))
     dist = ops.distmat(qh, gh, "cosine")
     idx0, val0 = ops.rank_topk(dist, k, idx_offset=1000)

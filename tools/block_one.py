@@ -5,25 +5,26 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops
+from torchreid._hip import LP_DTYPE
 dev = "cuda:0"
 which = sys.argv[1] if len(sys.argv) > 1 else "block"
 N = 256
 if which == "block":
     H, W = 64, 32
-    z = torch.randn((N, H, W, 64), device=dev).bfloat16()
-    res = torch.randn((N, H, W, 256), device=dev).bfloat16()
-    w2 = (torch.randn((64, 3, 3, 64), device=dev) / 24).bfloat16()
-    w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
-    w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).bfloat16()
+    z = torch.randn((N, H, W, 64), device=dev).to(LP_DTYPE)
+    res = torch.randn((N, H, W, 256), device=dev).to(LP_DTYPE)
+    w2 = (torch.randn((64, 3, 3, 64), device=dev) / 24).to(LP_DTYPE)
+    w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).to(LP_DTYPE)
+    w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).to(LP_DTYPE)
     b2, b3, b1 = torch.randn(64, device=dev), torch.randn(256, device=dev), torch.randn(64, device=dev)
     for _ in range(5):
         ops.bottleneck_block(z, w2, b2, w3, b3, res, w1, b1)
 else:
     H, W = 32, 16
-    y2 = torch.randn((N, H, W, 128), device=dev).bfloat16()
-    res = torch.randn((N, H, W, 512), device=dev).bfloat16()
-    w3 = (torch.randn((512, 1, 1, 128), device=dev) / 11).bfloat16()
-    w1 = (torch.randn((128, 1, 1, 512), device=dev) / 22).bfloat16()
+    y2 = torch.randn((N, H, W, 128), device=dev).to(LP_DTYPE)
+    res = torch.randn((N, H, W, 512), device=dev).to(LP_DTYPE)
+    w3 = (torch.randn((512, 1, 1, 128), device=dev) / 11).to(LP_DTYPE)
+    w1 = (torch.randn((128, 1, 1, 512), device=dev) / 22).to(LP_DTYPE)
     b3, b1 = torch.randn(512, device=dev), torch.randn(128, device=dev)
     for _ in range(5):
         ops.bottleneck_tail(y2, w3, b3, res, w1, b1)

@@ -6,6 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops, _hip
+from torchreid._hip import LP_DTYPE
 dev = "cuda:0"
 SHAPES = [  # N, H, W, Cin, Cout, R, stride, res
     (256, 64, 32, 64, 256, 1, 1, False),
@@ -41,10 +42,10 @@ keys = sorted({k for _, d in variants for k in d})
 ROUNDS, REPS = 7, 10
 print("%-38s " % "shape" + " ".join("%14s" % n for n, _ in variants))
 for (N, H, W, Cin, Cout, R, stride, res) in SHAPES:
-    x = torch.randn((N, H, W, Cin), device=dev).bfloat16()
-    w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).bfloat16()
+    x = torch.randn((N, H, W, Cin), device=dev).to(LP_DTYPE)
+    w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).to(LP_DTYPE)
     b = torch.randn((Cout,), device=dev)
-    r = torch.randn((N, H, W, Cout), device=dev).bfloat16() if res else None
+    r = torch.randn((N, H, W, Cout), device=dev).to(LP_DTYPE) if res else None
     times = {n: [] for n, _ in variants}
     for rnd in range(ROUNDS + 1):
         for name, env in variants:

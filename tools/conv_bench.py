@@ -5,6 +5,7 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops
+from torchreid._hip import LP_DTYPE
 dev = "cuda:0"
 SHAPES = [  # N, H, W, Cin, Cout, R, stride, res
     (256, 64, 32, 64, 128, 1, 1, False),
@@ -20,12 +21,12 @@ SHAPES = [  # N, H, W, Cin, Cout, R, stride, res
 if len(sys.argv) > 1:
     SHAPES = [SHAPES[int(i)] for i in sys.argv[1].split(",")]
 for (N, H, W, Cin, Cout, R, stride, res) in SHAPES:
-    x = torch.randn((N, H, W, Cin), device=dev).bfloat16()
-    w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).bfloat16()
+    x = torch.randn((N, H, W, Cin), device=dev).to(LP_DTYPE)
+    w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).to(LP_DTYPE)
     b = torch.randn((Cout,), device=dev)
     OH = (H + 2 * (R // 2) - R) // stride + 1
     OW = (W + 2 * (R // 2) - R) // stride + 1
-    r = torch.randn((N, OH, OW, Cout), device=dev).bfloat16() if res else None
+    r = torch.randn((N, OH, OW, Cout), device=dev).to(LP_DTYPE) if res else None
     for _ in range(3):
         ops.conv_bn_act(x, w, b, stride, R // 2, True, r)
     torch.cuda.synchronize()

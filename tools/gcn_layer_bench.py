@@ -8,10 +8,11 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd"), os.path.join(ROOT, "test
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops
+from torchreid._hip import LP_DTYPE, LP_NAME
 dev = "cuda:0"
 B, V, C = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (32, 56, 2048)
-prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
-dt = torch.bfloat16 if prec == "bf16" else torch.float32
+prec = sys.argv[4] if len(sys.argv) > 4 else LP_NAME
+dt = LP_DTYPE if prec == LP_NAME else torch.float32
 f = torch.rand((B, 1, C), device=dev) + 0.02 * torch.randn((B, V, C), device=dev)
 f_lp = f.to(dt)
 w = (torch.randn((C, C), device=dev) * 0.02).to(dt)
@@ -22,7 +23,7 @@ sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
 def old():
     h = ops.linear_nobias(f_lp.view(B * V, C), w).view(B, V, C)
     G = ops.graph_matrix(f, adj, True, True)
-    return ops.graph_propagate(f, h, G, sc, sh, 0.1, 0.1, want_lp=prec == "bf16")[0]
+    return ops.graph_propagate(f, h, G, sc, sh, 0.1, 0.1, want_lp=prec == LP_NAME)[0]
 
 
 def new():

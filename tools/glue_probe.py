@@ -7,18 +7,19 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
+from torchreid._hip import LP_DTYPE, LP_NAME
 
 dev = torch.device("cuda:0")
-model, sd = bench.build_model(dev, "bf16")
+model, sd = bench.build_model(dev, LP_NAME)
 gen = torch.Generator(device=dev); gen.manual_seed(1)
 clips = torch.randn((32, 8, 3, 256, 128), device=dev, generator=gen)
 adj = bench.synthetic_pose_adjacency(32, 8, dev, gen)
 from torchreid import hip_ops as ops
-g = ops.row_l2_normalize(torch.randn((12180, 4096), device=dev), True, torch.bfloat16)
+g = ops.row_l2_normalize(torch.randn((12180, 4096), device=dev), True, LP_DTYPE)
 out = torch.empty((32, 12180), device=dev)
 def step():
     emb = model(clips, adj)
-    q = ops.row_l2_normalize(emb, True, torch.bfloat16)
+    q = ops.row_l2_normalize(emb, True, LP_DTYPE)
     return ops.distmat(q, g, "cosine", out=out)
 for _ in range(3): step()
 torch.cuda.synchronize()

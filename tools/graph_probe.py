@@ -5,10 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch
+from torchreid._hip import LP_NAME
 from bench import build_model
 from recipe import synthetic_adj
 dev = torch.device("cuda:0")
-model, _ = build_model(dev, "bf16")
+model, _ = build_model(dev, LP_NAME)
 B, S = 32, 8
 x = torch.randn((B, S, 3, 256, 128), device=dev)
 adj = synthetic_adj(B, S).to(dev)

@@ -6,6 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops, _hip
+from torchreid._hip import LP_DTYPE
 dev = "cuda:0"
 variants = []
 for a in sys.argv[1:]:
@@ -16,8 +17,8 @@ if not variants:
 keys = sorted({k for _, d in variants for k in d})
 B, V, C = 32, 56, 2048
 f = torch.randn((B, V, C), device=dev)
-flp = f.bfloat16()
-w = (torch.randn((C, C), device=dev) * 0.01).bfloat16()
+flp = f.to(LP_DTYPE)
+w = (torch.randn((C, C), device=dev) * 0.01).to(LP_DTYPE)
 w32 = w.float()
 adj = (torch.rand((B, V, V), device=dev) > 0.5).float()
 sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)

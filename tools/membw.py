@@ -3,7 +3,7 @@ import torch, time
 dev = "cuda:0"
 for mb in (268, 1024):
     n = mb * 1024 * 1024 // 2
-    a = torch.empty(n, dtype=torch.bfloat16, device=dev).normal_()
+    a = torch.empty(n, dtype=LP_DTYPE, device=dev).normal_()
     b = torch.empty_like(a)
     for name, fn, bytes_ in (("copy", lambda: b.copy_(a), 2 * n * 2), ("fill", lambda: b.fill_(1.0), n * 2), ("sum", lambda: a.sum(), n * 2)):
         for _ in range(3):

@@ -13,7 +13,7 @@ from bench import build_model  # noqa: E402
 from recipe import synthetic_adj  # noqa: E402
 from torchreid import _hip, hip_ops as ops  # noqa: E402
 
-prec = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+prec = sys.argv[1] if len(sys.argv) > 1 else _hip.LP_NAME
 B, S = 32, 8
 dev = torch.device("cuda:0")
 model, _ = build_model(dev, prec)

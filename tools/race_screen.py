@@ -7,16 +7,17 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops, _hip
+from torchreid._hip import LP_DTYPE
 dev = "cuda:0"
 torch.manual_seed(0)
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 
 def conv_case(N, H, W, Cin, Cout, R, stride, res, env_alt):
-    x = torch.randn((N, H, W, Cin), device=dev).bfloat16()
-    w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).bfloat16()
+    x = torch.randn((N, H, W, Cin), device=dev).to(LP_DTYPE)
+    w = (torch.randn((Cout, R, R, Cin), device=dev) / (Cin * R * R) ** 0.5).to(LP_DTYPE)
     b = torch.randn((Cout,), device=dev)
     OH, OW = (H + 2 * (R // 2) - R) // stride + 1, (W + 2 * (R // 2) - R) // stride + 1
-    r = torch.randn((N, OH, OW, Cout), device=dev).bfloat16() if res else None
+    r = torch.randn((N, OH, OW, Cout), device=dev).to(LP_DTYPE) if res else None
     for k in env_alt:
         os.environ[k] = env_alt[k]
     _hip.reload_options()
@@ -45,13 +46,13 @@ for name, c in cases:
 
 # fused layer-1 block (3x3 + conv3 + residual + next conv1) vs the split launches
 Nb, Hb, Wb = 256, 64, 32
-zin = torch.randn((Nb, Hb, Wb, 64), device=dev).bfloat16()
-resb = torch.randn((Nb, Hb, Wb, 256), device=dev).bfloat16()
-w2b = (torch.randn((64, 3, 3, 64), device=dev) / 24).bfloat16()
-w3b = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+zin = torch.randn((Nb, Hb, Wb, 64), device=dev).to(LP_DTYPE)
+resb = torch.randn((Nb, Hb, Wb, 256), device=dev).to(LP_DTYPE)
+w2b = (torch.randn((64, 3, 3, 64), device=dev) / 24).to(LP_DTYPE)
+w3b = (torch.randn((256, 1, 1, 64), device=dev) / 8).to(LP_DTYPE)
 b2b, b3b = torch.randn(64, device=dev), torch.randn(256, device=dev)
 for cn in (64, 128):
-    w1b = (torch.randn((cn, 1, 1, 256), device=dev) / 16).bfloat16()
+    w1b = (torch.randn((cn, 1, 1, 256), device=dev) / 16).to(LP_DTYPE)
     b1b = torch.randn(cn, device=dev)
     yb = ops.conv_bn_act(zin, w2b, b2b, 1, 1, True)
     ob = ops.conv_bn_act(yb, w3b, b3b, 1, 0, True, residual=resb)
@@ -62,10 +63,10 @@ for cn in (64, 128):
         bad += int(not (torch.equal(o, ob) and torch.equal(zz, zb)))
     total += bad
     print("bottleneck block cnext=%-3d     %d / %d runs differ from the split convs" % (cn, bad, REPS))
-xsb = torch.randn((Nb, Hb, Wb, 64), device=dev).bfloat16()
-wsb = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+xsb = torch.randn((Nb, Hb, Wb, 64), device=dev).to(LP_DTYPE)
+wsb = (torch.randn((256, 1, 1, 64), device=dev) / 8).to(LP_DTYPE)
 bsb = torch.randn(256, device=dev)
-w1b = (torch.randn((64, 1, 1, 256), device=dev) / 16).bfloat16()
+w1b = (torch.randn((64, 1, 1, 256), device=dev) / 16).to(LP_DTYPE)
 b1b = torch.randn(64, device=dev)
 o0, z0 = ops.bottleneck_block(zin, w2b, b2b, w3b, b3b, None, w1b, b1b, shortcut=(xsb, wsb, bsb))
 o0, z0 = o0.clone(), z0.clone()
@@ -79,12 +80,12 @@ del zin, resb, xsb
 
 # fused tails vs the split convs
 N, H, W = 256, 64, 32
-y2 = torch.randn((N, H, W, 64), device=dev).bfloat16()
-res = torch.randn((N, H, W, 256), device=dev).bfloat16()
-w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+y2 = torch.randn((N, H, W, 64), device=dev).to(LP_DTYPE)
+res = torch.randn((N, H, W, 256), device=dev).to(LP_DTYPE)
+w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).to(LP_DTYPE)
 b3 = torch.randn(256, device=dev)
 for cn in (64, 128):
-    w1 = (torch.randn((cn, 1, 1, 256), device=dev) / 16).bfloat16()
+    w1 = (torch.randn((cn, 1, 1, 256), device=dev) / 16).to(LP_DTYPE)
     b1 = torch.randn(cn, device=dev)
     o_ref = ops.conv_bn_act(y2, w3, b3, 1, 0, True, residual=res)
     z_ref = ops.conv_bn_act(o_ref, w1, b1, 1, 0, True)
@@ -94,10 +95,10 @@ for cn in (64, 128):
         bad += int(not (torch.equal(o, o_ref) and torch.equal(z, z_ref)))
     total += bad
     print("%-28s %d / %d runs differ from the split convs" % ("bottleneck tail cnext=%d" % cn, bad, REPS))
-x0 = torch.randn((N, H, W, 64), device=dev).bfloat16()
-ws = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+x0 = torch.randn((N, H, W, 64), device=dev).to(LP_DTYPE)
+ws = (torch.randn((256, 1, 1, 64), device=dev) / 8).to(LP_DTYPE)
 bs = torch.randn(256, device=dev)
-w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).bfloat16()
+w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).to(LP_DTYPE)
 b1 = torch.randn(64, device=dev)
 o0, z0 = ops.bottleneck_tail(y2, w3, b3, None, w1, b1, shortcut=(x0, ws, bs))
 o0, z0 = o0.clone(), z0.clone()
@@ -111,7 +112,7 @@ print("%-28s %d / %d runs differ from the first run" % ("bottleneck tail + downs
 f = torch.randn((32, 56, 2048), device=dev); h = torch.randn((32, 56, 2048), device=dev); G = torch.rand((32, 56, 56), device=dev)
 sc, sh = torch.rand(2048, device=dev) + 0.5, torch.randn(2048, device=dev)
 p0 = ops.graph_propagate(f, h, G, sc, sh, 0.1, 0.1, want_lp=True)
-q = torch.randn((32, 4096), device=dev).bfloat16(); g = torch.randn((12180, 4096), device=dev).bfloat16()
+q = torch.randn((32, 4096), device=dev).to(LP_DTYPE); g = torch.randn((12180, 4096), device=dev).to(LP_DTYPE)
 d0 = ops.distmat(q, g, "cosine").clone()
 bad = 0
 for _ in range(REPS):
@@ -123,15 +124,15 @@ print("%-28s %d / %d runs differ from the first run" % ("propagate + distmat", b
 # round-3 kernels: GraphLayer in the commuted form (graph, G f, GEMM with the fused epilogue), its one-workgroup-per-tracklet
 # form at 256 tracklets, the single-pass top-k (LDS atomics + in-launch radix fallback) and the full-row argsort
 adj = (torch.rand((32, 56, 56), device=dev) > 0.5).float()
-wl = (torch.randn((2048, 2048), device=dev) * 0.02).bfloat16()
+wl = (torch.randn((2048, 2048), device=dev) * 0.02).to(LP_DTYPE)
 def commuted(ff, aa):
     Gm = ops.graph_matrix(ff, aa, True, True)
-    P = ops.graph_apply_operand(Gm, ff, torch.bfloat16)
+    P = ops.graph_apply_operand(Gm, ff, LP_DTYPE)
     return ops.graph_linear_mix(P, wl, ff, sc, sh, 0.1, 0.1)
 c0 = commuted(f, adj).clone()
 f256 = torch.rand((256, 1, 2048), device=dev) + 0.02 * torch.randn((256, 56, 2048), device=dev)
 adj256 = (torch.rand((256, 56, 56), device=dev) > 0.5).float()
-t0 = [t.clone() for t in ops.graph_tracklet_operand(f256, adj256, True, True, torch.bfloat16, want_graph=True)]
+t0 = [t.clone() for t in ops.graph_tracklet_operand(f256, adj256, True, True, LP_DTYPE, want_graph=True)]
 dk = torch.randn((1980, 12180), device=dev)
 dk[5] = 0.25   # a row of equal values: the radix path inside the single-pass launch
 k0 = [t.clone() for t in ops.rank_topk(dk, 50)]
@@ -139,7 +140,7 @@ a0 = ops.rank_argsort(dk[:64]).clone()
 bad = 0
 for _ in range(REPS):
     bad += int(not torch.equal(commuted(f, adj), c0))
-    t1 = ops.graph_tracklet_operand(f256, adj256, True, True, torch.bfloat16, want_graph=True)
+    t1 = ops.graph_tracklet_operand(f256, adj256, True, True, LP_DTYPE, want_graph=True)
     bad += int(not (torch.equal(t1[0], t0[0]) and torch.equal(t1[1], t0[1])))
     k1 = ops.rank_topk(dk, 50)
     bad += int(not (torch.equal(k1[0], k0[0]) and torch.equal(k1[1], k0[1])))

@@ -6,6 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops, _hip
+from torchreid._hip import LP_DTYPE
 dev = "cuda:0"
 variants = []
 for a in sys.argv[1:]:
@@ -20,8 +21,8 @@ h = torch.randn((B, V, C), device=dev)
 G = torch.rand((B, V, V), device=dev)
 sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
 m, n, D = 32, 12180, 4096
-q = torch.randn((m, D), device=dev).bfloat16()
-g = torch.randn((n, D), device=dev).bfloat16()
+q = torch.randn((m, D), device=dev).to(LP_DTYPE)
+g = torch.randn((n, D), device=dev).to(LP_DTYPE)
 q32, g32 = q.float(), g.float()
 trash = torch.empty((512 << 20,), dtype=torch.uint8, device=dev)  # flushes L2 + MALL between timed calls
 def prop(): ops.graph_propagate(f, h, G, sc, sh, 0.1, 0.1, want_lp=True)
@@ -59,7 +60,7 @@ for label, fn, nbytes in CASES:
             "%s %6.1fus %5.2fTB/s" % (nm, statistics.median(times[nm]), nbytes / statistics.median(times[nm]) / 1e6) for nm, _ in variants))
 
 # the N = 8 match stage of bench.py: 256 gathered queries against a 1523-row gallery shard
-q8 = torch.randn((256, D), device=dev).bfloat16(); g8 = torch.randn((1523, D), device=dev).bfloat16()
+q8 = torch.randn((256, D), device=dev).to(LP_DTYPE); g8 = torch.randn((1523, D), device=dev).to(LP_DTYPE)
 for _ in range(3): ops.distmat(q8, g8, "cosine")
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -6,16 +6,17 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd"), os.path.join(ROOT, "test
 import torch
 import bench
 from torchreid import hip_ops as ops
+from torchreid._hip import LP_DTYPE, LP_NAME
 dev = torch.device("cuda:0")
-model, sd = bench.build_model(dev, "bf16")
+model, sd = bench.build_model(dev, LP_NAME)
 gen = torch.Generator(device=dev); gen.manual_seed(1)
 clips = torch.randn((32, 8, 3, 256, 128), device=dev, generator=gen)
 adj = bench.synthetic_pose_adjacency(32, 8, dev, gen)
-gal = ops.row_l2_normalize(torch.randn((12180, 4096), device=dev), True, torch.bfloat16)
+gal = ops.row_l2_normalize(torch.randn((12180, 4096), device=dev), True, LP_DTYPE)
 out = torch.empty((32, 12180), device=dev)
 def step():
     emb = model(clips, adj)
-    q = ops.row_l2_normalize(emb, True, torch.bfloat16)
+    q = ops.row_l2_normalize(emb, True, LP_DTYPE)
     return ops.distmat(q, gal, "cosine", out=out)
 for _ in range(3): step()
 torch.cuda.synchronize()

@@ -5,12 +5,13 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
     sys.path.insert(0, p)
 import torch
 from torchreid import hip_ops as ops
+from torchreid._hip import LP_DTYPE
 dev = "cuda:0"
 N, H, W = 256, 64, 32
-y2 = torch.randn((N, H, W, 64), device=dev).bfloat16()
-res = torch.randn((N, H, W, 256), device=dev).bfloat16()
-w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
-w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).bfloat16()
+y2 = torch.randn((N, H, W, 64), device=dev).to(LP_DTYPE)
+res = torch.randn((N, H, W, 256), device=dev).to(LP_DTYPE)
+w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).to(LP_DTYPE)
+w1 = (torch.randn((64, 1, 1, 256), device=dev) / 16).to(LP_DTYPE)
 b3, b1 = torch.randn(256, device=dev), torch.randn(64, device=dev)
 def fused(): return ops.bottleneck_tail(y2, w3, b3, res, w1, b1)
 def split():
@@ -30,10 +31,10 @@ for name, fn in (("fused", fused), ("split", split)):
 
 # layer-2 form: conv3 128 -> 512 + residual, next conv1 512 -> 128 at 32 x 16
 H, W = 32, 16
-y2 = torch.randn((N, H, W, 128), device=dev).bfloat16()
-res = torch.randn((N, H, W, 512), device=dev).bfloat16()
-w3 = (torch.randn((512, 1, 1, 128), device=dev) / 11).bfloat16()
-w1 = (torch.randn((128, 1, 1, 512), device=dev) / 22).bfloat16()
+y2 = torch.randn((N, H, W, 128), device=dev).to(LP_DTYPE)
+res = torch.randn((N, H, W, 512), device=dev).to(LP_DTYPE)
+w3 = (torch.randn((512, 1, 1, 128), device=dev) / 11).to(LP_DTYPE)
+w1 = (torch.randn((128, 1, 1, 512), device=dev) / 22).to(LP_DTYPE)
 b3, b1 = torch.randn(512, device=dev), torch.randn(128, device=dev)
 for name, fn in (("layer2 fused", fused), ("layer2 split", split)):
     ts = []
@@ -49,13 +50,13 @@ for name, fn in (("layer2 fused", fused), ("layer2 split", split)):
 
 # whole layer-1 block: 3x3 64 -> 64, conv3 64 -> 256 + residual, next conv1 256 -> 64 at 64 x 32
 H, W = 64, 32
-zin = torch.randn((N, H, W, 64), device=dev).bfloat16()
-res = torch.randn((N, H, W, 256), device=dev).bfloat16()
-w2 = (torch.randn((64, 3, 3, 64), device=dev) / 24).bfloat16()
-w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).bfloat16()
+zin = torch.randn((N, H, W, 64), device=dev).to(LP_DTYPE)
+res = torch.randn((N, H, W, 256), device=dev).to(LP_DTYPE)
+w2 = (torch.randn((64, 3, 3, 64), device=dev) / 24).to(LP_DTYPE)
+w3 = (torch.randn((256, 1, 1, 64), device=dev) / 8).to(LP_DTYPE)
 b2, b3 = torch.randn(64, device=dev), torch.randn(256, device=dev)
 for cn in (64, 128):
-    w1 = (torch.randn((cn, 1, 1, 256), device=dev) / 16).bfloat16()
+    w1 = (torch.randn((cn, 1, 1, 256), device=dev) / 16).to(LP_DTYPE)
     b1 = torch.randn(cn, device=dev)
     def fusedb(): return ops.bottleneck_block(zin, w2, b2, w3, b3, res, w1, b1)
     def splitb():

@@ -25,7 +25,7 @@ def timed(fn, reps=20):
     return statistics.median(ts[3:])
 
 
-for prec in ("bf16", "fp32"):
+for prec in (ops.LP_NAME, "fp32"):
     d = hip_distmat_device(q, gal, "cosine", prec)
     t_topk = timed(lambda: ops.rank_topk(d, k))
     t_sep = timed(lambda: ops.rank_topk(hip_distmat_device(q, gal, "cosine", prec), k))
