@@ -3,7 +3,8 @@
 
 Workload (BASELINE.json configs[1], the config the metric is quoted on): MARS-shaped synthetic clips, seq_len 8,
 32 tracklets per GPU per step (256 frames of 256x128), VMGN eval forward (ResNet50 two-branch + 2 graph layers +
-attention pooling) in bf16, then the cosine distance of the step's embeddings against the resident gallery
+attention pooling) in the library's 16-bit type (fp16 by default, bf16 with --precision bf16: 16-bit storage and MFMA
+operands, fp32 accumulation), then the cosine distance of the step's embeddings against the resident gallery
 (12 180 x 4096, row-sharded over the ranks). One "step" = forward + [RCCL all-gather of embeddings, N > 1] +
 distance matrix against the rank's gallery shard. Inputs are resident in HBM before the timed region.
 
@@ -19,7 +20,7 @@ Rank 0 prints ONE JSON line: value = whole-job frames/s (all ranks) over EXACTLY
   roofline_*      : conv family, layer-4 pointwise convs, GCN message pass (the WHOLE SURVEY 8(d) unit: sim +
                     normalise + mix + G h + BN + LeakyReLU + residual), distance matrix -- the HBM-bound ones with
                     the read-stream yardstick of this chip at the same byte count beside them
-  accuracy        : Rank-1 / mAP of bf16 and exact fp32 on the 625-identity 1980 x 12180 split of tests/fullsplit.py, both held
+  accuracy        : Rank-1 / mAP of the 16-bit mode and exact fp32 on the 625-identity 1980 x 12180 split of tests/fullsplit.py, both held
                     against the CPU oracle's committed result for the same split (tests/golden/fullsplit_oracle.npz)
   modes           : the same step timed in the two precision modes that meet the 1e-3 / bit-exact-ranking bar (fp32, bf16x3)
   config5         : the full-eval distance matrix 1980 x 12180 x 4096 + top-50 + MARS AP/CMC, timed
@@ -757,7 +758,7 @@ def main():
                    "devices_visible": torch.cuda.device_count(), "library": os.path.basename(_hip.LIB_PATH),
                    "per_rank_ms_per_step": [round(x, 3) for x in per_rank_ms]},
     }
-    if (args.embedding_error or lp) and world == 1 and args.precision != "fp32":
+    if (args.embedding_error or (lp and not args.no_modes)) and world == 1 and args.precision != "fp32":
         with torch.no_grad():
             e_lp = model(clips, adj).float()
             model.hip_precision = "fp32"

@@ -1,7 +1,8 @@
 """GPU parity tests, kernel by kernel, through the C-ABI (libagrl_hip.so) against the CPU oracle.
 
 fp32 (exact-fp32 MFMA) must agree with the oracle to ~1e-5 relative; the north-star bar is 1e-3.
-bf16 is the throughput mode: operands rounded to bf16, fp32 accumulation -> tolerance 2e-2 of the output scale.
+The 16-bit type of the loaded build (lp16.LP_DTYPE: fp16 by default, bf16 with AGRL_HIP_LP16=bf16) is the throughput mode:
+operands rounded to it, fp32 accumulation -> tolerance 2e-2 of the output scale (set for bf16; fp16 sits 8 x below it).
 """
 import os
 

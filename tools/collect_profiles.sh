@@ -9,7 +9,7 @@ CMD="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-accuracy --no-config5
 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python3 $CMD > $O/bench_under_rocprof.json 2> $O/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 $CMD > /dev/null 2> $O/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 $CMD > /dev/null 2> $O/write.err
-python3 tools/rocprof_stats.py $(ls $O/trace/*results.db $O/trace/*/*results.db 2>/dev/null | head -1) $O/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 $CMD (1x MI355X, bf16, B=32 S=8; 13 steps + 3 profiled steps + the 256-tracklet GraphLayer and 8x-gallery distance-matrix measurements); torch:* / copyBuffer rows are one-off weight packing, input generation and the yardstick's buffers, not part of a step (tools/step_ops.py)"
-python3 tools/pmc_traffic.py $(ls $O/fetch/*counter_collection.csv $O/fetch/*/*counter_collection.csv 2>/dev/null | head -1) $(ls $O/write/*counter_collection.csv $O/write/*/*counter_collection.csv 2>/dev/null | head -1) 16 bf16 $O/traffic.json > $O/traffic.txt 2>&1
+python3 tools/rocprof_stats.py $(ls $O/trace/*results.db $O/trace/*/*results.db 2>/dev/null | head -1) $O/kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python3 $CMD (1x MI355X, fp16, B=32 S=8; 13 steps + 3 profiled steps + the 256-tracklet GraphLayer and 8x-gallery distance-matrix measurements); torch:* / copyBuffer rows are one-off weight packing, input generation and the yardstick's buffers, not part of a step (tools/step_ops.py)"
+python3 tools/pmc_traffic.py $(ls $O/fetch/*counter_collection.csv $O/fetch/*/*counter_collection.csv 2>/dev/null | head -1) $(ls $O/write/*counter_collection.csv $O/write/*/*counter_collection.csv 2>/dev/null | head -1) 16 fp16 $O/traffic.json > $O/traffic.txt 2>&1
 python3 bench.py > $O/bench_n1.json 2> $O/bench_n1.err
 ls -la $O
