@@ -117,6 +117,11 @@ __device__ inline __attribute__((ext_vector_type(4))) float mfma_lp16_16x16x32(c
     }
 }
 
+// ReLU that keeps a NaN: fmaxf(NaN, 0) is 0, which would turn an out-of-range activation of the fp16 build (inf, then
+// inf - inf = NaN in the next layer) into a plausible-looking zero; with this form inf / NaN reach the embedding and
+// evaluation.extract_features refuses them. One instruction on gfx950: v_maximum3_f32 (IEEE-754-2019 maximum, NaN-propagating).
+__device__ inline float relu_nan(float v) { return __builtin_elementwise_maximum(v, 0.f); }
+
 // ---- wavefront reductions (64 lanes) -------------------------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

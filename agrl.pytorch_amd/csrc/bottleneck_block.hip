@@ -246,8 +246,8 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int c = wn * 32 + a * 16 + fc * 4;
-                float v[4] = {fmaxf(acc0[a][0] + b2v[a].x, 0.f), fmaxf(acc0[a][1] + b2v[a].y, 0.f),
-                              fmaxf(acc0[a][2] + b2v[a].z, 0.f), fmaxf(acc0[a][3] + b2v[a].w, 0.f)};
+                float v[4] = {relu_nan(acc0[a][0] + b2v[a].x), relu_nan(acc0[a][1] + b2v[a].y),
+                              relu_nan(acc0[a][2] + b2v[a].z), relu_nan(acc0[a][3] + b2v[a].w)};
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(s_y + prow * 128 + (((c >> 3) ^ ((prow >> 1) & 7)) << 4) + ((c & 4) << 1)), v);
             }
         }
@@ -316,10 +316,10 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
                     unpack_lp16x2(rcell[b][a].y, rr[2], rr[3]);
                 }
                 float v[4];
-                v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
-                v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
-                v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
-                v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
+                v[0] = relu_nan(acc[a][b][0] + b3v[a].x + rr[0]);
+                v[1] = relu_nan(acc[a][b][1] + b3v[a].y + rr[1]);
+                v[2] = relu_nan(acc[a][b][2] + b3v[a].z + rr[2]);
+                v[3] = relu_nan(acc[a][b][3] + b3v[a].w + rr[3]);
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
             }
         }
@@ -374,10 +374,10 @@ __global__ __launch_bounds__(512) void bottleneck_block_kernel(const BlockParams
             for (int a = 0; a < NA2; ++a) {
                 const int c = wn4 * (CN / 4) + a * 16 + fc * 4;
                 float v[4];
-                v[0] = fmaxf(acc2[a][b][0] + b1v[a].x, 0.f);
-                v[1] = fmaxf(acc2[a][b][1] + b1v[a].y, 0.f);
-                v[2] = fmaxf(acc2[a][b][2] + b1v[a].z, 0.f);
-                v[3] = fmaxf(acc2[a][b][3] + b1v[a].w, 0.f);
+                v[0] = relu_nan(acc2[a][b][0] + b1v[a].x);
+                v[1] = relu_nan(acc2[a][b][1] + b1v[a].y);
+                v[2] = relu_nan(acc2[a][b][2] + b1v[a].z);
+                v[3] = relu_nan(acc2[a][b][3] + b1v[a].w);
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(sz + px * (CN * 2) + (((c >> 3) ^ (px & (CN / 8 - 1))) << 4) + ((c & 4) << 1)), v);
             }
         }

@@ -155,10 +155,10 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
                 float rr[4] = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (!CAT) load4<lp16_t>(reinterpret_cast<const lp16_t*>(cell), rr);
                 float v[4];
-                v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
-                v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
-                v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
-                v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
+                v[0] = relu_nan(acc[a][b][0] + b3v[a].x + rr[0]);
+                v[1] = relu_nan(acc[a][b][1] + b3v[a].y + rr[1]);
+                v[2] = relu_nan(acc[a][b][2] + b3v[a].z + rr[2]);
+                v[3] = relu_nan(acc[a][b][3] + b3v[a].w + rr[3]);
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
             }
         }
@@ -193,10 +193,10 @@ __global__ __launch_bounds__(512) void bottleneck_tail_kernel(const TailParams p
             const int px = wm2 * 32 + b * 16 + frow;
             const int c = wn4 * 16 + fchunk * 4;
             float v[4];
-            v[0] = fmaxf(acc2[b][0] + b1v.x, 0.f);
-            v[1] = fmaxf(acc2[b][1] + b1v.y, 0.f);
-            v[2] = fmaxf(acc2[b][2] + b1v.z, 0.f);
-            v[3] = fmaxf(acc2[b][3] + b1v.w, 0.f);
+            v[0] = relu_nan(acc2[b][0] + b1v.x);
+            v[1] = relu_nan(acc2[b][1] + b1v.y);
+            v[2] = relu_nan(acc2[b][2] + b1v.z);
+            v[3] = relu_nan(acc2[b][3] + b1v.w);
             store4<lp16_t>(reinterpret_cast<lp16_t*>(sz + px * 128 + (((c >> 3) ^ (px & 7)) << 4) + ((c & 4) << 1)), v);
         }
         wg_barrier();  // z tile complete; every read of the out tile done
@@ -315,10 +315,10 @@ __global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParam
                 float rr[4];
                 load4<lp16_t>(reinterpret_cast<const lp16_t*>(cell), rr);
                 float v[4];
-                v[0] = fmaxf(acc[a][b][0] + b3v[a].x + rr[0], 0.f);
-                v[1] = fmaxf(acc[a][b][1] + b3v[a].y + rr[1], 0.f);
-                v[2] = fmaxf(acc[a][b][2] + b3v[a].z + rr[2], 0.f);
-                v[3] = fmaxf(acc[a][b][3] + b3v[a].w + rr[3], 0.f);
+                v[0] = relu_nan(acc[a][b][0] + b3v[a].x + rr[0]);
+                v[1] = relu_nan(acc[a][b][1] + b3v[a].y + rr[1]);
+                v[2] = relu_nan(acc[a][b][2] + b3v[a].z + rr[2]);
+                v[3] = relu_nan(acc[a][b][3] + b3v[a].w + rr[3]);
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
             }
         }
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(512) void bottleneck_tail128_kernel(const TailParam
             for (int a = 0; a < 2; ++a) {
                 const int c = wn4 * 32 + a * 16 + fchunk * 4;
                 float v[4];
-                v[0] = fmaxf(acc2[a][b][0] + b1v[a].x, 0.f);
-                v[1] = fmaxf(acc2[a][b][1] + b1v[a].y, 0.f);
-                v[2] = fmaxf(acc2[a][b][2] + b1v[a].z, 0.f);
-                v[3] = fmaxf(acc2[a][b][3] + b1v[a].w, 0.f);
+                v[0] = relu_nan(acc2[a][b][0] + b1v[a].x);
+                v[1] = relu_nan(acc2[a][b][1] + b1v[a].y);
+                v[2] = relu_nan(acc2[a][b][2] + b1v[a].z);
+                v[3] = relu_nan(acc2[a][b][3] + b1v[a].w);
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(sr + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
             }
         }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
                     unpack_lp16x2(rcell[b][a].y, rr[2], rr[3]);
                     float v[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[a][b][r] + bv[a][r] + rr[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = relu_nan(acc[a][b][r] + bv[a][r] + rr[r]);
                     store4<lp16_t>(reinterpret_cast<lp16_t*>(cell), v);
                 }
             }
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(512) void bottleneck_tail_l2_kernel(const TailParam
             const int c = wave * 16 + fchunk * 4;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc2[b][r] + lane_bias(b1l, fchunk * 4 + r), 0.f);
+            for (int r = 0; r < 4; ++r) v[r] = relu_nan(acc2[b][r] + lane_bias(b1l, fchunk * 4 + r));
             store4<lp16_t>(reinterpret_cast<lp16_t*>(sz + px * 256 + (((c >> 3) ^ (px & 15)) << 4) + ((c & 4) << 1)), v);
         }
         wg_barrier();  // z tile complete; every read of the out tile done

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
             float v[4] = {acc[a][b][0] + cv.x, acc[a][b][1] + cv.y, acc[a][b][2] + cv.z, acc[a][b][3] + cv.w};
             if (p.relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
             }
             store4<lp16_t>(reinterpret_cast<lp16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
         }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const IgemmParams p, i
                 float v[4] = {acc[a][b][0] + cv[a].x, acc[a][b][1] + cv[a].y, acc[a][b][2] + cv[a].z, acc[a][b][3] + cv[a].w};
                 if (p.relu) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
                 }
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(s_o + prow * 128 + (((c >> 3) ^ (prow & 7)) << 4) + ((c & 4) << 1)), v);
             }

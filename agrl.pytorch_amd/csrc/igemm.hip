@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                 }
                 if (p.relu) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
                 }
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(slot), v);
             }
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                     }
                     if (p.relu) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
                     }
                     store4<TOUT>(outp + o, v);
                     if (do_stats) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                         if (gn + r < p.N) {
                             float t = fmaf(p.alpha, acc[a][b][r], rv + (p.colv ? p.colv[gn + r] : 0.f));
                             if (resp) t += DT<TOUT>::ld(resp + o + r);
-                            if (p.relu) t = fmaxf(t, 0.f);
+                            if (p.relu) t = relu_nan(t);
                             DT<TOUT>::st(outp + o + r, t);
                         }
                     }
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_persist_kernel(const IgemmParam
                     }
                     if (p.relu) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                        for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
                     }
                     store4<lp16_t>(reinterpret_cast<lp16_t*>(slot), v);
                 }
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const IgemmParams p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[a][b][r] + cvr[a][r];
-                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+                if (p.relu) v[r] = relu_nan(v[r]);
             }
             store4<lp16_t>(reinterpret_cast<lp16_t*>(so + prow * ROWB + (((c >> 3) ^ (prow & (CPR - 1))) << 4) + ((c & 4) << 1)), v);
         }

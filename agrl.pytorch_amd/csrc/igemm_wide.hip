@@ -364,7 +364,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 }
                 if (p.relu) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
                 }
                 const uint4 pk = make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
                 if (gm < p.M && (!POOL || p.pool_store_out) && (!(DBG & 1) || p.relu == 12345)) *reinterpret_cast<uint4*>(outp + (size_t)gm * p.ldo + cb + 32 * j) = pk;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 }
                 if (p.relu) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
                 }
                 store4<lp16_t>(reinterpret_cast<lp16_t*>(slot), v);
             }

@@ -93,10 +93,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
             const int cr = cr0 + cy, cc = cc0 + cx;
             const bool in = (unsigned)cr < (unsigned)CH && (unsigned)cc < (unsigned)CW;
             float4 v;
-            v.x = in ? fmaxf(acc[i][0] + bv.x, 0.f) : 0.f;
-            v.y = in ? fmaxf(acc[i][1] + bv.y, 0.f) : 0.f;
-            v.z = in ? fmaxf(acc[i][2] + bv.z, 0.f) : 0.f;
-            v.w = in ? fmaxf(acc[i][3] + bv.w, 0.f) : 0.f;
+            v.x = in ? relu_nan(acc[i][0] + bv.x) : 0.f;
+            v.y = in ? relu_nan(acc[i][1] + bv.y) : 0.f;
+            v.z = in ? relu_nan(acc[i][2] + bv.z) : 0.f;
+            v.w = in ? relu_nan(acc[i][3] + bv.w) : 0.f;
             *reinterpret_cast<float4*>(&s_wc[pos * 64 + og * 4]) = v;
         }
     }

@@ -167,8 +167,8 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
 #pragma unroll
             for (int i = 0; i < FPW; ++i) {
                 if (live[i]) {
-                    const float v0 = fmaxf(acc[i][a][0] + bv.x, 0.f), v1 = fmaxf(acc[i][a][1] + bv.y, 0.f);
-                    const float v2 = fmaxf(acc[i][a][2] + bv.z, 0.f), v3 = fmaxf(acc[i][a][3] + bv.w, 0.f);
+                    const float v0 = relu_nan(acc[i][a][0] + bv.x), v1 = relu_nan(acc[i][a][1] + bv.y);
+                    const float v2 = relu_nan(acc[i][a][2] + bv.z), v3 = relu_nan(acc[i][a][3] + bv.w);
                     uint2 u;
                     u.x = pack_lp16x2(v0, v1);
                     u.y = pack_lp16x2(v2, v3);

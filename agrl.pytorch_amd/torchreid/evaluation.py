@@ -91,7 +91,18 @@ def extract_features(model, batches, pool="avg", prefetch=True):
         feats.append(pool_clips(model(imgs, adj), clips, pool))
         pids.extend(np.asarray(pid).tolist())
         camids.extend(np.asarray(camid).tolist())
-    return torch.cat(feats, 0), np.asarray(pids), np.asarray(camids)
+    out = torch.cat(feats, 0)
+    # One check per extraction, after the last batch (no per-batch synchronisation): the fp16 build stores activations with a
+    # range of 65504 -- a checkpoint whose activations leave it yields inf / nan embeddings, and ranking those would be silent
+    # garbage. (Nothing on this path comes near the limit with the recipe or with trained ResNet50 statistics.)
+    if out.is_cuda and not bool(torch.isfinite(out).all()):
+        from torchreid import _hip
+        raise FloatingPointError(
+            "non-finite embeddings from the %s forward (hip_precision=%r)%s" % (
+                _hip.LP_NAME if getattr(model, "hip_precision", "fp32") == _hip.LP_NAME else "HIP", getattr(model, "hip_precision", None),
+                ": activations left fp16's range -- set AGRL_HIP_LP16=bf16 (libagrl_hip_bf16.so) or hip_precision='fp32'"
+                if _hip.LP_NAME == "fp16" and getattr(model, "hip_precision", "fp32") == "fp16" else ""))
+    return out, np.asarray(pids), np.asarray(camids)
 
 
 def _i32(a, device):

@@ -144,3 +144,24 @@ def test_re_rank_branch_matches_oracle_pipeline(world):
     cmc, mAP = evaluation.match_and_rank(qf.to(DEV), q_pids, q_cams, gf.to(DEV), g_pids, g_cams, "cosine", 50, "fp32", re_rank=True)
     assert abs(mAP - map_ref) < 1e-3 and np.abs(cmc - cmc_ref).max() < 0.1  # near-ties of the Jaccard term may swap
     print("re-rank branch: mAP %.6f (oracle %.6f) rank-1 %.4f (oracle %.4f)" % (mAP, map_ref, cmc[0], cmc_ref[0]))
+
+
+def test_out_of_range_activations_fail_loudly_in_the_16_bit_mode():
+    """fp16 build: a checkpoint whose activations leave fp16's range (here: the stem's folded BatchNorm scaled by 1e6) gives
+    inf / nan embeddings; extract_features refuses them instead of ranking garbage. The bf16 build has fp32's range and passes."""
+    from torchreid import evaluation, models
+    m = models.init_model("vmgn", num_classes=4, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    sd["bn1.weight"] = sd["bn1.weight"] * 1e6
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.hip_precision = LP16
+    x, adj = synthetic_clips(2, 4, seed=3), synthetic_adj(2, 4, seed=3)
+    batch = [(x, np.zeros(2, dtype=np.int64), np.zeros(2, dtype=np.int64), adj)]
+    if LP16 == "fp16":
+        with pytest.raises(FloatingPointError, match="fp16's range"):
+            evaluation.extract_features(m, batch, prefetch=False)
+    else:
+        f, _, _ = evaluation.extract_features(m, batch, prefetch=False)
+        assert torch.isfinite(f).all()
