@@ -183,6 +183,7 @@ struct AgrlOpts {
     int wgrad_wgs;   // AGRL_WGRAD_WGS: workgroups the pixel-axis split of agrl_conv_wgrad aims for
     int topk_radix;        // AGRL_TOPK_RADIX: every top-k through the five-pass radix kernel
     int graph_linear_mmajor;  // AGRL_GRAPH_LINEAR_MMAJOR: conv-style XCD map for agrl_graph_linear_mix
+    int conv3x3_n128;         // AGRL_CONV3X3_N128: conv3x3_wide_kernel with 128-channel tiles also where 256-channel ones apply
     int graph_linear_igemm;   // AGRL_GRAPH_LINEAR_IGEMM: agrl_graph_linear_mix through igemm_kernel also for bf16 operands
     int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library
 };

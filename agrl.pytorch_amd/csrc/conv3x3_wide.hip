@@ -20,19 +20,26 @@
 
 namespace {
 
-template <int DBG>  // ablation bits (profiling only): 1 no weight DMA after the prologue, 2 no MFMA, 4 no fragment reads, 8 no waits / barriers
+// BN_ = 256 (Cout % 256 == 0 and enough tiles: the 512-channel convs of layer 4): wave tile 64 pixels x 128 channels. The LDS
+// delivers 128 B/clk/CU (tools/lds_rate.hip); with 64 x 64 wave tiles a tap-step asks it for 8 waves x 16 fragment reads =
+// 128 KiB + 21 KiB of DMA writes per 1024 MFMA cycles per SIMD -- 146 B/clk, MORE than it has, so the matrix pipe cannot
+// exceed 0.88 and sits at 0.5 once the two are not perfectly overlapped. 64 x 128 wave tiles read 24 fragments per 64 MFMAs:
+// 192 + 37 KiB per 2048 cycles = 112 B/clk. Two 32 KiB weight slots (the weights of step + 1 land during step), the out tile
+// (128 KiB) overlays patches + weight ring, the lane's 36 first-k-step patch offsets are held and the second k-step's derived
+// (offset ^ 64) to stay inside 256 registers with 128 of them accumulators.
+template <int DBG, int BN_ = 128>  // DBG: ablation bits (profiling only): 1 no weight DMA after the prologue, 2 no MFMA, 4 no fragment reads, 8 no waits / barriers
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, int nblocks) {
-    constexpr int BN = 128, NW = 8, WM = 4, BM = 256;
-    constexpr int FM = BM / (16 * WM), FN = BN / 32;  // 4 x 4 fragments per wave
+    constexpr int BN = BN_, NW = 8, WM = 4, BM = 256;
+    constexpr int FM = BM / (16 * WM), FN = BN / 32;  // 4 x 4 (x 8) fragments per wave
     constexpr int PW = 10, PPIX = 18 * PW;            // 18 x 10 halo patch per block
     constexpr int PPIECES = (PPIX + 7) / 8;           // 23 one-KiB pieces (8 patch pixels each)
     constexpr int PATCH_BYTES = PPIECES * 1024;       // 23552
     constexpr int SLAB_BYTES = 2 * PATCH_BYTES;       // both blocks
     constexpr int PJ = (2 * PPIECES + NW - 1) / NW;   // patch pieces per wave per slab (6, two of the 48 are dummies)
-    constexpr int B_BYTES = BN * 128, WSLOTS = 3;
+    constexpr int B_BYTES = BN * 128, WSLOTS = BN == 256 ? 2 : 3;
     constexpr int BJ = BN / 64;                       // weight pieces per wave per tap-step (2)
     constexpr int CPR = BN * 2 / 16, ROWB = BN * 2;
-    static_assert(BM * ROWB <= 2 * SLAB_BYTES, "out tile must fit over the patch buffers");
+    static_assert(BM * ROWB <= 2 * SLAB_BYTES + (BN == 256 ? WSLOTS * B_BYTES : 0), "out tile must fit over the patch buffers (+ the weight ring)");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SLAB_BYTES + WSLOTS * B_BYTES + 1024];
     unsigned char* s_b = smem + 2 * SLAB_BYTES;
     unsigned char* s_dummy = s_b + WSLOTS * B_BYTES;
@@ -131,7 +138,15 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
 #pragma unroll
     for (int i = 0; i < PJ; ++i) stage_patch_piece(0, i);
     stage_b(0, 0, 0);
-    stage_b(0, 1, 1);
+    if (WSLOTS == 3) stage_b(0, 1, 1);
+    // BN = 256: first-k-step patch offsets of the nine taps (the second k-step's chunk index differs in bit 2: offset ^ 64)
+    int xoff[BN == 256 ? 9 : 1][FM];
+    if constexpr (BN == 256) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) xoff[t][b] = patch_off<PW>(py0[b] + t / 3, px0[b] + t % 3, fchunk);
+    }
 
     int wslot = 0;  // weight ring slot of the current step
     for (int slab = 0; slab < nslab; ++slab) {
@@ -153,47 +168,54 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
                 const int ptap = tap - 1;  // the tap of step-1 (same slab unless tap == 0)
                 const bool patch_younger = (tap >= 1) && (ptap < PJ) && next_slab;
                 if (DBG & 8) {
-                } else if (!more) wait_vmcnt<0>();
+                } else if (!more || WSLOTS == 2) wait_vmcnt<0>();  // two slots: this step's weights are the youngest request
                 else if (patch_younger) wait_vmcnt<BJ + 1>();
                 else wait_vmcnt<BJ>();
             }
             if (!(DBG & 8)) wg_barrier();
             // refill: next slab's patch piece, then the weights two steps ahead (into the slot read at step-1)
             if (tap < PJ && next_slab && !(DBG & 1)) stage_patch_piece(slab + 1, tap);
-            if (step + 2 < nsteps && !(DBG & 1)) {
-                int t2 = tap + 2, s2 = slab;
+            if (step + (WSLOTS - 1) < nsteps && !(DBG & 1)) {
+                int t2 = tap + (WSLOTS - 1), s2 = slab;
                 if (t2 >= 9) { t2 -= 9; ++s2; }
-                int slot2 = wslot + 2;
+                int slot2 = wslot + (WSLOTS - 1);
                 slot2 = slot2 >= WSLOTS ? slot2 - WSLOTS : slot2;
                 stage_b(s2, t2, slot2);
             }
             const int tr = tap / 3, ts = tap - tr * 3;
             const unsigned char* sb = s_b + wslot * B_BYTES;
-            // 8 groups of 4 MFMAs: group g = (k-step g >> 2, channel fragment g & 3)
+            // 2 FN groups of FM MFMAs: group g = (k-step g / FN, channel fragment g % FN)
+            constexpr int NG = 2 * FN;
             uint4 xfr[2][FM], wfr[3];
+            int k64 = 64;
+            if constexpr (BN == 256) asm volatile("" : "+v"(k64));  // keeps offset ^ 64 a per-step instruction, not 36 more registers
             auto ldx = [&](int kk, int b) {
                 if ((DBG & 4) && step) return make_uint4(step, kk, b, lane);
-                return *reinterpret_cast<const uint4*>(sp + patch_off<PW>(py0[b] + tr, px0[b] + ts, kk * 4 + fchunk));
+                if constexpr (BN == 256) return *reinterpret_cast<const uint4*>(sp + (kk ? xoff[tap][b] ^ k64 : xoff[tap][b]));
+                else return *reinterpret_cast<const uint4*>(sp + patch_off<PW>(py0[b] + tr, px0[b] + ts, kk * 4 + fchunk));
             };
             auto ldw = [&](int g) {
                 if ((DBG & 4) && step) return make_uint4(step, g, 7, lane);
-                return *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + (g & 3) * 16 + frow, (g >> 2) * 4 + fchunk));
+                return *reinterpret_cast<const uint4*>(sb + lds_off(wn * (BN / 2) + (g % FN) * 16 + frow, (g / FN) * 4 + fchunk));
             };
             wfr[0] = ldw(0);
 #pragma unroll
             for (int b = 0; b < FM; ++b) xfr[0][b] = ldx(0, b);
             wfr[1] = ldw(1);
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                if (g + 2 < 8) wfr[(g + 2) % 3] = ldw(g + 2);
+            for (int g = 0; g < NG; ++g) {
+                if (g + 2 < NG) wfr[(g + 2) % 3] = ldw(g + 2);
                 if (g < FM) xfr[1][g] = ldx(1, g);
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
-                    if (!(DBG & 2)) acc[g & 3][b] = Frag<lp16_t>::mma(wfr[g % 3], xfr[g >> 2][b], acc[g & 3][b]);
-                    else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g >> 2][b].x), "v"(xfr[g >> 2][b].w));
+                    if (!(DBG & 2)) acc[g % FN][b] = Frag<lp16_t>::mma(wfr[g % 3], xfr[g / FN][b], acc[g % FN][b]);
+                    else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g / FN][b].x), "v"(xfr[g / FN][b].w));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            // (BN = 256: carrying the first k-step's pixel fragments from step to step -- read under the previous step's second
+            // k-step so that a step starts with two reads instead of six -- was measured: the longer live ranges spill inside
+            // the slab loop, 154 us against 125 us)
             wslot = wslot + 1 == WSLOTS ? 0 : wslot + 1;
         }
     }
@@ -383,7 +405,11 @@ int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream) {
         C3_CASE(1); C3_CASE(2); C3_CASE(4); C3_CASE(8); C3_CASE(5); C3_CASE(13); C3_CASE(6); C3_CASE(9);
 #undef C3_CASE
 #endif
-        default: hipLaunchKernelGGL(conv3x3_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p, nblocks);
+        default:
+            // 256-channel tiles when they still cover the chip (layer 4: 128 pixel tiles x 2 = 256 workgroups); AGRL_CONV3X3_N128=1: A/B
+            if ((p.N % 256) == 0 && cdiv(nblocks, 2) * (p.N / 256) >= 192 && !agrl_opts().conv3x3_n128)
+                hipLaunchKernelGGL((conv3x3_wide_kernel<0, 256>), dim3(cdiv(nblocks, 2) * (p.N / 256)), dim3(512), 0, stream, p, nblocks);
+            else hipLaunchKernelGGL(conv3x3_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p, nblocks);
     }
     AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 wide)");
     return 0;

@@ -863,9 +863,9 @@ def main():
                   "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2), "ms_per_step": round(a["ms"] / nprof, 4)}
         dom = cls["dom"]
         if dom["launches"]:
-            # THE dominant kernel by time (profiles/*_bench_kernel_stats.csv): conv3x3_wide_kernel<0>
+            # THE dominant kernel by time (profiles/*_bench_kernel_stats.csv): conv3x3_wide_kernel<0, 128 | 256>
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_wide_kernel<0> (3x3 stride-1 convs of layers 3-4, csrc/conv3x3_wide.hip)",
+            result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_wide_kernel<0, 128> + <0, 256> (3x3 stride-1 convs of layers 3-4: 128-channel tiles in layer 3, 256-channel tiles in layer 4; csrc/conv3x3_wide.hip)",
                                   "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                   "traffic": traffic, "traffic_source": traffic_src,
                                   "flops_per_launch": round(dom["flops"] / dom["launches"], 1),
