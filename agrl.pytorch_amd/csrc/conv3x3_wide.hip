@@ -27,7 +27,7 @@ namespace {
 // 192 + 37 KiB per 2048 cycles = 112 B/clk. Two 32 KiB weight slots (the weights of step + 1 land during step), the out tile
 // (128 KiB) overlays patches + weight ring, the lane's 36 first-k-step patch offsets are held and the second k-step's derived
 // (offset ^ 64) to stay inside 256 registers with 128 of them accumulators.
-template <int DBG, int BN_ = 128>  // DBG: ablation bits (profiling only): 1 no weight DMA after the prologue, 2 no MFMA, 4 no fragment reads, 8 no waits / barriers
+template <int DBG, int BN_ = 128, int WRING = 3>  // WRING: weight-fragment ring of the 256-channel form (look-ahead WRING - 1 groups; 3 / 4 / 5: 127.2 / 123.8 / 123.5 us); DBG: ablation bits (profiling only): 1 no weight DMA after the prologue, 2 no MFMA, 4 no fragment reads, 8 no waits / barriers
 __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, int nblocks) {
     constexpr int BN = BN_, NW = 8, WM = 4, BM = 256;
     constexpr int FM = BM / (16 * WM), FN = BN / 32;  // 4 x 4 (x 8) fragments per wave
@@ -186,7 +186,8 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
             const unsigned char* sb = s_b + wslot * B_BYTES;
             // 2 FN groups of FM MFMAs: group g = (k-step g / FN, channel fragment g % FN)
             constexpr int NG = 2 * FN;
-            uint4 xfr[2][FM], wfr[3];
+            constexpr int WR = BN == 256 ? WRING : 3;   // weight-fragment ring: WR - 1 groups of look-ahead
+            uint4 xfr[2][FM], wfr[WR];
             int k64 = 64;
             if constexpr (BN == 256) asm volatile("" : "+v"(k64));  // keeps offset ^ 64 a per-step instruction, not 36 more registers
             auto ldx = [&](int kk, int b) {
@@ -201,15 +202,16 @@ __global__ __launch_bounds__(512) void conv3x3_wide_kernel(const IgemmParams p, 
             wfr[0] = ldw(0);
 #pragma unroll
             for (int b = 0; b < FM; ++b) xfr[0][b] = ldx(0, b);
-            wfr[1] = ldw(1);
+#pragma unroll
+            for (int q = 1; q < WR - 1; ++q) wfr[q] = ldw(q);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if (g + 2 < NG) wfr[(g + 2) % 3] = ldw(g + 2);
+                if (g + WR - 1 < NG) wfr[(g + WR - 1) % WR] = ldw(g + WR - 1);
                 if (g < FM) xfr[1][g] = ldx(1, g);
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
-                    if (!(DBG & 2)) acc[g % FN][b] = Frag<lp16_t>::mma(wfr[g % 3], xfr[g / FN][b], acc[g % FN][b]);
-                    else asm volatile("" ::"v"(wfr[g % 3].x), "v"(wfr[g % 3].w), "v"(xfr[g / FN][b].x), "v"(xfr[g / FN][b].w));
+                    if (!(DBG & 2)) acc[g % FN][b] = Frag<lp16_t>::mma(wfr[g % WR], xfr[g / FN][b], acc[g % FN][b]);
+                    else asm volatile("" ::"v"(wfr[g % WR].x), "v"(wfr[g % WR].w), "v"(xfr[g / FN][b].x), "v"(xfr[g / FN][b].w));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -408,7 +410,7 @@ int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream) {
         default:
             // 256-channel tiles when they still cover the chip (layer 4: 128 pixel tiles x 2 = 256 workgroups); AGRL_CONV3X3_N128=1: A/B
             if ((p.N % 256) == 0 && cdiv(nblocks, 2) * (p.N / 256) >= 192 && !agrl_opts().conv3x3_n128)
-                hipLaunchKernelGGL((conv3x3_wide_kernel<0, 256>), dim3(cdiv(nblocks, 2) * (p.N / 256)), dim3(512), 0, stream, p, nblocks);
+                hipLaunchKernelGGL((conv3x3_wide_kernel<0, 256, 5>), dim3(cdiv(nblocks, 2) * (p.N / 256)), dim3(512), 0, stream, p, nblocks);
             else hipLaunchKernelGGL(conv3x3_wide_kernel<0>, dim3(grid), dim3(512), 0, stream, p, nblocks);
     }
     AGRL_CHECK_LAUNCH("agrl_conv2d_bn_act(3x3 wide)");
