@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -22,6 +23,25 @@ __global__ __launch_bounds__(512) void k16(int iters, float* sink, const bf16x8*
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][3];
+    if (s == 12345.678f) *sink = s;
+}
+// the fp16 instruction on the same registers (the operand bits are then read as fp16: random sign / mantissa around 1)
+__global__ __launch_bounds__(512) void k16h(int iters, float* sink, const bf16x8* src) {
+    bf16x8 a[4], b[8];
+    for (int i = 0; i < 4; ++i) a[i] = src[threadIdx.x + 64 * i];
+    for (int i = 0; i < 8; ++i) b[i] = src[threadIdx.x + 64 * (4 + i)];
+    f32x4 acc[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
     }
     float s = 0.f;
     for (int i = 0; i < 4; ++i)
@@ -147,6 +167,7 @@ int main() {
         for (int iters : {2000, 20000, 100000}) {
             run("16x16x32 (32 acc x 4 regs)", k16, 4, iters, sink, src);
             run("16x16x32 (32 acc x 4 regs)", k16, 8, iters, sink, src);
+            run("16x16x32 f16 (32 acc x 4 regs)", k16h, 8, iters, sink, src);
             run("32x32x16 (8 acc x 16 regs)", k32, 4, iters, sink, src);
             run("32x32x16 (8 acc x 16 regs)", k32, 8, iters, sink, src);
         }
