@@ -393,6 +393,39 @@ def test_conv3x3_wide_tile(case, monkeypatch):
     assert torch.equal(wide, narrow)  # same k order per output -> identical bf16 results
 
 
+@pytest.mark.parametrize("case", [(385, 16, 8, 128, 512, True), (192, 32, 8, 64, 256, False), (400, 16, 8, 512, 768, True)])
+def test_conv3x3_wide_256_channel_tiles(case, monkeypatch):
+    """The 256-channel-tile form of the two-block 3x3 kernel (64 x 128 wave tiles, two weight slots, out tile over patches +
+    weight ring: layer 4's 512 -> 512 convs at the bench size) is taken when Cout % 256 == 0 and >= 192 such tiles exist:
+    odd block count (the last workgroup has one valid block), two blocks per frame, three channel tiles -- against the
+    reference conv and BITWISE against the 128-channel-tile form (same k order per output)."""
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, Cout, relu = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn((N, Cin, H, W), generator=g).to(LP_DTYPE).float()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / np.sqrt(9 * Cin)).to(LP_DTYPE).float()
+    b = torch.randn((Cout,), generator=g)
+    args = (nhwc(x, LP_DTYPE), w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV), b.to(DEV), 1, 1, relu)
+    monkeypatch.setenv("AGRL_CONV3X3_WIDE", "1")
+    monkeypatch.delenv("AGRL_CONV3X3_N128", raising=False)
+    _hip.reload_options()
+    t256 = ops.conv_bn_act(*args)
+    monkeypatch.setenv("AGRL_CONV3X3_N128", "1")
+    _hip.reload_options()
+    t128 = ops.conv_bn_act(*args)
+    monkeypatch.delenv("AGRL_CONV3X3_N128")
+    _hip.reload_options()
+    torch.cuda.synchronize()
+    rows = torch.randperm(N, generator=g)[:24]          # the reference conv of a sample of frames (CPU time)
+    ref = F.conv2d(x[rows], w, bias=b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    e = rel_err(t256[rows.to(DEV)].float().permute(0, 3, 1, 2), ref)
+    print("3x3, 256-channel tiles", case, "rel err %.3e" % e)
+    assert e < 1e-2
+    assert torch.equal(t256, t128)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, LP_DTYPE])
 @pytest.mark.parametrize("shape", [(2, 256, 128), (3, 64, 48), (1, 37, 29)])
 def test_stem(shape, dtype):
