@@ -2,13 +2,11 @@
 // :168-172), as a kernel shaped for THIS problem: few rows (M = tracklets x V = 1792 at the bench size) against a
 // 2048 x 2048 weight matrix, bf16 operands, fp32 result.
 //
-// Why not igemm_kernel: M x N / 256 CUs = 14 336 outputs per CU, so a CU owns about one 128 x 128 tile, and what bounds
-// that tile is the LDS, not the matrix pipe or the DMA (tools/stage_rate.hip: the staging path alone sustains 28-65 B/clk/CU).
-// A wave whose tile is FM x FN fragments reads FM + FN fragments (1 KiB each) from LDS per FM x FN MFMAs (16 cycles each),
-// i.e. 4 SIMDs ask for 256 (FM + FN) / (FM FN) bytes per clock of a 128 B/clk LDS: igemm_kernel's 16 x 64 wave tile (FM 1,
-// FN 4) asks for 320, its 32 x 64 one (8 waves on 128 x 128) for 192; only a 64 x 64 wave tile (FM = FN = 4) gets down to
-// 128. Four waves of 64 x 64 cover the 128 x 128 tile but leave ONE wave per SIMD, and the k loop then shows every LDS
-// round trip (measured: 43-48 us against 28-32 us for the 8-wave forms).
+// Why not igemm_kernel: M x N / 256 CUs = 14 336 outputs per CU, so a CU owns about one 128 x 128 tile. A wave whose tile is
+// FM x FN fragments reads FM + FN fragments (1 KiB each) from LDS per FM x FN MFMAs: igemm_kernel's 16 x 64 wave tile (FM 1,
+// FN 4) reads five fragments per four MFMAs, its 32 x 64 one (8 waves on 128 x 128) six per eight; a 64 x 64 wave tile
+// (FM = FN = 4) eight per sixteen. Four waves of 64 x 64 cover the 128 x 128 tile but leave ONE wave per SIMD, and the k loop
+// then shows every LDS round trip (measured: 43-48 us against 28-32 us for the 8-wave forms).
 //
 // So: 8 waves = 2 x 2 wave tiles of 64 x 64 TIMES 2 k-halves. The two waves of a SIMD (w, w + 4) own the same 64 x 64
 // outputs and split every 64-deep k-tile between them (k-step 0 / k-step 1), so the LDS is read as by four waves
@@ -17,13 +15,15 @@
 // Ring of four 32 KiB k-tiles (LDS-DMA, counted vmcnt, one raw barrier per k-tile); one workgroup per CU; every XCD owns a
 // range of N-tiles so its slice of W stays in its L2.
 //
-// Measured at 32 tracklets (1792 x 2048 x 2048, rocprofv3): 27.9 us against 31.7 us for igemm_kernel's 64 x 128 tiles. Where
-// the 27.9 go (compile-time ablations of this kernel): 5.6 us launch + first k-tiles + the exchange with a one-k-tile loop
-// and no epilogue memory; ~6 us the epilogue's 29 MB of f reads and result writes (HBM-bandwidth, not latency: requesting f
-// twelve k-tiles early made the kernel SLOWER -- loads retire in order, so the ring behind them starved for an HBM round
-// trip); ~17 us the 32 k-tiles, of which the steady-state DMA is 6.2, the fragment reads 3.7, the barrier 2.4 and the
-// MFMAs nothing -- the LDS serves ~1000 cycles of DMA writes + fragment reads per k-tile against 512 MFMA cycles per SIMD.
-// Collapsing both operands onto 128 L2-resident rows changes nothing (the operand fetch is not the limit).
+// Measured at 32 tracklets (1792 x 2048 x 2048, rocprofv3): 27.9 us against 31.7 us for igemm_kernel's 64 x 128 tiles (26.8 us
+// inside a layer). Where the time goes (compile-time ablations of this kernel): 5.6 us launch + first k-tiles + the exchange
+// with a one-k-tile loop and no epilogue memory; ~6 us the epilogue's 29 MB of f reads and result writes (HBM-bandwidth, not
+// latency: requesting f twelve k-tiles early made the kernel SLOWER -- loads retire in order, so the ring behind them starved
+// for an HBM round trip); ~17 us the 32 k-tiles, of which the steady-state DMA is 6.2, the fragment reads 3.7, the barrier
+// 2.4 and the MFMAs nothing. Collapsing both operands onto 128 L2-resident rows changes nothing (the operand fetch is not
+// the limit). Counters (profiles/r03_pmc_graph_gemm.txt): matrix pipe busy 23 % of the launch, LDS index-active 15 %, 43 % of
+// the wave cycles parked at s_waitcnt / the barrier -- a latency chain per k-tile (wait, barrier, eight reads, sixteen MFMAs)
+// that one workgroup per CU cannot hide; double-buffering the fragment registers across k-tiles did not help (29.5 us).
 #include "igemm_dev.h"
 
 namespace {
