@@ -169,12 +169,20 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
     return pooled, pooled_lp
 
 
+# (Cout, Cmid, Cnext) of the layer-3 / layer-4 seams csrc/bottleneck_seam.hip is built for (the third: layer 3 -> a layer-4 branch)
+SEAM_SHAPES = ((1024, 256, 256), (2048, 512, 512), (1024, 256, 512))
+
+
 def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
     """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 and layer-2 shapes in bf16. ``shortcut_conv`` =
     (weight, stride) of the block's downsample conv when the residual is to be computed in the same pass."""
     if (y2.dtype == LP_DTYPE and tuple(w3.shape) == (512, 1, 1, 128) and tuple(w1_next.shape) == (128, 1, 1, 512)
             and shortcut_conv is None and os.environ.get('AGRL_HIP_FUSE_TAIL_L2', '1') != '0'):
         return True  # layer-2 form (weights resident in registers)
+    if (y2.dtype == LP_DTYPE and shortcut_conv is None and os.environ.get('AGRL_HIP_FUSE_SEAM', '1') != '0'
+            and (w3.shape[0], w3.shape[3], w1_next.shape[0]) in SEAM_SHAPES and tuple(w1_next.shape[1:]) == (1, 1, w3.shape[0])
+            and (y2.numel() // y2.shape[-1]) % 128 == 0):
+        return True  # layers 3 / 4: the two GEMMs back to back over 128-pixel tiles (csrc/bottleneck_seam.hip)
     ok = (y2.dtype == LP_DTYPE and tuple(w3.shape) == (256, 1, 1, 64)
           and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)))
     if shortcut_conv is not None:

@@ -242,6 +242,47 @@ def test_bottleneck_tail_layer2(shape):
     assert torch.equal(out, out2) and torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("frames", [1, 3, 40])
+@pytest.mark.parametrize("dims", [(256, 1024, 256), (512, 2048, 512), (256, 1024, 512)])
+def test_bottleneck_seam(dims, frames, monkeypatch):
+    """conv3 + residual + relu of a layer-3 / layer-4 block back to back with the next block's conv1 (bottleneck_seam.hip:
+    128-pixel tiles, 256-channel chunks, the chunk handed over through LDS) against the fp32 reference and against the two
+    separate launches. Not bitwise: a chunk's accumulators start as the residual, so the fp32 summation order differs from
+    (acc + bias) + residual -- the 16-bit outputs may differ by one rounding. 40 frames = 40 tiles (every k-tile / unit slot
+    and the chunk loop at its real trip count), 1 frame a single workgroup."""
+    from torchreid import hip_ops as ops
+    cmid, cout, cnext = dims
+    H, W = 16, 8
+    g = torch.Generator().manual_seed(frames * cmid + cnext)
+    y2 = torch.randn((frames, cmid, H, W), generator=g).to(LP_DTYPE).float()
+    res = torch.randn((frames, cout, H, W), generator=g).to(LP_DTYPE).float()
+    w3 = (torch.randn((cout, cmid, 1, 1), generator=g) / np.sqrt(cmid)).to(LP_DTYPE).float()
+    w1 = (torch.randn((cnext, cout, 1, 1), generator=g) / np.sqrt(cout)).to(LP_DTYPE).float()
+    b3, b1 = torch.randn(cout, generator=g), torch.randn(cnext, generator=g)
+    out_ref = F.relu(F.conv2d(y2, w3, bias=b3) + res)
+    z_ref = F.relu(F.conv2d(out_ref.to(LP_DTYPE).float(), w1, bias=b1))
+    dy2, dres = nhwc(y2, LP_DTYPE), nhwc(res, LP_DTYPE)
+    dw3 = w3.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    dw1 = w1.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    assert ops.bottleneck_tail_supported(dy2, dw3, dw1)
+    out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
+    out_b, z_b = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))   # repeatable bit for bit
+    out2 = ops.conv_bn_act(dy2, dw3, b3.to(DEV), 1, 0, True, residual=dres)
+    z2 = ops.conv_bn_act(out2, dw1, b1.to(DEV), 1, 0, True)
+    torch.cuda.synchronize()
+    e1, e2 = rel_err(out.float().permute(0, 3, 1, 2), out_ref), rel_err(z.float().permute(0, 3, 1, 2), z_ref)
+    d1 = (out.float() - out2.float()).abs().max().item() / out2.float().abs().max().item()
+    d2 = (z.float() - z2.float()).abs().max().item() / z2.float().abs().max().item()
+    print("bottleneck seam", dims, frames, "out %.3e z %.3e | vs two launches out %.3e z %.3e" % (e1, e2, d1, d2))
+    tol = 3e-3 if LP_DTYPE == torch.float16 else 2e-2
+    assert e1 < tol and e2 < tol
+    assert d1 < tol and d2 < tol
+    assert torch.equal(out, out_b) and torch.equal(z, z_b)
+    # a frame count that is not a whole number of 128-pixel tiles is not taken (10 x 6 frames): the caller runs the two convs
+    odd = torch.zeros((1, 10, 6, cmid), dtype=LP_DTYPE, device=DEV)
+    assert not ops.bottleneck_tail_supported(odd, dw3, dw1)
+
+
 @pytest.mark.parametrize("tile", ["2", "3"])
 @pytest.mark.parametrize("case", [(3, 16, 8, 256, 512), (2, 32, 16, 512, 256), (1, 10, 6, 128, 256)])
 def test_conv_wide_tile_strided(case, tile, monkeypatch):
