@@ -40,6 +40,12 @@ struct SeamParams {
     int M;
 };
 
+// Ablation bits for profiling builds (-DSEAM_ABL=n through tools/seam_ablate.sh; wrong results by design, never in the shipped
+// library): 1 no residual loads / out stores, 2 no GEMM 1 MFMAs, 4 no GEMM 2 MFMAs, 8 no DMA, 16 no fragment reads, 32 no barriers,
+// 64 weight pieces from contiguous addresses, 128 pixel pieces from contiguous addresses (is the row stride what the DMA waits for?)
+#ifndef SEAM_ABL
+#define SEAM_ABL 0
+#endif
 constexpr int SBM = 128;          // pixels per tile
 constexpr int SCH = 256;          // conv3 output channels per chunk
 constexpr int RA = 0, RB = 48 * 1024, XO = 96 * 1024;
@@ -69,7 +75,13 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) unsigned char lds_u8_t;      // every LDS access through 32-bit address-space-3 pointers:
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;         // generic pointers cost a 64-bit add + null check per address
 typedef __attribute__((address_space(3))) f32x4_t lds_f32x4_t;
-__device__ __forceinline__ u32x4_t lds_ld16(const lds_u8_t* p) { return *reinterpret_cast<const lds_u32x4_t*>(p); }
+__device__ __forceinline__ u32x4_t lds_ld16(const lds_u8_t* p) {
+#if defined(SEAM_ABL) && (SEAM_ABL & 16)
+    return u32x4_t{(unsigned)(size_t)p, 1u, 2u, 3u};
+#else
+    return *reinterpret_cast<const lds_u32x4_t*>(p);
+#endif
+}
 template <int IMM>
 __device__ __forceinline__ void gload16_asm(u32x4_t& dst, unsigned off, const unsigned char* base) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(off), "s"(base), "n"(IMM) : "memory");
@@ -82,6 +94,7 @@ __device__ __forceinline__ void fence16(u32x4_t& v) { asm volatile("" : "+v"(v))
 // the global AND the LDS address.
 template <int LDS_IMM>
 __device__ __forceinline__ void dma16s(const unsigned char* sbase, unsigned voff, unsigned lds_wave_base) {
+    if constexpr (SEAM_ABL & 8) return;
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -164,12 +177,18 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
     const unsigned ldsC = __builtin_amdgcn_readfirstlane(lds0 + BIAS_OFF + wave * 1024);
     auto issue_k = [&](auto slot_c, const unsigned char* w3c, auto t_c, auto i_c) {
         constexpr int SLOT = decltype(slot_c)::value, T = decltype(t_c)::value, I = decltype(i_c)::value;
-        if constexpr (I < 2) dma16s<SLOT + I * 1024>(p.y2 + T * 128, a_off[I], ldsA);
-        else dma16s<SLOT + KT_Y + (I - 2) * 1024>(w3c + (4 * ((I - 2) >> 1) * (K1 * 2) + T * 128), b_off[(I - 2) & 1], ldsB);
+        if constexpr (I < 2) {
+            if constexpr (SEAM_ABL & 128) dma16s<SLOT + I * 1024>(p.y2 + (size_t)m0 * (K1 * 2) + (T * 16 + I) * 1024 + wave * 2048, (unsigned)lane * 16u, ldsA);
+            else dma16s<SLOT + I * 1024>(p.y2 + T * 128, a_off[I], ldsA);
+        } else {
+            if constexpr (SEAM_ABL & 64) dma16s<SLOT + KT_Y + (I - 2) * 1024>(w3c + (T * 32 + (I - 2)) * 1024 + wave * 4096, (unsigned)lane * 16u, ldsB);
+            else dma16s<SLOT + KT_Y + (I - 2) * 1024>(w3c + (4 * ((I - 2) >> 1) * (K1 * 2) + T * 128), b_off[(I - 2) & 1], ldsB);
+        }
     };
     auto issue_u = [&](auto third_c, const unsigned char* w1c, auto u_c, auto i_c) {
         constexpr int THIRD = decltype(third_c)::value, U = decltype(u_c)::value, I = decltype(i_c)::value;
-        if constexpr (WIDE2) dma16s<THIRD * 32768 + I * 1024>(w1c + ((32 * (I >> 1) + 4 * (I & 1)) * (N1 * 2) + U * 64), d_off[0], ldsB);
+        if constexpr (SEAM_ABL & 64) dma16s<THIRD * 32768 + I * 1024>(w1c + (U * 32 + I) * 1024 + wave * 4096, (unsigned)lane * 16u, ldsB);
+        else if constexpr (WIDE2) dma16s<THIRD * 32768 + I * 1024>(w1c + ((32 * (I >> 1) + 4 * (I & 1)) * (N1 * 2) + U * 64), d_off[0], ldsB);
         else dma16s<THIRD * 32768 + I * 1024>(w1c + (4 * (I >> 1) * (N1 * 2) + U * 128), d_off[I & 1], ldsB);
     };
     auto issue_bias = [&](int c) {
@@ -186,10 +205,12 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
         for (int b = 0; b < 4; ++b) acc2[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     u32x4_t rres[4][2];
+    constexpr int S_OPS = (SEAM_ABL & 1) ? 0 : 16;  // the epilogue's 8 stores + 8 residual loads per lane
     auto load_residual = [&](int c) {  // one lane offset; fragment / chunk offsets on the scalar side, the channel half as immediate
         const unsigned char* rc = p.res + (size_t)c * (SCH * 2);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
+            if constexpr (SEAM_ABL & 1) { rres[b][0] = u32x4_t{(unsigned)c, r_off, 1u, 2u}; rres[b][1] = rres[b][0]; continue; }
             gload16_asm<0>(rres[b][0], r_off, rc + b * (16 * N1 * 2));
             gload16_asm<64>(rres[b][1], r_off, rc + b * (16 * N1 * 2));
         }
@@ -239,7 +260,8 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
             issue_for_group(gc, np_c, issue);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                acc1[g & 3][b] = mfma_lp16_16x16x32(wfr[g % WR], xfr[TIGHT ? 0 : g >> 2][b], acc1[g & 3][b]);
+                if constexpr (SEAM_ABL & 2) asm volatile("" ::"v"(wfr[g % WR]), "v"(xfr[TIGHT ? 0 : g >> 2][b]));
+                else acc1[g & 3][b] = mfma_lp16_16x16x32(wfr[g % WR], xfr[TIGHT ? 0 : g >> 2][b], acc1[g & 3][b]);
                 if constexpr (TIGHT && g == 3) {
                     __builtin_amdgcn_sched_barrier(0);
                     xfr[0][b] = ldx(1, b);
@@ -267,7 +289,10 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
                 if constexpr (g + 2 < 8) wfr[(g + 2) % 3] = lds_ld16(sb + (g + 2) * 1024);
                 issue_for_group(gc, np_c, issue);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc2[g][b] = mfma_lp16_16x16x32(wfr[g % 3], xfr[b], acc2[g][b]);
+                for (int b = 0; b < 4; ++b) {
+                    if constexpr (SEAM_ABL & 4) asm volatile("" ::"v"(wfr[g % 3]), "v"(xfr[b]));
+                    else acc2[g][b] = mfma_lp16_16x16x32(wfr[g % 3], xfr[b], acc2[g][b]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         } else {
@@ -287,15 +312,18 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
                 if constexpr (g < 4) xfr[1][g] = ldx(1, g);
                 issue_for_group(gc, np_c, issue);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc2[g & 3][b] = mfma_lp16_16x16x32(wfr[g % 3], xfr[g >> 2][b], acc2[g & 3][b]);
+                for (int b = 0; b < 4; ++b) {
+                    if constexpr (SEAM_ABL & 4) asm volatile("" ::"v"(wfr[g % 3]), "v"(xfr[g >> 2][b]));
+                    else acc2[g & 3][b] = mfma_lp16_16x16x32(wfr[g % 3], xfr[g >> 2][b], acc2[g & 3][b]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
     };
 
     auto step_sync = [&](auto allowed_c) {  // the awaited pieces of THIS wave have landed; the barrier covers everybody else's
-        wait_vmcnt<decltype(allowed_c)::value>();
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(SEAM_ABL & 8)) wait_vmcnt<decltype(allowed_c)::value>();
+        if constexpr (!(SEAM_ABL & 32)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
     using std::integral_constant;
@@ -375,7 +403,7 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
                     v[4 + e] = relu_nan(acc1[2 * j + 1][b][e] + bias[j][4 + e]);
                 }
                 const u32x4_t pk = {pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7])};
-                *reinterpret_cast<u32x4_t*>(oc + b * (16 * N1 * 2) + j * 64 + r_off) = pk;
+                if (!(SEAM_ABL & 1) || pk[0] == 0x12345678u) *reinterpret_cast<u32x4_t*>(oc + b * (16 * N1 * 2) + j * 64 + r_off) = pk;
                 *reinterpret_cast<lds_u32x4_t*>(smem + XO + ((((2 * wn + j) * 2 + wm) * 4 + b) * 1024) + xrd) = pk;
             }
         // the last chunk requests chunk 0's residual and first k-tiles again (never used, drained at the end): the code stays
@@ -393,7 +421,7 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
             // younger than unit U: the later units requested so far and the epilogue's 8 stores (+ 8 residual loads)
             constexpr int AFTER = U == 0 ? 2 * P2 : (U == 1 ? P2 : (U + 1 < NU ? P2 : 0));
             constexpr bool WITH_S = U <= 2;
-            step_sync(integral_constant<int, AFTER + (WITH_S ? 16 : 0)>{});
+            step_sync(integral_constant<int, AFTER + (WITH_S ? S_OPS : 0)>{});
             if constexpr (U + 1 == NU) {
                 // RB and the consumed front of X are free: the next chunk's first k-tile(s)
                 constexpr int NP = EARLY1 ? 2 * P1 : P1;
