@@ -609,13 +609,6 @@ extern "C" int agrl_bottleneck_tail(const void* y2, const void* w3, const float*
                    "agrl_bottleneck_tail: pass either the residual map or the downsample conv's input, not both");
     AGRL_CHECK_ARG(!x_short || (w_short && b_short), "agrl_bottleneck_tail: the downsample form needs its weights and bias");
     AGRL_CHECK_ARG(M > 0, "agrl_bottleneck_tail: empty problem");
-    if (Cmid >= 256) {  // layers 3 / 4: the two GEMMs back to back over 128-pixel tiles (bottleneck_seam.hip), identity shortcut only
-        AGRL_CHECK_ARG(!x_short, "agrl_bottleneck_tail: the layer-3/4 form takes the residual map, not a downsample conv");
-        const uintptr_t al2 = (uintptr_t)y2 | (uintptr_t)w3 | (uintptr_t)b3 | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)w1_next |
-                              (uintptr_t)b1_next | (uintptr_t)z;
-        AGRL_CHECK_ARG((al2 & 15) == 0, "agrl_bottleneck_tail: pointers must be 16-byte aligned");
-        return launch_bottleneck_seam(y2, w3, b3, residual, out, w1_next, b1_next, z, M, Cmid, Cout, Cnext, (hipStream_t)stream);
-    }
     const bool layer2 = Cmid == L2K1 && Cout == L2N1 && Cnext == L2N2 && !x_short;
     AGRL_CHECK_ARG(layer2 || (Cmid == TK1 && Cout == TN1 && (Cnext == TN2 || (Cnext == 128 && !x_short)) && (!x_short || Cshort == TK1)),
                    "agrl_bottleneck_tail: built for Cmid=64, Cout=256, Cnext=64 (128 without downsample), Cshort=64 "

@@ -180,7 +180,3 @@ int launch_graph_gemm(const void* p_op, const void* w, const float* f, const flo
 int launch_conv3x3_wide(const IgemmParams& p, hipStream_t stream);
 int launch_conv3x3_c64(const IgemmParams& p, hipStream_t stream);
 
-// conv3 + residual -> next conv1 back to back for the layer-3 / layer-4 shapes (bottleneck_seam.hip; entry point agrl_bottleneck_tail)
-bool bottleneck_seam_applicable(int M, int Cmid, int Cout, int Cnext);
-int launch_bottleneck_seam(const void* y2, const void* w3, const float* b3, const void* residual, void* out, const void* w1_next,
-                           const float* b1_next, void* z, int M, int Cmid, int Cout, int Cnext, hipStream_t stream);

@@ -169,8 +169,50 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
     return pooled, pooled_lp
 
 
-# (Cout, Cmid, Cnext) of the layer-3 / layer-4 seams csrc/bottleneck_seam.hip is built for (the third: layer 3 -> a layer-4 branch)
-SEAM_SHAPES = ((1024, 256, 256), (2048, 512, 512), (1024, 256, 512))
+# (Cmid, Cout, Cnext) of the layer-3 / layer-4 seams csrc/bottleneck_seam.hip is built for (the third: layer 3 -> a layer-4 branch)
+SEAM_SHAPES = ((256, 1024, 256), (512, 2048, 512), (256, 1024, 512))
+
+
+def bottleneck_seam_supported(w3, w1_next, pixels=None):
+    """conv3 + residual -> next conv1 back to back (agrl_bottleneck_seam): 16-bit weights of a layer-3 / layer-4 seam, and --
+    when ``pixels`` is given -- a pixel count made of whole 128-pixel tiles (16 x 8 frames)."""
+    return (w3.dtype == LP_DTYPE and w1_next.dtype == LP_DTYPE and w3.dim() == 4 and tuple(w3.shape[1:3]) == (1, 1)
+            and (w3.shape[3], w3.shape[0], w1_next.shape[0]) in SEAM_SHAPES and tuple(w1_next.shape[1:]) == (1, 1, w3.shape[0])
+            and (pixels is None or pixels % 128 == 0) and os.environ.get('AGRL_HIP_FUSE_SEAM', '1') != '0')
+
+
+def bottleneck_seam_pack(w3, w1_next):
+    """The two (static) weight matrices of a seam re-ordered once into the per-wave MFMA fragment streams the kernel loads
+    straight into registers -> one uint8 tensor of agrl_bottleneck_seam_packed_bytes bytes."""
+    assert bottleneck_seam_supported(w3, w1_next)
+    Cout, Cmid, Cnext = w3.shape[0], w3.shape[3], w1_next.shape[0]
+    w3, w1_next = w3.contiguous(), w1_next.contiguous()
+    nbytes = int(_hip.lib().agrl_bottleneck_seam_packed_bytes(Cmid, Cout, Cnext))
+    assert nbytes == 2 * (w3.numel() + w1_next.numel())
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w3.device)
+    with _dev(w3):
+        call("agrl_bottleneck_seam_pack", ptr(w3), ptr(w1_next), ptr(packed), Cmid, Cout, Cnext, _stream(w3))
+    return packed
+
+
+def bottleneck_seam(y2, packed, b3, residual, b1_next, dims):
+    """out = relu(conv3(y2) + residual), z = relu(conv1_next(out)) in one pass over 128-pixel tiles; ``packed`` from
+    bottleneck_seam_pack, ``dims`` = (Cmid, Cout, Cnext). vmgn.py:56-64 (block i) + :48-50 (block i+1).
+    -> out (N,H,W,Cout), z (N,H,W,Cnext) 16-bit NHWC."""
+    Cmid, Cout, Cnext = dims
+    N, H, W, C = y2.shape
+    M = N * H * W
+    assert y2.dtype == LP_DTYPE and C == Cmid and residual.shape == (N, H, W, Cout) and residual.dtype == y2.dtype and M % 128 == 0
+    assert y2.is_contiguous() and residual.is_contiguous()
+    out = torch.empty((N, H, W, Cout), dtype=y2.dtype, device=y2.device)
+    z = torch.empty((N, H, W, Cnext), dtype=y2.dtype, device=y2.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * (Cmid * Cout + Cout * Cnext),
+                            "bytes": 2.0 * (y2.numel() + residual.numel() + out.numel() + z.numel()) + packed.numel()}
+    with _dev(y2):
+        call("agrl_bottleneck_seam", ptr(y2), ptr(packed), ptr(b3), ptr(residual), ptr(out), ptr(b1_next), ptr(z), M, Cmid, Cout,
+             Cnext, _stream(y2))
+    return out, z
 
 
 def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
@@ -179,10 +221,6 @@ def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
     if (y2.dtype == LP_DTYPE and tuple(w3.shape) == (512, 1, 1, 128) and tuple(w1_next.shape) == (128, 1, 1, 512)
             and shortcut_conv is None and os.environ.get('AGRL_HIP_FUSE_TAIL_L2', '1') != '0'):
         return True  # layer-2 form (weights resident in registers)
-    if (y2.dtype == LP_DTYPE and shortcut_conv is None and os.environ.get('AGRL_HIP_FUSE_SEAM', '1') != '0'
-            and (w3.shape[0], w3.shape[3], w1_next.shape[0]) in SEAM_SHAPES and tuple(w1_next.shape[1:]) == (1, 1, w3.shape[0])
-            and (y2.numel() // y2.shape[-1]) % 128 == 0):
-        return True  # layers 3 / 4: the two GEMMs back to back over 128-pixel tiles (csrc/bottleneck_seam.hip)
     ok = (y2.dtype == LP_DTYPE and tuple(w3.shape) == (256, 1, 1, 64)
           and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)))
     if shortcut_conv is not None:

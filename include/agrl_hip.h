@@ -120,6 +120,22 @@ int agrl_bottleneck_tail(const void* y2, const void* w3, const float* b3, const 
                          const void* w1_next, const float* b1_next, void* z, int M, int Cmid, int Cout,
                          int Cnext, int Cshort, agrl_stream_t stream);
 
+/* The seam between two Bottlenecks of layers 3 / 4, back to back in one kernel (16-bit build type only;
+ * torchreid/models/vmgn.py:56-64 of block i + :48-50 of block i + 1):
+ *   out (M,Cout)  = relu(y2 (M,Cmid) @ w3 (Cout,Cmid)^T + b3 + residual (M,Cout))
+ *   z   (M,Cnext) = relu(out @ w1_next (Cnext,Cout)^T + b1_next)
+ * out is written once (it is the next block's residual) and never read back. The two weight matrices are static, so they are
+ * first re-ordered ONCE into the fragment streams the kernel's waves consume (agrl_bottleneck_seam_pack; `packed` holds
+ * agrl_bottleneck_seam_packed_bytes(...) = 2 (Cout Cmid + Cnext Cout) bytes) -- the kernel then streams them global -> registers,
+ * perfectly coalesced, with no LDS staging. Built for Cmid/Cout/Cnext = 256/1024/256 (layer 3), 512/2048/512 (layer 4) and
+ * 256/1024/512 (layer 3 -> one layer-4 branch); M must be a multiple of 128 (whole 16 x 8 frames). Other shapes are rejected
+ * (the caller then runs the two convs through agrl_conv2d_bn_act). */
+long long agrl_bottleneck_seam_packed_bytes(int Cmid, int Cout, int Cnext);
+int agrl_bottleneck_seam_pack(const void* w3, const void* w1_next, void* packed, int Cmid, int Cout, int Cnext,
+                              agrl_stream_t stream);
+int agrl_bottleneck_seam(const void* y2, const void* packed, const float* b3, const void* residual, void* out,
+                         const float* b1_next, void* z, int M, int Cmid, int Cout, int Cnext, agrl_stream_t stream);
+
 /* Whole body of a layer-1 Bottleneck behind its first conv, fused with the head of the next block (bf16 only;
  * torchreid/models/vmgn.py:45-65: conv2/bn2/relu :52-54, conv3/bn3/+residual/relu :56-64 of block i, conv1/bn1/relu
  * :48-50 of block i+1):

@@ -244,12 +244,12 @@ def test_bottleneck_tail_layer2(shape):
 
 @pytest.mark.parametrize("frames", [1, 3, 40])
 @pytest.mark.parametrize("dims", [(256, 1024, 256), (512, 2048, 512), (256, 1024, 512)])
-def test_bottleneck_seam(dims, frames, monkeypatch):
+def test_bottleneck_seam(dims, frames):
     """conv3 + residual + relu of a layer-3 / layer-4 block back to back with the next block's conv1 (bottleneck_seam.hip:
-    128-pixel tiles, 256-channel chunks, the chunk handed over through LDS) against the fp32 reference and against the two
-    separate launches. Not bitwise: a chunk's accumulators start as the residual, so the fp32 summation order differs from
-    (acc + bias) + residual -- the 16-bit outputs may differ by one rounding. 40 frames = 40 tiles (every k-tile / unit slot
-    and the chunk loop at its real trip count), 1 frame a single workgroup."""
+    128-pixel tiles, 256-channel chunks handed over through LDS, the pre-packed weights streamed into register rings) against
+    the fp32 reference and against the two separate launches. Not bitwise: a chunk's accumulators start as residual + bias, so
+    the fp32 summation order differs from (acc + bias) + residual -- the 16-bit outputs may differ by one rounding. 40 frames =
+    40 tiles, 1 frame a single workgroup; every call twice (bit-for-bit repeatable: no race between the rings' counted waits)."""
     from torchreid import hip_ops as ops
     cmid, cout, cnext = dims
     H, W = 16, 8
@@ -264,9 +264,10 @@ def test_bottleneck_seam(dims, frames, monkeypatch):
     dy2, dres = nhwc(y2, LP_DTYPE), nhwc(res, LP_DTYPE)
     dw3 = w3.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
     dw1 = w1.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
-    assert ops.bottleneck_tail_supported(dy2, dw3, dw1)
-    out, z = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))
-    out_b, z_b = ops.bottleneck_tail(dy2, dw3, b3.to(DEV), dres, dw1, b1.to(DEV))   # repeatable bit for bit
+    assert ops.bottleneck_seam_supported(dw3, dw1, frames * H * W)
+    packed = ops.bottleneck_seam_pack(dw3, dw1)
+    out, z = ops.bottleneck_seam(dy2, packed, b3.to(DEV), dres, b1.to(DEV), dims)
+    out_b, z_b = ops.bottleneck_seam(dy2, packed, b3.to(DEV), dres, b1.to(DEV), dims)
     out2 = ops.conv_bn_act(dy2, dw3, b3.to(DEV), 1, 0, True, residual=dres)
     z2 = ops.conv_bn_act(out2, dw1, b1.to(DEV), 1, 0, True)
     torch.cuda.synchronize()
@@ -278,9 +279,11 @@ def test_bottleneck_seam(dims, frames, monkeypatch):
     assert e1 < tol and e2 < tol
     assert d1 < tol and d2 < tol
     assert torch.equal(out, out_b) and torch.equal(z, z_b)
-    # a frame count that is not a whole number of 128-pixel tiles is not taken (10 x 6 frames): the caller runs the two convs
-    odd = torch.zeros((1, 10, 6, cmid), dtype=LP_DTYPE, device=DEV)
-    assert not ops.bottleneck_tail_supported(odd, dw3, dw1)
+    # a pixel count that is not a whole number of 128-pixel tiles is not taken (10 x 6 frames): the caller runs the two convs
+    assert not ops.bottleneck_seam_supported(dw3, dw1, 60)
+    with pytest.raises(_hip.HipKernelError):
+        ops.call("agrl_bottleneck_seam", ops.ptr(dy2), ops.ptr(packed), ops.ptr(b3.to(DEV)), ops.ptr(dres), ops.ptr(out), ops.ptr(b1.to(DEV)),
+                 ops.ptr(z), 60, cmid, cout, cnext, None)
 
 
 @pytest.mark.parametrize("tile", ["2", "3"])

@@ -30,8 +30,10 @@ for cmid, cout, cnext in ((256, 1024, 256), (512, 2048, 512), (256, 1024, 512)):
     w1 = (torch.randn((cnext, 1, 1, cout), device=dev) / cout ** 0.5).to(LP_DTYPE)
     b3, b1 = torch.randn((cout,), device=dev), torch.randn((cnext,), device=dev)
 
+    packed = ops.bottleneck_seam_pack(w3, w1)
+
     def fused():
-        return ops.bottleneck_tail(y2, w3, b3, res, w1, b1)
+        return ops.bottleneck_seam(y2, packed, b3, res, b1, (cmid, cout, cnext))
 
     def split():
         o = ops.conv_bn_act(y2, w3, b3, 1, 0, True, residual=res)
