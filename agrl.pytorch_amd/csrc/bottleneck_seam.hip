@@ -80,11 +80,56 @@ __device__ __forceinline__ void gload16_asm(u32x4_t& dst, unsigned off, const un
     static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(off), "s"(base), "n"(IMM) : "memory");
 }
-// counted wait tied to the registers it guards: their consumers (register-only MFMAs) cannot be scheduled above it
-template <int N>
-__device__ __forceinline__ void wait_for(u32x4_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
-template <int N>
-__device__ __forceinline__ void wait_for(u32x4_t& a, u32x4_t& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+// Register files by hand. One wave per SIMD owns 512 registers: 256 architectural VGPRs + 256 accumulation registers (AGPRs).
+// The AGPRs are asm-owned for the whole kernel, NAMED in the asm text and invisible to hipcc:
+//   a[0 : 4 RING)            the weight-fragment ring -- global_load straight into AGPRs, read by the MFMAs as their A operand.
+//                            hipcc never sees a register with a load in flight (given the chance it "spills" such registers
+//                            while the data is still on its way: silent garbage);
+//   a[4 RING : ...)          GEMM 2's accumulators (N2 / 4 channels x 128 pixels per wave), as many quads as fit; with N2 = 512
+//                            the last few live in VGPRs as ordinary operands.
+// hipcc itself never allocates an AGPR (every MFMA is asm) unless it spills VGPRs into them -- which the register budget excludes
+// and tools/seam_check_isa.sh checks on every build (no v_accvgpr_* outside the asm blocks, no scratch). Everything the VALU
+// touches (GEMM 1's accumulators start as the residual and end in the epilogue) lives in VGPRs. Left to hipcc, which picks ONE
+// register file for all MFMA accumulators of a function, the 384 accumulator registers of the layer-4 shape end in scratch.
+// hipcc pads no hazards around these statements: consecutive MFMAs here never share an accumulator (eight apart), A / B
+// operands come from loads behind counted waits, and the VALU touches accumulators only behind explicit s_nops.
+template <int RQ>  // acc (VGPRs) += ring quad RQ x b
+__device__ __forceinline__ void mfma_v(f32x4_t& acc, const u32x4_t& b) {
+    if constexpr (kLpF16) asm volatile("v_mfma_f32_16x16x32_f16 %0, a[%c2:%c3], %1, %0" : "+v"(acc) : "v"(b), "n"(4 * RQ), "n"(4 * RQ + 3));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, a[%c2:%c3], %1, %0" : "+v"(acc) : "v"(b), "n"(4 * RQ), "n"(4 * RQ + 3));
+}
+template <int AQ, int RQ>  // AGPR quad AQ += ring quad RQ x b
+__device__ __forceinline__ void mfma_a(const u32x4_t& b) {
+    if constexpr (kLpF16)
+        asm volatile("v_mfma_f32_16x16x32_f16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" ::"v"(b), "n"(4 * AQ), "n"(4 * AQ + 3), "n"(4 * RQ), "n"(4 * RQ + 3));
+    else
+        asm volatile("v_mfma_f32_16x16x32_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" ::"v"(b), "n"(4 * AQ), "n"(4 * AQ + 3), "n"(4 * RQ), "n"(4 * RQ + 3));
+}
+template <int AQ>
+__device__ __forceinline__ void acc_zero() {
+    asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0" ::"n"(4 * AQ),
+                 "n"(4 * AQ + 1), "n"(4 * AQ + 2), "n"(4 * AQ + 3));
+}
+template <int AQ>
+__device__ __forceinline__ f32x4_t acc_read() {
+    float x, y, z, w;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(x), "=v"(y), "=v"(z), "=v"(w)
+                 : "n"(4 * AQ), "n"(4 * AQ + 1), "n"(4 * AQ + 2), "n"(4 * AQ + 3));
+    return f32x4_t{x, y, z, w};
+}
+// 16 bytes per lane VGPRs -> global, same addressing (hipcc's own stores take a 64-bit address pair each: 16 VGPRs in the epilogue)
+template <int IMM>
+__device__ __forceinline__ void gstore16_asm(const u32x4_t& v, unsigned off, unsigned char* base) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base), "n"(IMM) : "memory");
+}
+// 16 bytes per lane global -> ring quad RQ: SGPR base + 32-bit lane offset + immediate
+template <int RQ, int IMM>
+__device__ __forceinline__ void ring_load(unsigned off, const unsigned char* base) {
+    static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
+    asm volatile("global_load_dwordx4 a[%c2:%c3], %0, %1 offset:%4" ::"v"(off), "s"(base), "n"(4 * RQ), "n"(4 * RQ + 3), "n"(IMM) : "memory");
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // LDS-DMA with the source as SGPR base + 32-bit lane offset and the destination as SGPR base (the instruction's own offset
 // field is NOT used: it is added to the global AND the LDS address)
@@ -100,13 +145,15 @@ __device__ __forceinline__ void dma16s(const unsigned char* sbase, unsigned voff
 // ---- the vmcnt budget of every weight-fragment wait, from a simulation of the issue order over three consecutive chunks (the
 // middle one is the steady state every chunk sees: the prologue issues what a previous chunk's tail would have).
 //   allowed = operations issued AFTER the awaited fragment's load and before the wait.
+constexpr int NWV = 4;     // waves per workgroup: one per SIMD, 512 registers each
+constexpr int FW1 = 4;     // GEMM 1 channel fragments per wave: 64 of the chunk's 256 channels
+constexpr int Y2P = 4;     // LDS-DMA pieces per wave and y2 k-tile (16 KB / 4 waves)
+constexpr int S_OPS = (SEAM_ABL & 1) ? 0 : 32;  // per chunk epilogue: 16 out stores + 16 residual loads per lane
 template <int KS1, int FW2, bool Y2RING, int RING>
 struct Sched {
-    static constexpr int G1F = 2 * KS1, G2F = 8 * FW2, FPC = G1F + G2F;
-    int g1[KS1];   // wait in front of GEMM 1 k-step ks (both fragments)
-    int g2[G2F];   // wait in front of GEMM 2 fragment f
+    static constexpr int G1F = FW1 * KS1, G2F = 8 * FW2, FPC = G1F + G2F;
+    int allowed[FPC];
 };
-constexpr int S_OPS = (SEAM_ABL & 1) ? 0 : 16;  // per chunk epilogue: 8 out stores + 8 residual loads per lane
 template <int KS1, int FW2, bool Y2RING, int RING>
 constexpr Sched<KS1, FW2, Y2RING, RING> make_sched() {
     using S = Sched<KS1, FW2, Y2RING, RING>;
@@ -115,18 +162,11 @@ constexpr Sched<KS1, FW2, Y2RING, RING> make_sched() {
     int seq = 0;
     for (int p = 0; p < RING; ++p) issued[0][p] = seq++;
     for (int k = 0; k < 3; ++k) {
-        for (int ks = 0; ks < KS1; ++ks) {
-            if (k == 1) s.g1[ks] = seq - 1 - issued[k][2 * ks + 1];
-            if (Y2RING && (ks & 1) == 0) seq += 2;  // the y2 k-tile three tiles ahead: 2 DMA pieces, right behind the wait + barrier
-            for (int q = 2 * ks + RING; q < 2 * ks + 2 + RING; ++q) {
-                if (q >= S::FPC) issued[k + 1][q - S::FPC] = seq++;
-                else issued[k][q] = seq++;
-            }
-        }
-        seq += S_OPS;
-        for (int f = 0; f < S::G2F; ++f) {
-            const int p = S::G1F + f;
-            if (k == 1) s.g2[f] = seq - 1 - issued[k][p];
+        for (int p = 0; p < S::FPC; ++p) {
+            if (p == S::G1F) seq += S_OPS;  // the chunk epilogue sits between the two GEMMs
+            if (k == 1) s.allowed[p] = seq - 1 - issued[k][p];
+            // the y2 ring's barrier + the k-tile AHEAD tiles down the stream: in front of the last fragment of every odd k-step
+            if (Y2RING && p < S::G1F && (p % FW1) == FW1 - 1 && ((p / FW1) & 1)) seq += Y2P;
             const int q = p + RING;
             if (q >= S::FPC) issued[k + 1][q - S::FPC] = seq++;
             else issued[k][q] = seq++;
@@ -134,38 +174,31 @@ constexpr Sched<KS1, FW2, Y2RING, RING> make_sched() {
     }
     return s;
 }
-
 template <int KS1, int FW2, bool Y2RING, int RING>
 struct SchedOf {
     static constexpr Sched<KS1, FW2, Y2RING, RING> value = make_sched<KS1, FW2, Y2RING, RING>();
 };
 
 template <int K1, int N1, int N2>
-__global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p) {
+__global__ __launch_bounds__(NWV * 64) void bottleneck_seam_kernel(const SeamParams p) {
     static_assert((K1 == 256 || K1 == 512) && N1 % SCH == 0 && (N2 == 256 || N2 == 512), "shapes");
     constexpr int NC = N1 / SCH;            // chunks
     constexpr int KS1 = K1 / 32;            // GEMM 1 k-steps per chunk
-    constexpr int FW2 = N2 / 128;           // GEMM 2 channel fragments per wave (2 / 4): N2 / 8 channels
+    constexpr int FW2 = N2 / 64;            // GEMM 2 channel fragments per wave (4 / 8): N2 / 4 channels
     constexpr bool Y2RING = K1 > 256;       // the y2 tile does not fit beside X: 16-KB k-tiles through five slots, three ahead
     constexpr int NKT = K1 / 64;            // y2 k-tiles
     constexpr int NSL = 5, AHEAD = 3;       // slots of the y2 ring, k-tiles requested ahead
     constexpr int XO = Y2RING ? NSL * 16384 : 64 * 1024;
     constexpr int BIAS_OFF = XO + 64 * 1024;  // b3 (N1 floats), resident
-    // With both accumulator sets at their largest (K1 = N2 = 512) hipcc is one register quad short during GEMM 1 and spills a
-    // GEMM 2 accumulator to scratch -- whose reload waits vmcnt(0) and drains the weight ring once per chunk. The last PARK pixel
-    // fragments' accumulators of the last channel fragment are therefore parked in LDS (8 KB each, a lane's own 16 bytes) across
-    // GEMM 1: an LDS round trip per chunk, counted on lgkmcnt.
-    constexpr int PARK = (K1 == 512 && N2 == 512) ? 1 : 0;
-    constexpr int PARK_OFF = BIAS_OFF + N1 * 4;
-    constexpr int FPC = 2 * KS1 + 8 * FW2;  // weight fragments per chunk and wave
-    // weight fragments in flight per wave: 16 where the accumulators leave room (N2 = 256), else 8. The ring is what keeps a wave
-    // fed while the chunk's HBM accesses (residual in, out) sit in front of its younger fragment loads in the in-order return queue
+    // weight fragments in flight per wave (ring quads a[0 : 4 RING)): 16, or 8 where GEMM 2's accumulators need the AGPRs
     constexpr int RING = N2 == 256 ? 16 : 8;
+    constexpr int NA2 = (64 - RING) < FW2 * 8 ? (64 - RING) : FW2 * 8;  // GEMM 2 accumulator quads in AGPRs (quad q = AGPR quad RING + q)
+    constexpr int NV2 = FW2 * 8 - NA2;                                  // ... and in VGPRs
     using SCHED = SchedOf<KS1, FW2, Y2RING, RING>;
+    constexpr int G1F = FW1 * KS1, G2F = 8 * FW2, FPC = G1F + G2F;  // weight fragments per chunk and wave
     static_assert(FPC % RING == 0, "the ring index of a fragment must not depend on the chunk");
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem_[PARK_OFF + PARK * 8192];
-    typedef __attribute__((address_space(3))) f32x4_t lds_f32x4_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_[BIAS_OFF + N1 * 4];
     lds_u8_t* const smem = (lds_u8_t*)smem_;
     const unsigned lds0 = (unsigned)(size_t)smem;
 
@@ -176,105 +209,117 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
     const int m0 = blockIdx.x * SBM;
     const unsigned lane16 = (unsigned)lane * 16u;
 
-    // ---- y2 staging: piece j of a k-tile covers tile rows wave*16 + 8j + (lane >> 3), 16-byte chunk lane & 7 (swizzled)
+    // ---- y2 staging: piece j of a k-tile covers tile rows wave*32 + 8j + (lane >> 3), 16-byte chunk lane & 7 (swizzled). Rows
+    // 16 apart share the swizzle term, rows 8 apart differ by chunk ^ 4: two lane offsets + 16 rows on the scalar side.
     unsigned a_off[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int row = wave * 16 + j * 8 + (lane >> 3);
+        const int row = wave * 32 + j * 8 + (lane >> 3);
         a_off[j] = (unsigned)(m0 + row) * (K1 * 2) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
     }
-    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wave * 2048);
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + wave * 4096);
     auto issue_y2 = [&](int kt, int slot) {  // k-tile kt of the tile's y2 rows into slot
         const unsigned char* src = p.y2 + kt * 128;
         const unsigned dst = ldsA + slot * 16384;
         dma16s(src, a_off[0], dst);
         dma16s(src, a_off[1], dst + 1024);
+        dma16s(src + 16 * (K1 * 2), a_off[0], dst + 2048);
+        dma16s(src + 16 * (K1 * 2), a_off[1], dst + 3072);
     };
     // fragment reads: pixel fragment b = tile rows 16 b + frow; 128-byte rows, chunk ^ ((row >> 1) & 7)
     const int lo128 = frow * 128 + ((fchunk ^ ((frow >> 1) & 7)) << 4);
-    // residual / out: lane (f = fchunk, pixel frow of fragment b) owns channels 32 wave + 8 f .. + 7 of a chunk
-    const unsigned r_off = (unsigned)(m0 + frow) * (N1 * 2) + (unsigned)(wave * 32 + 8 * fchunk) * 2;
+    // residual / out: lane (f = fchunk, pixel frow of fragment b) owns channels 64 wave + 32 j + 8 f .. + 7 of a chunk
+    const unsigned r_off = (unsigned)(m0 + frow) * (N1 * 2) + (unsigned)(wave * 64 + 8 * fchunk) * 2;
 
     // LDS bases as opaque registers: every access below is base + immediate (< 64 KB). Left to itself hipcc folds XO into each of
     // the 64 hand-over addresses and keeps them in 64 VGPRs.
     const lds_u8_t* xptr = smem + XO + lane16;
-    asm volatile("" : "+v"(xptr));
+    const lds_u8_t* sa0 = smem + lo128;          // y2 k-step parity 0 / 1 of a k-tile: chunk ^ 4
+    const lds_u8_t* sa1 = smem + (lo128 ^ 64);
+    asm volatile("" : "+v"(xptr), "+v"(sa0), "+v"(sa1));
 
-    // ---- the weight stream of this wave: fragment position q of chunk c at wpk + ((c * 8 + wave) * FPC + q) KiB
-    u32x4_t wr[RING];
+    // ---- the weight stream of this wave: fragment position q of chunk c at wpk + ((c * NWV + wave) * FPC + q) KiB
     auto issue_w = [&](auto slot_c, const unsigned char* chunk_base, auto pos_c) {
         constexpr int SLOT = decltype(slot_c)::value, POS = decltype(pos_c)::value;
-        if constexpr (SEAM_ABL & 8) { wr[SLOT] = u32x4_t{lane16, 2u, 3u, 4u}; return; }
-        gload16_asm<(POS & 3) * 1024>(wr[SLOT], lane16, chunk_base + (POS & ~3) * 1024);
+        if constexpr (SEAM_ABL & 8) return;
+        ring_load<SLOT, (POS & 3) * 1024>(lane16, chunk_base + (POS & ~3) * 1024);
     };
-    auto chunk_stream = [&](int c) { return p.wpk + (size_t)(c * 8 + wave) * (FPC * 1024); };
+    auto chunk_stream = [&](int c) { return p.wpk + (size_t)(c * NWV + wave) * (FPC * 1024); };
 
-    f32x4_t acc1[2][8];
-    f32x4_t acc2[FW2][8];
+    f32x4_t acc1[FW1][8];
+    // GEMM 2's accumulator (a, b) = quad q = 8 a + b: AGPR quad RING + q for q < NA2, else acc2v[q - NA2]; the clobber makes the
+    // kernel descriptor allocate all 256 AGPRs
+    asm volatile("" ::: "a255");
+    static_for<NA2>([&](auto qc) { acc_zero<RING + decltype(qc)::value>(); });
+    f32x4_t acc2v[NV2 > 0 ? NV2 : 1];
 #pragma unroll
-    for (int a = 0; a < FW2; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) acc2[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (NV2 > 0 ? NV2 : 1); ++i) acc2v[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    u32x4_t rres[8];
-    auto load_residual = [&](int c) {  // one lane offset; fragment / chunk offsets on the scalar side
+    u32x4_t rres[8][2];
+    auto load_residual = [&](int c) {  // one lane offset; fragment / chunk offsets on the scalar side, the channel half as immediate
         const unsigned char* rc = p.res + (size_t)c * (SCH * 2);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            if constexpr (SEAM_ABL & 1) { rres[b] = u32x4_t{(unsigned)c, r_off, 1u, 2u}; continue; }
-            gload16_asm<0>(rres[b], r_off, rc + b * (16 * N1 * 2));
+            if constexpr (SEAM_ABL & 1) { rres[b][0] = u32x4_t{(unsigned)c, r_off, 1u, 2u}; rres[b][1] = rres[b][0]; continue; }
+            gload16_asm<0>(rres[b][0], r_off, rc + b * (16 * N1 * 2));
+            gload16_asm<64>(rres[b][1], r_off, rc + b * (16 * N1 * 2));
         }
     };
     auto init_acc1 = [&](int c) {  // the chunk's accumulators start as residual + bias (landed: older than fragments already waited for)
-        float bias[8];
-        {
-            const lds_u8_t* bs = smem + BIAS_OFF + (c * SCH + wave * 32 + 8 * fchunk) * 4;
-            const u32x4_t b0 = *reinterpret_cast<const lds_u32x4_t*>(bs), b1 = *reinterpret_cast<const lds_u32x4_t*>(bs + 16);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { bias[e] = __uint_as_float(b0[e]); bias[4 + e] = __uint_as_float(b1[e]); }
-        }
+        for (int j = 0; j < 2; ++j) {
+            float bias[8];
+            {
+                const lds_u8_t* bs = smem + BIAS_OFF + (c * SCH + wave * 64 + 32 * j + 8 * fchunk) * 4;
+                const u32x4_t b0 = *reinterpret_cast<const lds_u32x4_t*>(bs), b1 = *reinterpret_cast<const lds_u32x4_t*>(bs + 16);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint32_t w4[4] = {rres[b][0], rres[b][1], rres[b][2], rres[b][3]};
-            float v[8];
+                for (int e = 0; e < 4; ++e) { bias[e] = __uint_as_float(b0[e]); bias[4 + e] = __uint_as_float(b1[e]); }
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) unpack_lp16x2(w4[e], v[2 * e], v[2 * e + 1]);
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t w4[4] = {rres[b][j][0], rres[b][j][1], rres[b][j][2], rres[b][j][3]};
+                float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (SEAM_ABL & 1) ? bias[e] : v[e] + bias[e];
-            acc1[0][b] = f32x4_t{v[0], v[1], v[2], v[3]};
-            acc1[1][b] = f32x4_t{v[4], v[5], v[6], v[7]};
+                for (int e = 0; e < 4; ++e) unpack_lp16x2(w4[e], v[2 * e], v[2 * e + 1]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (SEAM_ABL & 1) ? bias[e] : v[e] + bias[e];
+                acc1[2 * j][b] = f32x4_t{v[0], v[1], v[2], v[3]};
+                acc1[2 * j + 1][b] = f32x4_t{v[4], v[5], v[6], v[7]};
+                __builtin_amdgcn_sched_barrier(0);  // piece by piece: a residual quad dies where two accumulator quads are born
+            }
         }
     };
 
     using std::integral_constant;
 
-    if constexpr (PARK > 0) {
-#pragma unroll
-        for (int k = 0; k < PARK; ++k) *reinterpret_cast<lds_f32x4_t*>(smem + PARK_OFF + k * 8192 + tid * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    // ---- prologue: residual + bias of chunk 0, the y2 tile (or its first four k-tiles), then the first RING weight fragments
+    // ---- prologue: residual of chunk 0, the conv3 bias, the y2 tile (or its first AHEAD k-tiles), then the first RING fragments
     load_residual(0);
-    if (wave < N1 / 256) dma16s(reinterpret_cast<const unsigned char*>(p.b3) + wave * 1024, lane16, lds0 + BIAS_OFF + wave * 1024);
-    if constexpr (Y2RING) {
 #pragma unroll
-        for (int t = 0; t < AHEAD; ++t) issue_y2(t, t);
-    } else {
+    for (int i = 0; i < N1 / 1024; ++i)
+        dma16s(reinterpret_cast<const unsigned char*>(p.b3) + (wave * (N1 / 1024) + i) * 1024, lane16, lds0 + BIAS_OFF + (wave * (N1 / 1024) + i) * 1024);
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) issue_y2(t, t);
-    }
+    for (int t = 0; t < (Y2RING ? AHEAD : NKT); ++t) issue_y2(t, t);
     {
         const unsigned char* s0 = chunk_stream(0);
         static_for<RING>([&](auto ic) { issue_w(ic, s0, ic); });
     }
-    // everything older than the weight fragments has landed; the barrier publishes the y2 pieces of the other waves
+    // everything older than the weight fragments has landed; the barrier publishes the DMA pieces of the other waves
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SEAM_ABL & 8) ? 0 : RING) : "memory");
-    static_assert(RING <= 16, "vmcnt is a 6-bit field: ring + epilogue accesses must stay below 64");
-#pragma unroll
-    for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(rres[b]));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    int kt_slot = 0;  // slot of the chunk's y2 k-tile 0 (Y2RING: global k-tile n sits in slot n % NSL)
+    // the B fragments of the current k-step (8 pixel fragments of y2 in GEMM 1, of X in GEMM 2): held in registers, each replaced
+    // by its successor of the NEXT k-step right behind its last reader
+    u32x4_t bf[8];
+    int kt_slot = 0;   // slot of the chunk's y2 k-tile 0 (Y2RING: global k-tile n sits in slot n % NSL)
+    int slot_off = 0;  // byte offset of the slot the next y2 reads go to
+    auto ld_y2 = [&](auto ks_c, int b) {
+        constexpr int KS = decltype(ks_c)::value;
+        const lds_u8_t* base = (KS & 1) ? sa1 : sa0;
+        if constexpr (Y2RING) return lds_ld16(base + slot_off + b * 2048);
+        else return lds_ld16(base + (KS >> 1) * 16384 + b * 2048);
+    };
+
     for (int c = 0;; ++c) {
         const bool last = c + 1 == NC;
         // the last chunk requests chunk 0's residual and first fragments again (never used, drained at the end): the code stays
@@ -283,185 +328,156 @@ __global__ __launch_bounds__(512) void bottleneck_seam_kernel(const SeamParams p
         const unsigned char* ws = chunk_stream(c);
         const unsigned char* wsn = chunk_stream(cn);
 
-        // residual + bias were requested one GEMM 2 ago and are older than fragments that have been waited for since; the empty
-        // statements keep their (register-only) consumers behind those waits
+        // residual was requested one GEMM 2 ago and is older than fragments that have been waited for since; the empty statements
+        // keep its (register-only) consumers behind those waits
 #pragma unroll
-        for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(rres[b]));
+        for (int b = 0; b < 8; ++b) asm volatile("" : "+v"(rres[b][0]), "+v"(rres[b][1]));
         init_acc1(c);
         __builtin_amdgcn_sched_barrier(0);
+        // the first y2 k-step (its k-tile was published in the prologue / during the previous chunk's GEMM 1)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) bf[b] = ld_y2(integral_constant<int, 0>{}, b);
+        asm volatile("s_nop 4" ::: "memory");  // VALU-written accumulators -> the first MFMA's C operand
 
-        // ================= GEMM 1: acc1 (32 channels x 128 pixels) += w3 fragments x y2 fragments ===========================
-        // One pixel-fragment read feeds two MFMAs; the reads run PD fragments ahead of their MFMAs through a ring of PD + 1
-        // registers, in an order pinned by sched_barrier (left alone hipcc reads two fragments, waits, issues four MFMAs: the
-        // two waves of a SIMD leave every barrier in lock step, so nothing overlaps the LDS round trips). With the y2 ring
-        // the pipeline restarts at every k-tile: a k-tile may only be read behind its barrier.
-        {
-            constexpr int PD = N2 == 256 ? 4 : 2;  // reads ahead: what the registers beside the two accumulator sets allow
-            constexpr int NR = KS1 * 8;  // pixel-fragment reads of the chunk
-            u32x4_t px[PD + 1];
-            const lds_u8_t* sa0 = smem + lo128;          // k-step parity 0 / 1 of a k-tile: chunk ^ 4
-            const lds_u8_t* sa1 = smem + (lo128 ^ 64);
-            asm volatile("" : "+v"(sa0), "+v"(sa1));
-            int slot_off = 0;                            // byte offset of the current k-tile's slot (y2 ring)
-            auto ldpx = [&](auto rc) {
-                constexpr int R = decltype(rc)::value, KS = R / 8, B = R % 8;
-                const lds_u8_t* base = (KS & 1) ? sa1 : sa0;
-                if constexpr (Y2RING) return lds_ld16(base + slot_off + B * 2048);
-                else return lds_ld16(base + (KS >> 1) * 16384 + B * 2048);
-            };
-            if constexpr (!Y2RING) static_for<PD>([&](auto rc) { px[decltype(rc)::value % (PD + 1)] = ldpx(rc); });
-            static_for<NR>([&](auto rc) {
-                constexpr int R = decltype(rc)::value, KS = R / 8, B = R % 8;
-                constexpr int S0 = (2 * KS) % RING, S1 = (2 * KS + 1) % RING;
-                if constexpr (B == 0) {
-                    if constexpr (SEAM_ABL & 8) { asm volatile("" : "+v"(wr[S0]), "+v"(wr[S1])); }
-                    else wait_for<SCHED::value.g1[KS]>(wr[S0], wr[S1]);
-                    if constexpr (Y2RING && (KS & 1) == 0) {
-                        // this wave's pieces of the k-tile are older than the fragments just waited for; the barrier covers the
-                        // other waves' pieces and frees the slot read two k-tiles ago for the k-tile AHEAD tiles down the stream
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-                        const int slot = (kt_slot + (KS >> 1)) % NSL;
-                        issue_y2(((KS >> 1) + AHEAD) % NKT, (slot + AHEAD) % NSL);
-                        slot_off = slot * 16384;
-                        static_for<PD>([&](auto dc) { px[(R + decltype(dc)::value) % (PD + 1)] = ldpx(integral_constant<int, R + decltype(dc)::value>{}); });
+        // ================= the chunk's FPC weight fragments, one at a time: wait, 8 MFMAs against the held B fragments, refill ===
+        static_for<FPC>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            constexpr bool G1 = P < G1F;
+            constexpr int F = G1 ? P : P - G1F;
+            constexpr int FW = G1 ? FW1 : FW2;
+            constexpr int KS = F / FW, A = F % FW;
+            constexpr int SL = P % RING;
+            constexpr bool LAST_A = A + 1 == FW;
+
+            if constexpr (P == G1F) {
+                // ============ chunk epilogue: ReLU, round once; the packed registers go to HBM (next block's residual) and to X ==
+                if constexpr (!Y2RING) {
+                    // every wave is past its reads of X (the previous chunk's GEMM 2) -- the y2 ring's barriers say the same
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                mfma_drain();  // the last GEMM 1 results are in their registers before the VALU reads them
+                unsigned char* oc = p.out + (size_t)c * (SCH * 2);
+                const lds_u8_t* xw = xptr + wave * 16384;
+                static_for<2>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) {
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = relu_nan(acc1[2 * j][b][e]);
+                            v[4 + e] = relu_nan(acc1[2 * j + 1][b][e]);
+                        }
+                        const u32x4_t pk = {pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7])};
+                        if constexpr (!(SEAM_ABL & 1)) gstore16_asm<j * 64>(pk, r_off, oc + b * (16 * N1 * 2));
+                        *reinterpret_cast<lds_u32x4_t*>(const_cast<lds_u8_t*>(xw) + (j * 8 + b) * 1024) = pk;
+                    }
+                });
+                load_residual(cn);
+                wg_barrier();  // X is complete
+#pragma unroll
+                for (int b = 0; b < 8; ++b) bf[b] = lds_ld16(xptr + b * 1024);
+            }
+
+            if constexpr (!(SEAM_ABL & 8)) wait_vmcnt<SCHED::value.allowed[P]>();
+
+            if constexpr (Y2RING && G1 && LAST_A && (KS & 1)) {
+                // The k-tile of the next k-step: this wave's pieces of it are older than fragments it has waited for, the barrier
+                // covers the other waves'; it also frees the slot read two k-tiles ago for the k-tile AHEAD tiles down the stream.
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const int nslot = (kt_slot + (KS >> 1) + 1) % NSL;
+                issue_y2(((KS >> 1) + AHEAD) % NKT, (nslot + AHEAD - 1) % NSL);  // tiles t+1 .. t+AHEAD are then in flight / resident
+                slot_off = nslot * 16384;
+            }
+            static_for<8>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                if constexpr (G1) {
+                    if constexpr (SEAM_ABL & 2) asm volatile("" ::"v"(bf[b]));
+                    else mfma_v<SL>(acc1[A][b], bf[b]);
+                } else {
+                    if constexpr (SEAM_ABL & 4) asm volatile("" ::"v"(bf[b]));
+                    else if constexpr (A * 8 + b < NA2) mfma_a<RING + A * 8 + b, SL>(bf[b]);
+                    else mfma_v<SL>(acc2v[A * 8 + b - NA2], bf[b]);
+                }
+                if constexpr (LAST_A) {  // the next k-step's B fragment replaces this one right behind its last reader
+                    if constexpr (G1 && KS + 1 < KS1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        bf[b] = ld_y2(integral_constant<int, KS + 1>{}, b);
+                    } else if constexpr (!G1 && KS + 1 < 8) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        bf[b] = lds_ld16(xptr + ((KS + 1) * 8 + b) * 1024);
                     }
                 }
-                if constexpr (R + PD < NR && !(Y2RING && (R + PD) / 16 != R / 16))
-                    px[(R + PD) % (PD + 1)] = ldpx(integral_constant<int, R + PD>{});
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (SEAM_ABL & 2) asm volatile("" ::"v"(wr[S0]), "v"(wr[S1]), "v"(px[R % (PD + 1)]));
-                else {
-                    acc1[0][B] = mfma_lp16_16x16x32(wr[S0], px[R % (PD + 1)], acc1[0][B]);
-                    acc1[1][B] = mfma_lp16_16x16x32(wr[S1], px[R % (PD + 1)], acc1[1][B]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (B == 7) {  // both fragments are consumed: their successors RING positions down the stream
-                    constexpr int Q0 = 2 * KS + RING, Q1 = Q0 + 1;
-                    if constexpr (Q0 >= FPC) issue_w(integral_constant<int, S0>{}, wsn, integral_constant<int, Q0 - FPC>{});
-                    else issue_w(integral_constant<int, S0>{}, ws, integral_constant<int, Q0>{});
-                    if constexpr (Q1 >= FPC) issue_w(integral_constant<int, S1>{}, wsn, integral_constant<int, Q1 - FPC>{});
-                    else issue_w(integral_constant<int, S1>{}, ws, integral_constant<int, Q1>{});
-                }
             });
-        }
-        if constexpr (Y2RING) {
-            kt_slot += NKT;
-            while (kt_slot >= NSL) kt_slot -= NSL;
-        } else {
-            // every wave is past its reads of X (the previous chunk's GEMM 2) -- the y2 ring's barriers say the same where it exists
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-
-        // ================= chunk epilogue: ReLU, round once; the packed registers go to HBM (next block's residual) and to X ====
-        {
-            unsigned char* oc = p.out + (size_t)c * (SCH * 2);
-            const lds_u8_t* xw = xptr + wave * 8192;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = relu_nan(acc1[0][b][e]);
-                    v[4 + e] = relu_nan(acc1[1][b][e]);
-                }
-                const u32x4_t pk = {pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7])};
-                if (!(SEAM_ABL & 1) || pk[0] == 0x12345678u) *reinterpret_cast<u32x4_t*>(oc + b * (16 * N1 * 2) + r_off) = pk;
-                *reinterpret_cast<lds_u32x4_t*>(const_cast<lds_u8_t*>(xw) + b * 1024) = pk;
-            }
-        }
-        load_residual(cn);
-        wg_barrier();  // X is complete
-
-        // ================= GEMM 2: acc2 (N2 / 8 channels x 128 pixels) += w1n fragments x X fragments ============================
-        u32x4_t xf[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) xf[b] = lds_ld16(xptr + b * 1024);
-        static_for<8 * FW2>([&](auto fc) {
-            constexpr int F = decltype(fc)::value;
-            constexpr int KS = F / FW2, A = F % FW2;
-            constexpr int SL = (2 * KS1 + F) % RING;
-            if constexpr (SEAM_ABL & 8) { asm volatile("" : "+v"(wr[SL])); }
-            else wait_for<SCHED::value.g2[F]>(wr[SL]);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                if constexpr (PARK > 0 && A + 1 == FW2 && KS == 0) {
-                    if (b >= 8 - PARK) acc2[A][b] = *reinterpret_cast<const lds_f32x4_t*>(smem + PARK_OFF + (b - (8 - PARK)) * 8192 + tid * 16);
-                }
-                if constexpr (SEAM_ABL & 4) asm volatile("" ::"v"(wr[SL]), "v"(xf[b]));
-                else acc2[A][b] = mfma_lp16_16x16x32(wr[SL], xf[b], acc2[A][b]);
-                if constexpr (PARK > 0 && A + 1 == FW2 && KS == 7) {
-                    if (b >= 8 - PARK) *reinterpret_cast<lds_f32x4_t*>(smem + PARK_OFF + (b - (8 - PARK)) * 8192 + tid * 16) = acc2[A][b];
-                }
-                if constexpr (A + 1 == FW2 && KS + 1 < 8) {  // the next k-step's fragment replaces this one right behind its last reader
-                    __builtin_amdgcn_sched_barrier(0);
-                    xf[b] = lds_ld16(xptr + ((KS + 1) * 8 + b) * 1024);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int Q = 2 * KS1 + F + RING;
+            constexpr int Q = P + RING;
             if constexpr (Q >= FPC) issue_w(integral_constant<int, SL>{}, wsn, integral_constant<int, Q - FPC>{});
             else issue_w(integral_constant<int, SL>{}, ws, integral_constant<int, Q>{});
+            if constexpr (Y2RING && P + 1 == G1F) kt_slot = (kt_slot + NKT) % NSL;
         });
         if (last) break;
     }
-    // the fragments requested for a chunk that does not exist are still landing in registers the compiler now considers free
-    // (the empty statements keep the ring registers allocated up to the drain)
-#pragma unroll
-    for (int i = 0; i < RING; ++i) asm volatile("" : "+v"(wr[i]));
+    // the fragments requested for a chunk that does not exist are still landing
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < RING; ++i) asm volatile("" : "+v"(wr[i]));
+    mfma_drain();
 
-    if constexpr (PARK > 0) {
-#pragma unroll
-        for (int k = 0; k < PARK; ++k) acc2[FW2 - 1][8 - PARK + k] = *reinterpret_cast<const lds_f32x4_t*>(smem + PARK_OFF + k * 8192 + tid * 16);
-    }
     // ---- z = relu(acc2 + b1n), rounded, 16-byte stores (64 contiguous bytes per pixel row and instruction)
+    // (the lane's coordinates are derived afresh: a lane constant kept alive across the chunk loop for this is one VGPR too many
+    // with N2 = 512 -- hipcc parks it in an AGPR, i.e. in the weight ring)
+    unsigned lane_z;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_z));
+    const int frow_z = lane_z & 15, fchunk_z = lane_z >> 4;
     lp16_t* __restrict__ zp = reinterpret_cast<lp16_t*>(p.z);
-    const int cb2 = wave * (N2 / 8) + 8 * fchunk;
-#pragma unroll
-    for (int j = 0; j < FW2 / 2; ++j) {
+    const int cb2 = wave * (N2 / NWV) + 8 * fchunk_z;
+    static_for<FW2 / 2>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         const float4 b0 = *reinterpret_cast<const float4*>(p.b1n + cb2 + 32 * j);
         const float4 b1 = *reinterpret_cast<const float4*>(p.b1n + cb2 + 32 * j + 4);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int gm = m0 + b * 16 + frow;
+        static_for<8>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const int gm = m0 + b * 16 + frow_z;
+            f32x4_t lo, hi;
+            if constexpr ((2 * j) * 8 + b < NA2) lo = acc_read<RING + (2 * j) * 8 + b>();
+            else lo = acc2v[(2 * j) * 8 + b - NA2];
+            if constexpr ((2 * j + 1) * 8 + b < NA2) hi = acc_read<RING + (2 * j + 1) * 8 + b>();
+            else hi = acc2v[(2 * j + 1) * 8 + b - NA2];
             float v[8];
-            v[0] = acc2[2 * j][b][0] + b0.x; v[1] = acc2[2 * j][b][1] + b0.y; v[2] = acc2[2 * j][b][2] + b0.z; v[3] = acc2[2 * j][b][3] + b0.w;
-            v[4] = acc2[2 * j + 1][b][0] + b1.x; v[5] = acc2[2 * j + 1][b][1] + b1.y; v[6] = acc2[2 * j + 1][b][2] + b1.z; v[7] = acc2[2 * j + 1][b][3] + b1.w;
+            v[0] = lo[0] + b0.x; v[1] = lo[1] + b0.y; v[2] = lo[2] + b0.z; v[3] = lo[3] + b0.w;
+            v[4] = hi[0] + b1.x; v[5] = hi[1] + b1.y; v[6] = hi[2] + b1.z; v[7] = hi[3] + b1.w;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
             *reinterpret_cast<uint4*>(zp + (size_t)gm * N2 + cb2 + 32 * j) =
                 make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
-        }
-    }
+        });
+    });
 }
 
 // ---- one-off packing of the two weight matrices into the per-(chunk, wave) fragment streams.
-//   GEMM 1 fragment (k-step ks, a in {0, 1}): row i of the MFMA A operand = conv3 channel 256 c + 32 w + 8 (i >> 2) + 4 a + (i & 3)
-//   GEMM 2 fragment (k-step ks, a < FW2):      row i = conv1 channel (N2 / 8) w + 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1) + (i & 3)
-// (the MFMA result rows 4 f + r of a fragment PAIR of a lane are then 8 consecutive channels: one 16-byte piece; igemm_wide.hip)
+//   GEMM 1 fragment (k-step ks, a < 4):   row i of the MFMA A operand = conv3 channel 256 c + 64 w + sigma(a, i)
+//   GEMM 2 fragment (k-step ks, a < FW2): row i = conv1 channel (N2 / 4) w + sigma(a, i)
+//   sigma(a, i) = 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1) + (i & 3): the MFMA result rows 4 f + r of a fragment PAIR of a lane are
+//   then 8 consecutive channels (one 16-byte piece; igemm_wide.hip)
 // lane (i = lane & 15, f = lane >> 4) holds the row's k-elements 32 ks + 8 f .. + 7.
 __global__ void seam_pack_kernel(const lp16_t* __restrict__ w3, const lp16_t* __restrict__ w1n, uint4* __restrict__ wpk, int K1, int N1, int N2) {
-    const int KS1 = K1 / 32, FW2 = N2 / 128, FPC = 2 * KS1 + 8 * FW2;
-    const long long total = (long long)(N1 / SCH) * 8 * FPC * 64;
+    const int KS1 = K1 / 32, FW2 = N2 / 64, G1F = FW1 * KS1, FPC = G1F + 8 * FW2;
+    const long long total = (long long)(N1 / SCH) * NWV * FPC * 64;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int lane = (int)(t & 63);
         long long r = t >> 6;
         const int q = (int)(r % FPC);
         r /= FPC;
-        const int w = (int)(r & 7), c = (int)(r >> 3);
+        const int w = (int)(r % NWV), c = (int)(r / NWV);
         const int i = lane & 15, f = lane >> 4;
         const lp16_t* src;
-        if (q < 2 * KS1) {
-            const int ks = q >> 1, a = q & 1;
-            const int ch = c * SCH + w * 32 + 8 * (i >> 2) + 4 * a + (i & 3);
+        if (q < G1F) {
+            const int ks = q / FW1, a = q % FW1;
+            const int ch = c * SCH + w * 64 + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
             src = w3 + (size_t)ch * K1 + ks * 32 + f * 8;
         } else {
-            const int g = q - 2 * KS1, ks = g / FW2, a = g % FW2;
-            const int och = w * (N2 / 8) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
+            const int g = q - G1F, ks = g / FW2, a = g % FW2;
+            const int och = w * (N2 / NWV) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
             src = w1n + (size_t)och * N1 + c * SCH + ks * 32 + f * 8;
         }
         wpk[t] = *reinterpret_cast<const uint4*>(src);
@@ -510,7 +526,7 @@ extern "C" int agrl_bottleneck_seam(const void* y2, const void* packed, const fl
     p.b1n = b1_next;
     p.z = reinterpret_cast<unsigned char*>(z);
     p.M = M;
-    const dim3 grid(M / SBM), block(512);
+    const dim3 grid(M / SBM), block(NWV * 64);
     if (Cmid == 256 && Cnext == 256) hipLaunchKernelGGL((bottleneck_seam_kernel<256, 1024, 256>), grid, block, 0, (hipStream_t)stream, p);
     else if (Cmid == 256) hipLaunchKernelGGL((bottleneck_seam_kernel<256, 1024, 512>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((bottleneck_seam_kernel<512, 2048, 512>), grid, block, 0, (hipStream_t)stream, p);
