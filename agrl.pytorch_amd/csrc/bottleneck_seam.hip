@@ -7,27 +7,44 @@
 // and at once contracted against the matching 256-deep k-slice of the next conv1 into an accumulator set that lives across
 // the chunks (128 x N2 fp32: 64 / 128 registers per lane).
 //
-// Round-4 history. The first form staged BOTH weight matrices through an LDS ring (48-KB k-tiles, LDS-DMA, one barrier per
-// k-tile, two tiles ahead -- all that fits beside the 64-KB hand-over buffer): parity-green and no faster than the two
-// launches (layer 4: 185 us against 190). Ablations said why: without a single MFMA it still took 171 us, and a lone tile on
-// an idle chip 103 us -- 0.8 us per 32-MFMA step: a chain of barrier-gated LDS-DMA round trips (issue -> landed ~1.1 us) with
-// at most two steps in flight. This form therefore takes the weights OUT of the LDS:
-//
+// How it works (form 3 of the history below):
 //   * The weights are static, so they are packed once (agrl_bottleneck_seam_pack) into the exact order the kernel consumes them:
 //     per chunk and wave one contiguous stream of 1-KiB MFMA A-fragments (lane-linear: 16 rows x 64 B of one 32-deep k-step).
-//     A wave streams ITS fragments global -> registers with plain 16-byte loads (one KiB per instruction, perfectly coalesced)
-//     through a ring of 8 fragments that is refilled the moment a fragment's last MFMA has issued: no staging instruction, no
-//     barrier, no slot that waits for seven other waves, and 64 KB in flight per CU in registers that cost nothing extra.
-//   * 512 threads = 8 waves, each owning 32 conv3 channels of the chunk (GEMM 1: 2 fragments x 8 pixel fragments) and N2 / 8
-//     conv1 channels (GEMM 2: 2 / 4 fragments x 8 pixel fragments) of ALL 128 pixels, so that no weight fragment is needed by
-//     two waves. Wave w's 32 finished channels are exactly k-step w of GEMM 2.
+//     A wave streams ITS fragments global -> AGPRs with plain 16-byte loads (one KiB per instruction, perfectly coalesced) through
+//     a ring of 16 (8) fragments that is refilled the moment a fragment's eight MFMAs have issued: no LDS staging, no barrier.
+//   * 256 threads = 4 waves, one per SIMD with 512 registers each. A wave owns 64 conv3 channels of the chunk (GEMM 1: 4 channel
+//     fragments x 8 pixel fragments) and N2 / 4 conv1 channels (GEMM 2) of ALL 128 pixels: no weight fragment is needed by two
+//     waves, and the 8 pixel fragments of a k-step are read from LDS once per wave and held in registers while the k-step's
+//     weight fragments pass (each replaced by its successor right behind its last reader).
 //   * LDS holds activations only: the y2 tile (K1 = 256: resident, 64 KB; K1 = 512: 16-KB k-tiles through a 5-slot ring, three
-//     tiles ahead, LDS-DMA), the conv3 bias and the hand-over buffer X (64 KB): a lane's packed epilogue registers (8 consecutive channels of
-//     one pixel) ARE the B fragment of one k-step of GEMM 2, so X is an array of 1-KiB fragment blocks [k-step][pixel
+//     tiles ahead, LDS-DMA), the conv3 bias, and the hand-over buffer X (64 KB): a lane's packed epilogue registers (8 consecutive
+//     channels of one pixel) ARE the B fragment of one k-step of GEMM 2, so X is an array of 1-KiB fragment blocks [k-step][pixel
 //     fragment], written and read lane-linearly, and the same registers go to HBM as 16-byte stores.
-//   * The residual never touches LDS: a chunk's accumulators START as residual + bias (8 loads per lane, issued one GEMM 2
-//     earlier). Every load of the kernel is inline asm with hand-counted vmcnt waits (hipcc's own waits would drain the rings);
+//   * The residual never touches LDS: a chunk's accumulators START as residual + bias (16 loads per lane, issued one GEMM 2
+//     earlier). Every load of the kernel is inline asm with hand-counted vmcnt waits (hipcc's own waits would drain the ring);
 //     the counts come from a constexpr simulation of one chunk's issue order (make_sched).
+//
+// Round-4 history (every number: rocprofv3 kernel-trace minimum over 10 launches, 256 frames of 16 x 8, fp16, same box):
+//   1. BOTH weight matrices staged through an LDS ring (48-KB k-tiles, LDS-DMA, one barrier per k-tile, two tiles ahead -- all
+//      that fits beside the 64-KB hand-over buffer): parity-green, layer 4 185 us against 190 us for the two launches. Ablations:
+//      171 us without a single MFMA, a lone tile on an idle chip 103 us -- 0.8 us per 32-MFMA step: a chain of barrier-gated
+//      LDS-DMA round trips (issue -> landed ~1.1 us) with at most two steps in flight.
+//   2. Weights out of the LDS: packed once (agrl_bottleneck_seam_pack) into the order the kernel consumes them and streamed
+//      global -> registers; eight waves, each owning 32 channels of all 128 pixels. Same time (layer 3: 52 us, layer 4: 180 us):
+//      now every wave reads every pixel fragment from LDS -- 12 MB per layer-4 tile at the ~128 B/clk the LDS delivers = 45 us
+//      beside 62 us of MFMA -- and the skeleton without MFMAs, weight loads and HBM traffic still took 50 us.
+//   3. This form: FOUR waves of 512 registers (one per SIMD), each owning 64 channels: half the LDS reads, B fragments of a k-step
+//      held in registers, weight ring and GEMM 2's accumulators in asm-owned AGPRs. Layer 3 51.4 us against 59.1 us (37.5 + 22.6)
+//      for the two launches; layer 4 178 us against 180 us; 256/1024/512 67.5 us against 70 us. What the time is: layer 3 / 4
+//      without the chunk epilogues' HBM accesses 36 / 116 us (residual loads 10 / 17 us, out stores 8 / 37 us of the rest),
+//      without weight loads as well 29 / 94 us, MFMA alone 16 / 62 us.
+//   Tried on top of 3 and withdrawn: the weight ring 32 deep instead of 16 (52.3 us); the chunk's 32 HBM accesses spread one by
+//   one behind GEMM 2's fragments instead of in a burst (52.1 us); lanes p / p + 8 swapping a piece by DPP so that every store /
+//   load covers 8 pixels x 128 B = whole cache lines instead of 16 half lines (53.2 us); odd tiles starting half a chunk late so
+//   that the CUs' bursts interleave (layer 4 +3.5 us with a 9 us delay). The HBM accesses of a chunk cost the same 16 us (layer 3)
+//   however they are issued: they do not overlap the matrix work of the wave that issues them, and with one wave per SIMD nothing
+//   else does either. The model uses the kernel where it wins (the five seams of layer 3: 3.578 -> 3.552 ms per step, same box).
+//
 #include <utility>
 
 #include "igemm_dev.h"

@@ -173,6 +173,11 @@ def conv1x1_bn_act_pool(x, w_ohwi, bias, residual, splits, mean, want_lp, relu=T
 SEAM_SHAPES = ((256, 1024, 256), (512, 2048, 512), (256, 1024, 512))
 
 
+def seam_enabled():
+    """AGRL_HIP_FUSE_SEAM=0 runs the layer-3 seams as two launches (A/B)."""
+    return os.environ.get('AGRL_HIP_FUSE_SEAM', '1') != '0'
+
+
 def bottleneck_seam_supported(w3, w1_next, pixels=None):
     """conv3 + residual -> next conv1 back to back (agrl_bottleneck_seam): 16-bit weights of a layer-3 / layer-4 seam, and --
     when ``pixels`` is given -- a pixel count made of whole 128-pixel tiles (16 x 8 frames)."""

@@ -40,7 +40,7 @@ def pack_weights(model, device, precision):
             'dtype': dtype,
             'stem': (stem_w, stem_b),
             'stem_lp': ops.pack_stem_weights_lp16(stem_w) if dtype == ops.LP_DTYPE else None,
-            'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype),
+            'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype, seam=True),
             'l4': _pack_stage(model.layer4, dtype),
             # stacked query / key conv as one OHWI weight (2*Cq, 1, 1, C) + bias; value conv as a Linear weight (C, C) + bias
             'qk_w': torch.cat([pam.query_conv.weight, pam.key_conv.weight], 0).detach().float().permute(0, 2, 3, 1).contiguous().to(dtype),

@@ -38,7 +38,7 @@ def _fold_bn1d(bn):
     return scale.contiguous(), shift.contiguous()
 
 
-def _pack_stage(stage, dtype):
+def _pack_stage(stage, dtype, seam=False):
     blocks = []
     for unit in stage:
         blk = {
@@ -57,6 +57,13 @@ def _pack_stage(stage, dtype):
                 blk['dual'] = (torch.cat([blk['ds'][0].view(cout, -1), blk['c3'][0].view(cout, -1)], dim=1).contiguous(),
                                (blk['ds'][1] + blk['c3'][1]).contiguous())
         blocks.append(blk)
+    if seam and dtype == ops.LP_DTYPE:
+        # conv3 + residual of block i back to back with conv1 of block i + 1 (ops.bottleneck_seam, layer 3): the two static
+        # weight matrices re-ordered once into the fragment streams the kernel's waves load straight into registers
+        for blk, nxt in zip(blocks[:-1], blocks[1:]):
+            if ops.bottleneck_seam_supported(blk['c3'][0], nxt['c1'][0]):
+                blk['seam'] = ops.bottleneck_seam_pack(blk['c3'][0], nxt['c1'][0])
+                blk['seam_dims'] = (blk['c3'][0].shape[3], blk['c3'][0].shape[0], nxt['c1'][0].shape[0])
     return blocks
 
 
@@ -81,7 +88,7 @@ def pack_weights(model, device, precision):
             'dtype': dtype,
             'stem': (stem_w, stem_b),
             'stem_lp': ops.pack_stem_weights_lp16(stem_w) if dtype == ops.LP_DTYPE else None,
-            'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype),
+            'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype, seam=True),
             'graph': [],
         }
         if hasattr(model, 'layer4_1'):   # vmgn: two layer4 branches, two BNNecks
@@ -134,6 +141,9 @@ def _run_trunk(a, blocks, fuse_tail=True):
                                        shortcut=(a, blk['ds'][0], blk['ds'][1]))
             continue
         shortcut = a if blk['ds'] is None else ops.conv_bn_act(a, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
+        if fuse_tail and nxt is not None and 'seam' in blk and (y.numel() // y.shape[-1]) % 128 == 0 and ops.seam_enabled():
+            a, z = ops.bottleneck_seam(y, blk['seam'], blk['c3'][1], shortcut, nxt['c1'][1], blk['seam_dims'])
+            continue
         if fusable:
             a, z = ops.bottleneck_tail(y, blk['c3'][0], blk['c3'][1], shortcut, nxt['c1'][0], nxt['c1'][1])
         else:
