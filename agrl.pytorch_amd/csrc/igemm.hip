@@ -867,6 +867,10 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     if (p.ksplit < 1) p.ksplit = 1;
     p.vec_ok = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 && (!p.colv || (((uintptr_t)p.colv) & 15) == 0) &&
                (!p.res || (((uintptr_t)p.res) & 15) == 0);
+    // The GraphLayer epilogue (mix_f: BatchNorm + LeakyReLU + residual mix) exists only in the vectorised fp32 register epilogue of
+    // igemm_kernel: the scalar tail, the wide and the persistent kernels would silently compute a plain Linear + shift.
+    AGRL_CHECK_ARG(!p.mix_f || (sizeof(TOUT) == 4 && p.vec_ok && (p.N % 4) == 0 && p.mix_scale && p.ksplit == 1 && p.pool_nparts == 0),
+                   "%s: the GraphLayer epilogue needs fp32 output, N %% 4 == 0 (got %d), 16-byte aligned out / shift and no split-K", who, p.N);
     // bf16 outputs whose rows are whole 16-byte chunks take the LDS-staged (fully coalesced) epilogue
     const bool lds_epi = sizeof(TOUT) == 2 && (p.N % 8) == 0 && (p.ldo % 8) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
                          (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.colv || (((uintptr_t)p.colv) & 15) == 0);

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void clip_pool_kernel(const float* __restrict_
         for (int i = 0; i < 8; ++i) v[i] = i0 + i < n ? src[(size_t)(i0 + i) * D] : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            if (i0 + i < n) acc = mode ? fmaxf(acc, v[i]) : acc + v[i];
+            if (i0 + i < n) acc = mode ? __builtin_elementwise_maximum(acc, v[i]) : acc + v[i];  // IEEE-754-2019 maximum: a NaN clip stays a NaN (fmaxf drops it)
     }
     out[(size_t)t * D + c] = mode ? acc : acc / (float)n;
 }

@@ -24,7 +24,11 @@ METRIC_COSINE = 1
 # The 16-bit type is a property of the LIBRARY (the same sources built twice, include/agrl_hip.h): AGRL_HIP_LP16 = fp16
 # (default: 8 x smaller rounding error at the same MFMA rate, the path's outputs stay within the north star's 1e-3 of the
 # fp32 oracle) or bf16. It is fixed for the process when this module is imported.
-LP_NAME = os.environ.get("AGRL_HIP_LP16", "fp16")
+LP_NAME = os.environ.get("AGRL_HIP_LP16")
+if LP_NAME is None:
+    # not chosen explicitly: a 16-bit AGRL_HIP_PRECISION names the type (round-2 scripts exported AGRL_HIP_PRECISION=bf16 alone and
+    # would otherwise fail at the first forward, after the model is built and the data loaded)
+    LP_NAME = os.environ.get("AGRL_HIP_PRECISION") if os.environ.get("AGRL_HIP_PRECISION") in ("fp16", "bf16") else "fp16"
 if LP_NAME not in ("fp16", "bf16"):
     raise ValueError("AGRL_HIP_LP16 must be fp16 or bf16, not %r" % LP_NAME)
 LP_DTYPE = torch.float16 if LP_NAME == "fp16" else torch.bfloat16

@@ -79,6 +79,7 @@ def extract_features(model, batches, pool="avg", prefetch=True):
     device = next(model.parameters()).device
     model.eval()
     feats, pids, camids = [], [], []
+    nonfinite = None
     if prefetch:
         batches = device_prefetch(batches, device)
     for imgs, pid, camid, adj in batches:
@@ -88,20 +89,30 @@ def extract_features(model, batches, pool="avg", prefetch=True):
             b, clips = imgs.shape[:2]
             imgs = imgs.reshape((b * clips,) + tuple(imgs.shape[2:]))
             adj = adj.reshape((b * clips,) + tuple(adj.shape[2:]))
-        feats.append(pool_clips(model(imgs, adj), clips, pool))
+        raw = model(imgs, adj)
+        if raw.is_cuda:   # accumulated on the device, read once after the last batch: no per-batch synchronisation
+            bad = ~torch.isfinite(raw).all()
+            nonfinite = bad if nonfinite is None else (nonfinite | bad)
+        feats.append(pool_clips(raw, clips, pool))
         pids.extend(np.asarray(pid).tolist())
         camids.extend(np.asarray(camid).tolist())
     out = torch.cat(feats, 0)
-    # One check per extraction, after the last batch (no per-batch synchronisation): the fp16 build stores activations with a
-    # range of 65504 -- a checkpoint whose activations leave it yields inf / nan embeddings, and ranking those would be silent
-    # garbage. (Nothing on this path comes near the limit with the recipe or with trained ResNet50 statistics.)
-    if out.is_cuda and not bool(torch.isfinite(out).all()):
-        from torchreid import _hip
-        raise FloatingPointError(
-            "non-finite embeddings from the %s forward (hip_precision=%r)%s" % (
-                _hip.LP_NAME if getattr(model, "hip_precision", "fp32") == _hip.LP_NAME else "HIP", getattr(model, "hip_precision", None),
-                ": activations left fp16's range -- set AGRL_HIP_LP16=bf16 (libagrl_hip_bf16.so) or hip_precision='fp32'"
-                if _hip.LP_NAME == "fp16" and getattr(model, "hip_precision", "fp32") == "fp16" else ""))
+    # One check per extraction, on the RAW model outputs (before the dense samplers' clip pooling): the fp16 build stores
+    # activations with a range of 65504 -- a checkpoint whose activations leave it yields inf / nan embeddings, and ranking those
+    # would be silent garbage. (Nothing on this path comes near the limit with the recipe or with trained ResNet50 statistics.)
+    # Under a process group the flag is all-reduced (MAX) first, so that every rank raises instead of one rank leaving the others
+    # blocked in the next collective.
+    if nonfinite is not None:
+        flag = nonfinite.to(torch.int32).reshape(1)
+        if parallel.world_size() > 1:
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if bool(flag.item()):
+            from torchreid import _hip
+            raise FloatingPointError(
+                "non-finite embeddings from the %s forward (hip_precision=%r)%s" % (
+                    _hip.LP_NAME if getattr(model, "hip_precision", "fp32") == _hip.LP_NAME else "HIP", getattr(model, "hip_precision", None),
+                    ": activations (or BatchNorm-folded weights) left fp16's range -- set AGRL_HIP_LP16=bf16 (libagrl_hip_bf16.so) or "
+                    "hip_precision='fp32'" if _hip.LP_NAME == "fp16" and getattr(model, "hip_precision", "fp32") == "fp16" else ""))
     return out, np.asarray(pids), np.asarray(camids)
 
 

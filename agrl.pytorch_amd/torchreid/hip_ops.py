@@ -581,7 +581,10 @@ def rank_topk(dist, k, idx_offset=0):
 def distmat_topk(q, g, metric, k, qn=None, gn=None, idx_offset=0, workspace_bytes=None):
     """q (m,D), g (n,D) prepared operands (as for ``distmat``) -> idx int32 (m,k), val fp32 (m,k): the k nearest gallery rows
     of every query in ascending (distance, index) order, without the (m,n) matrix (distance.py:59-89 + rank.py:171-172).
-    Bit-identical to ``rank_topk(distmat(q, g, ...), k)``."""
+    Bit-identical to ``rank_topk(distmat(q, g, ...), k)`` when ONE query block covers m (the default workspace at the MARS sizes);
+    with several blocks (a small ``workspace_bytes``, very many queries) a block's row count picks the GEMM's kernel family and
+    split-K, so a distance can differ from the full-matrix path in its last bit and near-ties may swap: equal up to that
+    (tests/test_gpu_kernels.py::test_distmat_topk_blocks_tie_aware)."""
     m, D = q.shape
     n, D2 = g.shape
     assert D == D2 and q.dtype == g.dtype

@@ -19,7 +19,8 @@ import torch
 
 from torchreid import hip_ops as ops
 from torchreid import _hip
-from torchreid.models._vmgn_hip import (_PRECISIONS, _fingerprint, _fold_bn1d, _fold_conv_bn, _pack_stage, _run_block, _run_trunk)
+from torchreid.models._vmgn_hip import (_PRECISIONS, _fingerprint, _fold_bn1d, _fold_conv_bn, _pack_stage, _run_block, _run_trunk,
+                                         check_packed_range)
 
 
 def pack_weights(model, device, precision):
@@ -57,6 +58,8 @@ def pack_weights(model, device, precision):
             pack['graph'].append({'w': layer.linear.weight.detach().to(dtype).contiguous(), 'scale': scale, 'shift': shift,
                                   'slope': float(layer.relu.negative_slope), 'use_pose': bool(layer.use_pose),
                                   'learn_graph': bool(layer.learn_graph)})
+    if dtype == ops.LP_DTYPE:
+        check_packed_range(pack, 'ganet')
     pack['fingerprint'] = _fingerprint(model)
     model._hip_packs[key] = pack
     return pack

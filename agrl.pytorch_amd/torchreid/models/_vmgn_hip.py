@@ -32,6 +32,24 @@ def _fold_conv_bn(conv, bn, dtype):
     return w.to(dtype).contiguous(), shift.contiguous()
 
 
+def check_packed_range(pack, where="vmgn"):
+    """BatchNorm-folded weights are cast to the library's 16-bit type at pack time: with fp16 a checkpoint with a tiny
+    running_var or a large gamma can fold to inf (|w| > 65504). Checked once per pack, with the layer named -- the end-of-
+    extraction check would blame the activations."""
+    def walk(obj, path):
+        if torch.is_tensor(obj):
+            if obj.dtype == ops.LP_DTYPE and obj.numel() and not bool(torch.isfinite(obj).all()):
+                raise FloatingPointError("%s: the BatchNorm-folded weights of %s overflow %s (abs-max of the fp32 fold is beyond its "
+                                         "range): load the bf16 build (AGRL_HIP_LP16=bf16) or use hip_precision='fp32'" % (where, path, ops.LP_NAME))
+        elif isinstance(obj, dict):
+            for k, v in obj.items():
+                walk(v, "%s.%s" % (path, k))
+        elif isinstance(obj, (list, tuple)):
+            for i, v in enumerate(obj):
+                walk(v, "%s[%d]" % (path, i))
+    walk({k: v for k, v in pack.items() if k != 'fingerprint'}, "pack")
+
+
 def _fold_bn1d(bn):
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
@@ -108,6 +126,8 @@ def pack_weights(model, device, precision):
                 'gamma': float(layer.gamma), 'slope': float(layer.relu.negative_slope),
                 'use_pose': bool(layer.use_pose), 'learn_graph': bool(layer.learn_graph),
             })
+    if dtype == ops.LP_DTYPE:
+        check_packed_range(pack)
     pack['fingerprint'] = _fingerprint(model)
     model._hip_packs[key] = pack
     return pack

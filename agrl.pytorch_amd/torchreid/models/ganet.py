@@ -153,6 +153,8 @@ class GANet(nn.Module):
 
         # MI355X path configuration (not part of the state dict)
         self.hip_precision = os.environ.get('AGRL_HIP_PRECISION', 'fp32')
+        from torchreid import hip_ops as _ops   # a precision the loaded library cannot serve fails HERE, not at the first forward
+        _ops.check_precision(self.hip_precision)
         self.hip_static_weights = False
         self.hip_fuse_tail = os.environ.get('AGRL_HIP_FUSE_TAIL', '1') != '0'
         self._hip_packs = {}

@@ -116,6 +116,33 @@ def test_bench_self_launches_two_ranks():
     print("bench --gpus 2 (2 ranks on one GPU, gloo): %.0f frames/s, all-gather %.0f us" % (r["value"], r["config"]["allgather_us"]))
 
 
+def test_bench_config3_eight_ranks_on_one_gpu():
+    """BASELINE configs[2] at its real shape without the hardware: ``python bench.py --gpus 8 --batch 32`` = 8 ranks x 32
+    tracklets (256 global), the 12 180-row gallery in 1 523 / 1 522-row shards, all-gather of embeddings, per-shard distance --
+    the 8 processes share the one GPU over gloo (RCCL needs a GPU per rank; the transport is all that differs). Rank 0's line
+    must report 8 ranks, the shard sizes, and a sharded top-50 (per-shard top-k + candidate merge) equal to a single-process
+    top-50 over the whole gallery."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                          "--batch", "32", "--sustain-seconds", "0", "--profile-steps", "1", "--dist-timeout", "1200"], env=env, cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    cfg = r["config"]
+    assert r["n_gpus"] == 8 and cfg["ranks"] == 8 and cfg["global_batch"] == 256 and cfg["frames_per_step"] == 2048
+    assert cfg["gallery_rows_all_ranks"] == [1523] * 4 + [1522] * 4 and cfg["gallery_rows_per_gpu"] == 1523
+    assert len(cfg["per_rank_ms_per_step"]) == 8 and r["scaling"] == "weak" and r["value"] > 0
+    assert cfg["sharded_top50_equals_single_process"] is True, cfg.get("sharded_top50_max_abs_diff")
+    assert cfg["allgather_bytes_per_rank"] == 32 * 4096 * 4
+    print("bench --gpus 8 --batch 32 (8 ranks on one GPU, gloo): %.0f frames/s, all-gather %.0f us, top-50 merge equal" % (
+        r["value"], cfg["allgather_us"]))
+
+
 def test_bench_launcher_notices_a_rank_that_dies_mid_run():
     """``python bench.py --gpus 2`` with rank 1 exiting (code 3) right after the warm-up: rank 0 is then blocked in the
     all-gather; the launcher must terminate it and return non-zero well inside --dist-timeout."""

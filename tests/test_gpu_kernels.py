@@ -843,6 +843,30 @@ def test_distmat_topk_equals_distmat_then_topk(cfg):
         ops.distmat_topk(qh, gh, "cosine", n + 1)
 
 
+@pytest.mark.parametrize("rows", [64, 200, 333])
+def test_distmat_topk_blocks_tie_aware(rows):
+    """Several query blocks (a workspace of ``rows`` rows, incl. a short tail block that takes another kernel family): a distance
+    may differ from the full-matrix path in its last bits, so the lists are compared tie-aware -- distances within 4e-6, and
+    wherever the indices differ the two candidates' full-matrix distances are within that same bound (a swap inside a near-tie)."""
+    from torchreid import hip_ops as ops
+    m, n, D, k = 700, 3000, 256, 50
+    g = torch.Generator().manual_seed(rows)
+    q, gal = torch.randn((m, D), generator=g).to(DEV), torch.randn((n, D), generator=g).to(DEV)
+    gal[11] = gal[5]
+    qh, gh = ops.row_l2_normalize(q, True, LP_DTYPE, ops.k_multiple(LP_DTYPE)), ops.row_l2_normalize(gal, True, LP_DTYPE, ops.k_multiple(LP_DTYPE))
+    dist = ops.distmat(qh, gh, "cosine")
+    idx0, val0 = ops.rank_topk(dist, k)
+    idx1, val1 = ops.distmat_topk(qh, gh, "cosine", k, workspace_bytes=rows * 4 * (-(-n // 4) * 4))
+    torch.cuda.synchronize()
+    tol = 4e-6
+    assert (val0 - val1).abs().max().item() <= tol
+    diff = idx0 != idx1
+    if bool(diff.any()):
+        d_at_other = torch.gather(dist, 1, idx1.to(torch.int64))
+        assert ((d_at_other - val0).abs()[diff] <= tol).all(), "an index differs outside a near-tie"
+    print("distmat_topk in blocks of %d rows: %d of %d positions differ (all inside near-ties)" % (rows, int(diff.sum()), diff.numel()))
+
+
 def test_rank_mars_bit_exact():
     from torchreid import metrics
     rng = np.random.RandomState(7)

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the data-parallel match logic (no GPU): tracklet shards, all-gather of embeddings,
+"""world_size-2 / 3 / 8 gloo tests of the data-parallel match logic (no GPU): tracklet shards, all-gather of embeddings,
 gallery shards, candidate merge -> identical to the single-process result."""
 import os
 import socket
@@ -65,9 +65,12 @@ def test_shard_bounds():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.timeout(300)
-def test_sharded_match_equals_single_process(tmp_path):
-    world = 2
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_match_equals_single_process(tmp_path, world):
+    """world 3: ragged shards (101 = 34 + 34 + 33); world 8: every gallery shard (12-13 rows) is SMALLER than k = 20, so every
+    rank pads its candidate list -- the merged list must still be the single-process top-20, ties (rows 7 / 40 / 90, three
+    different shards) in gallery-index order."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     g = torch.Generator().manual_seed(0)
     emb = torch.randn((6 * world, 64), generator=g)
