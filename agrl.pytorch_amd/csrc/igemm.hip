@@ -914,6 +914,11 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
             if (p.pool_nparts > 0 && wide != 0 && wtiles >= 64 && !opt.pool_persist) return launch_igemm_wide(p, stream, who);
         }
     }
+    if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 4) {
+        // the full query x gallery distance matrix (BASELINE configs[4]): 256 x 256 tiles once they cover the chip
+        if (opt.igemm_wide != 0 && !agrl_opts().distmat_tiled && igemm_wide_f32out_applicable(p) && cdiv(p.M, 256) * cdiv(p.N, 256) >= 224 && p.K >= 512)
+            return launch_igemm_wide_f32out(p, stream, who);
+    }
     if constexpr (sizeof(TOUT) == 2) {
         // persistent tiles pay off where a tile is short (<= 8 k-tiles): its first DMA round trip and its store
         // drain are a large share of the tile; long K loops run better as independent workgroups (A/B measured)

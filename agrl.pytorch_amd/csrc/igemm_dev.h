@@ -166,6 +166,8 @@ __device__ inline int patch_off(int py, int px, int chunk) { return (py * PW_ + 
 // 256 x 256 tile kernel for the MFMA-bound pointwise layers (igemm_wide.hip)
 bool igemm_wide_applicable(const IgemmParams& p);
 int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who);
+bool igemm_wide_f32out_applicable(const IgemmParams& p);   // fp32 output + distance epilogue (the full query x gallery matrix)
+int launch_igemm_wide_f32out(const IgemmParams& p, hipStream_t stream, const char* who);
 
 // streaming distance matrix (few queries x long gallery, distmat_stream.hip)
 bool distmat_stream_applicable(const IgemmParams& p, int elem_size);

@@ -23,6 +23,7 @@ namespace {
 
 constexpr int WBM = 256, WBN = 256;
 
+constexpr bool REGEPI_OK(int dbg) { return (dbg & 8192) == 0; }
 template <int DBG, int WBN_ = 256, bool RES = false>  // RES: + residual (its 64 staging registers leave no room for the persistent form's carried state); WBN_: channels per tile (256, or 128 for N = 256 layers: twice the tiles); DBG: ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     static_assert(WBN_ == 256 || (WBN_ == 128 && (DBG & (4096 | 8192 | 16384)) == 0), "the 128-channel tile has the plain schedule + register epilogue only");
@@ -32,6 +33,12 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     // shortcut map is neither written nor read back and the sum is formed in fp32. x rows are exactly twice as long as x2
     // rows (ResNet: inplanes = 2 planes in the first block of layers 2-4), which lets ONE stored offset per piece serve both.
     constexpr bool DUAL = (DBG & 32768) != 0;
+    // F32OUT (bit 65536): fp32 output with the distance epilogue out = alpha * acc + rowv[m] (or rowc) + colv[n] -- the full
+    // query x gallery distance matrix of BASELINE configs[4] (metrics/distance.py:59-89) through the 256 x 256 tile: the tiled
+    // igemm_kernel it used before sits at 0.30 of the MFMA peak on that shape. M and N need not be tile multiples: rows of
+    // either operand beyond the matrix are staged as zeros and their results are not stored (N % 4 == 0 for the 16-byte stores).
+    constexpr bool F32OUT = (DBG & 65536) != 0;
+    static_assert(!F32OUT || (WBN_ == 256 && !RES && !POOL && !DUAL && REGEPI_OK(DBG)), "fp32 output: plain 256-channel tiles, register epilogue");
     constexpr bool REGEPI = (DBG & 8192) == 0;  // bit 8192: the LDS-staged two-half epilogue (kept for A/B)
     constexpr int BM = WBM, BN = WBN_, NW = 8, WM = 4;
     constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     // is requested BEFORE the epilogue's stores are issued, so the stores drain under the next tile's matrix work
     // (a workgroup that ends instead holds its LDS until its last store is acknowledged, and its successor on the CU
     // starts with a cold pipeline).
-    const int nNt = p.N / BN;
+    const int nNt = F32OUT ? (p.N + BN - 1) / BN : p.N / BN;
     const int ntiles = ((p.M + BM - 1) / BM) * nNt;
     const int xcd = blockIdx.x & 7;
     int tl = blockIdx.x >> 3;                                                  // tile index inside the XCD's range
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     const unsigned row_bytes_a = DUAL ? (unsigned)(p.K - p.K1) * 2u : row_bytes;
     const unsigned split_bytes = DUAL ? (unsigned)p.K1 * 2u : 0u;
     unsigned a_off[AJ], b_off[BJ];
-    unsigned a_okmask = 0;
+    unsigned a_okmask = 0, b_okmask = 0;
     int m0 = 0, n0 = 0;
     auto setup_tile = [&](int tile) {
         const int mt = tile / nNt;
@@ -112,6 +119,11 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 const int rp = row & (SLAB - 1), a = rp >> 4, i = rp & 15;
                 ch = (row & ~(SLAB - 1)) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
             }
+            if constexpr (F32OUT) {
+                if (j == 0) b_okmask = 0;
+                if (n0 + ch < p.N) b_okmask |= 1u << j;
+                else ch = 0;
+            }
             b_off[j] = (unsigned)(n0 + ch) * row_bytes + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
         }
     };
@@ -130,6 +142,8 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         } else {
             const int j = idx - AJ;
             unsigned char* sb = smem + buf * BUF_BYTES + A_BYTES + wave * (BN / NW) * 128;
+            if constexpr (F32OUT) dma16((b_okmask >> j) & 1u ? wg + b_off[j] + kbyte : zsrc, sb + j * 1024);
+            else
             dma16(wg + b_off[j] + kbyte, sb + j * 1024);
         }
     };
@@ -309,6 +323,35 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
         // cb + 32 j + {0..7} (cb = n0 + 128 wn + 8 f) in acc[2j][b], acc[2j+1][b]: residual in / result out as one
         // 16-byte access per (b, j); the four lanes of a pixel cover 64 contiguous bytes per instruction.
         const int cb = en0 + wn * (BN / 2) + 8 * fchunk;
+        if constexpr (F32OUT) {
+            // lane (f, row = lane & 15 of fragment b): columns cb + 32 j + {0..7} of acc[2j][b], acc[2j+1][b]: two 16-byte stores,
+            // the four lanes of a row cover 128 contiguous bytes per instruction
+            float* __restrict__ out32 = reinterpret_cast<float*>(p.out);
+            constexpr int NJ = FN / 2;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c0 = cb + 32 * j;
+                float4 cv0 = make_float4(0.f, 0.f, 0.f, 0.f), cv1 = cv0;
+                if (p.colv && c0 + 3 < p.N) cv0 = *reinterpret_cast<const float4*>(p.colv + c0);
+                if (p.colv && c0 + 7 < p.N) cv1 = *reinterpret_cast<const float4*>(p.colv + c0 + 4);
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const int gm = em0 + wm * (BM / WM) + b * 16 + frow;
+                    if (gm >= p.M) continue;
+                    const float rv = p.rowv ? p.rowv[gm] : p.rowc;
+                    float* dst = out32 + (size_t)gm * p.ldo + c0;
+                    if (c0 + 3 < p.N)
+                        *reinterpret_cast<float4*>(dst) = make_float4(fmaf(p.alpha, acc[2 * j][b][0], rv + cv0.x), fmaf(p.alpha, acc[2 * j][b][1], rv + cv0.y),
+                                                                      fmaf(p.alpha, acc[2 * j][b][2], rv + cv0.z), fmaf(p.alpha, acc[2 * j][b][3], rv + cv0.w));
+                    if (c0 + 7 < p.N)
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(fmaf(p.alpha, acc[2 * j + 1][b][0], rv + cv1.x), fmaf(p.alpha, acc[2 * j + 1][b][1], rv + cv1.y),
+                                                                          fmaf(p.alpha, acc[2 * j + 1][b][2], rv + cv1.z), fmaf(p.alpha, acc[2 * j + 1][b][3], rv + cv1.w));
+                }
+            }
+            carried = false;  // (the counted wait of a carried tile assumes EPI_STORES stores per lane: not with masked fp32 stores)
+            if (!has_next) return;
+            continue;
+        }
         const lp16_t* __restrict__ resp = reinterpret_cast<const lp16_t*>(p.res);
         lp16_t* __restrict__ outp = reinterpret_cast<lp16_t*>(p.out);
         constexpr int NJ = FN / 2;  // 16-byte pieces (8 channels) per lane and pixel fragment
@@ -491,6 +534,23 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
 }
 
 }  // namespace
+
+// fp32-output distance form (F32OUT): 16-bit operands, any M, N % 4 == 0, no residual / pooling / second source
+bool igemm_wide_f32out_applicable(const IgemmParams& p) {
+    const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
+    if (!pointwise || p.x2 || p.res || p.pool_nparts > 0 || p.ksplit > 1 || p.mix_f || p.stats || p.relu) return false;
+    if (p.K % 64 || p.N % 4 || p.ldo % 4) return false;
+    if ((size_t)p.M * p.K * 2 >= (1ull << 32) || (size_t)p.N * p.K * 2 >= (1ull << 32)) return false;
+    const uintptr_t al = (uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.out | (uintptr_t)p.colv;
+    return (al & 15) == 0;
+}
+
+int launch_igemm_wide_f32out(const IgemmParams& p, hipStream_t stream, const char* who) {
+    const int tiles = cdiv(p.M, WBM) * cdiv(p.N, WBN);
+    hipLaunchKernelGGL((igemm_wide_kernel<65536, 256, false>), dim3(tiles), dim3(512), 0, stream, p);
+    AGRL_CHECK_LAUNCH(who);
+    return 0;
+}
 
 bool igemm_wide_applicable(const IgemmParams& p) {
     if (p.x2 && (p.stride != 1 || p.res || p.pool_nparts > 0 || p.K1 <= 0 || p.K1 != 2 * (p.K - p.K1) || (p.K1 % 64) || (p.N % WBN) ||

@@ -741,6 +741,30 @@ def test_distmat(shape, metric):
     assert e < 1e-5 and elp < 1e-2
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("shape", [(2000, 7428, 512), (1793, 8190 + 2, 576)])
+def test_distmat_wide_tile_f32out(shape, metric, monkeypatch):
+    """The full query x gallery form through the 256 x 256 tile with fp32 output (igemm_wide_kernel<65536>: ragged M and N, both
+    metrics' epilogues) against the tiled igemm form it replaces (AGRL_DISTMAT_TILED=1) and the fp64 oracle."""
+    from torchreid.metrics.distance import hip_distmat_device
+    m, n, D = shape
+    g = torch.Generator().manual_seed(n)
+    q, gal = torch.randn((m, D), generator=g), torch.randn((n, D), generator=g)
+    ref = O.euclidean_squared(q.double(), gal.double()) if metric == "euclidean" else O.cosine(q.double(), gal.double())
+    qd, gd = q.to(DEV), gal.to(DEV)
+    wide = hip_distmat_device(qd, gd, metric, LP16)
+    monkeypatch.setenv("AGRL_DISTMAT_TILED", "1")
+    _hip.reload_options()
+    tiled = hip_distmat_device(qd, gd, metric, LP16)
+    monkeypatch.delenv("AGRL_DISTMAT_TILED")
+    _hip.reload_options()
+    torch.cuda.synchronize()
+    e = rel_err(wide, ref)
+    d = (wide - tiled).abs().max().item() / tiled.abs().max().item()
+    print("distmat wide f32out", shape, metric, "vs fp64 %.3e, vs tiled %.3e" % (e, d))
+    assert e < 1e-2 and d < 1e-6 and torch.isfinite(wide).all()
+
+
 def test_distmat_public_api_and_errors():
     from torchreid import metrics
     q, gal = torch.randn(7, 64), torch.randn(60, 64)
