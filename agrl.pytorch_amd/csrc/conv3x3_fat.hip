@@ -1,0 +1,338 @@
+// 3x3 / stride 1 / pad 1 convolution + folded BatchNorm + ReLU on 16 x 8 pixel blocks (16-bit build type), as FOUR waves of 512
+// registers -- the form the seam kernel (bottleneck_seam.hip) arrived at, applied to the dominant kernel family of the step.
+//   Bottleneck.conv2 / bn2 / relu, torchreid/models/vmgn.py:52-54.
+//
+// conv3x3_wide_kernel (8 waves, 64 x 128 wave tiles) reads 24 LDS fragments per 64 MFMAs and stages pixels AND weights through
+// LDS-DMA: 0.51 of the MFMA peak on layer 4, 0.39 on layer 3 (64 x 64 wave tiles). Here:
+//   * a workgroup = PB pixel blocks (PB x 128 pixels) x 256 output channels, 4 waves, one per SIMD; wave w owns 64 channels
+//     (4 MFMA A fragments) of ALL the tile's pixels (8 PB B fragments): 4 x 8 PB accumulator quads = 256 (PB = 2) / 128 (PB = 1)
+//     registers, asm-owned AGPRs a[0 : ...) for the whole kernel (hipcc never allocates an AGPR: every MFMA is asm, and
+//     tools/seam_check_isa.sh checks that it neither spills into them nor to scratch);
+//   * the weights are static: packed once (agrl_conv3x3_pack) into per-(channel tile, wave) streams of 1-KiB fragments in the
+//     order (64-channel slab, tap, k-step, fragment) and streamed global -> VGPR ring (8 fragments) with plain coalesced loads,
+//     a fragment refilled the moment its 8 PB MFMAs have issued. No weight touches the LDS, no wave waits for another's weights;
+//   * LDS holds only the halo patches of the current and the next 64-channel slab (PB x 23.5 KB each, LDS-DMA one piece per
+//     k-step); the 8 PB pixel fragments of a (tap, k-step) are read once per wave -- shifted, swizzled reads as in
+//     conv3x3_wide_kernel (igemm_dev.h: frag_px / patch_g) -- and held in registers while the k-step's four weight fragments pass;
+//     each is replaced by its successor right behind its last reader: 8 PB LDS reads per 32 PB MFMAs;
+//   * one barrier per slab (1152 PB MFMAs per wave) instead of one per tap-step.
+// Waits are hand-counted (every load is inline asm; hipcc's own waits would drain the ring) from a constexpr simulation of
+// one slab's issue order.
+#include <utility>
+
+#include "igemm_dev.h"
+
+namespace {
+
+struct FatParams {
+    const unsigned char* x;     // (F, H, W, Cin) 16-bit NHWC
+    const unsigned char* wpk;   // packed weight streams (agrl_conv3x3_pack)
+    const float* bias;          // (Cout)
+    unsigned char* out;         // (F, H, W, Cout)
+    int H, W, Cin, Cout, nblocks, relu;
+};
+
+template <typename F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+    sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4_t;
+
+template <int AQ>  // AGPR quad AQ += a x b
+__device__ __forceinline__ void fat_mfma(const u32x4_t& a, const u32x4_t& b) {
+    if constexpr (kLpF16) asm volatile("v_mfma_f32_16x16x32_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * AQ), "n"(4 * AQ + 3));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(4 * AQ), "n"(4 * AQ + 3));
+}
+template <int AQ>
+__device__ __forceinline__ void fat_zero() {
+    asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0" ::"n"(4 * AQ),
+                 "n"(4 * AQ + 1), "n"(4 * AQ + 2), "n"(4 * AQ + 3));
+}
+template <int AQ>
+__device__ __forceinline__ f32x4_t fat_read() {
+    float x, y, z, w;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(x), "=v"(y), "=v"(z), "=v"(w)
+                 : "n"(4 * AQ), "n"(4 * AQ + 1), "n"(4 * AQ + 2), "n"(4 * AQ + 3));
+    return f32x4_t{x, y, z, w};
+}
+// 16 bytes per lane global -> VGPRs behind hipcc's back: valid only after a counted wait that names the register
+template <int IMM>
+__device__ __forceinline__ void fat_gload(u32x4_t& dst, unsigned off, const unsigned char* base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(off), "s"(base), "n"(IMM) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void fat_wait(u32x4_t& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+__device__ __forceinline__ void fat_dma(const unsigned char* src, unsigned lds_wave_addr) {  // lane L's 16 bytes -> LDS lds_wave_addr + 16 L
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_wave_addr)
+                 : "memory");
+}
+
+#ifndef FAT_ABL
+#define FAT_ABL 0  // timing ablations (results wrong): 1 no weight loads in the loop, 2 no patch DMA, 4 no LDS reads, 8 no MFMA
+#endif
+#ifndef FAT_RING
+#define FAT_RING 8
+#endif
+constexpr int FRING = FAT_RING;  // weight fragments in flight per wave
+constexpr int FPS = 9 * 2 * 4;  // weight fragments per slab and wave: 9 taps x 2 k-steps x 4 channel fragments
+constexpr int PATCH_PIECES = 23, PATCH_BYTES_F = PATCH_PIECES * 1024;  // 18 x 10 halo pixels x 128 B, rounded to whole DMA pieces
+
+// vmcnt budget of the wait in front of fragment p of a slab (steady state): operations issued after that fragment's load
+template <int PPW>  // patch DMA pieces per wave and slab, one behind the first fragment of k-steps 0 .. PPW - 1
+struct FatSched {
+    int allowed[FPS];
+};
+template <int PPW>
+constexpr FatSched<PPW> make_fat_sched() {
+    FatSched<PPW> s{};
+    int issued[4][FPS] = {};
+    int seq = 0;
+    for (int p = 0; p < FRING; ++p) issued[0][p] = seq++;
+    for (int k = 0; k < 3; ++k)
+        for (int p = 0; p < FPS; ++p) {
+            if (k == 1) s.allowed[p] = seq - 1 - issued[k][p];
+            const int q = p + FRING;
+            if (q >= FPS) issued[k + 1][q - FPS] = seq++;
+            else issued[k][q] = seq++;
+            if ((p & 3) == 0 && (p >> 2) < PPW) seq += 1;  // the next slab's patch piece
+        }
+    return s;
+}
+template <int PPW>
+struct FatSchedOf {
+    static constexpr FatSched<PPW> value = make_fat_sched<PPW>();
+};
+
+template <int PB>  // pixel blocks per workgroup
+__global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
+    constexpr int NBF = 8 * PB;                                   // pixel (B) fragments per wave
+    constexpr int SLAB = PB * PATCH_BYTES_F;                      // one slab's patches
+    constexpr int PPW = (PB * PATCH_PIECES + 3) / 4;              // patch pieces per wave and slab (the last ones may be dummies)
+    using SCHED = FatSchedOf<PPW>;
+    static_assert(PPW <= 18, "one patch piece per k-step");
+    static_assert(FPS % FRING == 0, "a slab is a whole number of ring turns");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_[2 * SLAB + 1024];
+    lds_u8_t* const smem = (lds_u8_t*)smem_;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int frow = lane & 15, fchunk = lane >> 4;
+
+    // tile = (pixel tile mt, channel tile nt): neighbouring workgroups (same XCD: blockIdx % 8) share the pixel tile
+    const int nNt = p.Cout >> 8;
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, within = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int mt = bid / nNt, nt = bid - mt * nNt;
+    const int tw = p.W >> 3, th = p.H >> 4;
+    auto block_origin = [&](int bsel, int& img, int& oy0, int& ox0) {
+        const int blk = min(PB * mt + bsel, p.nblocks - 1);
+        img = blk / (tw * th);
+        const int trem = blk - img * (tw * th);
+        oy0 = (trem / tw) << 4;
+        ox0 = (trem % tw) << 3;
+    };
+
+    // ---- patch staging: piece pi = wave + 4 i of the PB x 23 pieces (8 patch pixels x 128 B each)
+    unsigned poff[PPW];
+    bool pok[PPW];
+    int pdst[PPW];
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pi = wave + 4 * i;
+        const int bsel = pi / PATCH_PIECES;
+        const int piece = pi - bsel * PATCH_PIECES;
+        const bool real = pi < PB * PATCH_PIECES;
+        int img, oy0, ox0;
+        block_origin(real ? bsel : 0, img, oy0, ox0);
+        const int row = piece * 8 + (lane >> 3);
+        const int py = row / 10, px = row - py * 10;
+        const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+        pok[i] = real && row < 180 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (PB * mt + bsel < p.nblocks);
+        poff[i] = (unsigned)((((size_t)img * p.H + iy) * p.W + ix) * p.Cin * 2 + (((lane & 7) ^ patch_g(py, px)) << 4));
+        pdst[i] = real ? bsel * PATCH_BYTES_F + piece * 1024 : -1;
+    }
+    auto stage_patch_piece = [&](int slab, int buf, int i) {  // always exactly one DMA (dummies keep every wave's vmcnt equal)
+        if ((FAT_ABL & 2) && buf) return;
+        const unsigned dst = pdst[i] >= 0 ? lds0 + buf * SLAB + pdst[i] : lds0 + 2 * SLAB;
+        fat_dma(pok[i] ? p.x + poff[i] + slab * 128 : zsrc, __builtin_amdgcn_readfirstlane(dst));
+    };
+
+    // ---- pixel fragment b = block b >> 3, pixels 16 (b & 7) + frag_px(lane & 15): patch pixel (2 (b & 7) + r0 + tr, x0 + ts) at tap
+    // (tr, ts); the swizzle term depends on (py & 1, px): not on b. One lane offset per tap, the rest immediates.
+    const int fp = frag_px(frow);
+    const int r0 = fp >> 3, x0 = fp & 7;
+    int tbase[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tbase[t] = patch_off<10>(r0 + t / 3, x0 + t % 3, fchunk);
+
+    // ---- weight stream of this wave: fragment q of slab s at wpk + ((nt * 4 + wave) * nslab * FPS + s * FPS + q) KiB
+    const int nslab = p.Cin >> 6;
+    const unsigned char* wstream = p.wpk + (size_t)(nt * 4 + wave) * nslab * (FPS * 1024);
+    u32x4_t wr[FRING];
+    auto issue_w = [&](auto slot_c, const unsigned char* slab_base, auto pos_c) {
+        constexpr int SLOT = decltype(slot_c)::value, POS = decltype(pos_c)::value;
+        if ((FAT_ABL & 1) && slab_base != wstream) return;
+        fat_gload<(POS & 3) * 1024>(wr[SLOT], lane16, slab_base + (POS & ~3) * 1024);
+    };
+
+    asm volatile("" ::: "a255");
+    sfor<4 * NBF>([&](auto qc) { fat_zero<decltype(qc)::value>(); });
+
+    // ---- prologue: slab 0's patches, then the first FRING weight fragments
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) stage_patch_piece(0, 0, i);
+    sfor<FRING>([&](auto ic) { issue_w(ic, wstream, ic); });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FRING) : "memory");
+
+    using std::integral_constant;
+    u32x4_t xf[NBF];
+    for (int slab = 0; slab < nslab; ++slab) {
+        // this wave's pieces of the slab are older than fragments it has waited for; the barrier covers the other waves' and says
+        // that the other buffer (read during the previous slab) is free for the next slab's pieces
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = slab + 1 < nslab;
+        const unsigned char* ws = wstream + (size_t)slab * (FPS * 1024);
+        const unsigned char* wsn = wstream + (size_t)(more ? slab + 1 : 0) * (FPS * 1024);  // past the end: slab 0 again (never used)
+        const lds_u8_t* sp = smem + (slab & 1) * SLAB;
+        auto ldx = [&](auto ks_c, auto b_c) {
+            constexpr int KS = decltype(ks_c)::value, B = decltype(b_c)::value;
+            const lds_u8_t* a = sp + (tbase[KS >> 1] ^ ((KS & 1) * 64));
+            return *reinterpret_cast<const lds_u32x4_t*>(a + (B >> 3) * PATCH_BYTES_F + (B & 7) * 2560);
+        };
+        sfor<NBF>([&](auto bc) { xf[decltype(bc)::value] = ldx(integral_constant<int, 0>{}, bc); });
+
+        sfor<FPS>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            constexpr int KS = P >> 2, A = P & 3, SL = P % FRING;
+            fat_wait<SCHED::value.allowed[P]>(wr[SL]);
+            sfor<NBF>([&](auto bc) {
+                constexpr int B = decltype(bc)::value;
+                if constexpr (!(FAT_ABL & 8)) fat_mfma<A * NBF + B>(wr[SL], xf[B]);
+                else asm volatile("" ::"v"(wr[SL]), "v"(xf[B]));
+                if constexpr (A == 3 && KS + 1 < 18 && !(FAT_ABL & 4)) {  // the next k-step's fragment replaces this one right behind its last reader
+                    __builtin_amdgcn_sched_barrier(0);
+                    xf[B] = ldx(integral_constant<int, KS + 1>{}, bc);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int Q = P + FRING;
+            if constexpr (Q >= FPS) issue_w(integral_constant<int, SL>{}, wsn, integral_constant<int, Q - FPS>{});
+            else issue_w(integral_constant<int, SL>{}, ws, integral_constant<int, Q>{});
+            if constexpr (A == 0 && KS < PPW) stage_patch_piece(more ? slab + 1 : slab, (slab + 1) & 1, KS);  // (last slab: its own pieces again, into the idle buffer)
+        });
+    }
+    // fragments requested past the end are still landing
+#pragma unroll
+    for (int i = 0; i < FRING; ++i) asm volatile("" : "+v"(wr[i]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FRING; ++i) asm volatile("" : "+v"(wr[i]));
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- epilogue: + bias, ReLU, round once; lane (f, pixel) holds channels 64 wave + 32 j + 8 f .. + 7 of (b, j): 16-byte stores
+    const int cb = nt * 256 + wave * 64 + 8 * fchunk;
+    sfor<2>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j + 4);
+        sfor<NBF>([&](auto bc) {
+            constexpr int B = decltype(bc)::value;
+            const f32x4_t lo = fat_read<(2 * j) * NBF + B>(), hi = fat_read<(2 * j + 1) * NBF + B>();
+            float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
+            }
+            if (PB * mt + (B >> 3) < p.nblocks) {
+                int img, oy0, ox0;
+                block_origin(B >> 3, img, oy0, ox0);
+                const int m = (B & 7) * 16 + fp;
+                const size_t gm = ((size_t)img * p.H + oy0 + (m >> 3)) * p.W + ox0 + (m & 7);
+                *reinterpret_cast<uint4*>(p.out + (gm * p.Cout + cb + 32 * j) * 2) =
+                    make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
+            }
+        });
+    });
+}
+
+// ---- one-off packing: OHWI (Cout, 3, 3, Cin) -> per (channel tile nt, wave w) streams [slab][tap][k-step][fragment a] of 1-KiB
+// MFMA A fragments: lane (i = lane & 15, f = lane >> 4) holds the k-elements 64 slab + 32 kk + 8 f .. + 7 of tap t of output
+// channel 256 nt + 64 w + sigma(a, i), sigma(a, i) = 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1) + (i & 3) (igemm_wide.hip)
+__global__ void conv3x3_fat_pack_kernel(const lp16_t* __restrict__ w, uint4* __restrict__ wpk, int Cin, int Cout) {
+    const int nslab = Cin >> 6;
+    const long long total = (long long)(Cout >> 8) * 4 * nslab * FPS * 64;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(t & 63);
+        long long r = t >> 6;
+        const int q = (int)(r % FPS);
+        r /= FPS;
+        const int slab = (int)(r % nslab);
+        r /= nslab;
+        const int wv = (int)(r & 3), nt = (int)(r >> 2);
+        const int a = q & 3, kk = (q >> 2) & 1, tap = q >> 3;
+        const int i = lane & 15, f = lane >> 4;
+        const int ch = nt * 256 + wv * 64 + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
+        wpk[t] = *reinterpret_cast<const uint4*>(w + ((size_t)ch * 9 + tap) * Cin + slab * 64 + kk * 32 + f * 8);
+    }
+}
+
+bool fat_shape_ok(int H, int W, int Cin, int Cout) { return H % 16 == 0 && W % 8 == 0 && Cin % 64 == 0 && Cin >= 128 && Cout % 256 == 0; }
+
+}  // namespace
+
+extern "C" long long agrl_conv3x3_packed_bytes(int Cin, int Cout) {
+    if (Cin % 64 || Cout % 256) return 0;
+    return (long long)Cout * 9 * Cin * 2;
+}
+
+extern "C" int agrl_conv3x3_pack(const void* w_ohwi, void* packed, int Cin, int Cout, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(w_ohwi && packed, "agrl_conv3x3_pack: null pointer");
+    AGRL_CHECK_ARG(Cin % 64 == 0 && Cout % 256 == 0, "agrl_conv3x3_pack: needs Cin %% 64 == 0 and Cout %% 256 == 0, got %d / %d", Cin, Cout);
+    AGRL_CHECK_ARG((((uintptr_t)w_ohwi | (uintptr_t)packed) & 15) == 0, "agrl_conv3x3_pack: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(conv3x3_fat_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const lp16_t*>(w_ohwi),
+                       reinterpret_cast<uint4*>(packed), Cin, Cout);
+    AGRL_CHECK_LAUNCH("agrl_conv3x3_pack");
+    return 0;
+}
+
+extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin,
+                                          int Cout, int relu, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && packed && bias && out, "agrl_conv3x3_packed_bn_act: null pointer");
+    AGRL_CHECK_ARG(N > 0 && fat_shape_ok(H, W, Cin, Cout),
+                   "agrl_conv3x3_packed_bn_act: needs 16 x 8-divisible maps, Cin %% 64 == 0 (>= 128), Cout %% 256 == 0; got %dx%d %d->%d", H, W, Cin, Cout);
+    AGRL_CHECK_ARG((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 < (1ull << 32), "agrl_conv3x3_packed_bn_act: maps beyond 4 GB are not addressed");
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)out) & 15) == 0, "agrl_conv3x3_packed_bn_act: pointers must be 16-byte aligned");
+    FatParams p;
+    p.x = reinterpret_cast<const unsigned char*>(x);
+    p.wpk = reinterpret_cast<const unsigned char*>(packed);
+    p.bias = bias;
+    p.out = reinterpret_cast<unsigned char*>(out);
+    p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+    p.nblocks = N * (H >> 4) * (W >> 3);
+    const int nNt = Cout >> 8;
+    // two pixel blocks per workgroup where that still gives every CU a workgroup, else one
+    if ((p.nblocks / 2) * nNt >= 224) hipLaunchKernelGGL(conv3x3_fat_kernel<2>, dim3(((p.nblocks + 1) / 2) * nNt), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv3x3_fat_kernel<1>, dim3(p.nblocks * nNt), dim3(256), 0, (hipStream_t)stream, p);
+    AGRL_CHECK_LAUNCH("agrl_conv3x3_packed_bn_act");
+    return 0;
+}

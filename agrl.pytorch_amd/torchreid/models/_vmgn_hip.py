@@ -74,6 +74,9 @@ def _pack_stage(stage, dtype, seam=False):
                 cout = blk['c3'][0].shape[0]
                 blk['dual'] = (torch.cat([blk['ds'][0].view(cout, -1), blk['c3'][0].view(cout, -1)], dim=1).contiguous(),
                                (blk['ds'][1] + blk['c3'][1]).contiguous())
+        if dtype == ops.LP_DTYPE and blk['stride'] == 1 and ops.conv3x3_packed_supported(blk['c2'][0]):
+            # layers 3 / 4: the 3x3 weights as per-wave fragment streams for the four-wave kernel (ops.conv3x3_packed)
+            blk['c2p'] = ops.conv3x3_pack(blk['c2'][0])
         blocks.append(blk)
     if seam and dtype == ops.LP_DTYPE:
         # conv3 + residual of block i back to back with conv1 of block i + 1 (ops.bottleneck_seam, layer 3): the two static
@@ -133,6 +136,14 @@ def pack_weights(model, device, precision):
     return pack
 
 
+def _conv2(y, blk):
+    """conv2 / bn2 / relu of a Bottleneck (vmgn.py:52-54): the packed-weight kernel where it was packed and the map is made of
+    whole 16 x 8 blocks, else the general conv."""
+    if 'c2p' in blk and y.shape[1] % 16 == 0 and y.shape[2] % 8 == 0 and ops.conv3x3_packed_enabled():
+        return ops.conv3x3_packed(y, blk['c2p'], blk['c2'][1], blk['c2'][0].shape[0], True)
+    return ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
+
+
 def _run_trunk(a, blocks, fuse_tail=True):
     """layer1..layer3 Bottlenecks. Where the fused kernel exists (layer 1, bf16) the last conv of block i also
     produces the first conv of block i+1 from the tile it still holds in LDS (ops.bottleneck_tail)."""
@@ -152,7 +163,7 @@ def _run_trunk(a, blocks, fuse_tail=True):
                     a, z = ops.bottleneck_block(y, blk['c2'][0], blk['c2'][1], blk['c3'][0], blk['c3'][1], None,
                                                 nxt['c1'][0], nxt['c1'][1], shortcut=(a, blk['ds'][0], blk['ds'][1]))
                 continue
-        y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
+        y = _conv2(y, blk)
         fusable = fuse_tail and nxt is not None and ops.bottleneck_tail_supported(y, blk['c3'][0], nxt['c1'][0])
         if fusable and blk['ds'] is not None and ops.bottleneck_tail_supported(
                 y, blk['c3'][0], nxt['c1'][0], (blk['ds'][0], blk['ds_stride'])) and a.shape[3] == 64:
@@ -176,7 +187,7 @@ def _run_block(x, blk, pool=None):
     """One Bottleneck. ``pool`` = (splits, mean, want_lp): fuse the frame pooling into the last conv's epilogue and
     return the pooled tensors instead of the activation map (which is then never written to HBM)."""
     y = ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
-    y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
+    y = _conv2(y, blk)
     if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
         return ops.conv1x1_dual(x, y, blk['dual'][0], blk['dual'][1], True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)

@@ -136,6 +136,18 @@ int agrl_bottleneck_seam_pack(const void* w3, const void* w1_next, void* packed,
 int agrl_bottleneck_seam(const void* y2, const void* packed, const float* b3, const void* residual, void* out,
                          const float* b1_next, void* z, int M, int Cmid, int Cout, int Cnext, agrl_stream_t stream);
 
+/* The 3x3 conv of a layer-3 / layer-4 Bottleneck (torchreid/models/vmgn.py:52-54: conv2 / bn2 / relu, stride 1, pad 1) with its
+ * static weights re-ordered ONCE into per-wave MFMA fragment streams (16-bit build type only):
+ *   out (N,H,W,Cout) = act(conv3x3(x (N,H,W,Cin), w (Cout,3,3,Cin) OHWI) + bias)
+ * agrl_conv3x3_pack writes agrl_conv3x3_packed_bytes(Cin, Cout) = 2 * 9 * Cin * Cout bytes; agrl_conv3x3_packed_bn_act then
+ * streams them global -> registers (no LDS staging of weights) while the LDS holds only the pixel halo patches. Needs maps made
+ * of whole 16 x 8 blocks, Cin % 64 == 0 (>= 128), Cout % 256 == 0; other shapes are rejected (the caller runs them through
+ * agrl_conv2d_bn_act). Same arithmetic as agrl_conv2d_bn_act: fp32 accumulation over (slab, tap, k) in that order, one rounding. */
+long long agrl_conv3x3_packed_bytes(int Cin, int Cout);
+int agrl_conv3x3_pack(const void* w_ohwi, void* packed, int Cin, int Cout, agrl_stream_t stream);
+int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin,
+                               int Cout, int relu, agrl_stream_t stream);
+
 /* Whole body of a layer-1 Bottleneck behind its first conv, fused with the head of the next block (bf16 only;
  * torchreid/models/vmgn.py:45-65: conv2/bn2/relu :52-54, conv3/bn3/+residual/relu :56-64 of block i, conv1/bn1/relu
  * :48-50 of block i+1):

@@ -286,6 +286,40 @@ def test_bottleneck_seam(dims, frames):
                  ops.ptr(z), 60, cmid, cout, cnext, None)
 
 
+@pytest.mark.parametrize("case", [(1, 16, 8, 128, 256, True), (3, 16, 8, 256, 256, True), (5, 32, 16, 192, 512, False),
+                                  (250, 16, 8, 512, 512, True), (231, 16, 8, 256, 256, True)])
+def test_conv3x3_packed(case):
+    """3x3 conv through the four-wave kernel with the pre-packed weight stream (conv3x3_fat.hip) against the fp32 reference and
+    against conv_bn_act (same summation order: equal bit for bit). 1 frame = a single workgroup with an absent second block;
+    5 frames of 32 x 16 = blocks with real neighbours on all sides (halo rows / columns from the map, zeros at the border);
+    250 frames x 512 channels takes the two-blocks-per-workgroup form, 231 an odd block count in it. Every call twice."""
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, Cout, relu = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn((N, Cin, H, W), generator=g).to(LP_DTYPE).float()
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) / np.sqrt(9 * Cin)).to(LP_DTYPE).float()
+    b = torch.randn((Cout,), generator=g)
+    dx = nhwc(x, LP_DTYPE)
+    dw = w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    assert ops.conv3x3_packed_supported(dw, H, W)
+    packed = ops.conv3x3_pack(dw)
+    out = ops.conv3x3_packed(dx, packed, b.to(DEV), Cout, relu)
+    out_b = ops.conv3x3_packed(dx, packed, b.to(DEV), Cout, relu)
+    other = ops.conv_bn_act(dx, dw, b.to(DEV), 1, 1, relu)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.to(DEV), w.to(DEV), bias=b.to(DEV), padding=1)
+    ref = F.relu(ref) if relu else ref
+    e = rel_err(out.float().permute(0, 3, 1, 2).cpu(), ref.cpu())
+    d = (out.float() - other.float()).abs().max().item()
+    print("conv3x3 packed", case, "vs fp32 %.3e | max |packed - conv_bn_act| %.3g" % (e, d))
+    assert e < (3e-3 if LP_DTYPE == torch.float16 else 2e-2)
+    assert torch.equal(out, out_b)
+    assert torch.equal(out, other)
+    assert not ops.conv3x3_packed_supported(dw, 10, 6)
+    with pytest.raises(_hip.HipKernelError):
+        ops.call("agrl_conv3x3_packed_bn_act", ops.ptr(dx), ops.ptr(packed), ops.ptr(b.to(DEV)), ops.ptr(out), N, 10, 6, Cin, Cout, 1, None)
+
+
 @pytest.mark.parametrize("tile", ["2", "3"])
 @pytest.mark.parametrize("case", [(3, 16, 8, 256, 512), (2, 32, 16, 512, 256), (1, 10, 6, 128, 256)])
 def test_conv_wide_tile_strided(case, tile, monkeypatch):
