@@ -61,6 +61,9 @@ SIGNATURES = {
     "agrl_bottleneck_seam_pack": [_p, _p, _p, _i, _i, _i, _p],
     "agrl_bottleneck_seam": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_conv3x3_packed_bytes": [_i, _i],               # returns long long
+    "agrl_conv1x1_packed_bytes": [_i, _i],               # returns long long
+    "agrl_conv1x1_pack": [_p, _p, _i, _i, _p],
+    "agrl_conv1x1_packed_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_conv3x3_pack": [_p, _p, _i, _i, _p],
     "agrl_conv3x3_packed_bn_act": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_block": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -152,6 +155,7 @@ def lib():
         h.agrl_distmat_topk_workspace.restype = C.c_size_t
         h.agrl_bottleneck_seam_packed_bytes.restype = C.c_longlong
         h.agrl_conv3x3_packed_bytes.restype = C.c_longlong
+        h.agrl_conv1x1_packed_bytes.restype = C.c_longlong
         for name in ("agrl_reload_options", "agrl_built_with_ablation", "agrl_lp16_is_f16"):
             getattr(h, name).argtypes = []
             getattr(h, name).restype = _i

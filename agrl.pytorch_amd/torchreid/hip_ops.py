@@ -213,7 +213,8 @@ def bottleneck_seam(y2, packed, b3, residual, b1_next, dims):
     z = torch.empty((N, H, W, Cnext), dtype=y2.dtype, device=y2.device)
     if _hip.PROFILE is not None:
         _hip.PROFILE_TAG = {"flops": 2.0 * M * (Cmid * Cout + Cout * Cnext),
-                            "bytes": 2.0 * (y2.numel() + residual.numel() + out.numel() + z.numel()) + packed.numel()}
+                            "bytes": 2.0 * (y2.numel() + residual.numel() + out.numel() + z.numel()) + packed.numel(),
+                            "conv": (1, 1, Cmid, Cout, H, W)}
     with _dev(y2):
         call("agrl_bottleneck_seam", ptr(y2), ptr(packed), ptr(b3), ptr(residual), ptr(out), ptr(b1_next), ptr(z), M, Cmid, Cout,
              Cnext, _stream(y2))
@@ -251,9 +252,54 @@ def conv3x3_packed(x, packed, bias, Cout, relu=True):
     assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * 9 * Cin * Cout
     out = torch.empty((N, H, W, Cout), dtype=x.dtype, device=x.device)
     if _hip.PROFILE is not None:
-        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * 9 * Cin * Cout, "bytes": 2.0 * (x.numel() + out.numel()) + packed.numel()}
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * 9 * Cin * Cout, "bytes": 2.0 * (x.numel() + out.numel()) + packed.numel(),
+                            "conv": (3, 1, Cin, Cout, H, W)}
     with _dev(x):
         call("agrl_conv3x3_packed_bn_act", ptr(x), ptr(packed), ptr(bias), ptr(out), N, H, W, Cin, Cout, 1 if relu else 0, _stream(x))
+    return out
+
+
+def conv1x1_packed_enabled():
+    """AGRL_HIP_CONV1X1_PACKED=0 runs the layer-3 / layer-4 1x1 convs through conv_bn_act / conv1x1_dual (A/B; bit-identical)."""
+    return os.environ.get('AGRL_HIP_CONV1X1_PACKED', '1') != '0'
+
+
+def conv1x1_packed_supported(w):
+    """1x1 / stride 1 conv through the four-wave kernel with a pre-packed weight stream (csrc/conv1x1_fat.hip): 16-bit weights
+    (Cout, 1, 1, K) or (Cout, K) with K % 128 == 0 and Cout % 256 == 0."""
+    w2 = w.reshape(w.shape[0], -1) if w.dim() == 4 and tuple(w.shape[1:3]) == (1, 1) else w
+    return w2.dtype == LP_DTYPE and w2.dim() == 2 and w2.shape[1] % 128 == 0 and w2.shape[0] % 256 == 0
+
+
+def conv1x1_pack(w):
+    """(Cout, K) 16-bit weights (K = K1 + K2 for the two-source form: [W1 | W2]) re-ordered once into per-wave MFMA fragment
+    streams (agrl_conv1x1_pack) -> uint8 tensor."""
+    assert conv1x1_packed_supported(w)
+    w = w.reshape(w.shape[0], -1).contiguous()
+    Cout, K = w.shape
+    nbytes = int(_hip.lib().agrl_conv1x1_packed_bytes(K, Cout))
+    assert nbytes == 2 * w.numel()
+    packed = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+    with _dev(w):
+        call("agrl_conv1x1_pack", ptr(w), ptr(packed), K, Cout, _stream(w))
+    return packed
+
+
+def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None):
+    """act([x | x2] @ W^T + bias) over pixel rows, weights from conv1x1_pack. vmgn.py:48-50 (conv1), :56-64 with x2 (conv3 +
+    downsample conv of a first block as one GEMM: x = the block input, x2 = conv2's output). -> (N,H,W,Cout) 16-bit NHWC."""
+    N, H, W, K1 = x.shape
+    K2 = 0 if x2 is None else x2.shape[3]
+    M = N * H * W
+    assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * (K1 + K2) * Cout
+    assert x2 is None or (x2.dtype == x.dtype and x2.is_contiguous() and tuple(x2.shape[:3]) == (N, H, W))
+    out = torch.empty((N, H, W, Cout), dtype=x.dtype, device=x.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * (K1 + K2) * Cout,
+                            "bytes": 2.0 * (x.numel() + (0 if x2 is None else x2.numel()) + out.numel()) + packed.numel(),
+                            "conv": (1, 1, K1 + K2, Cout, H, W)}
+    with _dev(x):
+        call("agrl_conv1x1_packed_bn_act", ptr(x), ptr(x2), ptr(packed), ptr(bias), ptr(out), M, K1, K2, Cout, 1 if relu else 0, _stream(x))
     return out
 
 

@@ -14,6 +14,8 @@ The packed weights are cached per (device, precision) and rebuilt when any param
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from torchreid import hip_ops as ops
@@ -74,6 +76,11 @@ def _pack_stage(stage, dtype, seam=False):
                 cout = blk['c3'][0].shape[0]
                 blk['dual'] = (torch.cat([blk['ds'][0].view(cout, -1), blk['c3'][0].view(cout, -1)], dim=1).contiguous(),
                                (blk['ds'][1] + blk['c3'][1]).contiguous())
+                if ops.conv1x1_packed_supported(blk['dual'][0]) and blk['dual'][0].shape[1] >= 1536:
+                    blk['dualp'] = ops.conv1x1_pack(blk['dual'][0])     # the same GEMM through the four-wave kernel
+        if dtype == ops.LP_DTYPE and ops.conv1x1_packed_supported(blk['c1'][0]) and blk['c1'][0].shape[3] >= 2048:
+            # layer 4's 2048 -> 512 convs: the shape where the four-wave kernel is ahead of the 8-wave tile (ops.conv1x1_packed)
+            blk['c1p'] = ops.conv1x1_pack(blk['c1'][0])
         if dtype == ops.LP_DTYPE and blk['stride'] == 1 and ops.conv3x3_packed_supported(blk['c2'][0]):
             # layers 3 / 4: the 3x3 weights as per-wave fragment streams for the four-wave kernel (ops.conv3x3_packed)
             blk['c2p'] = ops.conv3x3_pack(blk['c2'][0])
@@ -144,6 +151,13 @@ def _conv2(y, blk):
     return ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
 
 
+def _conv1(x, blk):
+    """conv1 / bn1 / relu of a Bottleneck (vmgn.py:48-50)."""
+    if 'c1p' in blk and ops.conv1x1_packed_enabled():
+        return ops.conv1x1_packed(x, blk['c1p'], blk['c1'][1], blk['c1'][0].shape[0], True)
+    return ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
+
+
 def _run_trunk(a, blocks, fuse_tail=True):
     """layer1..layer3 Bottlenecks. Where the fused kernel exists (layer 1, bf16) the last conv of block i also
     produces the first conv of block i+1 from the tile it still holds in LDS (ops.bottleneck_tail)."""
@@ -186,8 +200,10 @@ def _run_trunk(a, blocks, fuse_tail=True):
 def _run_block(x, blk, pool=None):
     """One Bottleneck. ``pool`` = (splits, mean, want_lp): fuse the frame pooling into the last conv's epilogue and
     return the pooled tensors instead of the activation map (which is then never written to HBM)."""
-    y = ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
+    y = _conv1(x, blk)
     y = _conv2(y, blk)
+    if pool is None and 'dualp' in blk and ops.conv1x1_packed_enabled() and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0':
+        return ops.conv1x1_packed(x, blk['dualp'], blk['dual'][1], blk['dual'][0].shape[0], True, x2=y)
     if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
         return ops.conv1x1_dual(x, y, blk['dual'][0], blk['dual'][1], True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)

@@ -849,8 +849,8 @@ def main():
                 a["bytes"] += tag["bytes"]
                 c = tag.get("conv")
                 which = None
-                # dispatch rule of agrl_conv2d_bn_act (csrc/igemm.hip): bf16 3x3 stride-1 convs with >= 256 input channels
-                # on 16 x 8 maps go to conv3x3_wide_kernel -- the 3x3 convs of layers 3 and 4
+                # the 3x3 stride-1 convs of layers 3 and 4 (>= 256 input channels on 16 x 8 maps): conv3x3_fat_kernel through
+                # agrl_conv3x3_packed_bn_act (conv3x3_wide_kernel through agrl_conv2d_bn_act with AGRL_HIP_CONV3X3_PACKED=0)
                 if lp and c and c[0] == 3 and c[1] == 1 and c[2] >= 256:
                     which = "dom"
                 elif lp and c and c[0] == 1 and max(c[2], c[3]) >= 2048:   # the pointwise convs of the layer-4 branches
@@ -873,7 +873,7 @@ def main():
         # layer-1 block and layer-2 tail, the pool-fused last conv)
         a = {"ms": 0.0, "launches": 0, "flops": 0.0}
         for fam in ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block",
-                    "agrl_conv1x1_dual_bn_act"):
+                    "agrl_conv1x1_dual_bn_act", "agrl_conv3x3_packed_bn_act", "agrl_conv1x1_packed_bn_act", "agrl_bottleneck_seam"):
             if fam in agg:
                 for key in a:
                     a[key] += agg[fam][key]
@@ -896,15 +896,15 @@ def main():
                 except Exception:
                     traffic = fam_traffic = None
         family = {"bound": "mfma (layers 3-4) / hbm (layers 1-2)",
-                  "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv1x1_dual_bn_act + agrl_conv1x1_bn_act_pool + agrl_bottleneck_tail + agrl_bottleneck_block)",
+                  "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv3x3_packed_bn_act + agrl_conv1x1_packed_bn_act + agrl_conv1x1_dual_bn_act + agrl_conv1x1_bn_act_pool + agrl_bottleneck_tail + agrl_bottleneck_block + agrl_bottleneck_seam)",
                   "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                   "traffic": fam_traffic, "traffic_source": traffic_src, "flops_per_launch": round(a["flops"] / a["launches"], 1),
                   "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2), "ms_per_step": round(a["ms"] / nprof, 4)}
         dom = cls["dom"]
         if dom["launches"]:
-            # THE dominant kernel by time (profiles/*_bench_kernel_stats.csv): conv3x3_wide_kernel<0, 128 | 256>
+            # THE dominant kernel by time (profiles/*_bench_kernel_stats.csv): conv3x3_fat_kernel<1 | 2>
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_wide_kernel<0, 128> + <0, 256> (3x3 stride-1 convs of layers 3-4: 128-channel tiles in layer 3, 256-channel tiles in layer 4; csrc/conv3x3_wide.hip)",
+            result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_fat_kernel<1> + <2> (3x3 stride-1 convs of layers 3-4: one 16 x 8 block x 256 channels per workgroup in layer 3, two in layer 4; csrc/conv3x3_fat.hip)" if ops.conv3x3_packed_enabled() else "conv3x3_wide_kernel<0, 128> + <0, 256> (csrc/conv3x3_wide.hip; AGRL_HIP_CONV3X3_PACKED=0)",
                                   "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                   "traffic": traffic, "traffic_source": traffic_src,
                                   "flops_per_launch": round(dom["flops"] / dom["launches"], 1),

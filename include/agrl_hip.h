@@ -148,6 +148,18 @@ int agrl_conv3x3_pack(const void* w_ohwi, void* packed, int Cin, int Cout, agrl_
 int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin,
                                int Cout, int relu, agrl_stream_t stream);
 
+/* The MFMA-bound 1x1 convs of layers 3 / 4 with their static weights re-ordered ONCE into per-wave MFMA fragment streams (16-bit
+ * build type only; torchreid/models/vmgn.py:48-50: conv1 / bn1 / relu; with a second source :56-64 of a layer's first block:
+ * conv3 / bn3 + downsample conv / BN as one GEMM over the concatenated K axis, W = [W_x | W_x2], bias = b_x + b_x2):
+ *   out (M,Cout) = act([x (M,K1) | x2 (M,K2)] @ W (Cout, K1 + K2)^T + bias)        x2 == NULL <=> K2 == 0
+ * agrl_conv1x1_pack writes agrl_conv1x1_packed_bytes(K, Cout) = 2 * K * Cout bytes (K = K1 + K2). Needs K1, K2 % 128 == 0 and
+ * Cout % 256 == 0, any M; other shapes are rejected (the caller runs them through agrl_conv2d_bn_act / agrl_conv1x1_dual_bn_act).
+ * Same arithmetic as those: fp32 accumulation in k order, one rounding. */
+long long agrl_conv1x1_packed_bytes(int K, int Cout);
+int agrl_conv1x1_pack(const void* w, void* packed, int K, int Cout, agrl_stream_t stream);
+int agrl_conv1x1_packed_bn_act(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1,
+                               int K2, int Cout, int relu, agrl_stream_t stream);
+
 /* Whole body of a layer-1 Bottleneck behind its first conv, fused with the head of the next block (bf16 only;
  * torchreid/models/vmgn.py:45-65: conv2/bn2/relu :52-54, conv3/bn3/+residual/relu :56-64 of block i, conv1/bn1/relu
  * :48-50 of block i+1):

@@ -320,6 +320,50 @@ def test_conv3x3_packed(case):
         ops.call("agrl_conv3x3_packed_bn_act", ops.ptr(dx), ops.ptr(packed), ops.ptr(b.to(DEV)), ops.ptr(out), N, 10, 6, Cin, Cout, 1, None)
 
 
+@pytest.mark.parametrize("case", [(1, 16, 8, 128, 0, 256, True), (3, 10, 6, 256, 0, 512, False), (40, 16, 8, 2048, 0, 512, True),
+                                  (37, 16, 8, 1024, 512, 2048, True), (2, 16, 8, 256, 128, 256, True), (250, 16, 8, 1024, 0, 512, True)])
+def test_conv1x1_packed(case):
+    """1x1 conv through the four-wave kernel with the pre-packed weight stream (conv1x1_fat.hip), one source and two (K axis
+    concatenated: conv3 + downsample conv of a first block), against the fp32 reference and against conv_bn_act /
+    conv1x1_dual (same summation order: equal bit for bit). 1 frame = half a pixel tile; 3 frames of 10 x 6 = 180 rows (ragged
+    tile, no ReLU); 37 frames = an odd tile count with the layer-4 first-block shape. Every call twice."""
+    from torchreid import hip_ops as ops
+    N, H, W, K1, K2, Cout, relu = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn((N, K1, H, W), generator=g).to(LP_DTYPE).float()
+    w = (torch.randn((Cout, K1 + K2, 1, 1), generator=g) / np.sqrt(K1 + K2)).to(LP_DTYPE).float()
+    b = torch.randn((Cout,), generator=g)
+    dx = nhwc(x, LP_DTYPE)
+    dw = w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    assert ops.conv1x1_packed_supported(dw)
+    packed = ops.conv1x1_pack(dw)
+    if K2:
+        x2 = torch.randn((N, K2, H, W), generator=g).to(LP_DTYPE).float()
+        dx2 = nhwc(x2, LP_DTYPE)
+        ref = F.conv2d(torch.cat([x, x2], dim=1).to(DEV), w.to(DEV), bias=b.to(DEV))
+    else:
+        dx2 = None
+        ref = F.conv2d(x.to(DEV), w.to(DEV), bias=b.to(DEV))
+    ref = F.relu(ref) if relu else ref
+    out = ops.conv1x1_packed(dx, packed, b.to(DEV), Cout, relu, x2=dx2)
+    out_b = ops.conv1x1_packed(dx, packed, b.to(DEV), Cout, relu, x2=dx2)
+    torch.cuda.synchronize()
+    e = rel_err(out.float().permute(0, 3, 1, 2).cpu(), ref.cpu())
+    assert e < (3e-3 if LP_DTYPE == torch.float16 else 2e-2), e
+    assert torch.equal(out, out_b)
+    if K2 == 0:
+        other = ops.conv_bn_act(dx, dw, b.to(DEV), 1, 0, relu)
+    elif ops.conv1x1_dual_supported(dx, dx2, dw.view(Cout, -1)):
+        other = ops.conv1x1_dual(dx, dx2, dw.view(Cout, -1).contiguous(), b.to(DEV), relu)
+    else:
+        other = None
+    d = None if other is None else (out.float() - other.float()).abs().max().item()
+    print("conv1x1 packed", case, "vs fp32 %.3e | max |packed - other launch|" % e, d)
+    assert other is None or torch.equal(out, other)
+    with pytest.raises(_hip.HipKernelError):
+        ops.call("agrl_conv1x1_packed_bn_act", ops.ptr(dx), None, ops.ptr(packed), ops.ptr(b.to(DEV)), ops.ptr(out), N * H * W, K1 + 64, 0, Cout, 1, None)
+
+
 @pytest.mark.parametrize("tile", ["2", "3"])
 @pytest.mark.parametrize("case", [(3, 16, 8, 256, 512), (2, 32, 16, 512, 256), (1, 10, 6, 128, 256)])
 def test_conv_wide_tile_strided(case, tile, monkeypatch):

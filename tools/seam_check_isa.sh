@@ -1,5 +1,5 @@
 #!/bin/bash
-# The seam kernel (csrc/bottleneck_seam.hip) and the four-wave 3x3 kernel (csrc/conv3x3_fat.hip) name their AGPRs in inline asm;
+# The seam kernel (csrc/bottleneck_seam.hip) and the four-wave conv kernels (csrc/conv3x3_fat.hip, conv1x1_fat.hip) name their AGPRs in inline asm;
 # hipcc must therefore never touch an AGPR itself and never spill: this compiles both files for both 16-bit types and fails if a
 # kernel instance contains scratch accesses or v_accvgpr_* instructions outside the asm blocks.
 # usage: tools/seam_check_isa.sh [EXTRA hipcc flags]  (exit 0 = clean)
@@ -9,7 +9,7 @@ src=$PWD
 tmp=$(mktemp -d)
 trap 'rm -rf "$tmp"' EXIT
 rc=0
-for f in bottleneck_seam:bottleneck_seam_kernel conv3x3_fat:conv3x3_fat_kernel; do
+for f in bottleneck_seam:bottleneck_seam_kernel conv3x3_fat:conv3x3_fat_kernel conv1x1_fat:conv1x1_fat_kernel; do
   file=${f%%:*}; kern=${f##*:}
   for lp in 1 0; do
     (cd "$tmp" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DAGRL_LP_F16=$lp "$@" -I"$src" -c "$src/$file.hip" -o x.o -save-temps=obj 2>/dev/null)
