@@ -14,6 +14,22 @@
 //     once per wave and held while its four weight fragments pass, each replaced by its successor behind its last reader;
 //   * one barrier per slab (256 MFMAs per wave), placed where no wave has to wait for LDS data behind it (see BARRIER_AT).
 // M need not be a tile multiple: rows beyond M are staged from row M - 1 and not stored.
+//
+// Measured (rocprofv3 kernel durations, 256 frames of 16 x 8, fp16, tools/kernel_trace.sh tools/conv1x1_bench.py), this kernel /
+// igemm_wide_kernel: 2048 -> 512: 58.4 / 61.0 us; 1024 -> 512: 35.3 / 35.2; [1024 | 512] -> 2048: 176-186 / 192-206;
+// 1024 -> 256 (128 workgroups): 31.9 / 24.1; 512 -> 2048: 82.0 / 77.0. The model routes the first and third shape here.
+// With the loop's weight loads, pixel DMA and LDS reads all compiled out (-DFAT1_ABL=7) the 2048 -> 512 case still takes 49.4 us:
+// the MFMA stream itself, on random operands, runs at 1.78 PFLOP/s (tools/ubench/mfma_stream.hip; 2.39 on zeros) -- 38.7 us here.
+// Tried on top of it and withdrawn (round 4, same tool):
+//   * residual as two more slabs: the residual tile through the same LDS pipeline, multiplied by a 256 x 256 identity appended
+//     to each channel tile's weight stream (exact; no epilogue loads, no staging registers): correct, 512 -> 2048 + residual
+//     121.4 us against igemm_wide_kernel<0, 256, true>'s 114.9 -- the two extra slabs cost what the epilogue loads did;
+//   * a persistent form (one workgroup per CU walks its tiles, pixel pieces and weight fragments requested across tile
+//     boundaries, bias through a per-wave LDS copy, first products written with C = 0, epilogue stores counted in the next
+//     tile's first waits): correct, but 126 us (residual form) / 205.8 us (two-source form) against 121.4 / 186.8 for one
+//     workgroup per tile. Ablations of the persistent residual form: no pixel DMA -42 us, no stores -31, no weight loads -11,
+//     no LDS reads -5, none of them 73.4: the tile is bound by its 256 + 128 KB of DMA'd rows and 128 KB of stores per 31 us,
+//     not by per-tile start-up -- what a longer-lived workgroup cannot change.
 #include "fat_dev.h"
 
 namespace {

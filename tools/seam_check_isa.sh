@@ -9,7 +9,7 @@ src=$PWD
 tmp=$(mktemp -d)
 trap 'rm -rf "$tmp"' EXIT
 rc=0
-for f in bottleneck_seam:bottleneck_seam_kernel conv3x3_fat:conv3x3_fat_kernel conv1x1_fat:conv1x1_fat_kernel; do
+for f in bottleneck_seam:bottleneck_seam_kernel conv3x3_fat:conv3x3_fat_kernel conv1x1_fat:conv1x1_fat; do
   file=${f%%:*}; kern=${f##*:}
   for lp in 1 0; do
     (cd "$tmp" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DAGRL_LP_F16=$lp "$@" -I"$src" -c "$src/$file.hip" -o x.o -save-temps=obj 2>/dev/null)
