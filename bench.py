@@ -882,13 +882,13 @@ def main():
         # HBM traffic per launch: NOT measured in this run -- PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command, tools/collect_profiles.sh) are committed under profiles/ and quoted with their source
         traffic = fam_traffic = traffic_src = None
-        for tname in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath)).get(args.precision, {})
                     fam_traffic = tj.get("igemm_bytes_per_launch")
-                    k3 = tj.get("other_kernels", {}).get("conv3x3_wide_kernel")
+                    k3 = tj.get("other_kernels", {}).get("conv3x3_fat_kernel" if ops.conv3x3_packed_enabled() else "conv3x3_wide_kernel")
                     if k3:
                         traffic = k3["fetch_bytes_per_launch"] + (k3["write_bytes_per_launch"] or 0.0)
                     traffic_src = "profiles/%s (earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)" % tname

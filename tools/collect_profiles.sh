@@ -2,7 +2,7 @@
 # Round profile collection on the GPU box (run through gpurun): kernel-trace summary + the two PMC traffic passes of
 # the SAME bench command, then the bench line itself. Outputs under gpurun_out/prof_<round>/; copy the summaries into profiles/.
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/prof_$R
 mkdir -p $O
 CMD="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-accuracy --no-config5 --no-config4 --no-modes --sustain-seconds 0"

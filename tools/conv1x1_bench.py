@@ -12,6 +12,7 @@ from torchreid._hip import LP_DTYPE
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None   # run one shape of the list (PMC passes: one kernel name = one shape)
 dev = "cuda:0"
 
 
@@ -24,7 +25,9 @@ def timed(fn):
     return e0.elapsed_time(e1) * 1e3
 
 
-for k1, k2, cout in ((2048, 0, 512), (1024, 0, 512), (1024, 512, 2048), (1024, 0, 256), (512, 0, 2048)):
+for si, (k1, k2, cout) in enumerate(((2048, 0, 512), (1024, 0, 512), (1024, 512, 2048), (1024, 0, 256), (512, 0, 2048))):
+    if only is not None and si != only:
+        continue
     x = torch.relu(torch.randn((frames, 16, 8, k1), device=dev)).to(LP_DTYPE)
     x2 = torch.relu(torch.randn((frames, 16, 8, k2), device=dev)).to(LP_DTYPE) if k2 else None
     w = (torch.randn((cout, k1 + k2), device=dev) / (k1 + k2) ** 0.5).to(LP_DTYPE)

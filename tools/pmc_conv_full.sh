@@ -10,10 +10,10 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CY
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/c -o c --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/d -o d --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d $out/e -o e --output-format csv -- python3 ${PMC_SCRIPT:-tools/conv_one.py} "$@" > /dev/null 2>&1
-python3 - $out "$tag" "$*" > gpurun_out/pmc_$tag.txt <<'PY'
+python3 - $out "$tag" "$*" "${PMC_SCRIPT:-tools/conv_one.py}" > gpurun_out/pmc_$tag.txt <<'PY'
 import csv, sys, glob, collections
-out, tag, args = sys.argv[1], sys.argv[2], sys.argv[3]
-print("# rocprofv3 --pmc (5 passes) -- python3 tools/conv_one.py %s   [%s]" % (args, tag))
+out, tag, args, script = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+print("# rocprofv3 --pmc (5 passes) -- python3 %s %s   [%s]" % (script, args, tag))
 dur = collections.defaultdict(list)
 for f in sorted(glob.glob(out + "/*/*kernel_trace.csv")):
     for r in csv.DictReader(open(f)):

@@ -1,21 +1,22 @@
 """Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/traffic_r01.json (the conv
-family = every igemm_* / conv3x3_* / bottleneck_tail kernel).
+family = every igemm_* / conv3x3_* / conv1x1_fat / bottleneck_* kernel).
 usage: pmc_traffic.py <fetch_csv> <write_csv> <steps_total> <precision> [out.json]
 FETCH_SIZE / WRITE_SIZE are in KiB (x1024); on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide
 coalesced reads (MI355X_MICROARCH.md, HBM section) -> the read side is doubled."""
 import csv, json, sys, collections
 fetch_csv, write_csv, steps, prec = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r03.json"
+out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r04.json"
 def load(path, counter):
     per = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] != counter:
             continue
         name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "bottleneck_")) else name.split("(")[0][-40:]
-        if "conv3x3_wide_kernel" in name:   # the dominant kernel is also reported on its own
-            per["conv3x3_wide_kernel"][0] += float(row["Counter_Value"])
-            per["conv3x3_wide_kernel"][1] += 1
+        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "conv1x1_fat_kernel", "bottleneck_")) and "pack_kernel" not in name else name.split("(")[0][-40:]
+        for dom in ("conv3x3_wide_kernel", "conv3x3_fat_kernel"):   # the dominant kernel is also reported on its own
+            if dom in name:
+                per[dom][0] += float(row["Counter_Value"])
+                per[dom][1] += 1
         per[key][0] += float(row["Counter_Value"])
         per[key][1] += 1
     return per
@@ -25,9 +26,9 @@ launches = fi[1]
 fetch_b = fi[0] * 1024 * 2.0   # gfx950 correction for wide coalesced reads
 write_b = wi[0] * 1024
 extra = {}
-for k in ("graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "graph_apply_stream_kernel", "graph_tracklet_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel", "rank_topk_fast_kernel"):
+for k in ("graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "graph_apply_stream_kernel", "graph_tracklet_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel", "conv3x3_fat_kernel", "rank_topk_fast_kernel"):
     for kk in f:
-        if k in kk and not (k == "conv3x3_wide_kernel" and kk != k):
+        if k in kk and not (k in ("conv3x3_wide_kernel", "conv3x3_fat_kernel") and kk != k):
             extra[k] = {"fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
                         "write_bytes_per_launch": (w[kk][0] * 1024 / max(w[kk][1], 1)) if kk in w else None}
 out = {prec: {"igemm_launches": launches, "steps": steps, "other_kernels": extra,

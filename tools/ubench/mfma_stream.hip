@@ -3,6 +3,7 @@
 //   mode 0: v_mfma_f32_16x16x32_f16, accumulators in VGPRs (compiler-allocated)
 //   mode 1: the same, accumulators in asm-owned AGPRs (the form of conv3x3_fat.hip / bottleneck_seam.hip)
 //   mode 2: v_mfma_f32_32x32x16_f16, 16 accumulators of 16 AGPRs (asm-owned), half the instructions for the same FLOPs
+//   mode 3: mode 1 with 8 waves per workgroup (two per SIMD, 256 registers each) and the same work per SIMD
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/mfma_stream.hip -o gpurun_out/mfma_stream ; run: ./mfma_stream
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -29,8 +30,8 @@ template <int R> __device__ __forceinline__ float aread() { float x; asm volatil
 template <int R> __device__ __forceinline__ void azero() { asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"n"(R)); }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(const u32x4_t* __restrict__ src, float* __restrict__ dst, int iters) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(MODE == 3 ? 512 : 256) void k(const u32x4_t* __restrict__ src, float* __restrict__ dst, int iters) {
+    const int lane = threadIdx.x & 255;
     u32x4_t a[4], b[16];
     for (int i = 0; i < 4; ++i) a[i] = src[(blockIdx.x * 20 + i) * 256 + lane];
     for (int i = 0; i < 16; ++i) b[i] = src[(blockIdx.x * 20 + 4 + i) * 256 + lane];
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256) void k(const u32x4_t* __restrict__ src, float*
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8_t, a[q]), __builtin_bit_cast(h8_t, b[i]), acc[i], 0, 0, 0);
         }
         for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    } else if constexpr (MODE == 1) {
-        asm volatile("" ::: "a255");
+    } else if constexpr (MODE == 1 || MODE == 3) {
+        asm volatile("" ::: "a63");
         sfor<64>([&](auto r) { azero<decltype(r)::value>(); });
         for (int it = 0; it < iters; ++it) {
             sfor<4>([&](auto q) { sfor<16>([&](auto i) { mf16<decltype(i)::value>(a[decltype(q)::value], b[decltype(i)::value]); }); });
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void k(const u32x4_t* __restrict__ src, float*
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         sfor<256>([&](auto r) { s += aread<decltype(r)::value>(); });
     }
-    dst[blockIdx.x * 256 + lane] = s;
+    dst[blockIdx.x * 256 + lane] = s;  // (mode 3: the two waves of a SIMD write the same value)
 }
 
 int main() {
@@ -84,13 +85,14 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int zero = 0; zero < 2; ++zero) {
         if (zero) hipMemset(src, 0, h.size() * 4);
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             float best = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 hipEventRecord(e0);
                 if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblk), dim3(256), 0, 0, src, dst, iters);
                 if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nblk), dim3(256), 0, 0, src, dst, iters);
                 if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(nblk), dim3(256), 0, 0, src, dst, iters);
+                if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(nblk), dim3(512), 0, 0, src, dst, iters / 2);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (rep >= 2 && ms < best) best = ms;
