@@ -174,17 +174,13 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // AGRL_OPT_UNSET = the variable is not set -> the measured-best default applies. Flags are 1 when set to anything but "0".
 #define AGRL_OPT_UNSET (-2147483647 - 1)
 struct AgrlOpts {
-    int igemm_ns, igemm_bm, igemm_nw, igemm_wide, igemm_persist, igemm_wgs, igemm_wide_persist;  // AGRL_IGEMM_*
-    int igemm_no_w128, pool_persist;                                                             // flags
-    int conv3x3_generic, conv3x3_wide, conv3x3_c64;                                              // AGRL_CONV3X3_*
-    int distmat_tiled, distmat_ring;                                                             // flags
-    int gcn_lds, gcn_valu, gcn_nwv, gcn_split;                                                   // AGRL_GCN_*
-    int stem_wgs;
-    int wgrad_wgs;   // AGRL_WGRAD_WGS: workgroups the pixel-axis split of agrl_conv_wgrad aims for
+    int igemm_wide;      // AGRL_IGEMM_WIDE: 0 generic igemm, 1 auto -> wide, 2 / 3 force the 256 x 256 / 256 x 128 tile
+    int pool_persist;    // AGRL_POOL_PERSIST: fused pooling through the persistent igemm instead of the wide kernel
+    int conv3x3_wide, conv3x3_c64;   // AGRL_CONV3X3_{WIDE,C64}: two-block wide kernel / persistent 64-channel kernel on or off
+    int distmat_tiled;   // AGRL_DISTMAT_TILED: tiled igemm (+ split-K) instead of the streaming distance kernel
     int topk_radix;        // AGRL_TOPK_RADIX: every top-k through the five-pass radix kernel
     int graph_linear_mmajor;  // AGRL_GRAPH_LINEAR_MMAJOR: conv-style XCD map for agrl_graph_linear_mix
     int conv3x3_n128;         // AGRL_CONV3X3_N128: conv3x3_wide_kernel with 128-channel tiles also where 256-channel ones apply
-    int graph_linear_igemm;   // AGRL_GRAPH_LINEAR_IGEMM: agrl_graph_linear_mix through igemm_kernel also for bf16 operands
     int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library
 };
 const AgrlOpts& agrl_opts();

@@ -28,29 +28,15 @@ static int opt_flag(const char* name) {
 }
 static AgrlOpts load_opts() {
     AgrlOpts o;
-    o.igemm_ns = opt_int("AGRL_IGEMM_NS");
-    o.igemm_bm = opt_int("AGRL_IGEMM_BM");
-    o.igemm_nw = opt_int("AGRL_IGEMM_NW");
+    // the switches the kernel tests and the A/B tools flip; the tuning knobs of rounds 1-3 whose other setting was measured
+    // slower (ring depth, tile height, waves, workgroup counts, older message-pass / distance forms) were retired in round 4
     o.igemm_wide = opt_int("AGRL_IGEMM_WIDE");
-    o.igemm_persist = opt_int("AGRL_IGEMM_PERSIST");
-    o.igemm_wgs = opt_int("AGRL_IGEMM_WGS");
-    o.igemm_wide_persist = opt_int("AGRL_IGEMM_WIDE_PERSIST");
-    o.igemm_no_w128 = opt_flag("AGRL_IGEMM_NO_W128");
     o.pool_persist = opt_flag("AGRL_POOL_PERSIST");
-    o.conv3x3_generic = opt_flag("AGRL_CONV3X3_GENERIC");
     o.conv3x3_wide = opt_int("AGRL_CONV3X3_WIDE");
     o.conv3x3_c64 = opt_int("AGRL_CONV3X3_C64");
     o.distmat_tiled = opt_flag("AGRL_DISTMAT_TILED");
-    o.distmat_ring = opt_flag("AGRL_DISTMAT_RING");
-    o.gcn_lds = opt_flag("AGRL_GCN_LDS");
-    o.gcn_valu = opt_flag("AGRL_GCN_VALU");
-    o.gcn_nwv = opt_int("AGRL_GCN_NWV");
-    o.gcn_split = opt_flag("AGRL_GCN_SPLIT");
-    o.stem_wgs = opt_int("AGRL_STEM_WGS");
-    o.wgrad_wgs = opt_int("AGRL_WGRAD_WGS");
     o.topk_radix = opt_flag("AGRL_TOPK_RADIX");
     o.graph_linear_mmajor = opt_flag("AGRL_GRAPH_LINEAR_MMAJOR");
-    o.graph_linear_igemm = opt_flag("AGRL_GRAPH_LINEAR_IGEMM");
     o.conv3x3_n128 = opt_flag("AGRL_CONV3X3_N128");
 #ifdef AGRL_ABLATE
     o.igemm_dbg = agrl_opt_set(opt_int("AGRL_IGEMM_DBG")) ? opt_int("AGRL_IGEMM_DBG") : 0;

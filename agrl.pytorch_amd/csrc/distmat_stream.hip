@@ -295,7 +295,7 @@ int launch_distmat_stream(const IgemmParams& p_in, int dtype, hipStream_t stream
     IgemmParams p = p_in;
     p.vec_ok = (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
     if (dtype == AGRL_F32) return launch_stream<float>(p, stream);
-    if (p.M <= 32 && !agrl_opts().distmat_ring) {  // queries-in-registers form: D = 256 NS
+    if (p.M <= 32) {  // queries-in-registers form: D = 256 NS
         const int qf = p.M <= 16 ? 1 : 2;
 #define REGQ(NS_) return qf == 1 ? launch_regq<1, NS_>(p, stream) : launch_regq<2, NS_>(p, stream)
         if (p.K == 4096) REGQ(16);

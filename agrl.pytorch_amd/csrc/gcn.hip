@@ -1082,11 +1082,10 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
     const float omg_m = keep;
     const bool aligned = ((((uintptr_t)f | (uintptr_t)h | (uintptr_t)out | (uintptr_t)out_lp | (uintptr_t)bn_scale |
                             (uintptr_t)bn_shift) & 15) == 0);
-    if (V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned && (((uintptr_t)G) & 15) == 0 && !agrl_opts().gcn_lds) {
+    if (V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned && (((uintptr_t)G) & 15) == 0) {
         const int V4 = (V + 3) & ~3;
         const int nvf = (V + 15) / 16;
-        int nwv = (C % 256) == 0 ? 4 : 2;  // 4-wave workgroups: one wave per SIMD of a CU by construction
-        if (agrl_opts().gcn_nwv == 2) nwv = 2;
+        const int nwv = (C % 256) == 0 ? 4 : 2;  // 4-wave workgroups: one wave per SIMD of a CU by construction
         const size_t lds_s = (size_t)16 * nvf * V4 * sizeof(float) + 2048;  // padded fragment rows + DMA piece rounding + spare
 #define LAUNCH_PS(NT_)                                                                                                \
     case NT_:                                                                                                         \
@@ -1107,7 +1106,7 @@ extern "C" int agrl_graph_propagate(const float* f, const float* h, const float*
         AGRL_CHECK_LAUNCH("agrl_graph_propagate");
         return 0;
     }
-    if (V <= 128 && (C % 128) == 0 && !agrl_opts().gcn_valu) {
+    if (V <= 128 && (C % 128) == 0) {
         const int V4 = (V + 3) & ~3;
         const int hrows = (V4 + 1) & ~1;
         const int nvf = V <= 64 ? 4 : 8;

@@ -876,29 +876,18 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
                          (!p.res || (((uintptr_t)p.res) & 15) == 0) && (!p.colv || (((uintptr_t)p.colv) & 15) == 0);
     const bool narrow = p.N <= 64;
     // ring depth 2 at two workgroups per CU beats deeper rings at one (measured: 6.4 vs 9.1 ms per forward)
-    int ns = 2;
-    if (agrl_opt_set(opt.igemm_ns)) ns = opt.igemm_ns;
+    // (a 3-slot ring at one workgroup per CU and 4-wave workgroups were A/B switches until round 4: both measured slower)
     // short K loops (<= 2 k-tiles) are pure load->store latency chains: 64-row tiles halve the LDS footprint so
     // three workgroups fit a CU
     int bm = (p.K / BKE) <= 2 ? 64 : 128;
     if (cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128) < 400) bm = 64;  // too few 128-row tiles to fill 256 CUs twice
-    if (agrl_opt_set(opt.igemm_bm)) bm = opt.igemm_bm;
     const int grid = cdiv(p.M, bm) * cdiv(p.N, narrow ? 64 : 128);
-    int nw = 8;  // 8-wave workgroups (4 x 2 wave grid) beat 4-wave ones by 3-14 % at equal tile size (A/B measured)
-    if (agrl_opt_set(opt.igemm_nw)) nw = opt.igemm_nw;
+    // 8-wave workgroups (4 x 2 wave grid) beat 4-wave ones by 3-14 % at equal tile size (A/B measured)
 #define LAUNCH_IG(BM_, BN_, EPI_, NS_) \
-    do {                                                                                                          \
-        if (nw == 8)                                                                                              \
-            hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_, 8>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), \
-                               dim3(512), 0, stream, p);                                                          \
-        else                                                                                                      \
-            hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_, 4>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), \
-                               dim3(256), 0, stream, p);                                                          \
-    } while (0)
+    hipLaunchKernelGGL((igemm_kernel<TIN, TOUT, BM_, BN_, EPI_, NS_, 8>), dim3(grid, p.ksplit > 1 ? p.ksplit : 1), dim3(512), 0, stream, p)
 #define LAUNCH_NS(BN_, EPI_)                                  \
     do {                                                      \
         if (bm == 64) LAUNCH_IG(64, BN_, EPI_, 2);            \
-        else if (ns == 3) LAUNCH_IG(128, BN_, EPI_, 3);       \
         else LAUNCH_IG(128, BN_, EPI_, 2);                    \
     } while (0)
     bool done = false;
@@ -910,7 +899,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
             const int wtiles = cdiv(p.M, 256) * (p.N / 256);
             if (wide >= 1 || (wtiles >= 224 && p.K >= 256)) return launch_igemm_wide(p, stream, who);
             // N = 256 layers with long K (layer 3's 1024 -> 256): 256 x 128 tiles, one per CU
-            if (p.pool_nparts == 0 && p.N >= 256 && cdiv(p.M, 256) * (p.N / 128) >= 224 && p.K >= 512 && !opt.igemm_no_w128) return launch_igemm_wide(p, stream, who);
+            if (p.pool_nparts == 0 && p.N >= 256 && cdiv(p.M, 256) * (p.N / 128) >= 224 && p.K >= 512) return launch_igemm_wide(p, stream, who);
             if (p.pool_nparts > 0 && wide != 0 && wtiles >= 64 && !opt.pool_persist) return launch_igemm_wide(p, stream, who);
         }
     }
@@ -923,26 +912,18 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
         // persistent tiles pay off where a tile is short (<= 8 k-tiles): its first DMA round trip and its store
         // drain are a large share of the tile; long K loops run better as independent workgroups (A/B measured)
         int persist = (p.K / BKE) <= 8 ? 1 : 0;
-        if (agrl_opt_set(opt.igemm_persist)) persist = opt.igemm_persist;
         if (p.pool_nparts > 0) persist = 1;  // the fused pooling epilogue lives in the persistent kernel
         const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;
         if (lds_epi && persist && !p.rowv && pointwise) {
             const int ntiles = cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128);
-            int wgs = 512;  // two resident workgroups per CU
-            if (agrl_opt_set(opt.igemm_wgs)) wgs = opt.igemm_wgs;
+            const int wgs = 512;  // two resident workgroups per CU
             const int g = ntiles < wgs ? ntiles : wgs;
-            int pnw = 8;
-            if (agrl_opt_set(opt.igemm_nw)) pnw = opt.igemm_nw;
-            if (p.pool_nparts > 0) pnw = 8;  // the pooling epilogue exists for the 8-wave 128x128 instantiation only
-            if (p.pool_nparts > 0) {
+            if (p.pool_nparts > 0) {  // (the pooling epilogue exists for the 128 x 128 instantiation only)
                 AGRL_CHECK_ARG(!narrow, "%s: fused pooling needs more than 64 output channels", who);
                 hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 8, true>), dim3(g), dim3(512), 0, stream, p, ntiles);
-            } else if (pnw == 8) {
+            } else {
                 if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 8, false>), dim3(g), dim3(512), 0, stream, p, ntiles);
                 else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 8, false>), dim3(g), dim3(512), 0, stream, p, ntiles);
-            } else {
-                if (narrow) hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 64, 4, false>), dim3(g), dim3(256), 0, stream, p, ntiles);
-                else hipLaunchKernelGGL((igemm_persist_kernel<TIN, 128, 128, 4, false>), dim3(g), dim3(256), 0, stream, p, ntiles);
             }
             AGRL_CHECK_LAUNCH(who);
             return 0;
@@ -984,8 +965,7 @@ extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bia
     if (dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_conv2d_bn_act");
     const bool patch_ok = R == 3 && S == 3 && stride == 1 && pad == 1 && !residual && (H % 16) == 0 && (W % 8) == 0 &&
                           (Cin % 64) == 0 && (Cout % 8) == 0 && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) == 0 &&
-                          (!bias || (((uintptr_t)bias) & 15) == 0) && (size_t)N * H * W * Cin * 2 < (1ull << 32) &&
-                          !agrl_opts().conv3x3_generic;
+                          (!bias || (((uintptr_t)bias) & 15) == 0) && (size_t)N * H * W * Cin * 2 < (1ull << 32);
     if (patch_ok) {
         p.dbg = 0; p.vec_ok = 1;
         const int tiles = N * (H / 16) * (W / 8);
@@ -1118,8 +1098,8 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
     AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
     AGRL_CHECK_ARG((Nout % 4) == 0 && ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0),
                    "agrl_graph_linear_mix: Nout %% 4 == 0 and 16-byte aligned f / out / scale / shift required");
-    // bf16 operands: the kernel shaped for this problem (graph_gemm.hip); AGRL_GRAPH_LINEAR_IGEMM=1 keeps the generic one (A/B)
-    if (in_dtype == AGRL_LP16 && !agrl_opts().graph_linear_igemm && graph_gemm_applicable(M, K, Nout))
+    // 16-bit operands: the kernel shaped for this problem (graph_gemm.hip) where it applies
+    if (in_dtype == AGRL_LP16 && graph_gemm_applicable(M, K, Nout))
         return launch_graph_gemm(p_op, w, f, bn_scale, bn_shift, keep, gamma, slope, out, M, K, Nout, (hipStream_t)stream);
     IgemmParams p;
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;

@@ -585,7 +585,7 @@ int launch_igemm_wide(const IgemmParams& p, hipStream_t stream, const char* who)
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    const bool persist = opt.igemm_wide_persist != 0;
+    const bool persist = true;  // fewer workgroups than tiles: each walks its XCD's range (one workgroup per tile measured slower)
     const bool res = p.res != nullptr;
     if (half_n) {
         const int tiles = cdiv(p.M, WBM) * (p.N / 128);

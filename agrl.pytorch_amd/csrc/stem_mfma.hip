@@ -221,8 +221,7 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool_lp16(const float* x, const void* w
     const int tiles_h = cdiv(PH, PT), tiles_w = cdiv(PW, PT);
     const long long grid = (long long)N * tiles_h * tiles_w;
     AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_lp16: grid too large");
-    int wgs = 512;  // two persistent workgroups per CU (67 KB of LDS each)
-    if (agrl_opt_set(agrl_opts().stem_wgs) && agrl_opts().stem_wgs > 0) wgs = agrl_opts().stem_wgs;
+    const int wgs = 512;  // two persistent workgroups per CU (67 KB of LDS each)
     const unsigned launch = (unsigned)(grid < wgs ? grid : wgs);
     hipLaunchKernelGGL(stem_mfma_kernel, dim3(launch), dim3(NTH), 0, (hipStream_t)stream, x,
                        (const unsigned char*)w_packed, bias, (lp16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w,

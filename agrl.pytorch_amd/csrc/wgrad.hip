@@ -227,7 +227,7 @@ static WgradPlan wgrad_plan(int Mtot, int Cin, int Cout, int taps, int dtype) {
     pl.n_tiles = cdiv(Cin, pl.bn);
     pl.nk = cdiv(Mtot, 32);
     const int tiles = pl.m_tiles * pl.n_tiles * taps;
-    const int target = agrl_opt_set(agrl_opts().wgrad_wgs) ? agrl_opts().wgrad_wgs : wgrad_capacity(dtype, pl.bm, pl.bn);
+    const int target = wgrad_capacity(dtype, pl.bm, pl.bn);
     // slice count: fill whole resident rounds (at most three) as evenly as the tile count allows -- 144 tiles on 512 slots: 3 slices
     // fill 84 % of one round, 7 slices 98 % of two
     int ks_max = pl.nk / 4;               // at least four k-tiles per slice

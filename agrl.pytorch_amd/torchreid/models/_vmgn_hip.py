@@ -228,16 +228,6 @@ def hip_featuremaps(model, frames, pack):
     return x4_1, x4_2
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
-
-
 def hip_features_pooled(model, frames, pack, splits, want_lp=True):
     """Conv stages with the global / part pooling fused into the last conv of each layer4 branch (bf16, 16x8 maps):
     -> gsum (F,C) per-frame sums, nodes (F,P,C) fp32, nodes_lp bf16, hw. None when the fusion does not apply."""
@@ -255,38 +245,16 @@ def hip_features_pooled(model, frames, pack, splits, want_lp=True):
     a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))
     assert a.shape[1] == 16 and a.shape[2] == 8
     splits = list(splits)
-    if not model.hip_branch_streams:
-        x4_1 = a
-        for blk in pack['l4_1'][:-1]:
-            x4_1 = _run_block(x4_1, blk)
-        gsum, _ = _run_block(x4_1, pack['l4_1'][-1], pool=([1], False, False))
-        x4_2 = a
-        for blk in pack['l4_2'][:-1]:
-            x4_2 = _run_block(x4_2, blk)
-        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, want_lp))
-    else:
-        # the two layer4 branches are independent: run the global branch on a side stream so its memory-heavy
-        # kernels (conv3 + residual) overlap the other branch's MFMA-heavy ones (3x3) on the same CUs
-        main = torch.cuda.current_stream(a.device)
-        side = _side_stream(a.device)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            x4_1 = a
-            for blk in pack['l4_1'][:-1]:
-                x4_1 = _run_block(x4_1, blk)
-            gsum, _ = _run_block(x4_1, pack['l4_1'][-1], pool=([1], False, False))
-            del x4_1
-            done = torch.cuda.Event()
-            done.record(side)
-        a.record_stream(side)
-        x4_2 = a
-        for blk in pack['l4_2'][:-1]:
-            x4_2 = _run_block(x4_2, blk)
-        nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, want_lp))
-        main.wait_event(done)
-        gsum.record_stream(main)
+    # (the two branches on two HIP streams, and the graph matrix on a side stream under the Linear, were options until round 4:
+    # both measured no faster -- every kernel here fills the chip -- and were retired)
+    x4_1 = a
+    for blk in pack['l4_1'][:-1]:
+        x4_1 = _run_block(x4_1, blk)
+    gsum, _ = _run_block(x4_1, pack['l4_1'][-1], pool=([1], False, False))
+    x4_2 = a
+    for blk in pack['l4_2'][:-1]:
+        x4_2 = _run_block(x4_2, blk)
+    nodes, nodes_lp = _run_block(x4_2, pack['l4_2'][-1], pool=(splits, True, want_lp))
     return gsum.view(gsum.shape[0], gsum.shape[2]), nodes, nodes_lp, 128
 
 
@@ -299,16 +267,11 @@ def gcn_commute_enabled(model=None):
     return os.environ.get('AGRL_HIP_GCN_COMMUTE', '1') != '0'
 
 
-def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, commute=True):
-    """GraphLayer x num_gb on (B,V,C) fp32 nodes. reference vmgn.py:311-312 -> :142-172.
-    ``overlap``: the adaptive graph (Gram partials + finalize: 2 short latency-bound launches) is built on a side HIP stream
-    while the Linear (a 448-workgroup GEMM that does not fill the chip either) runs on the main one -- both only read the
-    layer's input nodes; the message pass joins them."""
+def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, commute=True):
+    """GraphLayer x num_gb on (B,V,C) fp32 nodes. reference vmgn.py:311-312 -> :142-172."""
     lp = pack['dtype'] == ops.LP_DTYPE
     B, V, C = nodes.shape
     n_layers = len(pack['graph'])
-    main = torch.cuda.current_stream(nodes.device)
-    side = _side_stream(nodes.device) if overlap else None
     for i, g in enumerate(pack['graph']):
         if commute:
             # G (f W^T) = (G f) W^T: graph -> P = G f (written once, in the GEMM's operand dtype) -> ONE GEMM whose epilogue
@@ -325,22 +288,8 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, overlap=False, com
         if lp and nodes_lp is None:   # A/B form entered without the pooled bf16 copy: native conversion kernel
             nodes_lp = ops.row_l2_normalize(nodes.view(B * V, C), False, ops.LP_DTYPE).view(B, V, C)
         operand = nodes_lp if lp else nodes
-        if side is not None:
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
-                done = torch.cuda.Event()
-                done.record(side)
-            nodes.record_stream(side)
-            adj.record_stream(side)
-            h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
-            main.wait_event(done)
-            G.record_stream(main)
-        else:
-            h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
-            G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
+        h = ops.linear_nobias(operand.view(B * V, C), g['w']).view(B, V, C)
+        G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
         if stages is not None:
             stages['G%d' % i] = G
         nodes, nodes_lp = ops.graph_propagate(nodes, h, G, g['scale'], g['shift'], g['gamma'], g['slope'],
@@ -383,7 +332,7 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
         adj32 = adj.detach().contiguous() if packed_adj else adj.detach().to(torch.float32).contiguous()
         if stages is not None:
             stages.update(gsum=gsum, hw=hw, nodes=nodes)
-        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages, overlap=getattr(model, 'hip_gcn_overlap', False), commute=commute)
+        nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages, commute=commute)
         sqn = ops.row_sqnorm(nodes.view(B * V, C))
         res = ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
                                    pack['a_bn'][1], B, S, P, hw, want_feats=return_feats or stages is not None)

@@ -179,11 +179,7 @@ class GSTA(nn.Module):
         _ops.check_precision(self.hip_precision)
         self.hip_static_weights = False
         self.hip_fuse_pool = os.environ.get('AGRL_HIP_FUSE_POOL', '1') != '0'
-        self.hip_branch_streams = os.environ.get('AGRL_HIP_BRANCH_STREAMS', '0') != '0'
         self.hip_fuse_tail = os.environ.get('AGRL_HIP_FUSE_TAIL', '1') != '0'
-        # graph matrix on a side stream under the Linear: measured 3.79 -> 3.82 ms per step (both fill the chip; the concurrent
-        # kernels only slow each other down: gram 12.7 -> 20.8 us, finalize 7.7 -> 12.9 us) -- off
-        self.hip_gcn_overlap = os.environ.get('AGRL_HIP_GCN_OVERLAP', '0') != '0' 
         self.hip_train = os.environ.get('AGRL_HIP_TRAIN', '1') != '0'   # train-mode conv trunk (fwd + bwd) on the HIP kernels
         self.hip_train_precision = os.environ.get('AGRL_HIP_TRAIN_PRECISION', 'fp32')   # 'fp32' exact | 'bf16x3' split-bf16 MFMA
         self.hip_train_tail = os.environ.get('AGRL_HIP_TRAIN_TAIL', '1') != '0'         # tail of the train forward native as well

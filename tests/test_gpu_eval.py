@@ -146,21 +146,23 @@ def test_re_rank_branch_matches_oracle_pipeline(world):
     print("re-rank branch: mAP %.6f (oracle %.6f) rank-1 %.4f (oracle %.4f)" % (mAP, map_ref, cmc[0], cmc_ref[0]))
 
 
-def test_out_of_range_activations_fail_loudly_in_the_16_bit_mode():
-    """fp16 build: a checkpoint whose activations leave fp16's range (here: the stem's folded BatchNorm scaled by 1e6) gives
-    inf / nan embeddings; extract_features refuses them instead of ranking garbage. The bf16 build has fp32's range and passes."""
+@pytest.mark.parametrize("factor, message", [(3e4, "fp16's range"), (1e6, "overflow fp16")])
+def test_out_of_range_activations_fail_loudly_in_the_16_bit_mode(factor, message):
+    """fp16 build: a checkpoint whose activations leave fp16's range (the stem's folded BatchNorm scaled by 3e4) gives inf / nan
+    embeddings and extract_features refuses them instead of ranking garbage; one whose FOLDED WEIGHTS already overflow (scaled
+    by 1e6) is refused at pack time with the layer named. The bf16 build has fp32's range and passes both."""
     from torchreid import evaluation, models
     m = models.init_model("vmgn", num_classes=4, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
                           pyramid_part=True, use_pose=True, learn_graph=True)
     sd = recipe_state_dict(m.state_dict(), seed=0)
-    sd["bn1.weight"] = sd["bn1.weight"] * 1e6
+    sd["bn1.weight"] = sd["bn1.weight"] * factor
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
     m.hip_precision = LP16
     x, adj = synthetic_clips(2, 4, seed=3), synthetic_adj(2, 4, seed=3)
     batch = [(x, np.zeros(2, dtype=np.int64), np.zeros(2, dtype=np.int64), adj)]
     if LP16 == "fp16":
-        with pytest.raises(FloatingPointError, match="fp16's range"):
+        with pytest.raises(FloatingPointError, match=message):
             evaluation.extract_features(m, batch, prefetch=False)
     else:
         f, _, _ = evaluation.extract_features(m, batch, prefetch=False)
