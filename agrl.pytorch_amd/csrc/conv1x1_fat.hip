@@ -29,7 +29,15 @@
 //     tile's first waits): correct, but 126 us (residual form) / 205.8 us (two-source form) against 121.4 / 186.8 for one
 //     workgroup per tile. Ablations of the persistent residual form: no pixel DMA -42 us, no stores -31, no weight loads -11,
 //     no LDS reads -5, none of them 73.4: the tile is bound by its 256 + 128 KB of DMA'd rows and 128 KB of stores per 31 us,
-//     not by per-tile start-up -- what a longer-lived workgroup cannot change.
+//     not by per-tile start-up -- what a longer-lived workgroup cannot change;
+//   * the residual in registers (first channel half requested before the main loop, second half behind it into the registers the
+//     pixel fragments leave; added behind the bias: bit-identical to conv_bn_act(residual=...)) and, on top, the frame pooling of
+//     agrl_conv1x1_bn_act_pool from the accumulators (wave-local bins, 16-lane shuffles): correct (stored map equal bit for bit,
+//     pooled sums to 7e-8), 512 -> 2048 + residual 119.4 us against igemm_wide_kernel<0, 256, true>'s 115.8, pooled 175.0
+//     against igemm_wide_kernel<16384, 256, true>'s 106.7.
+// Four designs for conv3 + residual of layer 4 (8-wave LDS ring, this kernel with the residual as slabs / in registers /
+// persistent, the back-to-back seam kernel) land within 5 % of each other at 2.6 TB/s of HBM traffic: 300 MB per launch, half of
+// it written, with 33 MB of operand rows re-read through L2 by eight channel tiles.
 #include "fat_dev.h"
 
 namespace {
