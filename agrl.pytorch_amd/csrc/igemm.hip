@@ -905,7 +905,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     }
     if constexpr (sizeof(TIN) == 2 && sizeof(TOUT) == 4) {
         // the full query x gallery distance matrix (BASELINE configs[4]): 256 x 256 tiles once they cover the chip
-        if (opt.igemm_wide != 0 && !agrl_opts().distmat_tiled && igemm_wide_f32out_applicable(p) && cdiv(p.M, 256) * cdiv(p.N, 256) >= 224 && p.K >= 512)
+        if (opt.igemm_wide != 0 && !agrl_opts().distmat_tiled && igemm_wide_f32out_applicable(p) && cdiv(p.M, 256) * cdiv(p.N, 256) >= 160 && p.K >= 512)
             return launch_igemm_wide_f32out(p, stream, who);
     }
     if constexpr (sizeof(TOUT) == 2) {
