@@ -19,7 +19,8 @@
 // Measured (rocprofv3 kernel durations, 256 frames, fp16, tools/kernel_trace.sh tools/conv3x3_bench.py; this kernel / conv3x3_wide_kernel):
 // 512 -> 512 on 16 x 8: 103-120 / 121-132 us; 256 -> 256: 35 / 40 us. A 128-channel-tile variant (waves 2 x 2) for layer 2's
 // 128 -> 128 convs on 32 x 16 maps was built (bit-identical) and withdrawn: 45.9 us against conv3x3_patch_kernel's 45.3 -- two
-// 64-channel slabs per tile are over before the pipeline has paid for its prologue.
+// 64-channel slabs per tile are over before the pipeline has paid for its prologue. The same variant on layer 3 (256 pixels x 128
+// channels, so that the two waves of a channel half fetch each weight fragment together): 37.1-37.3 us against 35.8-37.2.
 // Waits are hand-counted (every load is inline asm; hipcc's own waits would drain the ring) from a constexpr simulation of
 // one slab's issue order.
 #include "fat_dev.h"
