@@ -73,9 +73,14 @@ def _claim(pending, main):
 
 
 @torch.no_grad()
-def extract_features(model, batches, pool="avg", prefetch=True):
+def extract_features(model, batches, pool="avg", prefetch=True, sync_ranks=False):
     """``batches`` yields (imgs, pids, camids, adj) like the reference's loaders; imgs is (b,S,3,H,W) or, for the
-    dense samplers, (b,n,S,3,H,W) with adj (b,n,V,V). Returns (features (N,D) on the model's device, pids, camids)."""
+    dense samplers, (b,n,S,3,H,W) with adj (b,n,V,V). Returns (features (N,D) on the model's device, pids, camids).
+
+    No collective by default: the call is safe on one rank of an initialised process group (a rank-0-only ``evaluate``).
+    ``sync_ranks=True`` is for the sharded form, where EVERY rank extracts its slice and then meets the others in
+    ``match_and_rank``: the non-finite flag is all-reduced (MAX) -- by every rank, whatever device its model is on, so the
+    ranks cannot diverge -- and all of them raise together instead of one leaving the rest blocked in the next collective."""
     device = next(model.parameters()).device
     model.eval()
     feats, pids, camids = [], [], []
@@ -100,11 +105,10 @@ def extract_features(model, batches, pool="avg", prefetch=True):
     # One check per extraction, on the RAW model outputs (before the dense samplers' clip pooling): the fp16 build stores
     # activations with a range of 65504 -- a checkpoint whose activations leave it yields inf / nan embeddings, and ranking those
     # would be silent garbage. (Nothing on this path comes near the limit with the recipe or with trained ResNet50 statistics.)
-    # Under a process group the flag is all-reduced (MAX) first, so that every rank raises instead of one rank leaving the others
-    # blocked in the next collective.
-    if nonfinite is not None:
-        flag = nonfinite.to(torch.int32).reshape(1)
-        if parallel.world_size() > 1:
+    sync = sync_ranks and parallel.world_size() > 1
+    if nonfinite is not None or sync:
+        flag = (nonfinite.to(torch.int32) if nonfinite is not None else torch.zeros((), dtype=torch.int32, device=out.device)).reshape(1)
+        if sync:   # every rank takes part, also one whose features came from the CPU path (flag 0)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
         if bool(flag.item()):
             from torchreid import _hip
@@ -170,7 +174,9 @@ def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosi
 def evaluate(model, query_batches, gallery_batches, dist_metric="cosine", pool="avg", max_rank=50,
              ranks=(1, 5, 10, 20), verbose=False, re_rank=False):
     """Single-process form of the reference's ``test()``: returns (rank1, mAP) and, like the reference, can print the
-    CMC table. For the sharded form run ``extract_features`` on each rank's slice and call ``match_and_rank``."""
+    CMC table. Issues no collective (callable from one rank of a process group, provided the gallery is whole: ``match_and_rank``
+    shards by rank as soon as a group is initialised). For the sharded form run ``extract_features(..., sync_ranks=True)`` on each
+    rank's slice and call ``match_and_rank`` on every rank."""
     qf, q_pids, q_camids = extract_features(model, query_batches, pool)
     gf, g_pids, g_camids = extract_features(model, gallery_batches, pool)
     cmc, mAP = match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric, max_rank,

@@ -303,6 +303,49 @@ def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None):
     return out
 
 
+def conv1x1_duo_enabled():
+    """AGRL_HIP_CONV1X1_DUO=0 runs layer 4's conv3 + residual (and the pool-fused last conv) through conv_bn_act /
+    conv1x1_bn_act_pool (A/B; bit-identical results)."""
+    return os.environ.get('AGRL_HIP_CONV1X1_DUO', '1') != '0'
+
+
+def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
+    """act(x @ W^T + bias + residual) over pixel rows, weights from conv1x1_pack: conv3 / bn3 + identity shortcut + ReLU of a
+    Bottleneck (vmgn.py:56-64) through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip). -> (N,H,W,Cout) 16-bit NHWC."""
+    N, H, W, K = x.shape
+    M = N * H * W
+    assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * K * Cout
+    assert residual is None or (residual.dtype == x.dtype and residual.is_contiguous() and tuple(residual.shape) == (N, H, W, Cout))
+    out = torch.empty((N, H, W, Cout), dtype=x.dtype, device=x.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * K * Cout,
+                            "bytes": 2.0 * (x.numel() + out.numel() * (2 if residual is not None else 1)) + packed.numel(),
+                            "conv": (1, 1, K, Cout, H, W)}
+    with _dev(x):
+        call("agrl_conv1x1_packed_res_bn_act", ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(out), M, K, Cout, 1 if relu else 0,
+             _stream(x))
+    return out
+
+
+def conv1x1_packed_res_pool(x, packed, bias, Cout, residual, splits, mean, want_lp, relu=True):
+    """conv1x1_bn_act_pool through the two-workgroups-per-CU kernel with weights from conv1x1_pack: last conv of a layer-4 branch,
+    16 x 8 frames, the 2048-channel map never written. -> pooled fp32 (F, P, Cout) [, 16-bit copy]. vmgn.py:56-64 + :298-308."""
+    N, H, W, K = x.shape
+    assert x.dtype == LP_DTYPE and x.is_contiguous() and (H, W) == (16, 8) and packed.numel() == 2 * K * Cout
+    assert residual is None or (residual.dtype == x.dtype and residual.is_contiguous() and tuple(residual.shape) == (N, H, W, Cout))
+    P = int(sum(splits))
+    pooled = torch.empty((N, P, Cout), dtype=torch.float32, device=x.device)
+    pooled_lp = torch.empty((N, P, Cout), dtype=LP_DTYPE, device=x.device) if want_lp else None
+    arr = (C.c_int * len(splits))(*[int(s) for s in splits])
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * Cout * K,
+                            "bytes": 2.0 * (x.numel() + (residual.numel() if residual is not None else 0)) + packed.numel() + 4.0 * pooled.numel()}
+    with _dev(x):
+        call("agrl_conv1x1_packed_res_pool", ptr(x), ptr(packed), ptr(bias), ptr(residual), None, ptr(pooled), ptr(pooled_lp),
+             N, H, W, K, Cout, 1 if relu else 0, arr, len(splits), 1 if mean else 0, _stream(x))
+    return pooled, pooled_lp
+
+
 def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
     """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 and layer-2 shapes in bf16. ``shortcut_conv`` =
     (weight, stride) of the block's downsample conv when the residual is to be computed in the same pass."""

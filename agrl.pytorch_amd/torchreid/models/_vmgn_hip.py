@@ -76,11 +76,16 @@ def _pack_stage(stage, dtype, seam=False):
                 cout = blk['c3'][0].shape[0]
                 blk['dual'] = (torch.cat([blk['ds'][0].view(cout, -1), blk['c3'][0].view(cout, -1)], dim=1).contiguous(),
                                (blk['ds'][1] + blk['c3'][1]).contiguous())
-                if ops.conv1x1_packed_supported(blk['dual'][0]) and blk['dual'][0].shape[1] >= 1536:
+                if (ops.conv1x1_packed_supported(blk['dual'][0]) and blk['dual'][0].shape[1] >= 1536
+                        and blk['ds'][0].shape[3] % 128 == 0 and blk['c3'][0].shape[3] % 128 == 0):   # K1, K2 % 128 each
                     blk['dualp'] = ops.conv1x1_pack(blk['dual'][0])     # the same GEMM through the four-wave kernel
         if dtype == ops.LP_DTYPE and ops.conv1x1_packed_supported(blk['c1'][0]) and blk['c1'][0].shape[3] >= 2048:
             # layer 4's 2048 -> 512 convs: the shape where the four-wave kernel is ahead of the 8-wave tile (ops.conv1x1_packed)
             blk['c1p'] = ops.conv1x1_pack(blk['c1'][0])
+        if (dtype == ops.LP_DTYPE and blk['ds'] is None and ops.conv1x1_packed_supported(blk['c3'][0])
+                and blk['c3'][0].shape[0] >= 2048):
+            # layer 4's 512 -> 2048 conv3 + identity shortcut (+ the pool-fused last conv): two workgroups per CU (ops.conv1x1_packed_res)
+            blk['c3p'] = ops.conv1x1_pack(blk['c3'][0])
         if dtype == ops.LP_DTYPE and blk['stride'] == 1 and ops.conv3x3_packed_supported(blk['c2'][0]):
             # layers 3 / 4: the 3x3 weights as per-wave fragment streams for the four-wave kernel (ops.conv3x3_packed)
             blk['c2p'] = ops.conv3x3_pack(blk['c2'][0])
@@ -202,13 +207,19 @@ def _run_block(x, blk, pool=None):
     return the pooled tensors instead of the activation map (which is then never written to HBM)."""
     y = _conv1(x, blk)
     y = _conv2(y, blk)
-    if pool is None and 'dualp' in blk and ops.conv1x1_packed_enabled() and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0':
+    if (pool is None and 'dualp' in blk and ops.conv1x1_packed_enabled() and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0'
+            and x.shape[:3] == y.shape[:3] and x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()):
         return ops.conv1x1_packed(x, blk['dualp'], blk['dual'][1], blk['dual'][0].shape[0], True, x2=y)
     if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
         return ops.conv1x1_dual(x, y, blk['dual'][0], blk['dual'][1], True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
+    duo = 'c3p' in blk and blk['ds'] is None and ops.conv1x1_duo_enabled() and shortcut.is_contiguous() and y.is_contiguous()
     if pool is not None:
+        if duo and tuple(y.shape[1:3]) == (16, 8):
+            return ops.conv1x1_packed_res_pool(y, blk['c3p'], blk['c3'][1], blk['c3'][0].shape[0], shortcut, pool[0], pool[1], pool[2])
         return ops.conv1x1_bn_act_pool(y, blk['c3'][0], blk['c3'][1], shortcut, pool[0], pool[1], pool[2])
+    if duo:
+        return ops.conv1x1_packed_res(y, blk['c3p'], blk['c3'][1], blk['c3'][0].shape[0], shortcut)
     return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)
 
 

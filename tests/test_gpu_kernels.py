@@ -364,6 +364,100 @@ def test_conv1x1_packed(case):
         ops.call("agrl_conv1x1_packed_bn_act", ops.ptr(dx), None, ops.ptr(packed), ops.ptr(b.to(DEV)), ops.ptr(out), N * H * W, K1 + 64, 0, Cout, 1, None)
 
 
+DUO_CASES = [(256, 16, 8, 512, 2048, True, True), (1, 16, 8, 512, 2048, True, True), (3, 10, 6, 128, 256, True, False),
+             (37, 16, 8, 256, 1024, True, True), (5, 16, 8, 384, 512, False, True)]
+
+
+@pytest.mark.parametrize("stagger", ["default", "0"])
+@pytest.mark.parametrize("case", DUO_CASES)
+def test_conv1x1_packed_res(case, stagger, monkeypatch):
+    """conv3 + identity shortcut + ReLU through the two-workgroups-per-CU kernel (conv1x1_duo.hip) against the fp32 reference and
+    against conv_bn_act(residual=...) (same summation order, same order of bias / residual / ReLU / rounding: equal bit for bit).
+    The full layer-4 shape (2048 tiles: four resident rounds), one frame (8 tiles), a ragged 180-row map without ReLU, an odd tile
+    count, no residual with three slabs; with the second round's start delay and without it. Every call twice."""
+    from torchreid import hip_ops as ops
+    N, H, W, K, Cout, use_res, relu = case
+    if stagger == "0":
+        monkeypatch.setenv("AGRL_DUO_STAGGER", "0")
+        _hip.reload_options()
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn((N, K, H, W), generator=g).relu().to(LP_DTYPE).float()
+    w = (torch.randn((Cout, K, 1, 1), generator=g) / np.sqrt(K)).to(LP_DTYPE).float()
+    b = torch.randn((Cout,), generator=g)
+    res = torch.randn((N, Cout, H, W), generator=g).to(LP_DTYPE).float() if use_res else None
+    dx = nhwc(x, LP_DTYPE)
+    dw = w.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    dres = None if res is None else nhwc(res, LP_DTYPE)
+    packed = ops.conv1x1_pack(dw)
+    ref = F.conv2d(x.to(DEV), w.to(DEV), bias=b.to(DEV))
+    if res is not None:
+        ref = ref + res.to(DEV)
+    ref = F.relu(ref) if relu else ref
+    out = ops.conv1x1_packed_res(dx, packed, b.to(DEV), Cout, dres, relu)
+    out_b = ops.conv1x1_packed_res(dx, packed, b.to(DEV), Cout, dres, relu)
+    other = ops.conv_bn_act(dx, dw, b.to(DEV), 1, 0, relu, residual=dres)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("AGRL_DUO_STAGGER", raising=False)
+    _hip.reload_options()
+    e = rel_err(out.float().permute(0, 3, 1, 2).cpu(), ref.cpu())
+    print("conv1x1 duo", case, stagger, "vs fp32 %.3e | max |duo - conv_bn_act| %.3e" % (e, (out.float() - other.float()).abs().max().item()))
+    assert e < (3e-3 if LP_DTYPE == torch.float16 else 2e-2), e
+    assert torch.equal(out, out_b)
+    assert torch.equal(out, other)
+    with pytest.raises(_hip.HipKernelError):
+        ops.call("agrl_conv1x1_packed_res_bn_act", ops.ptr(dx), ops.ptr(packed), ops.ptr(b.to(DEV)), None, ops.ptr(out), N * H * W, K + 64, Cout, 1, None)
+
+
+@pytest.mark.parametrize("cfg", [(256, 512, 2048, [4, 2, 1], True), (256, 512, 2048, [1], False), (3, 128, 256, [4, 2, 1], True),
+                                 (9, 256, 512, [2, 1], True)])
+def test_conv1x1_packed_res_pool(cfg):
+    """The pool-fused last conv of a layer-4 branch through the two-workgroups-per-CU kernel: pooled sums / means and the 16-bit copy
+    equal BIT FOR BIT to agrl_conv1x1_bn_act_pool's (igemm_wide_kernel's pooled epilogue: same rounded activations, same order of
+    the quarter sums), and the optional stored map equal to conv_bn_act's."""
+    from torchreid import hip_ops as ops
+    N, Cin, Cout, splits, mean = cfg
+    g = torch.Generator().manual_seed(N + Cin)
+    x = torch.randn((N, 16, 8, Cin), generator=g).relu().to(LP_DTYPE).to(DEV)
+    w = (torch.randn((Cout, 1, 1, Cin), generator=g) / np.sqrt(Cin)).to(LP_DTYPE).to(DEV)
+    b = torch.randn((Cout,), generator=g).to(DEV)
+    res = torch.randn((N, 16, 8, Cout), generator=g).to(LP_DTYPE).to(DEV)
+    packed = ops.conv1x1_pack(w)
+    pooled, pooled_lp = ops.conv1x1_packed_res_pool(x, packed, b, Cout, res, splits, mean, True)
+    pooled_b, _ = ops.conv1x1_packed_res_pool(x, packed, b, Cout, res, splits, mean, False)
+    ref, ref_lp = ops.conv1x1_bn_act_pool(x, w, b, res, splits, mean, True)
+    act = ops.conv_bn_act(x, w, b, 1, 0, True, residual=res)
+    torch.cuda.synchronize()
+    a = act.float().cpu()
+    parts = []
+    for n in splits:
+        for j in range(n):
+            lo, hi = (j * 16) // n, -(-((j + 1) * 16) // n)
+            blk = a[:, lo:hi].reshape(N, -1, Cout)
+            parts.append(blk.mean(1) if mean else blk.sum(1))
+    e = rel_err(pooled, torch.stack(parts, 1))
+    print("duo pool conv", cfg, "rel err vs pooled conv_bn_act map %.3e" % e)
+    assert e < 1e-5
+    assert torch.equal(pooled, pooled_b)
+    if N >= 64:   # agrl_conv1x1_bn_act_pool through igemm_wide_kernel (small maps take the persistent igemm: another order of the sums)
+        assert torch.equal(pooled, ref) and torch.equal(pooled_lp, ref_lp)
+    else:
+        assert rel_err(pooled, ref) < 1e-6 and rel_err(pooled_lp.float(), ref_lp.float()) < 2e-3
+    # the optional map store
+    out = torch.empty_like(act)
+    P = int(sum(splits))
+    pooled_c = torch.empty((N, P, Cout), dtype=torch.float32, device=DEV)
+    import ctypes as C
+    arr = (C.c_int * len(splits))(*splits)
+    ops.call("agrl_conv1x1_packed_res_pool", ops.ptr(x), ops.ptr(packed), ops.ptr(b), ops.ptr(res), ops.ptr(out), ops.ptr(pooled_c), None,
+             N, 16, 8, Cin, Cout, 1, arr, len(splits), 1 if mean else 0, None)
+    torch.cuda.synchronize()
+    assert torch.equal(out, act) and torch.equal(pooled_c, pooled)
+    with pytest.raises(_hip.HipKernelError):   # bins that are not whole quarters
+        arr3 = (C.c_int * 1)(3)
+        ops.call("agrl_conv1x1_packed_res_pool", ops.ptr(x), ops.ptr(packed), ops.ptr(b), ops.ptr(res), None, ops.ptr(pooled_c), None,
+                 N, 16, 8, Cin, Cout, 1, arr3, 1, 1, None)
+
+
 @pytest.mark.parametrize("tile", ["2", "3"])
 @pytest.mark.parametrize("case", [(3, 16, 8, 256, 512), (2, 32, 16, 512, 256), (1, 10, 6, 128, 256)])
 def test_conv_wide_tile_strided(case, tile, monkeypatch):

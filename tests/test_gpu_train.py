@@ -381,7 +381,7 @@ def test_trunk_backward_at_the_fp32_noise_floor(shape):
     functional of the two layer-4 maps. Fifty conv + batch-statistics-BatchNorm layers make these gradients sums of large
     cancelling terms (a conv weight followed by BatchNorm has no gradient along its own direction), so in fp32 they carry
     percent-level noise whatever computes them: the stock module tree on the CPU is 1e-2 (median) / 1e-1 (worst) away from the
-    same computation in float64, stock torch on the GPU likewise (tools/dbg_trunk.py). Asserted: the feature maps agree with
+    same computation in float64, stock torch on the GPU likewise. Asserted: the feature maps agree with
     float64 like the CPU's do, and the native gradients' error distribution against float64 is within 3 x the CPU fp32's."""
     import copy
     from torchreid.models._train_hip import featuremaps_train
@@ -427,7 +427,7 @@ def test_train_step_loss_and_gradients_at_the_reference_noise_floor(shape):
     model are ill-conditioned in fp32 whatever computes them: GraphLayer.get_sim_matrix takes sqrt(clamp(d2, 1e-12)) of a
     diagonal d2_ii that is pure cancellation noise (vmgn.py:114-120), and the gradient of sqrt at ~1e-4 amplifies that
     noise -- the reference's own CPU fp32 step is 1-5 % away from the same step in float64, and so is stock torch on the
-    GPU (tools/dbg_train.py). Parity is therefore asserted at that floor: against the float64 CPU step the native step's
+    GPU. Parity is therefore asserted at that floor: against the float64 CPU step the native step's
     error distribution (median, 90th percentile, worst) must be within 3 x the CPU fp32 step's own."""
     import copy
     S, H, W = shape

@@ -1,27 +1,34 @@
 #!/bin/bash
-# The seam kernel (csrc/bottleneck_seam.hip) and the four-wave conv kernels (csrc/conv3x3_fat.hip, conv1x1_fat.hip) name their AGPRs in inline asm;
-# hipcc must therefore never touch an AGPR itself and never spill: this compiles both files for both 16-bit types and fails if a
-# kernel instance contains scratch accesses or v_accvgpr_* instructions outside the asm blocks.
-# usage: tools/seam_check_isa.sh [EXTRA hipcc flags]  (exit 0 = clean)
+# The seam kernel (csrc/bottleneck_seam.hip) and the four-wave conv kernels (csrc/conv3x3_fat.hip, conv1x1_fat.hip, conv1x1_duo.hip)
+# name their AGPRs in inline asm; hipcc must therefore never touch an AGPR itself and never spill: this compiles the files for both
+# 16-bit types and fails if a kernel instance contains scratch accesses or v_accvgpr_* instructions outside the asm blocks, if a
+# file yields NO kernel instance to check (a renamed kernel must not pass vacuously), or if a register budget is exceeded
+# (kernel:max = the allocation the occupancy the kernel is designed for allows).
+# usage: tools/seam_check_isa.sh [EXTRA hipcc flags]  (exit 0 = clean); HIPCC overrides the compiler as in csrc/Makefile
 set -e
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 cd "$(dirname "$0")/../agrl.pytorch_amd/csrc"
 src=$PWD
 tmp=$(mktemp -d)
 trap 'rm -rf "$tmp"' EXIT
 rc=0
-for f in bottleneck_seam:bottleneck_seam_kernel conv3x3_fat:conv3x3_fat_kernel conv1x1_fat:conv1x1_fat; do
-  file=${f%%:*}; kern=${f##*:}
+for f in bottleneck_seam:bottleneck_seam_kernel:512 conv3x3_fat:conv3x3_fat_kernel:512 conv1x1_fat:conv1x1_fat:512 conv1x1_duo:conv1x1_duo_kernel:256; do
+  IFS=: read -r file kern maxreg <<< "$f"
   for lp in 1 0; do
-    (cd "$tmp" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DAGRL_LP_F16=$lp "$@" -I"$src" -c "$src/$file.hip" -o x.o -save-temps=obj 2>/dev/null)
+    (cd "$tmp" && "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DAGRL_LP_F16=$lp "$@" -I"$src" -c "$src/$file.hip" -o x.o -save-temps=obj 2>/dev/null)
     s=$(ls "$tmp"/*gfx950.s)
+    found=0
     for k in $(grep -o "^_ZN12_GLOBAL__N_1[0-9]*${kern}[A-Za-z0-9_]*:" "$s" | tr -d ':'); do
+      found=$((found + 1))
       body=$(awk "/^$k:/,/s_endpgm/" "$s")
       nscr=$(echo "$body" | grep -c 'scratch_' || true)
       nacc=$(echo "$body" | awk '/#ASMSTART/{i=1} /#ASMEND/{i=0} { if(!i && /v_accvgpr/) n++ } END{print n+0}')
       vg=$(grep -A40 "^\s*.amdhsa_kernel $k" "$s" | grep -o 'amdhsa_next_free_vgpr [0-9]*' | head -1)
-      echo "LP_F16=$lp $k: scratch ops $nscr, compiler v_accvgpr ops $nacc ($vg)"
+      echo "LP_F16=$lp $k: scratch ops $nscr, compiler v_accvgpr ops $nacc ($vg, budget $maxreg)"
       if [ "$nscr" != 0 ] || [ "$nacc" != 0 ]; then rc=1; fi
+      if [ -n "$vg" ] && [ "${vg##* }" -gt "$maxreg" ]; then echo "  register budget exceeded"; rc=1; fi
     done
+    if [ "$found" = 0 ]; then echo "LP_F16=$lp $file.hip: no kernel matching $kern found -- nothing was checked"; rc=1; fi
     rm -f "$tmp"/*
   done
 done
