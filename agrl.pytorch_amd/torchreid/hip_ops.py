@@ -311,7 +311,7 @@ def conv1x1_duo_enabled():
 
 def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
     """act(x @ W^T + bias + residual) over pixel rows, weights from conv1x1_pack: conv3 / bn3 + identity shortcut + ReLU of a
-    Bottleneck (vmgn.py:56-64) through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip). -> (N,H,W,Cout) 16-bit NHWC."""
+    Bottleneck (vmgn.py:56-64) through the matrix-wave / memory-wave kernel (csrc/conv1x1_duo.hip). -> (N,H,W,Cout) 16-bit NHWC."""
     N, H, W, K = x.shape
     M = N * H * W
     assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * K * Cout
@@ -328,7 +328,7 @@ def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
 
 
 def conv1x1_packed_res_pool(x, packed, bias, Cout, residual, splits, mean, want_lp, relu=True):
-    """conv1x1_bn_act_pool through the two-workgroups-per-CU kernel with weights from conv1x1_pack: last conv of a layer-4 branch,
+    """conv1x1_bn_act_pool through the matrix-wave / memory-wave kernel with weights from conv1x1_pack: last conv of a layer-4 branch,
     16 x 8 frames, the 2048-channel map never written. -> pooled fp32 (F, P, Cout) [, 16-bit copy]. vmgn.py:56-64 + :298-308."""
     N, H, W, K = x.shape
     assert x.dtype == LP_DTYPE and x.is_contiguous() and (H, W) == (16, 8) and packed.numel() == 2 * K * Cout
@@ -341,7 +341,7 @@ def conv1x1_packed_res_pool(x, packed, bias, Cout, residual, splits, mean, want_
         _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * Cout * K,
                             "bytes": 2.0 * (x.numel() + (residual.numel() if residual is not None else 0)) + packed.numel() + 4.0 * pooled.numel()}
     with _dev(x):
-        call("agrl_conv1x1_packed_res_pool", ptr(x), ptr(packed), ptr(bias), ptr(residual), None, ptr(pooled), ptr(pooled_lp),
+        call("agrl_conv1x1_packed_res_pool", ptr(x), ptr(packed), ptr(bias), ptr(residual), ptr(pooled), ptr(pooled_lp),
              N, H, W, K, Cout, 1 if relu else 0, arr, len(splits), 1 if mean else 0, _stream(x))
     return pooled, pooled_lp
 

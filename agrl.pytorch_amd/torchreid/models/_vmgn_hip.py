@@ -84,7 +84,7 @@ def _pack_stage(stage, dtype, seam=False):
             blk['c1p'] = ops.conv1x1_pack(blk['c1'][0])
         if (dtype == ops.LP_DTYPE and blk['ds'] is None and ops.conv1x1_packed_supported(blk['c3'][0])
                 and blk['c3'][0].shape[0] >= 2048):
-            # layer 4's 512 -> 2048 conv3 + identity shortcut (+ the pool-fused last conv): two workgroups per CU (ops.conv1x1_packed_res)
+            # layer 4's 512 -> 2048 conv3 + identity shortcut (+ the pool-fused last conv): matrix waves + memory waves (ops.conv1x1_packed_res)
             blk['c3p'] = ops.conv1x1_pack(blk['c3'][0])
         if dtype == ops.LP_DTYPE and blk['stride'] == 1 and ops.conv3x3_packed_supported(blk['c2'][0]):
             # layers 3 / 4: the 3x3 weights as per-wave fragment streams for the four-wave kernel (ops.conv3x3_packed)

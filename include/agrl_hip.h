@@ -163,18 +163,20 @@ int agrl_conv1x1_packed_bn_act(const void* x, const void* x2, const void* packed
 /* conv3 / bn3 + identity shortcut + ReLU of a layer-4 Bottleneck (torchreid/models/vmgn.py:56-64), weights from agrl_conv1x1_pack
  * (the same packed tensor agrl_conv1x1_packed_bn_act takes), 16-bit build type only:
  *   out (M,Cout) = act(x (M,K) @ W (Cout,K)^T + bias + residual (M,Cout))          residual may be NULL
- * 128-pixel x 256-channel tiles, four waves, <= 256 registers and 64 KB of LDS per workgroup, so that a CU holds TWO workgroups:
- * one's residual-load / result-store epilogue (HBM-bound) runs under the other's k-loop (MFMA-bound) -- csrc/conv1x1_duo.hip.
- * Needs K % 128 == 0, Cout % 256 == 0, any M. Bit-identical to agrl_conv2d_bn_act(..., residual, ...) on the same operands
- * (fp32 accumulation in k order, + bias, + residual, ReLU, one rounding).
+ * One persistent 8-wave workgroup per 128-pixel tile walks the 256-channel tiles: four matrix waves (k-loop + combine, no HBM
+ * traffic of their own) and four memory waves that bring the residual in and stream the result out through an LDS image on their
+ * own memory counters, under the next tile's k-loop -- csrc/conv1x1_duo.hip. Needs K % 128 == 0, Cout % 256 == 0, any M.
+ * Bit-identical to agrl_conv2d_bn_act(..., residual, ...) on the same operands (fp32 accumulation in k order, + bias,
+ * + residual, ReLU, one rounding).
  * agrl_conv1x1_packed_res_pool: the same conv as the LAST conv of a layer-4 branch with the frame pooling of vmgn.py:298-308 in
- * its epilogue -- agrl_conv1x1_bn_act_pool's contract (frames of 16 x 8 pixels, bins made of whole 4-row quarters, pool_out (N, P,
- * Cout) fp32 sums or means + optional 16-bit copy, out may be NULL) and bit-identical pooled values. */
+ * its epilogue -- agrl_conv1x1_bn_act_pool's contract with out == NULL (frames of 16 x 8 pixels, bins made of whole 4-row
+ * quarters, pool_out (N, P, Cout) fp32 sums or means + optional 16-bit copy; the map itself is never written) and bit-identical
+ * pooled values. */
 int agrl_conv1x1_packed_res_bn_act(const void* x, const void* packed, const float* bias, const void* residual, void* out, int M,
                                    int K, int Cout, int relu, agrl_stream_t stream);
-int agrl_conv1x1_packed_res_pool(const void* x, const void* packed, const float* bias, const void* residual, void* out,
-                                 float* pool_out, void* pool_out_lp, int N, int H, int W, int K, int Cout, int relu,
-                                 const int* splits, int n_splits, int mean, agrl_stream_t stream);
+int agrl_conv1x1_packed_res_pool(const void* x, const void* packed, const float* bias, const void* residual, float* pool_out,
+                                 void* pool_out_lp, int N, int H, int W, int K, int Cout, int relu, const int* splits,
+                                 int n_splits, int mean, agrl_stream_t stream);
 
 /* Whole body of a layer-1 Bottleneck behind its first conv, fused with the head of the next block (bf16 only;
  * torchreid/models/vmgn.py:45-65: conv2/bn2/relu :52-54, conv3/bn3/+residual/relu :56-64 of block i, conv1/bn1/relu

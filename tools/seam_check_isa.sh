@@ -1,7 +1,7 @@
 #!/bin/bash
 # The seam kernel (csrc/bottleneck_seam.hip) and the four-wave conv kernels (csrc/conv3x3_fat.hip, conv1x1_fat.hip, conv1x1_duo.hip)
 # name their AGPRs in inline asm; hipcc must therefore never touch an AGPR itself and never spill: this compiles the files for both
-# 16-bit types and fails if a kernel instance contains scratch accesses or v_accvgpr_* instructions outside the asm blocks, if a
+# 16-bit types and fails if a kernel instance contains scratch accesses or any use of an AGPR (v_accvgpr_*, or an a-register operand) outside the asm blocks, if a
 # file yields NO kernel instance to check (a renamed kernel must not pass vacuously), or if a register budget is exceeded
 # (kernel:max = the allocation the occupancy the kernel is designed for allows).
 # usage: tools/seam_check_isa.sh [EXTRA hipcc flags]  (exit 0 = clean); HIPCC overrides the compiler as in csrc/Makefile
@@ -20,9 +20,9 @@ for f in bottleneck_seam:bottleneck_seam_kernel:512 conv3x3_fat:conv3x3_fat_kern
     found=0
     for k in $(grep -o "^_ZN12_GLOBAL__N_1[0-9]*${kern}[A-Za-z0-9_]*:" "$s" | tr -d ':'); do
       found=$((found + 1))
-      body=$(awk "/^$k:/,/s_endpgm/" "$s")
+      body=$(awk "/^$k:/,/^\\.Lfunc_end/" "$s")   # the whole function (a kernel may hold several s_endpgm)
       nscr=$(echo "$body" | grep -c 'scratch_' || true)
-      nacc=$(echo "$body" | awk '/#ASMSTART/{i=1} /#ASMEND/{i=0} { if(!i && /v_accvgpr/) n++ } END{print n+0}')
+      nacc=$(echo "$body" | awk '/#ASMSTART/{i=1} /#ASMEND/{i=0} { if(!i && /v_accvgpr|[ ,]a\[?[0-9]+[]: ,]/) n++ } END{print n+0}')
       vg=$(grep -A40 "^\s*.amdhsa_kernel $k" "$s" | grep -o 'amdhsa_next_free_vgpr [0-9]*' | head -1)
       echo "LP_F16=$lp $k: scratch ops $nscr, compiler v_accvgpr ops $nacc ($vg, budget $maxreg)"
       if [ "$nscr" != 0 ] || [ "$nacc" != 0 ]; then rc=1; fi
