@@ -181,7 +181,6 @@ struct AgrlOpts {
     int topk_radix;        // AGRL_TOPK_RADIX: every top-k through the five-pass radix kernel
     int graph_linear_mmajor;  // AGRL_GRAPH_LINEAR_MMAJOR: conv-style XCD map for agrl_graph_linear_mix
     int conv3x3_n128;         // AGRL_CONV3X3_N128: conv3x3_wide_kernel with 128-channel tiles also where 256-channel ones apply
-    int duo_nsplit;           // AGRL_DUO_NSPLIT: workgroups per pixel tile of conv1x1_duo_kernel (unset: one, more only when the pixel tiles do not cover the chip)
     int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library
 };
 const AgrlOpts& agrl_opts();

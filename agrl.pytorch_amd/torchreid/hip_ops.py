@@ -304,14 +304,13 @@ def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None):
 
 
 def conv1x1_duo_enabled():
-    """AGRL_HIP_CONV1X1_DUO=0 runs layer 4's conv3 + residual (and the pool-fused last conv) through conv_bn_act /
-    conv1x1_bn_act_pool (A/B; bit-identical results)."""
+    """AGRL_HIP_CONV1X1_DUO=0 runs the pool-fused last conv of a layer-4 branch through conv1x1_bn_act_pool (A/B; bit-identical)."""
     return os.environ.get('AGRL_HIP_CONV1X1_DUO', '1') != '0'
 
 
 def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
     """act(x @ W^T + bias + residual) over pixel rows, weights from conv1x1_pack: conv3 / bn3 + identity shortcut + ReLU of a
-    Bottleneck (vmgn.py:56-64) through the matrix-wave / memory-wave kernel (csrc/conv1x1_duo.hip). -> (N,H,W,Cout) 16-bit NHWC."""
+    Bottleneck (vmgn.py:56-64) through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip; equal in time to conv_bn_act: the model does not route it here). -> (N,H,W,Cout) 16-bit NHWC."""
     N, H, W, K = x.shape
     M = N * H * W
     assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * K * Cout
@@ -328,7 +327,7 @@ def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
 
 
 def conv1x1_packed_res_pool(x, packed, bias, Cout, residual, splits, mean, want_lp, relu=True):
-    """conv1x1_bn_act_pool through the matrix-wave / memory-wave kernel with weights from conv1x1_pack: last conv of a layer-4 branch,
+    """conv1x1_bn_act_pool through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip: 9 % ahead of igemm_wide_kernel's pooled form) with weights from conv1x1_pack: last conv of a layer-4 branch,
     16 x 8 frames, the 2048-channel map never written. -> pooled fp32 (F, P, Cout) [, 16-bit copy]. vmgn.py:56-64 + :298-308."""
     N, H, W, K = x.shape
     assert x.dtype == LP_DTYPE and x.is_contiguous() and (H, W) == (16, 8) and packed.numel() == 2 * K * Cout

@@ -22,12 +22,23 @@ import torch
 import torch.distributed as dist
 
 
+def forced_group():
+    """AGRL_DIST_FORCE_GROUP=1: build the process group and run every collective of this module even at world size 1 -- the way
+    to put the RCCL branch (device-bound communicator, all_gather_into_tensor on device tensors, the candidate merge) under a
+    real communicator on a 1-GPU box (tests/test_gpu_configs.py); never set in production."""
+    return os.environ.get("AGRL_DIST_FORCE_GROUP", "0") == "1"
+
+
+def collectives_active():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced_group())
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from torchrun's environment; returns (rank, world, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced_group()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -58,7 +69,7 @@ def shard_bounds(n, rank, world):
 def all_gather_rows(local):
     """All-gather of equally-sized row blocks: (b, D) on every rank -> (b*world, D), rank-major."""
     world = world_size()
-    if world == 1:
+    if not collectives_active():
         return local
     out = torch.empty((local.size(0) * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
@@ -68,7 +79,7 @@ def all_gather_rows(local):
 def all_gather_ragged_rows(local, counts):
     """All-gather of row blocks with per-rank row counts ``counts`` (list, same on every rank)."""
     world = world_size()
-    if world == 1:
+    if not collectives_active():
         return local
     cap = max(counts)
     padded = local.new_zeros((cap,) + tuple(local.shape[1:]))
@@ -93,7 +104,7 @@ def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn, match_f
         idx, val = topk_fn(distmat_fn(q_all, gallery_shard), k_local)
     idx = idx.to(torch.int64) + shard_lo
     world = world_size()
-    if world == 1:
+    if not collectives_active():
         return idx, val
     if k_local < k:  # a shard smaller than k: pad with +inf candidates
         pad = k - k_local

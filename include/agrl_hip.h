@@ -163,9 +163,9 @@ int agrl_conv1x1_packed_bn_act(const void* x, const void* x2, const void* packed
 /* conv3 / bn3 + identity shortcut + ReLU of a layer-4 Bottleneck (torchreid/models/vmgn.py:56-64), weights from agrl_conv1x1_pack
  * (the same packed tensor agrl_conv1x1_packed_bn_act takes), 16-bit build type only:
  *   out (M,Cout) = act(x (M,K) @ W (Cout,K)^T + bias + residual (M,Cout))          residual may be NULL
- * One persistent 8-wave workgroup per 128-pixel tile walks the 256-channel tiles: four matrix waves (k-loop + combine, no HBM
- * traffic of their own) and four memory waves that bring the residual in and stream the result out through an LDS image on their
- * own memory counters, under the next tile's k-loop -- csrc/conv1x1_duo.hip. Needs K % 128 == 0, Cout % 256 == 0, any M.
+ * 128-pixel x 256-channel tiles, four waves, <= 256 registers and 64 KB of LDS per workgroup, so that a CU holds TWO workgroups:
+ * one's epilogue (residual in, result out through an LDS image: whole 128-byte lines) runs under the other's k-loop --
+ * csrc/conv1x1_duo.hip. Needs K % 128 == 0, Cout % 256 == 0, any M.
  * Bit-identical to agrl_conv2d_bn_act(..., residual, ...) on the same operands (fp32 accumulation in k order, + bias,
  * + residual, ReLU, one rounding).
  * agrl_conv1x1_packed_res_pool: the same conv as the LAST conv of a layer-4 branch with the frame pooling of vmgn.py:298-308 in

@@ -47,6 +47,19 @@ def recipe_tensor(key, shape, seed):
     raise KeyError(key)
 
 
+def imagenet_like_state_dict(template, seed=0):
+    """The recipe with the BatchNorm statistics of a TRAINED ResNet50 instead of the damped ones: every bn3 / downsample gamma in
+    U(0.8, 1.2) (the recipe keeps them in 0.15 .. 0.35 so that the random residual trunk does not grow), every other gamma as
+    before -- the residual stream's magnitude then grows block by block the way an undamped trunk's does. Used to put numbers on
+    the fp16 build's headroom (activations against 65504) instead of assuming it."""
+    out = recipe_state_dict(template, seed)
+    for key in out:
+        if key.endswith(".weight") and (".bn3." in key or "downsample.1" in key) and out[key].dim() == 1:
+            g = _gen(key + "#imagenet", seed)
+            out[key] = 0.8 + 0.4 * torch.rand(out[key].shape, generator=g)
+    return out
+
+
 def recipe_state_dict(template, seed=0):
     """``template``: a state_dict (or dict name -> tensor/shape) giving keys and shapes."""
     out = {}

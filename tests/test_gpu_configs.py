@@ -116,6 +116,32 @@ def test_bench_self_launches_two_ranks():
     print("bench --gpus 2 (2 ranks on one GPU, gloo): %.0f frames/s, all-gather %.0f us" % (r["value"], r["config"]["allgather_us"]))
 
 
+def test_rccl_path_on_one_gpu():
+    """The RCCL branch under a REAL communicator before the first multi-GPU run: a fresh child (never a re-exec of a process that
+    touched the GPU) runs ``bench.py --gpus 1`` with AGRL_DIST_BACKEND=nccl and AGRL_DIST_FORCE_GROUP=1 -- world size 1, but
+    parallel.init_from_env binds the device and builds the communicator (device_id), every step's embeddings go through
+    all_gather_into_tensor on device tensors on the match stream (side-stream ordering against the next batch's forward), the barrier
+    / max-over-ranks timing collectives run, and parallel.sharded_topk takes its candidate all-gather + merge path. The line must say
+    rccl and the sharded top-50 must equal the single-process one."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(AGRL_DIST_BACKEND="nccl", AGRL_DIST_FORCE_GROUP="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8",
+                          "--sustain-seconds", "0", "--profile-steps", "1", "--no-modes", "--no-accuracy", "--no-config5", "--no-config4",
+                          "--no-cpu-baseline"], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    r = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+    cfg = r["config"]
+    assert r["n_gpus"] == 1 and cfg["collective_backend"] == "rccl" and cfg["ranks"] == 1
+    assert "allgather_us" in cfg and cfg["gallery_rows_all_ranks"] == [12180]
+    assert cfg["sharded_top50_equals_single_process"] and cfg["sharded_top50_swaps_not_explained_by_a_near_tie"] == 0
+    print("bench --gpus 1 over a real RCCL communicator: %.0f frames/s, all-gather %.0f us" % (r["value"], cfg["allgather_us"]))
+
+
 def test_bench_config3_eight_ranks_on_one_gpu():
     """BASELINE configs[2] at its real shape without the hardware: ``python bench.py --gpus 8 --batch 32`` = 8 ranks x 32
     tracklets (256 global), the 12 180-row gallery in 1 523 / 1 522-row shards, all-gather of embeddings, per-shard distance --

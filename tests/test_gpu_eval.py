@@ -167,3 +167,47 @@ def test_out_of_range_activations_fail_loudly_in_the_16_bit_mode(factor, message
     else:
         f, _, _ = evaluation.extract_features(m, batch, prefetch=False)
         assert torch.isfinite(f).all()
+
+
+@pytest.mark.parametrize("sample", ["evenly", "dense"])
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+def test_device_pipeline_equals_the_reference_test_function(metric, sample):
+    """SURVEY 8(a) row 13, end to end on the reference's OWN test() (train_vidreid_xent_htri.py:450-542): tests/golden/
+    test_harness.npz holds what that function returned -- (Rank-1, mAP), CMC, the distance matrix -- for the reference model on the
+    loaders of tests/harness_split.py (evenly-sampled batches, and the dense samplers' one-tracklet-of-n-clips batches with mean
+    pooling), both metrics. The device-resident harness (evaluation.evaluate: HIP forward in exact fp32, clip pooling, agrl_distmat_topk,
+    agrl_rank_mars) on the same inputs must give the same Rank-1 / mAP / CMC, and compute_distance_matrix on its features the same
+    matrix (1e-5; index-exact ranking up to near-ties of the reference's own distances)."""
+    import os
+    import harness_split as HS
+    from torchreid import evaluation, metrics, models
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "test_harness.npz"))
+    q_pids, q_cams, g_pids, g_cams = HS.make_split()
+    m = models.init_model("vmgn", num_classes=HS.N_ID, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2,
+                          num_scale=1, pyramid_part=True, use_pose=True, learn_graph=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    for name, mean, var in (("global_bottleneck", "g_mean", "g_var"), ("att_bottleneck", "a_mean", "a_var")):
+        sd[name + ".running_mean"] = torch.from_numpy(z[mean])
+        sd[name + ".running_var"] = torch.from_numpy(z[var])
+        sd[name + ".weight"] = torch.ones_like(sd[name + ".weight"])
+        sd[name + ".bias"] = torch.zeros_like(sd[name + ".bias"])
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.hip_precision = "fp32"
+    mk = HS.loader if sample == "evenly" else HS.dense_loader
+    tag = "%s_%s" % (metric, sample)
+    r1, mAP = evaluation.evaluate(m, mk(q_pids, q_cams, HS.Q_SEED), mk(g_pids, g_cams, HS.G_SEED), metric, pool="avg")
+    qf, _, _ = evaluation.extract_features(m, mk(q_pids, q_cams, HS.Q_SEED), pool="avg")
+    gf, _, _ = evaluation.extract_features(m, mk(g_pids, g_cams, HS.G_SEED), pool="avg")
+    d = metrics.compute_distance_matrix(qf, gf, metric).cpu().numpy()
+    ref = z[tag + "_distmat"]
+    err = np.abs(d - ref).max() / np.abs(ref).max()
+    cmc, mAP2 = metrics.evaluate_rank(d, q_pids, g_pids, q_cams, g_cams, use_metric_mars=True)
+    print("reference test() vs device harness, %s: distmat rel err %.2e, Rank-1 %.4f mAP %.6f (reference %.4f %.6f)" % (
+        tag, err, r1, mAP, z[tag + "_rank1"], z[tag + "_mAP"]))
+    assert err < 1e-5
+    assert abs(r1 - float(z[tag + "_rank1"])) < 1e-12 and abs(mAP - float(z[tag + "_mAP"])) < 1e-6
+    assert abs(mAP2 - mAP) < 1e-9 and abs(cmc[0] - r1) < 1e-12      # the API path and the fused device path agree
+    srt = np.sort(ref, axis=1)
+    if np.min(np.diff(srt[:, :51], axis=1)) > 4 * np.abs(d - ref).max():   # no near-tie in any top-50 list: index-exact
+        assert np.array_equal(cmc, z[tag + "_cmc"]) and mAP2 == float(z[tag + "_mAP"])

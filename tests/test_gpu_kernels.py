@@ -368,19 +368,14 @@ DUO_CASES = [(256, 16, 8, 512, 2048, True, True), (1, 16, 8, 512, 2048, True, Tr
              (37, 16, 8, 256, 1024, True, True), (5, 16, 8, 384, 512, False, True)]
 
 
-@pytest.mark.parametrize("nsplit", ["default", "1", "max"])
 @pytest.mark.parametrize("case", DUO_CASES)
-def test_conv1x1_packed_res(case, nsplit, monkeypatch):
-    """conv3 + identity shortcut + ReLU through the matrix-wave / memory-wave kernel (conv1x1_duo.hip) against the fp32 reference and
+def test_conv1x1_packed_res(case):
+    """conv3 + identity shortcut + ReLU through the two-workgroups-per-CU kernel (conv1x1_duo.hip) against the fp32 reference and
     against conv_bn_act(residual=...) (same summation order, same order of bias / residual / ReLU / rounding: equal bit for bit).
-    The full layer-4 shape (one workgroup per frame walks eight channel tiles), one frame, a ragged 180-row map without ReLU, an odd
-    tile count, no residual with three slabs; the walk whole (one workgroup per pixel tile), split by the launcher's rule, and one
-    channel tile per workgroup. Every call twice."""
+    The full layer-4 shape (2048 tiles: four resident rounds), one frame (8 tiles), a ragged 180-row map without ReLU, an odd tile
+    count, no residual with three slabs. Every call twice."""
     from torchreid import hip_ops as ops
     N, H, W, K, Cout, use_res, relu = case
-    if nsplit != "default":
-        monkeypatch.setenv("AGRL_DUO_NSPLIT", "1" if nsplit == "1" else str(Cout // 256))
-        _hip.reload_options()
     g = torch.Generator().manual_seed(sum(case[:5]))
     x = torch.randn((N, K, H, W), generator=g).relu().to(LP_DTYPE).float()
     w = (torch.randn((Cout, K, 1, 1), generator=g) / np.sqrt(K)).to(LP_DTYPE).float()
@@ -398,10 +393,8 @@ def test_conv1x1_packed_res(case, nsplit, monkeypatch):
     out_b = ops.conv1x1_packed_res(dx, packed, b.to(DEV), Cout, dres, relu)
     other = ops.conv_bn_act(dx, dw, b.to(DEV), 1, 0, relu, residual=dres)
     torch.cuda.synchronize()
-    monkeypatch.delenv("AGRL_DUO_NSPLIT", raising=False)
-    _hip.reload_options()
     e = rel_err(out.float().permute(0, 3, 1, 2).cpu(), ref.cpu())
-    print("conv1x1 duo", case, nsplit, "vs fp32 %.3e | max |duo - conv_bn_act| %.3e" % (e, (out.float() - other.float()).abs().max().item()))
+    print("conv1x1 duo", case, "vs fp32 %.3e | max |duo - conv_bn_act| %.3e" % (e, (out.float() - other.float()).abs().max().item()))
     assert e < (3e-3 if LP_DTYPE == torch.float16 else 2e-2), e
     assert torch.equal(out, out_b)
     assert torch.equal(out, other)
@@ -412,7 +405,7 @@ def test_conv1x1_packed_res(case, nsplit, monkeypatch):
 @pytest.mark.parametrize("cfg", [(256, 512, 2048, [4, 2, 1], True), (256, 512, 2048, [1], False), (3, 128, 256, [4, 2, 1], True),
                                  (9, 256, 512, [2, 1], True)])
 def test_conv1x1_packed_res_pool(cfg):
-    """The pool-fused last conv of a layer-4 branch through the matrix-wave / memory-wave kernel: pooled sums / means and the 16-bit
+    """The pool-fused last conv of a layer-4 branch through the two-workgroups-per-CU kernel: pooled sums / means and the 16-bit
     copy equal BIT FOR BIT to agrl_conv1x1_bn_act_pool's (igemm_wide_kernel's pooled epilogue: same rounded activations, same order
     of the quarter sums) on the layer-4 shapes."""
     from torchreid import hip_ops as ops

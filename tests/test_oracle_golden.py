@@ -399,3 +399,52 @@ def test_pose_adjacency():
     assert np.array_equal(adj, z["adj"])
     assert np.array_equal(adj, adj.T) and adj.diagonal().sum() == 0
     assert adj[3 * 7:(3 + 1) * 7].sum() == 0  # the undetected frame is an all-zero block
+
+
+def harness_model(z):
+    """this build's vmgn with the recipe weights + the BNNeck calibration the reference model was given (test_harness.npz)"""
+    import harness_split as HS
+    from torchreid import models
+    m = models.init_model("vmgn", num_classes=HS.N_ID, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2,
+                          num_scale=1, pyramid_part=True, use_pose=True, learn_graph=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    for name, mean, var in (("global_bottleneck", "g_mean", "g_var"), ("att_bottleneck", "a_mean", "a_var")):
+        sd[name + ".running_mean"] = torch.from_numpy(z[mean])
+        sd[name + ".running_var"] = torch.from_numpy(z[var])
+        sd[name + ".weight"] = torch.ones_like(sd[name + ".weight"])
+        sd[name + ".bias"] = torch.zeros_like(sd[name + ".bias"])
+    m.load_state_dict(sd)
+    return m.eval(), sd
+
+
+def test_reference_test_function_end_to_end_on_the_cpu():
+    """SURVEY 8(a) row 13 on the reference's OWN test() (train_vidreid_xent_htri.py:450-542; fixture test_harness.npz, written by
+    tests/golden/make_test_harness.py calling that function on the reference model over tests/harness_split.py's loaders): this
+    build's CPU path through the same API calls test() makes -- model(imgs, adj) per batch, torch.cat, compute_distance_matrix,
+    evaluate_rank(use_metric_mars=True) -- reproduces the distance matrix to fp32 rounding and Rank-1 / mAP / CMC exactly; the
+    oracle's restatement of the tail likewise."""
+    import harness_split as HS
+    from torchreid import metrics
+    z = gold("test_harness")
+    q_pids, q_cams, g_pids, g_cams = HS.make_split()
+    assert all(np.array_equal(a, z[k]) for a, k in ((q_pids, "q_pids"), (q_cams, "q_cams"), (g_pids, "g_pids"), (g_cams, "g_cams")))
+    m, sd = harness_model(z)
+    with torch.no_grad():
+        qf = torch.cat([m(x, adj) for x, _, _, adj in HS.loader(q_pids, q_cams, HS.Q_SEED)])
+        gf = torch.cat([m(x, adj) for x, _, _, adj in HS.loader(g_pids, g_cams, HS.G_SEED)])
+        # the oracle on the first query batch
+        x, _, _, adj = next(iter(HS.loader(q_pids, q_cams, HS.Q_SEED)))
+        close(O.vmgn_eval(x, adj, sd), qf[:x.shape[0]], 1e-4)   # (the calibrated BNNeck divides by near-zero variances: 2e-7 before it)
+    for metric in ("cosine", "euclidean"):
+        d = metrics.compute_distance_matrix(qf, gf, metric).numpy()
+        ref = z[metric + "_evenly_distmat"]
+        err = np.abs(d - ref).max() / np.abs(ref).max()
+        cmc, mAP = metrics.evaluate_rank(d, q_pids, g_pids, q_cams, g_cams, use_metric_mars=True)
+        print("test() harness, %s: distmat rel err %.2e, Rank-1 %.4f mAP %.6f (reference %.4f %.6f)" % (
+            metric, err, cmc[0], mAP, z[metric + "_evenly_rank1"], z[metric + "_evenly_mAP"]))
+        assert err < 1e-5
+        # the ranking is exact wherever the reference's own distances are further apart than the fp32 disagreement
+        srt = np.sort(ref, axis=1)
+        if np.min(np.diff(srt[:, :51], axis=1)) > 4 * np.abs(d - ref).max():
+            assert np.array_equal(cmc, z[metric + "_evenly_cmc"]) and mAP == float(z[metric + "_evenly_mAP"])
+        assert abs(cmc[0] - float(z[metric + "_evenly_rank1"])) < 1e-12 and abs(mAP - float(z[metric + "_evenly_mAP"])) < 1e-6

@@ -1,8 +1,8 @@
-"""Layer 4's conv3 + residual (512 -> 2048 on 256 frames of 16 x 8) and the pool-fused last conv: the matrix-wave / memory-wave kernel
+"""Layer 4's conv3 + residual (512 -> 2048 on 256 frames of 16 x 8) and the pool-fused last conv: the two-workgroups-per-CU kernel
 (csrc/conv1x1_duo.hip) against igemm_wide_kernel (conv_bn_act(residual=...) / conv1x1_bn_act_pool), interleaved in one process.
-usage: conv1x1_duo_bench.py [rounds] [frames] [nsplit,nsplit,...] [res,pool4,pool1]
+usage: conv1x1_duo_bench.py [rounds] [frames] [-] [res,pool4,pool1]
 Prints per form: bit equality, median / min of each arm in us (HIP events; ~8 us of launch overhead inside -- run under
-tools/kernel_trace.sh for the kernels' own durations), and the duo arm per split of the channel-tile walk (workgroups per pixel tile)."""
+tools/kernel_trace.sh for the kernels' own durations), . Before every timed call the block's conv1 and 3x3 conv run (the cache state of the model)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
@@ -14,7 +14,6 @@ from torchreid._hip import LP_DTYPE
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-nsplits = [s for s in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["default"])]
 dev = "cuda:0"
 K, Cout = 512, 2048
 
@@ -57,12 +56,7 @@ for form in forms:
         duo = lambda: ops.conv1x1_packed_res_pool(x, packed, b, Cout, res, splits, mean, False)
         wide = lambda: ops.conv1x1_bn_act_pool(x, w, b, res, splits, mean, False)
         same = torch.equal(duo()[0], wide()[0])
-    for st in nsplits:
-        if st == "default":
-            os.environ.pop("AGRL_DUO_NSPLIT", None)
-        else:
-            os.environ["AGRL_DUO_NSPLIT"] = st
-        _hip.reload_options()
+    for st in ["-"]:
         for _ in range(3):
             duo(), wide()
         torch.cuda.synchronize()
@@ -73,5 +67,5 @@ for form in forms:
             before()
             tw.append(timed(wide))
         td.sort(), tw.sort()
-        print("%-5s nsplit %-7s equal %s  duo %.1f us (min %.1f)  wide %.1f us (min %.1f)  duo %.0f TFLOP/s" % (
+        print("%-5s %s equal %s  duo %.1f us (min %.1f)  wide %.1f us (min %.1f)  duo %.0f TFLOP/s" % (
             form, st, same, td[len(td) // 2], td[0], tw[len(tw) // 2], tw[0], flops / td[len(td) // 2] * 1e-6))

@@ -1,5 +1,5 @@
 """Phase timeline of conv1x1_duo_kernel from the profiling build (tools/duo_ablate.sh 64 -> lib/libagrl_hip_duoabl64.so):
-s_memtime stamps of matrix wave 0 and memory wave 4 of every workgroup, per channel tile -> median phase durations.
+per-workgroup s_memtime stamps -> median phase durations, per-CU overlap of the two resident workgroups.
 usage: AGRL_HIP_LIB=.../libagrl_hip_duoabl64.so python tools/duo_timeline.py"""
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,8 +22,8 @@ w1 = (torch.randn((512, 1, 1, Cout), device=dev) / Cout ** 0.5).to(LP_DTYPE)
 w2 = (torch.randn((512, 3, 3, 512), device=dev) / (9 * 512) ** 0.5).to(LP_DTYPE)
 b1 = torch.randn((512,), device=dev)
 p1, p2 = ops.conv1x1_pack(w1), ops.conv3x3_pack(w2)
-nwg = frames
-buf = torch.zeros((nwg, 8, 2, 8), dtype=torch.int64, device=dev)
+nwg = frames * (Cout // 256)
+buf = torch.zeros((nwg, 12), dtype=torch.int64, device=dev)
 lib = _hip.lib()
 lib.agrl_duo_trace_buffer.argtypes = [ctypes.c_void_p]
 assert lib.agrl_duo_trace_buffer(buf.data_ptr()) == 0
@@ -33,22 +33,39 @@ for it in range(3):
     buf.zero_()
     ops.conv1x1_packed_res(x, packed, b, Cout, res)
     torch.cuda.synchronize()
-assert lib.agrl_duo_trace_buffer(None) == 0
 t = buf.cpu().numpy().astype(np.int64)
-mx, mem = t[:, :, 0, :], t[:, :, 1, :]
-t0 = mx[:, 0, 0].min()
-print("span %d ticks (first k-loop start -> last E2)" % (mx[:, 7, 3].max() - t0))
-def stat(name, d):
-    print("  %-58s median %7.0f  p10 %7.0f  p90 %7.0f" % (name, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
-stat("matrix: k-loop (4 slabs)", mx[:, :, 1] - mx[:, :, 0])
-stat("matrix: wait at E1 (memory wave not there yet)", mx[:, :, 2] - mx[:, :, 1])
-stat("matrix: combine", mx[:, :, 3] - mx[:, :, 2])
-stat("matrix: E2 -> next tile's loop start", mx[:, 1:, 0] - mx[:, :-1, 3])
-stat("matrix: whole tile period", mx[:, 1:, 0] - mx[:, :-1, 0])
-stat("memory: parked from E1 to E2", mem[:, :, 1] - mem[:, :, 0])
-stat("memory: image reads + store issue", mem[:, :, 2] - mem[:, :, 1])
-stat("memory: residual DMA issue", mem[:, :-1, 3] - mem[:, :-1, 2])
-stat("memory: after issue -> residual landed (next E1)", mem[:, 1:, 0] - mem[:, :-1, 3])
-print("  one workgroup, matrix wave (loop start, loop end, E1 passed, combined) per tile, ticks from start:")
+hw, xcc = t[:, 10], t[:, 11]
+cu = ((xcc & 0xf) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
+names = ["start", "setup", "prologue (first loads + barrier)", "k-loop", "drain + barrier", "residual DMA + wait", "combine", "issue stores", "stores acked"]
+# s_memtime: 100 MHz constant on gfx9? print the raw span to calibrate against the kernel's duration
+span = (t[:, 8].max() - t[:, 0].min())
+print("workgroups %d, distinct CUs %d, span of stamps %d ticks" % (nwg, len(np.unique(cu)), span))
+d = np.diff(t[:, :9], axis=1)
 for k in range(8):
-    print("    ", [int(v - t0) for v in mx[0, k, :4]], " memory wave:", [int(v - t0) for v in mem[0, k, :4]])
+    print("  %-34s median %7.0f  p10 %7.0f  p90 %7.0f ticks" % (names[k + 1], np.median(d[:, k]), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
+life = t[:, 8] - t[:, 0]
+print("  workgroup lifetime median %.0f ticks; sum of lifetimes / span / CUs = %.2f resident workgroups per CU" % (np.median(life), life.sum() / span / len(np.unique(cu))))
+# per CU: fraction of time with two workgroups in the SAME kind of phase
+same = tot = 0
+for c in np.unique(cu)[:64]:
+    rows = t[cu == c]
+    ev = []
+    for r in rows:
+        ev.append((r[2], r[3], 0))   # k-loop
+        ev.append((r[4], r[8], 1))   # epilogue
+    T0, T1 = rows[:, 0].min(), rows[:, 8].max()
+    grid = np.linspace(T0, T1, 2000)
+    kl = np.zeros_like(grid); ep = np.zeros_like(grid)
+    for a, b_, kind in ev:
+        m = (grid >= a) & (grid < b_)
+        if kind == 0: kl += m
+        else: ep += m
+    tot += len(grid)
+    same += ((kl >= 2) | (ep >= 2)).sum()
+print("  fraction of CU time with both resident workgroups in the same phase kind: %.2f" % (same / tot))
+order = np.argsort(t[:, 0])
+print("  first 6 workgroups on one CU (start, k-loop begin, k-loop end, epi begin, stores acked), ticks from kernel start:")
+c0 = cu[order[0]]
+rows = t[cu == c0]; rows = rows[np.argsort(rows[:, 0])][:8]
+for r in rows:
+    print("   ", [int(v - t[:, 0].min()) for v in (r[0], r[2], r[3], r[4], r[5], r[6], r[7], r[8])])
