@@ -99,6 +99,9 @@ def stem_lp16(x_nchw, w_packed, bias):
     CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
     out = torch.empty((N, PH, PW, 64), dtype=LP_DTYPE, device=x_nchw.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * CH * CW * 64 * 147, "bytes": 4.0 * x_nchw.numel() + 2.0 * out.numel() + 2.0 * w_packed.numel(),
+                            "conv": (7, 2, 3, 64, PH, PW)}
     with _dev(x_nchw):
         call("agrl_stem_conv_bn_relu_maxpool_lp16", ptr(x_nchw), ptr(w_packed), ptr(bias), ptr(out), N, H, W,
              _stream(x_nchw))

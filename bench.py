@@ -329,12 +329,13 @@ def accuracy_block(model, device, S, metric):
     top = {}
     LP = ops.LP_NAME
     out["lp16"] = LP
-    for prec in (LP, "fp32"):
+    for prec in (LP, "bf16x3", "fp32"):   # bf16x3: the embeddings from split-bf16 products, matched in exact fp32
         model.hip_precision = prec
         t0 = time.perf_counter()
         qf, _, _ = evaluation.extract_features(model, batches(q_pids, q_cams, 0), prefetch=False)
         gf, _, _ = evaluation.extract_features(model, batches(g_pids, g_cams, FS.QUERY_ROWS), prefetch=False)
-        cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, prec, return_topk=True)
+        cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50,
+                                                       "fp32" if prec == "bf16x3" else prec, return_topk=True)
         torch.cuda.synchronize()
         out[prec] = {"rank1": round(float(cmc[0]), 6), "rank5": round(float(cmc[4]), 6), "mAP": round(float(mAP), 6),
                      "seconds": round(time.perf_counter() - t0, 2)}
@@ -359,7 +360,7 @@ def accuracy_block(model, device, S, metric):
         ref = z["q_emb_head"].astype(np.float64)
         out["oracle"] = {"rank1": round(float(o_cmc[0]), 6), "rank5": round(float(o_cmc[4]), 6), "mAP": round(o_map, 6),
                          "source": "tests/golden/fullsplit_oracle.npz (oracle/vmgn_oracle.py on the build container's CPU, tests/golden/make_fullsplit.py)"}
-        for prec in ("fp32", LP):
+        for prec in ("fp32", "bf16x3", LP):
             c = FS.compare_topk(top[prec][0], top[prec][1], z[metric + "_idx"], z[metric + "_val"])
             out[prec + "_vs_oracle"] = {"rank1_delta": round(out[prec]["rank1"] - float(o_cmc[0]), 6),
                                         "mAP_delta": round(out[prec]["mAP"] - o_map, 6),
@@ -374,7 +375,7 @@ def accuracy_block(model, device, S, metric):
     return out
 
 
-def modes_block(model, clips, adj, g_shard, metric, steps=3):
+def modes_block(model, clips, adj, g_shard, metric, steps=3, blocks=3):
     """The same step (forward + distance matrix of the batch against the resident gallery) in the two precision modes that
     meet the north-star tolerance (1e-3 relative, ranking indices bit-exact on the test splits): exact fp32 and bf16x3
     (fp32 tensors, every conv / Linear product as three bf16 MFMAs). ``steps`` timed steps each after one warm-up, plus one
@@ -402,11 +403,14 @@ def modes_block(model, clips, adj, g_shard, metric, steps=3):
             model.hip_precision = prec
             one()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                one()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
+            dts = []
+            for _ in range(blocks):   # median of `blocks` timed blocks of `steps` steps
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    one()
+                torch.cuda.synchronize()
+                dts.append((time.perf_counter() - t0) / steps)
+            dt = sorted(dts)[len(dts) // 2]
             _hip.PROFILE = []
             one()
             torch.cuda.synchronize()
@@ -414,7 +418,8 @@ def modes_block(model, clips, adj, g_shard, metric, steps=3):
             ms = sum(s_ev.elapsed_time(e_ev) for name, s_ev, e_ev, tag in prof if name in fam)
             fl = sum(tag["flops"] for name, s_ev, e_ev, tag in prof if name in fam and tag)
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out[prec] = {"ms_per_step": round(1e3 * dt, 3), "frames_per_s": round(B * S / dt, 1), "steps": steps,
+            out[prec] = {"ms_per_step": round(1e3 * dt, 3), "frames_per_s": round(B * S / dt, 1), "steps": steps, "blocks": blocks,
+                         "ms_per_step_blocks": [round(1e3 * d, 3) for d in dts],
                          "conv_family_tflops": round(tf, 1), "peak_tflops": round(PEAK_TFLOPS[prec], 1),
                          "conv_family_frac_of_peak": round(tf / PEAK_TFLOPS[prec], 4)}
     finally:
@@ -869,7 +874,7 @@ def main():
                     which = "dom"
                 elif lp and c and c[0] == 1 and max(c[2], c[3]) >= 2048:   # the pointwise convs of the layer-4 branches
                     which = "pw4"
-                elif lp and name in ("agrl_conv1x1_bn_act_pool", "agrl_conv1x1_dual_bn_act"):
+                elif lp and name in ("agrl_conv1x1_bn_act_pool", "agrl_conv1x1_dual_bn_act", "agrl_conv1x1_packed_res_pool"):
                     which = "pw4"
                 if which:
                     cls[which]["ms"] += ms
@@ -883,11 +888,52 @@ def main():
             if a["flops"]:
                 kernels[name]["tflops"] = round(a["flops"] / sec / 1e12, 2)
                 kernels[name]["gbs"] = round(a["bytes"] / sec / 1e9, 1)
+        # ---- the HBM-bound third of the step, launch by launch (review item: stem + layers 1-2 + the entry of layer 3): algorithmic
+        # bytes of each call over its own duration, against the 8 TB/s roofline and against what a float4 copy of 256 MB reaches on
+        # THIS chip in THIS run (the "copy ceiling": read + write bytes per second)
+        if lp:
+            per_step = len(prof) // nprof
+            first_seam = next((i for i in range(per_step) if prof[i][0] == "agrl_bottleneck_seam"), None)
+            if first_seam is not None and all(prof[k * per_step + i][0] == prof[i][0] for k in range(nprof) for i in range(first_seam)):
+                cp_src = torch.empty((64 << 20,), dtype=torch.float32, device=device)
+                cp_dst = torch.empty_like(cp_src)
+                best = None
+                for rep in range(5):
+                    s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s_ev.record()
+                    cp_dst.copy_(cp_src)
+                    e_ev.record()
+                    e_ev.synchronize()
+                    if rep >= 1:
+                        best = s_ev.elapsed_time(e_ev) if best is None else min(best, s_ev.elapsed_time(e_ev))
+                copy_gbs = 2.0 * cp_src.numel() * 4 / (best * 1e-3) / 1e9
+                del cp_src, cp_dst
+                rows, tot_ms, tot_b = [], 0.0, 0.0
+                for i in range(first_seam):
+                    name, tag = prof[i][0], prof[i][3]
+                    ms = sum(prof[k * per_step + i][1].elapsed_time(prof[k * per_step + i][2]) for k in range(nprof)) / nprof
+                    c = tag.get("conv") if tag else None
+                    label = name.replace("agrl_", "") + (" %dx%d s%d %d->%d @%dx%d" % (c[0], c[0], c[1], c[2], c[3], c[4], c[5]) if c else "")
+                    gbs = tag["bytes"] / (ms * 1e-3) / 1e9 if tag else None
+                    rows.append({"call": label, "us": round(1e3 * ms, 1), "algorithmic_mb": round(tag["bytes"] / 1e6, 1) if tag else None,
+                                 "gbs": round(gbs, 0) if gbs else None, "frac_of_8tbs": round(gbs / PEAK_HBM_GBS, 3) if gbs else None,
+                                 "frac_of_copy": round(gbs / copy_gbs, 3) if gbs else None,
+                                 "tflops": round(tag["flops"] / (ms * 1e-3) / 1e12, 0) if tag else None})
+                    tot_ms += ms
+                    tot_b += tag["bytes"] if tag else 0.0
+                result["roofline_hbm_bound_trunk"] = {
+                    "bound": "hbm", "what": "stem + layer 1 + layer 2 + the first block of layer 3 (up to the first seam launch), HIP events "
+                                            "around each C-ABI call (each carries ~2 us of launch latency)",
+                    "copy_ceiling_gbs": round(copy_gbs, 0), "ms_per_step": round(tot_ms, 4), "algorithmic_mb_per_step": round(tot_b / 1e6, 1),
+                    "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 0), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    "frac_of_copy": round(tot_b / (tot_ms * 1e-3) / 1e9 / copy_gbs, 4), "launches": rows}
         # the conv family: every conv launch (generic / persistent / wide implicit GEMM, 3x3 patch kernels, the fused
         # layer-1 block and layer-2 tail, the pool-fused last conv)
         a = {"ms": 0.0, "launches": 0, "flops": 0.0}
         for fam in ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block",
-                    "agrl_conv1x1_dual_bn_act", "agrl_conv3x3_packed_bn_act", "agrl_conv1x1_packed_bn_act", "agrl_bottleneck_seam"):
+                    "agrl_conv1x1_dual_bn_act", "agrl_conv3x3_packed_bn_act", "agrl_conv1x1_packed_bn_act", "agrl_bottleneck_seam",
+                    "agrl_conv1x1_packed_res_pool"):
             if fam in agg:
                 for key in a:
                     a[key] += agg[fam][key]
@@ -896,7 +942,7 @@ def main():
         # HBM traffic per launch: NOT measured in this run -- PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command, tools/collect_profiles.sh) are committed under profiles/ and quoted with their source
         traffic = fam_traffic = traffic_src = None
-        for tname in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:
@@ -910,7 +956,7 @@ def main():
                 except Exception:
                     traffic = fam_traffic = None
         family = {"bound": "mfma (layers 3-4) / hbm (layers 1-2)",
-                  "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv3x3_packed_bn_act + agrl_conv1x1_packed_bn_act + agrl_conv1x1_dual_bn_act + agrl_conv1x1_bn_act_pool + agrl_bottleneck_tail + agrl_bottleneck_block + agrl_bottleneck_seam)",
+                  "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv3x3_packed_bn_act + agrl_conv1x1_packed_bn_act + agrl_conv1x1_dual_bn_act + agrl_conv1x1_bn_act_pool / agrl_conv1x1_packed_res_pool + agrl_bottleneck_tail + agrl_bottleneck_block + agrl_bottleneck_seam)",
                   "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                   "traffic": fam_traffic, "traffic_source": traffic_src, "flops_per_launch": round(a["flops"] / a["launches"], 1),
                   "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2), "ms_per_step": round(a["ms"] / nprof, 4)}
@@ -931,7 +977,7 @@ def main():
         if pw["launches"]:
             ach = pw["flops"] / (pw["ms"] * 1e-3) / 1e12
             result["roofline_pointwise_layer4"] = {
-                "bound": "mfma", "kernel": "1x1 convs of the two layer-4 branches (igemm_wide_kernel family + pool-fused last conv)",
+                "bound": "mfma", "kernel": "1x1 convs of the two layer-4 branches (conv1x1_fat_kernel / igemm_wide_kernel + the pool-fused last conv, conv1x1_duo_kernel)",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "launches_per_step": pw["launches"] // nprof, "ms_per_step": round(pw["ms"] / nprof, 4)}
 
@@ -1103,6 +1149,22 @@ def main():
                                            "the parity tests hold fp16 to 1e-3 against the CPU oracle" if LPN == "fp16" else "bf16 does not meet 1e-3",
                                            acc["top1_index_agreement"], acc["top50_index_agreement"]))
                 result["top1_index_agreement_%s_vs_fp32" % LPN] = acc["top1_index_agreement"]
+                # the index-exact modes in top-level fields: frames/s of this run (`modes`) beside their agreement with the ORACLE's
+                # ranked lists on the full split (tests/golden/fullsplit_oracle.npz)
+                ie = {}
+                for mode in ("fp32", "bf16x3"):
+                    vo = acc.get(mode + "_vs_oracle")
+                    if vo:
+                        ie[mode] = {"frames_per_s": (result.get("modes", {}).get(mode) or {}).get("frames_per_s"),
+                                    "top1_index_agreement_vs_oracle": vo["top1_index_agreement"],
+                                    "swaps_not_explained_by_a_near_tie": vo["swaps_not_explained_by_a_near_tie"],
+                                    "queries_with_identical_top50": vo["queries_with_identical_top50"], "mAP_delta_vs_oracle": vo["mAP_delta"]}
+                vo = acc.get(LPN + "_vs_oracle")
+                if vo:
+                    ie[LPN] = {"frames_per_s": result["value"], "top1_index_agreement_vs_oracle": vo["top1_index_agreement"],
+                               "swaps_not_explained_by_a_near_tie": vo["swaps_not_explained_by_a_near_tie"],
+                               "queries_with_identical_top50": vo["queries_with_identical_top50"], "mAP_delta_vs_oracle": vo["mAP_delta"]}
+                result["index_exactness_by_mode"] = ie
             else:
                 emb = None
             if not args.no_modes and lp:

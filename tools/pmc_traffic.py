@@ -1,18 +1,24 @@
 """Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/traffic_r01.json (the conv
 family = every igemm_* / conv3x3_* / conv1x1_fat / bottleneck_* kernel).
-usage: pmc_traffic.py <fetch_csv> <write_csv> <steps_total> <precision> [out.json]
+usage: pmc_traffic.py <fetch_csv> <write_csv> <steps_total | auto> <precision> [out.json]
+steps_total = auto: the number of forward steps the profiled command really ran = launches of the stem kernel (once per step; the
+bench's extra timed blocks, profiled steps and warm-up all count) -- a hand-passed count went stale in round 4 (ADVICE).
 FETCH_SIZE / WRITE_SIZE are in KiB (x1024); on gfx950 FETCH_SIZE counts 128-byte requests as 64 B for wide
 coalesced reads (MI355X_MICROARCH.md, HBM section) -> the read side is doubled."""
 import csv, json, sys, collections
-fetch_csv, write_csv, steps, prec = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r04.json"
+fetch_csv, write_csv, steps, prec = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r05.json"
+if steps == "auto":
+    steps = sum(1 for row in csv.DictReader(open(fetch_csv)) if row["Counter_Name"] == "FETCH_SIZE" and "stem_mfma_kernel" in row["Kernel_Name"])
+    assert steps > 0, "no stem_mfma_kernel launch in %s" % fetch_csv
+steps = int(steps)
 def load(path, counter):
     per = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] != counter:
             continue
         name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "conv1x1_fat_kernel", "bottleneck_")) and "pack_kernel" not in name else name.split("(")[0][-40:]
+        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "conv1x1_fat_kernel", "conv1x1_duo_kernel", "bottleneck_")) and "pack_kernel" not in name else name.split("(")[0][-40:]
         for dom in ("conv3x3_wide_kernel", "conv3x3_fat_kernel"):   # the dominant kernel is also reported on its own
             if dom in name:
                 per[dom][0] += float(row["Counter_Value"])
@@ -26,7 +32,7 @@ launches = fi[1]
 fetch_b = fi[0] * 1024 * 2.0   # gfx950 correction for wide coalesced reads
 write_b = wi[0] * 1024
 extra = {}
-for k in ("graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "graph_apply_stream_kernel", "graph_tracklet_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel", "conv3x3_fat_kernel", "rank_topk_fast_kernel"):
+for k in ("conv1x1_duo_kernel", "stem_mfma_kernel", "graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "graph_apply_stream_kernel", "graph_tracklet_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel", "conv3x3_fat_kernel", "rank_topk_fast_kernel"):
     for kk in f:
         if k in kk and not (k in ("conv3x3_wide_kernel", "conv3x3_fat_kernel") and kk != k):
             extra[k] = {"fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
