@@ -35,8 +35,10 @@ extra = {}
 for k in ("conv1x1_duo_kernel", "stem_mfma_kernel", "graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "graph_apply_stream_kernel", "graph_tracklet_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel", "conv3x3_fat_kernel", "rank_topk_fast_kernel"):
     for kk in f:
         if k in kk and not (k in ("conv3x3_wide_kernel", "conv3x3_fat_kernel") and kk != k):
-            extra[k] = {"fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
-                        "write_bytes_per_launch": (w[kk][0] * 1024 / max(w[kk][1], 1)) if kk in w else None}
+            # one entry per instantiation (distmat_regq_kernel<2, 3, 16> = the step's 12 180-row gallery, <2, 4, 16> = the 8 x gallery)
+            extra[kk if kk != k and "<" in kk else k] = {
+                "launches": f[kk][1], "fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
+                "write_bytes_per_launch": (w[kk][0] * 1024 / max(w[kk][1], 1)) if kk in w else None}
 out = {prec: {"igemm_launches": launches, "steps": steps, "other_kernels": extra,
               "igemm_fetch_bytes_per_step": fetch_b / steps, "igemm_write_bytes_per_step": write_b / steps,
               "igemm_bytes_per_launch": (fetch_b + write_b) / launches,
