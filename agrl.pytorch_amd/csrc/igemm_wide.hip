@@ -26,7 +26,8 @@ constexpr int WBM = 256, WBN = 256;
 constexpr bool REGEPI_OK(int dbg) { return (dbg & 8192) == 0; }
 template <int DBG, int WBN_ = 256, bool RES = false>  // RES: + residual (its 64 staging registers leave no room for the persistent form's carried state); WBN_: channels per tile (256, or 128 for N = 256 layers: twice the tiles); DBG: ablation bits, compile time (a runtime test inside the k-loop wrecks the schedule): 2 no MFMA, 8 no steady-state DMA, 16 no fragment reads, 32 no DMA waits, 128 no barrier
 __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
-    static_assert(WBN_ == 256 || (WBN_ == 128 && (DBG & (4096 | 8192 | 16384)) == 0), "the 128-channel tile has the plain schedule + register epilogue only");
+    static_assert(WBN_ == 256 || ((WBN_ == 128 || WBN_ == 192) && (DBG & (4096 | 8192 | 16384)) == 0), "the 128- / 192-channel tiles have the plain schedule + register epilogue only");
+    static_assert(WBN_ != 192 || (DBG & 65536) != 0, "the 192-column tile exists for the fp32-output distance form only");
     constexpr bool POOL = (DBG & 16384) != 0;   // fused frame pooling epilogue (a tile = two whole 16 x 8 frames)
     // DUAL (bit 32768): TWO pixel-row operands concatenated along K -- out = [x | x2] [W1 | W2]^T: a Bottleneck's last conv
     // and its 1x1 downsample conv as ONE GEMM (vmgn.py:56-64: bn3(conv3(y2)) + downsample(x), both BatchNorms folded), so the
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
     // igemm_kernel it used before sits at 0.30 of the MFMA peak on that shape. M and N need not be tile multiples: rows of
     // either operand beyond the matrix are staged as zeros and their results are not stored (N % 4 == 0 for the 16-byte stores).
     constexpr bool F32OUT = (DBG & 65536) != 0;
-    static_assert(!F32OUT || (WBN_ == 256 && !RES && !POOL && !DUAL && REGEPI_OK(DBG)), "fp32 output: plain 256-channel tiles, register epilogue");
+    static_assert(!F32OUT || ((WBN_ == 256 || WBN_ == 192) && !RES && !POOL && !DUAL && REGEPI_OK(DBG)), "fp32 output: plain 256- / 192-column tiles, register epilogue");
     constexpr bool REGEPI = (DBG & 8192) == 0;  // bit 8192: the LDS-staged two-half epilogue (kept for A/B)
     constexpr int BM = WBM, BN = WBN_, NW = 8, WM = 4;
     constexpr int FM = BM / (16 * WM);  // 4 pixel fragments per wave
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(const IgemmParams p) {
                 // 4 (a&1) + (i&3): the MFMA result rows 4 f + r of the 8 fragments of a lane are then 32 channels that the
                 // register epilogue reads / writes as 16-byte pieces, 64 contiguous bytes per pixel row and instruction
                 constexpr int SLAB = BN / 2;  // channels per wave column
-                const int rp = row & (SLAB - 1), a = rp >> 4, i = rp & 15;
-                ch = (row & ~(SLAB - 1)) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
+                const int rp = row % SLAB, a = rp >> 4, i = rp & 15;   // (SLAB = 128 / 64, or 96 for the 192-column distance tile)
+                ch = (row - rp) + 32 * (a >> 1) + 8 * (i >> 2) + 4 * (a & 1) + (i & 3);
             }
             if constexpr (F32OUT) {
                 if (j == 0) b_okmask = 0;
@@ -546,8 +547,21 @@ bool igemm_wide_f32out_applicable(const IgemmParams& p) {
 }
 
 int launch_igemm_wide_f32out(const IgemmParams& p, hipStream_t stream, const char* who) {
-    const int tiles = cdiv(p.M, WBM) * cdiv(p.N, WBN);
-    hipLaunchKernelGGL((igemm_wide_kernel<65536, 256, false>), dim3(tiles), dim3(512), 0, stream, p);
+    // One workgroup per tile and per CU: the launch takes ceil(tiles / CUs) rounds of a tile's time, and a 256 x 192 tile costs 3/4
+    // of a 256 x 256 one. The MARS matrix (1980 x 12 180: 8 x 48 = 384 tiles of 256 columns = 1.5 rounds, paid as 2) is 8 x 64 = 512
+    // tiles of 192 columns = 2 exact rounds at 3/4 of the cost each: take the 192-column tile whenever it is cheaper by that count.
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int mt = cdiv(p.M, WBM);
+    const int tiles256 = mt * cdiv(p.N, 256), tiles192 = mt * cdiv(p.N, 192);
+    const long long cost256 = (long long)cdiv(tiles256, cus) * 256, cost192 = (long long)cdiv(tiles192, cus) * 192;
+    const int force = agrl_opts().distmat_tile_n;   // AGRL_DISTMAT_TILE_N = 192 / 256: A/B
+    const bool use192 = agrl_opt_set(force) ? force == 192 : cost192 < cost256;
+    if (use192) hipLaunchKernelGGL((igemm_wide_kernel<65536, 192, false>), dim3(tiles192), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((igemm_wide_kernel<65536, 256, false>), dim3(tiles256), dim3(512), 0, stream, p);
     AGRL_CHECK_LAUNCH(who);
     return 0;
 }
