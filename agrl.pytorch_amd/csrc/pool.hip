@@ -229,6 +229,131 @@ __global__ __launch_bounds__(256) void attn_pool_bnneck_kernel(
     out[(size_t)b * 2 * C + C + c] = fmaf(att, a_scale[c], a_shift[c]);
 }
 
+// The whole per-tracklet tail in ONE launch (round 5: the review's "two extra launches in front of the distance matrix"): node norms
+// (row_sqnorm_kernel's job), attention pooling + BNNeck + cat (attn_pool_bnneck_kernel's), and the query operand of the distance
+// matrix -- the embedding row's squared norm and its L2-normalised copy in the distance matrix's operand type (row_sqnorm_kernel /
+// row_normalize_kernel on the (B, 2C) output). One 1024-thread workgroup per tracklet; every sum runs in the order of the kernel
+// it replaces (a wave per node / per row with the same eight loads in flight and the same shuffle tree; a thread per channel over
+// frames then parts; 256 threads x float4 strides and the four-partial tree for the row norm), so all outputs are BIT-IDENTICAL to
+// the three separate launches. vmgn.py:270-278, :313-321; distance.py:70-71, :86-87.
+__global__ __launch_bounds__(1024) void attn_tail_kernel(
+    const float* __restrict__ nodes, const float* __restrict__ gsum, const float* __restrict__ g_scale,
+    const float* __restrict__ g_shift, const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+    float* __restrict__ out, float* __restrict__ g_f, float* __restrict__ att_f, float* __restrict__ node_sqn,
+    float* __restrict__ out_sqn, lp16_t* __restrict__ q_lp, float* __restrict__ q_f32, int S, int P, int C, float inv_ghw) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];  // [V] attention weights | [2 C] the output row | [4] partials
+    const int b = blockIdx.x;
+    const int V = S * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* s_att = s_mem;
+    float* s_row = s_mem + ((V + 3) & ~3);
+    float* s_part = s_row + 2 * C;
+    // ---- node norms: one wavefront per node, row_sqnorm_kernel<float>'s loads and order
+    for (int v = wave; v < V; v += 16) {
+        const float* src = nodes + ((size_t)b * V + v) * C;
+        float s = 0.f;
+        for (int c0 = lane * 4; c0 < C; c0 += 8 * 64 * 4) {
+            float x[8][4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 + i * 64 * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[i][j] = 0.f;
+                if (c < C) load_vec<float>(src + c, x[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (c0 + i * 64 * 4 < C) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s = fmaf(x[i][j], x[i][j], s);
+                }
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            s_att[v] = sqrtf(s);
+            if (node_sqn) node_sqn[(size_t)b * V + v] = s;
+        }
+    }
+    __syncthreads();
+    // a[s,p] = ||f[s,p]|| / max(sum_s ||f[s,p]||, 1e-12)   (F.normalize p=1 over the frame axis)
+    for (int q = tid; q < P; q += blockDim.x) {
+        float tot = 0.f;
+        for (int s = 0; s < S; ++s) tot += s_att[s * P + q];
+        const float den = fmaxf(tot, 1e-12f);
+        for (int s = 0; s < S; ++s) s_att[s * P + q] = s_att[s * P + q] / den;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        // attention branch: mean over parts of the attention-weighted sum over frames (attn_pool_bnneck_kernel's order)
+        float att = 0.f;
+        for (int q = 0; q < P; ++q) {
+            float fuse = 0.f;
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                float nv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) nv[i] = s0 + i < S ? nodes[((size_t)b * V + (s0 + i) * P + q) * C + c] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (s0 + i < S) fuse = fmaf(s_att[(s0 + i) * P + q], nv[i], fuse);
+            }
+            att += fuse;
+        }
+        att /= (float)P;
+        float g = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            float gv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gv[i] = s0 + i < S ? gsum[((size_t)b * S + s0 + i) * C + c] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (s0 + i < S) g += gv[i];
+        }
+        g *= inv_ghw;
+        if (g_f) g_f[(size_t)b * C + c] = g;
+        if (att_f) att_f[(size_t)b * C + c] = att;
+        const float og = fmaf(g, g_scale[c], g_shift[c]), oa = fmaf(att, a_scale[c], a_shift[c]);
+        out[(size_t)b * 2 * C + c] = og;
+        out[(size_t)b * 2 * C + C + c] = oa;
+        s_row[c] = og;
+        s_row[C + c] = oa;
+    }
+    __syncthreads();
+    const int D = 2 * C;
+    if (out_sqn && wave == 4) {  // the row's squared norm as row_sqnorm_kernel<float> forms it (one wavefront)
+        float s = 0.f;
+        for (int c0 = lane * 4; c0 < D; c0 += 8 * 64 * 4) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 + i * 64 * 4;
+                if (c < D) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s = fmaf(s_row[c + j], s_row[c + j], s);
+                }
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) out_sqn[b] = s;
+    }
+    if (q_lp || q_f32) {  // x / max(||x||, 1e-12): row_normalize_kernel's 256 threads x float4 strides, four wave partials
+        if (tid < 256) {
+            float s = 0.f;
+            for (int c = tid * 4; c < D; c += 1024) {
+                s = fmaf(s_row[c], s_row[c], s); s = fmaf(s_row[c + 1], s_row[c + 1], s);
+                s = fmaf(s_row[c + 2], s_row[c + 2], s); s = fmaf(s_row[c + 3], s_row[c + 3], s);
+            }
+            s = wave_sum(s);
+            if (lane == 0) s_part[wave] = s;
+        }
+        __syncthreads();
+        const float den = fmaxf(sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])), 1e-12f);
+        for (int c = tid; c < D; c += blockDim.x) {
+            const float v = s_row[c] / den;
+            if (q_lp) q_lp[(size_t)b * D + c] = f32_to_lp16(v);
+            if (q_f32) q_f32[(size_t)b * D + c] = v;
+        }
+    }
+}
+
 // out[t][c] = mean / max over i < n of feats[t*n + i][c]; thread -> one channel of one tracklet, clips in ascending order
 __global__ __launch_bounds__(256) void clip_pool_kernel(const float* __restrict__ feats, float* __restrict__ out, int n, int D,
                                                         int mode) {
@@ -335,5 +460,19 @@ extern "C" int agrl_attn_pool_bnneck(const float* nodes, const float* sqn, const
     hipLaunchKernelGGL(attn_pool_bnneck_kernel, grid, dim3(256), lds, (hipStream_t)stream, nodes, sqn, gsum, g_scale,
                        g_shift, a_scale, a_shift, out, g_f, att_f, S, P, C, 1.f / ((float)S * (float)hw));
     AGRL_CHECK_LAUNCH("agrl_attn_pool_bnneck");
+    return 0;
+}
+
+extern "C" int agrl_attn_tail(const float* nodes, const float* gsum, const float* g_scale, const float* g_shift, const float* a_scale,
+                              const float* a_shift, float* out, float* g_f, float* att_f, float* node_sqn, float* out_sqn,
+                              void* q_lp, float* q_f32, int B, int S, int P, int C, int hw, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(nodes && gsum && g_scale && g_shift && a_scale && a_shift && out, "agrl_attn_tail: null pointer");
+    AGRL_CHECK_ARG(B > 0 && S > 0 && P > 0 && C > 0 && hw > 0 && C % 4 == 0, "agrl_attn_tail: bad shape (C must be a multiple of 4)");
+    AGRL_CHECK_ARG((((uintptr_t)nodes | (uintptr_t)out) & 15) == 0, "agrl_attn_tail: nodes / out must be 16-byte aligned");
+    const size_t lds = ((size_t)((S * P + 3) & ~3) + 2 * (size_t)C + 4) * sizeof(float);
+    AGRL_CHECK_ARG(lds <= 64 * 1024, "agrl_attn_tail: S * P + 2 C floats must fit 64 KB of LDS");
+    hipLaunchKernelGGL(attn_tail_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, nodes, gsum, g_scale, g_shift, a_scale, a_shift,
+                       out, g_f, att_f, node_sqn, out_sqn, reinterpret_cast<lp16_t*>(q_lp), q_f32, S, P, C, 1.f / ((float)S * (float)hw));
+    AGRL_CHECK_LAUNCH("agrl_attn_tail");
     return 0;
 }

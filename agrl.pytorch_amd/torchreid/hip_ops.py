@@ -655,6 +655,70 @@ def attn_pool_bnneck(nodes, sqn, gsum, g_scale, g_shift, a_scale, a_shift, B, S,
     return out
 
 
+def attn_tail_supported(S, P, Cc, B=None):
+    """The one-launch tail (agrl_attn_tail): C % 4 == 0 and S * P + 2 C floats within 64 KB of LDS. With ``B`` given: also whether the
+    model should TAKE it -- one workgroup per tracklet fills the chip only from ~224 tracklets per GPU (measured, tools/
+    attn_tail_bench.py, one launch / three launches: 37.6 / 35.7 us at 32 tracklets, 43.6 / 40.2 at 128, 53.7 / 58.2 at 256);
+    AGRL_HIP_FUSE_ATTN_TAIL=1 / 0 forces it on / off."""
+    ok = Cc % 4 == 0 and (((S * P + 3) & ~3) + 2 * Cc + 4) * 4 <= 64 * 1024
+    if B is None or not ok:
+        return ok
+    force = os.environ.get('AGRL_HIP_FUSE_ATTN_TAIL')
+    if force is not None:
+        return force != '0'
+    return B >= int(os.environ.get('AGRL_HIP_ATTN_TAIL_MIN_B', '224'))
+
+
+def attn_tail(nodes, gsum, g_scale, g_shift, a_scale, a_shift, B, S, P, hw, want_feats=False, query_dtype=None, want_node_sqn=False):
+    """row_sqnorm(nodes) + attn_pool_bnneck + the distance matrix's query operand in ONE launch (bit-identical to the separate
+    calls). -> out (B,2C), feats (g_f, att_f) or None, query dict or None: {'sqn': ||out||^2 (B,), 'normalized': out / ||out||
+    in ``query_dtype`` (LP_DTYPE or torch.float32)}, node_sqn (B*S*P,) or None. vmgn.py:270-278, :313-321; distance.py:70-71, :86-87."""
+    Cc = nodes.shape[-1]
+    dev = nodes.device
+    out = torch.empty((B, 2 * Cc), dtype=torch.float32, device=dev)
+    g_f = torch.empty((B, Cc), dtype=torch.float32, device=dev) if want_feats else None
+    att_f = torch.empty((B, Cc), dtype=torch.float32, device=dev) if want_feats else None
+    node_sqn = torch.empty((B * S * P,), dtype=torch.float32, device=dev) if want_node_sqn else None
+    q_lp = q_f32 = out_sqn = None
+    if query_dtype is not None:
+        out_sqn = torch.empty((B,), dtype=torch.float32, device=dev)
+        if query_dtype == LP_DTYPE:
+            q_lp = torch.empty((B, 2 * Cc), dtype=LP_DTYPE, device=dev)
+        else:
+            q_f32 = torch.empty((B, 2 * Cc), dtype=torch.float32, device=dev)
+    with _dev(nodes):
+        call("agrl_attn_tail", ptr(nodes), ptr(gsum), ptr(g_scale), ptr(g_shift), ptr(a_scale), ptr(a_shift), ptr(out), ptr(g_f),
+             ptr(att_f), ptr(node_sqn), ptr(out_sqn), ptr(q_lp), ptr(q_f32), B, S, P, Cc, hw, _stream(nodes))
+    query = None if query_dtype is None else {'sqn': out_sqn, 'normalized': q_lp if q_lp is not None else q_f32}
+    return out, ((g_f, att_f) if want_feats else None), query, node_sqn
+
+
+class QueryOperandCache:
+    """What agrl_attn_tail left beside an embedding batch: its rows' squared norms and L2-normalised copy in the distance matrix's
+    operand type. ``lookup(emb, dtype)`` answers only for THE tensor the forward returned (same storage, shape and version)."""
+
+    def __init__(self, emb, query):
+        self.key = (emb.data_ptr(), tuple(emb.shape), emb._version, emb.device)
+        self.query = query
+
+    def lookup(self, emb, dtype):
+        if self.key != (emb.data_ptr(), tuple(emb.shape), emb._version, emb.device) or self.query['normalized'].dtype != dtype:
+            return None
+        return self.query
+
+
+def query_operands(model, emb, metric, dtype):
+    """The query side of hip_distmat for one batch of embeddings ``emb`` (B,D) fp32 -> (operand, sq-norms or None): the cosine
+    operand / the euclidean norms straight from the tail kernel when ``emb`` is the tensor ``model`` just returned (no extra
+    launch), else agrl_row_l2_normalize / agrl_row_sqnorm. distance.py:59-89."""
+    cache = getattr(model, '_hip_query', None)
+    q = cache.lookup(emb, dtype) if cache is not None else None
+    if metric == 'cosine':
+        return (q['normalized'] if q is not None else row_l2_normalize(emb, True, dtype)), None
+    qn = q['sqn'] if q is not None else row_sqnorm(emb)
+    return (row_l2_normalize(emb, False, dtype) if dtype != torch.float32 else emb), qn
+
+
 def k_multiple(dtype):
     """K granularity of the GEMM kernel: one 128-byte k-tile."""
     return 64 if dtype == LP_DTYPE else 32

@@ -343,9 +343,18 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
         if stages is not None:
             stages.update(gsum=gsum, hw=hw, nodes=nodes)
         nodes = hip_graph_layers(nodes, nodes_lp, adj32, pack, stages, commute=commute)
-        sqn = ops.row_sqnorm(nodes.view(B * V, C))
-        res = ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
-                                   pack['a_bn'][1], B, S, P, hw, want_feats=return_feats or stages is not None)
+        model._hip_query = None
+        if ops.attn_tail_supported(S, P, C, B):
+            # many tracklets per GPU: node norms + attention pooling + BNNeck + the distance matrix's query operand in one launch
+            want = return_feats or stages is not None
+            out, feats, query, _ = ops.attn_tail(nodes, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0], pack['a_bn'][1],
+                                                 B, S, P, hw, want_feats=want, query_dtype=ops.LP_DTYPE if lp else torch.float32)
+            model._hip_query = ops.QueryOperandCache(out, query)
+            res = (out, feats[0], feats[1]) if want else out
+        else:
+            sqn = ops.row_sqnorm(nodes.view(B * V, C))
+            res = ops.attn_pool_bnneck(nodes, sqn, gsum, pack['g_bn'][0], pack['g_bn'][1], pack['a_bn'][0],
+                                       pack['a_bn'][1], B, S, P, hw, want_feats=return_feats or stages is not None)
         if stages is not None:
             stages.update(nodes_out=nodes, out=res[0], g_f=res[1], att_f=res[2])
             return res if return_feats else res[0]

@@ -660,11 +660,11 @@ def main():
 
     def match(emb):
         q_all = parallel.all_gather_rows(emb)         # RCCL all-gather over xGMI when world > 1
+        # the query side of the distance matrix: at N = 1 the forward's tail kernel has already left the normalised rows / norms
+        # beside the embeddings it returned (hip_ops.query_operands); gathered rows are normalised here
+        q_op, qn = ops.query_operands(model, q_all, args.metric, dt_g)
         if args.metric == "cosine":
-            q_op = ops.row_l2_normalize(q_all, True, dt_g)
             return ops.distmat(q_op, g_op, "cosine", out=dist_out)
-        qn = ops.row_sqnorm(q_all)
-        q_op = ops.row_l2_normalize(q_all, False, dt_g) if lp else q_all
         return ops.distmat(q_op, g_op, "euclidean", qn, g_norm, out=dist_out)
 
     main_stream = torch.cuda.current_stream(device)

@@ -318,6 +318,17 @@ int agrl_attn_pool_bnneck(const float* nodes, const float* sqn, const float* gsu
                           const float* a_shift, float* out, float* g_f, float* att_f, int B, int S,
                           int P, int C, int hw, agrl_stream_t stream);
 
+/* The whole per-tracklet tail in ONE launch: agrl_row_sqnorm over the nodes + agrl_attn_pool_bnneck + the query operand of the
+ * distance matrix (agrl_row_sqnorm / agrl_row_l2_normalize over the (B, 2C) output) -- torchreid/models/vmgn.py:270-278, :313-321
+ * followed by torchreid/metrics/distance.py:70-71 (row norms) / :86-87 (F.normalize p=2). One workgroup per tracklet; every sum in
+ * the order of the kernel it replaces: all outputs bit-identical to the separate launches.
+ *   nodes fp32 (B,S,P,C), gsum fp32 (B*S,C), folded BatchNorm1d scale / shift fp32 (C) -> out fp32 (B,2C);
+ *   optional (NULL = not wanted): g_f, att_f fp32 (B,C); node_sqn fp32 (B,S,P); out_sqn fp32 (B) = ||out[b]||^2;
+ *   q_lp (B,2C) in the library's 16-bit type / q_f32 fp32 (B,2C) = out[b] / max(||out[b]||, 1e-12).  C % 4 == 0. */
+int agrl_attn_tail(const float* nodes, const float* gsum, const float* g_scale, const float* g_shift, const float* a_scale,
+                   const float* a_shift, float* out, float* g_f, float* att_f, float* node_sqn, float* out_sqn, void* q_lp,
+                   float* q_f32, int B, int S, int P, int C, int hw, agrl_stream_t stream);
+
 /* Clip pooling of the dense / skipdense test samplers: every tracklet is evaluated as n clips and its embedding is the
  * mean (mode 0) or maximum (mode 1) over them (train_vidreid_xent_htri.py:471-476: features.view(n, 1, -1) ->
  * torch.mean / torch.max over dim 0).  feats fp32 (T*n, D), clip index fastest -> out fp32 (T, D). The mean adds the clips

@@ -211,3 +211,31 @@ def test_device_pipeline_equals_the_reference_test_function(metric, sample):
     srt = np.sort(ref, axis=1)
     if np.min(np.diff(srt[:, :51], axis=1)) > 4 * np.abs(d - ref).max():   # no near-tie in any top-50 list: index-exact
         assert np.array_equal(cmc, z[tag + "_cmc"]) and mAP2 == float(z[tag + "_mAP"])
+
+
+def test_query_operand_from_the_tail_kernel_equals_the_separate_launches(world, monkeypatch):
+    """hip_ops.query_operands: for the tensor the forward just returned the cosine operand / euclidean norms come from agrl_attn_tail
+    (no extra launch) and are bit-identical to agrl_row_l2_normalize / agrl_row_sqnorm on it; any other tensor (a clone, a gathered
+    batch) takes the separate launches; the distance matrix is the same either way."""
+    from torchreid import hip_ops as ops
+    monkeypatch.setenv("AGRL_HIP_FUSE_ATTN_TAIL", "1")   # (the model takes the one-launch tail from 224 tracklets per GPU on its own)
+    m = world["model"]
+    x, adj = synthetic_clips(4, S, seed=21).to(DEV), synthetic_adj(4, S, seed=21).to(DEV)
+    gal = torch.randn((300, 4096), device=DEV)
+    for prec, dt in ((LP16, LP_DTYPE), ("fp32", torch.float32)):
+        m.hip_precision = prec
+        emb = m(x, adj)
+        assert m._hip_query is not None and m._hip_query.lookup(emb, dt) is not None
+        assert m._hip_query.lookup(emb.clone(), dt) is None
+        for metric in ("cosine", "euclidean"):
+            q_op, qn = ops.query_operands(m, emb, metric, dt)
+            q_ref, qn_ref = ops.query_operands(None, emb, metric, dt)
+            assert torch.equal(q_op, q_ref) and (qn is None) == (qn_ref is None) and (qn is None or torch.equal(qn, qn_ref))
+            if metric == "cosine":
+                g_op = ops.row_l2_normalize(gal, True, dt)
+                assert torch.equal(ops.distmat(q_op, g_op, "cosine"), ops.distmat(q_ref, g_op, "cosine"))
+        monkeypatch.setenv("AGRL_HIP_FUSE_ATTN_TAIL", "0")
+        emb3 = m(x, adj)                                   # the three-launch tail: the same embedding bit for bit, no operand cache
+        monkeypatch.setenv("AGRL_HIP_FUSE_ATTN_TAIL", "1")
+        assert torch.equal(emb3, emb) and m._hip_query is None
+    m.hip_precision = "fp32"

@@ -881,6 +881,38 @@ def test_attention_tail():
     assert rel_err(out, ref) < 1e-5 and rel_err(gf, g_f) < 1e-5 and rel_err(af, att_f) < 1e-5
 
 
+@pytest.mark.parametrize("cfg", [(32, 8, 7, 2048, 128), (3, 8, 7, 2048, 128), (2, 16, 7, 2048, 128), (5, 4, 3, 512, 60), (1, 1, 7, 256, 128)])
+def test_attention_tail_one_launch(cfg):
+    """agrl_attn_tail = agrl_row_sqnorm (node norms) + agrl_attn_pool_bnneck + the distance matrix's query operand (agrl_row_sqnorm and
+    agrl_row_l2_normalize over the embedding rows, both operand types) in ONE launch: every output BIT-IDENTICAL to the separate
+    launches (each sum runs in the order of the kernel it replaces) -- bench shape, a zero frame, seq_len 16, small widths, one frame."""
+    from torchreid import hip_ops as ops
+    B, S, P, C, hw = cfg
+    g = torch.Generator().manual_seed(B * 7 + S)
+    nodes = torch.rand((B, S, P, C), generator=g)
+    if S > 2:
+        nodes[B // 2, 2] = 0  # a frame whose nodes are all zero
+    nd = nodes.to(DEV)
+    gsum = (torch.rand((B * S, C), generator=g) * hw).to(DEV)
+    gs, gsh = (0.8 + 0.4 * torch.rand(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    as_, ash = (0.8 + 0.4 * torch.rand(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    assert ops.attn_tail_supported(S, P, C)
+    sqn = ops.row_sqnorm(nd.view(B * S * P, C))
+    out0, gf0, af0 = ops.attn_pool_bnneck(nd, sqn, gsum, gs, gsh, as_, ash, B, S, P, hw, want_feats=True)
+    for qdt in (LP_DTYPE, torch.float32):
+        out, feats, query, node_sqn = ops.attn_tail(nd, gsum, gs, gsh, as_, ash, B, S, P, hw, want_feats=True, query_dtype=qdt, want_node_sqn=True)
+        torch.cuda.synchronize()
+        assert torch.equal(node_sqn, sqn)
+        assert torch.equal(out, out0) and torch.equal(feats[0], gf0) and torch.equal(feats[1], af0)
+        assert torch.equal(query['sqn'], ops.row_sqnorm(out0))
+        assert torch.equal(query['normalized'], ops.row_l2_normalize(out0, True, qdt))
+    out_plain, feats_none, q_none, _ = ops.attn_tail(nd, gsum, gs, gsh, as_, ash, B, S, P, hw)
+    assert torch.equal(out_plain, out0) and feats_none is None and q_none is None
+    with pytest.raises(_hip.HipKernelError):
+        ops.call("agrl_attn_tail", ops.ptr(nd), ops.ptr(gsum), ops.ptr(gs), ops.ptr(gsh), ops.ptr(as_), ops.ptr(ash), ops.ptr(out), None, None,
+                 None, None, None, None, B, S, P, C + 2, hw, None)
+
+
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
 @pytest.mark.parametrize("shape", [(37, 101, 4096), (5, 300, 96), (130, 257, 2048), (32, 12180, 4096), (8, 3000, 1024), (50, 2500, 512), (20, 2077, 256), (64, 4099, 128)])
 def test_distmat(shape, metric):
