@@ -27,7 +27,7 @@ def _worker(rank, world, port, tmp):
     from torchreid import parallel
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = parallel.init_from_env("gloo")
-    assert (r, w) == (rank, world)
+    assert (r, w) == (rank, world) and parallel.collectives_active()
     g = torch.Generator().manual_seed(0)
     emb = torch.randn((6 * world, 64), generator=g)            # what the forward would produce, all tracklets
     gallery = torch.randn((101, 64), generator=g)
@@ -82,6 +82,29 @@ def test_sharded_match_equals_single_process(tmp_path, world):
         idx, val = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert torch.equal(idx, ref_idx)
         assert torch.allclose(val, ref_val, atol=1e-6)
+
+
+def _forced_worker(rank, world, port, tmp):
+    os.environ["AGRL_DIST_FORCE_GROUP"] = "1"
+    _worker(rank, world, port, tmp)
+
+
+@pytest.mark.timeout(300)
+def test_forced_group_at_world_size_one_runs_the_collective_path(tmp_path):
+    """AGRL_DIST_FORCE_GROUP=1 (what tests/test_gpu_configs.py::test_rccl_path_on_one_gpu uses with the nccl backend): a process group
+    of ONE rank is built and all_gather_rows / sharded_topk take their collective + candidate-merge branches instead of the
+    single-process shortcut -- same result."""
+    from torchreid import parallel
+    assert not parallel.collectives_active()
+    mp.spawn(_forced_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn((6, 64), generator=g)
+    gallery = torch.randn((101, 64), generator=g)
+    gallery[40] = gallery[7]
+    gallery[90] = gallery[7]
+    ref_idx, ref_val = _cpu_topk(O.cosine(emb, gallery), 20)
+    idx, val = torch.load(os.path.join(str(tmp_path), "r0.pt"))
+    assert torch.equal(idx, ref_idx) and torch.allclose(val, ref_val, atol=1e-6)
 
 
 def _train_worker(rank, world, port, tmp):
