@@ -35,6 +35,10 @@
 //     agrl_conv1x1_bn_act_pool from the accumulators (wave-local bins, 16-lane shuffles): correct (stored map equal bit for bit,
 //     pooled sums to 7e-8), 512 -> 2048 + residual 119.4 us against igemm_wide_kernel<0, 256, true>'s 115.8, pooled 175.0
 //     against igemm_wide_kernel<16384, 256, true>'s 106.7.
+//   * (round 5) the result rows through a wave-private 32 KB LDS image so that every global store is a whole 128-byte line per
+//     eight lanes (what took 10 us off conv1x1_duo.hip's epilogue, where a second workgroup on the CU covers the round trip):
+//     bit-identical, [1024 | 512] -> 2048 183.7-185.0 us against 176.7-178.1, 512 -> 2048 87-88 against 86-87, 2048 -> 512 equal --
+//     with one workgroup per CU the barrier + LDS round trip is serial time that the better store pattern does not buy back.
 // Four designs for conv3 + residual of layer 4 (8-wave LDS ring, this kernel with the residual as slabs / in registers /
 // persistent, the back-to-back seam kernel) land within 5 % of each other at 2.6 TB/s of HBM traffic: 300 MB per launch, half of
 // it written, with 33 MB of operand rows re-read through L2 by eight channel tiles.
