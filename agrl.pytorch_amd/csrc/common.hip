@@ -39,6 +39,7 @@ static AgrlOpts load_opts() {
     o.graph_linear_mmajor = opt_flag("AGRL_GRAPH_LINEAR_MMAJOR");
     o.conv3x3_n128 = opt_flag("AGRL_CONV3X3_N128");
     o.distmat_tile_n = opt_int("AGRL_DISTMAT_TILE_N");
+    o.conv3x3_fat_pb = opt_int("AGRL_CONV3X3_FAT_PB");
 #ifdef AGRL_ABLATE
     o.igemm_dbg = agrl_opt_set(opt_int("AGRL_IGEMM_DBG")) ? opt_int("AGRL_IGEMM_DBG") : 0;
     o.conv3x3_dbg = agrl_opt_set(opt_int("AGRL_CONV3X3_DBG")) ? opt_int("AGRL_CONV3X3_DBG") : 0;

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
         fat_gload<(POS & 3) * 1024>(wr[SLOT], lane16, slab_base + (POS & ~3) * 1024);
     };
 
-    asm volatile("" ::: "a255");
+    // the accumulators' AGPRs: 256 (PB = 2) / 128 (PB = 1: 240 registers in all, so that TWO one-block workgroups share a CU)
+    if constexpr (PB == 2) asm volatile("" ::: "a255");
+    else asm volatile("" ::: "a127");
     sfor<4 * NBF>([&](auto qc) { fat_zero<decltype(qc)::value>(); });
 
     // ---- prologue: slab 0's patches, then the first FRING weight fragments
@@ -288,7 +290,8 @@ extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, con
     p.nblocks = N * (H >> 4) * (W >> 3);
     const int nNt = Cout >> 8;
     // two pixel blocks per workgroup where that still gives every CU a workgroup, else one
-    if ((p.nblocks / 2) * nNt >= 224) hipLaunchKernelGGL(conv3x3_fat_kernel<2>, dim3(((p.nblocks + 1) / 2) * nNt), dim3(256), 0, (hipStream_t)stream, p);
+    const int force_pb = agrl_opts().conv3x3_fat_pb;   // AGRL_CONV3X3_FAT_PB = 1 / 2: A/B
+    if (agrl_opt_set(force_pb) ? force_pb == 2 : (p.nblocks / 2) * nNt >= 224) hipLaunchKernelGGL(conv3x3_fat_kernel<2>, dim3(((p.nblocks + 1) / 2) * nNt), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv3x3_fat_kernel<1>, dim3(p.nblocks * nNt), dim3(256), 0, (hipStream_t)stream, p);
     AGRL_CHECK_LAUNCH("agrl_conv3x3_packed_bn_act");
     return 0;
