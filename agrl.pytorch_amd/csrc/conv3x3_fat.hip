@@ -21,6 +21,11 @@
 // 128 -> 128 convs on 32 x 16 maps was built (bit-identical) and withdrawn: 45.9 us against conv3x3_patch_kernel's 45.3 -- two
 // 64-channel slabs per tile are over before the pipeline has paid for its prologue. The same variant on layer 3 (256 pixels x 128
 // channels, so that the two waves of a channel half fetch each weight fragment together): 37.1-37.3 us against 35.8-37.2.
+// Round 5, two more measurements (tools/conv3x3_bench.py, HIP events, same box): (a) the one-block form now asks for 128 AGPRs
+// instead of 256 (240 registers in all), so that two of its workgroups share a CU: on layer 4 (AGRL_CONV3X3_FAT_PB=1: 512 one-block
+// workgroups, two per CU, against 256 two-block ones) 126.5-127.8 us against 126.3-128.2 -- equal: the kernel is at its matrix
+// stream either way; (b) weight-ring depth 8 / 12 / 18 fragments on layer 3 (256 workgroups, one per CU): 45.4 / 45.2 / 45.6 us --
+// the 17 us that layer 3's launch spends beside its 17.5 us of matrix work are not weight latency in the loop.
 // Waits are hand-counted (every load is inline asm; hipcc's own waits would drain the ring) from a constexpr simulation of
 // one slab's issue order.
 #include "fat_dev.h"
