@@ -25,7 +25,9 @@
 // instead of 256 (240 registers in all), so that two of its workgroups share a CU: on layer 4 (AGRL_CONV3X3_FAT_PB=1: 512 one-block
 // workgroups, two per CU, against 256 two-block ones) 126.5-127.8 us against 126.3-128.2 -- equal: the kernel is at its matrix
 // stream either way; (b) weight-ring depth 8 / 12 / 18 fragments on layer 3 (256 workgroups, one per CU): 45.4 / 45.2 / 45.6 us --
-// the 17 us that layer 3's launch spends beside its 17.5 us of matrix work are not weight latency in the loop.
+// the 17 us that layer 3's launch spends beside its 17.5 us of matrix work are not weight latency in the loop; (c) two sets of pixel
+// fragments for the one-block form (the next k-step's fragments read one weight fragment earlier: 256 instead of 128 cycles ahead
+// of their first use): 42.8 / 42.8 us -- not LDS latency either.
 // Waits are hand-counted (every load is inline asm; hipcc's own waits would drain the ring) from a constexpr simulation of
 // one slab's issue order.
 #include "fat_dev.h"
