@@ -43,7 +43,7 @@ struct FatParams {
 };
 
 #ifndef FAT_ABL
-#define FAT_ABL 0  // timing ablations (results wrong): 1 no weight loads in the loop, 2 no patch DMA, 4 no LDS reads, 8 no MFMA
+#define FAT_ABL 0  // timing ablations (results wrong): 1 no weight loads in the loop, 2 no patch DMA, 4 no LDS reads, 8 no MFMA; 16: phase stamps (s_memtime, results right; agrl_fat3_trace_buffer, tools/fat3_timeline.py)
 #endif
 #ifndef FAT_RING
 #define FAT_RING 8
@@ -78,8 +78,19 @@ struct FatSchedOf {
     static constexpr FatSched<PPW> value = make_fat_sched<PPW>();
 };
 
+#if FAT_ABL & 16
+__device__ unsigned long long* g_fat3_trace = nullptr;   // profiling build: 16 stamps per workgroup
+#define FAT3_STAMP(k)                                                                                                      \
+    do {                                                                                                                   \
+        if (g_fat3_trace && threadIdx.x == 0) g_fat3_trace[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+#else
+#define FAT3_STAMP(k) do { } while (0)
+#endif
+
 template <int PB>  // pixel blocks per workgroup
 __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
+    FAT3_STAMP(0);
     constexpr int NBF = 8 * PB;                                   // pixel (B) fragments per wave
     constexpr int SLAB = PB * PATCH_BYTES_F;                      // one slab's patches
     constexpr int PPW = (PB * PATCH_PIECES + 3) / 4;              // patch pieces per wave and slab (the last ones may be dummies)
@@ -168,6 +179,7 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
     for (int i = 0; i < PPW; ++i) stage_patch_piece(0, 0, i);
     sfor<FRING>([&](auto ic) { issue_w(ic, wstream, ic); });
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FRING) : "memory");
+    FAT3_STAMP(1);
 
     using std::integral_constant;
     u32x4_t xf[NBF];
@@ -176,6 +188,7 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
         // that the other buffer (read during the previous slab) is free for the next slab's pieces
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        FAT3_STAMP(2 + (slab < 8 ? slab : 8));
         const bool more = slab + 1 < nslab;
         const unsigned char* ws = wstream + (size_t)slab * (FPS * 1024);
         const unsigned char* wsn = wstream + (size_t)(more ? slab + 1 : 0) * (FPS * 1024);  // past the end: slab 0 again (never used)
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
             if constexpr (A == 0 && KS < PPW) stage_patch_piece(more ? slab + 1 : slab, (slab + 1) & 1, KS);  // (last slab: its own pieces again, into the idle buffer)
         });
     }
+    FAT3_STAMP(11);
     // fragments requested past the end are still landing
 #pragma unroll
     for (int i = 0; i < FRING; ++i) asm volatile("" : "+v"(wr[i]));
@@ -214,6 +228,7 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
 #pragma unroll
     for (int i = 0; i < FRING; ++i) asm volatile("" : "+v"(wr[i]));
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    FAT3_STAMP(12);
 
     // ---- epilogue: + bias, ReLU, round once; lane (f, pixel) holds channels 64 wave + 32 j + 8 f .. + 7 of (b, j): 16-byte stores
     const int cb = nt * 256 + wave * 64 + 8 * fchunk;
@@ -239,6 +254,11 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
             }
         });
     });
+    FAT3_STAMP(13);
+#if FAT_ABL & 16
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FAT3_STAMP(14);
+#endif
 }
 
 // ---- one-off packing: OHWI (Cout, 3, 3, Cin) -> per (channel tile nt, wave w) streams [slab][tap][k-step][fragment a] of 1-KiB
@@ -265,6 +285,12 @@ __global__ void conv3x3_fat_pack_kernel(const lp16_t* __restrict__ w, uint4* __r
 bool fat_shape_ok(int H, int W, int Cin, int Cout) { return H % 16 == 0 && W % 8 == 0 && Cin % 64 == 0 && Cin >= 128 && Cout % 256 == 0; }
 
 }  // namespace
+
+#if FAT_ABL & 16
+extern "C" int agrl_fat3_trace_buffer(void* buf) {  // profiling build only
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fat3_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" long long agrl_conv3x3_packed_bytes(int Cin, int Cout) {
     if (Cin % 64 || Cout % 256) return 0;
