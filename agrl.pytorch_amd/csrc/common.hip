@@ -40,6 +40,8 @@ static AgrlOpts load_opts() {
     o.conv3x3_n128 = opt_flag("AGRL_CONV3X3_N128");
     o.distmat_tile_n = opt_int("AGRL_DISTMAT_TILE_N");
     o.conv3x3_fat_pb = opt_int("AGRL_CONV3X3_FAT_PB");
+    o.conv3x3_half = opt_int("AGRL_CONV3X3_HALF");
+    o.conv3x3_half_stagger = opt_int("AGRL_CONV3X3_HALF_STAGGER");
 #ifdef AGRL_ABLATE
     o.igemm_dbg = agrl_opt_set(opt_int("AGRL_IGEMM_DBG")) ? opt_int("AGRL_IGEMM_DBG") : 0;
     o.conv3x3_dbg = agrl_opt_set(opt_int("AGRL_CONV3X3_DBG")) ? opt_int("AGRL_CONV3X3_DBG") : 0;

@@ -261,6 +261,184 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
 #endif
 }
 
+// ---- the one-block form split over TWO workgroups per pixel block: 128 output channels each (wave w owns 32: the A fragments
+// 2 (w & 1), 2 (w & 1) + 1 of the 64-channel stream of channel group 2 half + (w >> 1)), 64 accumulator AGPRs, ~190 registers and 48 KB
+// of LDS, so that a CU holds two (or three) of them. For layers whose one-block form is ONE workgroup per CU (layer 3: 256 frames x 256
+// channels): there every CU spends 10 % of the launch in its start-up and 13 % in its store burst, in lock step with every other CU
+// (profiles/r05_conv3x3_fat_timeline.txt); two half-width workgroups share a CU's matrix pipes and hide part of each other's waits.
+// Same k order: bit-identical. Measured (rocprofv3 kernel durations, tools/half_trace.sh): layer 3 (256 -> 256) 33.7 us against
+// conv3x3_fat_kernel<1>'s 35.5 -- taken there; layer 4 (512 -> 512) 120.8 against conv3x3_fat_kernel<2>'s 115 -- not taken. Starting
+// the second resident round `stagger` clocks late (so that one's start-up and store burst would fall under the other's k-loop) makes
+// it SLOWER: 41.4 us by events without, 42.5-43.7 with 4 k .. 20 k clocks -- the default is 0.
+constexpr int HRING = 12;                // weight fragments in flight per wave (a slab = 36 = 3 ring turns)
+constexpr int HPS = 9 * 2 * 2;           // weight fragments per slab and wave: 9 taps x 2 k-steps x 2 channel fragments
+constexpr int HPPW = (PATCH_PIECES + 3) / 4;
+struct HalfSched {
+    int allowed[HPS];
+};
+constexpr HalfSched make_half_sched() {
+    HalfSched s{};
+    int issued[4][HPS] = {};
+    int seq = 0;
+    for (int p = 0; p < HRING; ++p) issued[0][p] = seq++;
+    for (int k = 0; k < 3; ++k)
+        for (int p = 0; p < HPS; ++p) {
+            if (k == 1) s.allowed[p] = seq - 1 - issued[k][p];
+            const int q = p + HRING;
+            if (q >= HPS) issued[k + 1][q - HPS] = seq++;
+            else issued[k][q] = seq++;
+            if ((p & 1) == 0 && (p >> 1) < HPPW) seq += 1;  // the next slab's patch piece
+        }
+    return s;
+}
+struct HalfSchedOf {
+    static constexpr HalfSched value = make_half_sched();
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_half_kernel(const FatParams p, int stagger, int first) {
+    using SCHED = HalfSchedOf;
+    using std::integral_constant;
+    constexpr int NBF = 8;
+    constexpr int SLAB = PATCH_BYTES_F;
+    static_assert(HPS % HRING == 0 && HPPW <= 18, "a slab is a whole number of ring turns; one patch piece per k-step");
+    __shared__ __attribute__((aligned(16))) unsigned char smem_[2 * SLAB + 1024];
+    lds_u8_t* const smem = (lds_u8_t*)smem_;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int frow = lane & 15, fchunk = lane >> 4;
+
+    if (stagger > 0 && (int)blockIdx.x >= first && (int)blockIdx.x < 2 * first) {  // the second resident round starts late
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(16);
+    }
+
+    // tile = (pixel block mt, 128-channel half ht of channel tile nt): the two halves of a block are `first` workgroups apart, i.e. in
+    // different resident rounds (whichever CU they land on)
+    const int nNt = p.Cout >> 8;
+    const int per_half = gridDim.x >> 1;
+    const int half = (int)blockIdx.x >= per_half ? 1 : 0;
+    int bid = (int)blockIdx.x - half * per_half;
+    {
+        const int nblk = per_half, q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, within = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+    }
+    const int mt = bid / nNt, nt = bid - mt * nNt;
+    const int tw = p.W >> 3, th = p.H >> 4;
+    const int img = mt / (tw * th);
+    const int trem = mt - img * (tw * th);
+    const int oy0 = (trem / tw) << 4, ox0 = (trem % tw) << 3;
+
+    // ---- patch staging: piece pi = wave + 4 i of the 23 pieces (8 patch pixels x 128 B each)
+    unsigned poff[HPPW];
+    bool pok[HPPW];
+    int pdst[HPPW];
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(&g_zero16);
+#pragma unroll
+    for (int i = 0; i < HPPW; ++i) {
+        const int piece = wave + 4 * i;
+        const bool real = piece < PATCH_PIECES;
+        const int row = piece * 8 + (lane >> 3);
+        const int py = row / 10, px = row - py * 10;
+        const int iy = oy0 + py - 1, ix = ox0 + px - 1;
+        pok[i] = real && row < 180 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        poff[i] = (unsigned)((((size_t)img * p.H + iy) * p.W + ix) * p.Cin * 2 + (((lane & 7) ^ patch_g(py, px)) << 4));
+        pdst[i] = real ? piece * 1024 : -1;
+    }
+    auto stage_patch_piece = [&](int slab, int buf, int i) {  // always exactly one DMA (dummies keep every wave's vmcnt equal)
+        const unsigned dst = pdst[i] >= 0 ? lds0 + buf * SLAB + pdst[i] : lds0 + 2 * SLAB;
+        fat_dma(pok[i] ? p.x + poff[i] + slab * 128 : zsrc, __builtin_amdgcn_readfirstlane(dst));
+    };
+
+    const int fp = frag_px(frow);
+    const int r0 = fp >> 3, x0 = fp & 7;
+    int tbase[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tbase[t] = patch_off<10>(r0 + t / 3, x0 + t % 3, fchunk);
+
+    // ---- weight stream: the 64-channel stream of channel group grp = 2 half + (wave >> 1) of tile nt holds, per (tap, k-step), four
+    // 1-KiB fragments a = 0 .. 3; this wave takes a = 2 (wave & 1) + {0, 1}: fragment q of a slab at (q >> 1) * 4 + 2 (wave & 1) + (q & 1)
+    const int nslab = p.Cin >> 6;
+    const int grp = 2 * half + (wave >> 1);
+    const unsigned char* wstream = p.wpk + (size_t)(nt * 4 + grp) * nslab * (FPS * 1024) + (size_t)(wave & 1) * 2048;
+    u32x4_t wr[HRING];
+    auto issue_w = [&](auto slot_c, const unsigned char* slab_base, auto pos_c) {
+        constexpr int SLOT = decltype(slot_c)::value, POS = decltype(pos_c)::value;
+        fat_gload<(POS & 1) * 1024>(wr[SLOT], lane16, slab_base + (POS >> 1) * 4096);
+    };
+
+    asm volatile("" ::: "a63");
+    sfor<2 * NBF>([&](auto qc) { fat_zero<decltype(qc)::value>(); });
+
+#pragma unroll
+    for (int i = 0; i < HPPW; ++i) stage_patch_piece(0, 0, i);
+    sfor<HRING>([&](auto ic) { issue_w(ic, wstream, ic); });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HRING) : "memory");
+
+    u32x4_t xf[NBF];
+    for (int slab = 0; slab < nslab; ++slab) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = slab + 1 < nslab;
+        const unsigned char* ws = wstream + (size_t)slab * (FPS * 1024);
+        const unsigned char* wsn = wstream + (size_t)(more ? slab + 1 : 0) * (FPS * 1024);  // past the end: slab 0 again (never used)
+        const lds_u8_t* sp = smem + (slab & 1) * SLAB;
+        auto ldx = [&](auto ks_c, auto b_c) {
+            constexpr int KS = decltype(ks_c)::value, B = decltype(b_c)::value;
+            const lds_u8_t* a = sp + (tbase[KS >> 1] ^ ((KS & 1) * 64));
+            return *reinterpret_cast<const lds_u32x4_t*>(a + B * 2560);
+        };
+        sfor<NBF>([&](auto bc) { xf[decltype(bc)::value] = ldx(integral_constant<int, 0>{}, bc); });
+
+        sfor<HPS>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            constexpr int KS = P >> 1, A = P & 1, SL = P % HRING;
+            fat_wait<SCHED::value.allowed[P]>(wr[SL]);
+            sfor<NBF>([&](auto bc) {
+                constexpr int B = decltype(bc)::value;
+                fat_mfma<A * NBF + B>(wr[SL], xf[B]);
+                if constexpr (A == 1 && KS + 1 < 18) {  // the next k-step's fragment replaces this one right behind its last reader
+                    __builtin_amdgcn_sched_barrier(0);
+                    xf[B] = ldx(integral_constant<int, KS + 1>{}, bc);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int Q = P + HRING;
+            if constexpr (Q >= HPS) issue_w(integral_constant<int, SL>{}, wsn, integral_constant<int, Q - HPS>{});
+            else issue_w(integral_constant<int, SL>{}, ws, integral_constant<int, Q>{});
+            if constexpr (A == 0 && KS < HPPW) stage_patch_piece(more ? slab + 1 : slab, (slab + 1) & 1, KS);
+        });
+    }
+#pragma unroll
+    for (int i = 0; i < HRING; ++i) asm volatile("" : "+v"(wr[i]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < HRING; ++i) asm volatile("" : "+v"(wr[i]));
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- epilogue: + bias, ReLU, round once; lane (f, pixel) holds channels 64 grp + 32 (wave & 1) + 8 f .. + 7 of pixel fragment b
+    const int cb = nt * 256 + grp * 64 + 32 * (wave & 1) + 8 * fchunk;
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cb + 4);
+    sfor<NBF>([&](auto bc) {
+        constexpr int B = decltype(bc)::value;
+        const f32x4_t lo = fat_read<B>(), hi = fat_read<NBF + B>();
+        float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+        if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
+        }
+        const int m = B * 16 + fp;
+        const size_t gm = ((size_t)img * p.H + oy0 + (m >> 3)) * p.W + ox0 + (m & 7);
+        *reinterpret_cast<uint4*>(p.out + (gm * p.Cout + cb) * 2) =
+            make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
+    });
+}
+
 // ---- one-off packing: OHWI (Cout, 3, 3, Cin) -> per (channel tile nt, wave w) streams [slab][tap][k-step][fragment a] of 1-KiB
 // MFMA A fragments: lane (i = lane & 15, f = lane >> 4) holds the k-elements 64 slab + 32 kk + 8 f .. + 7 of tap t of output
 // channel 256 nt + 64 w + sigma(a, i), sigma(a, i) = 32 (a >> 1) + 8 (i >> 2) + 4 (a & 1) + (i & 3) (igemm_wide.hip)
@@ -323,6 +501,20 @@ extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, con
     p.nblocks = N * (H >> 4) * (W >> 3);
     const int nNt = Cout >> 8;
     // two pixel blocks per workgroup where that still gives every CU a workgroup, else one
+    // one-block launches that would put ONE workgroup on a CU (layer 3): two half-width workgroups per block instead
+    // (AGRL_CONV3X3_HALF = 0 / 1 forces it off / on; AGRL_CONV3X3_HALF_STAGGER: start delay of the second resident round, clocks)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int want_half = agrl_opts().conv3x3_half;
+    if (agrl_opt_set(want_half) ? want_half != 0 : ((p.nblocks / 2) * nNt < 224 && p.nblocks * nNt <= cus && p.nblocks * nNt >= cus / 2)) {
+        const int stagger = agrl_opt_set(agrl_opts().conv3x3_half_stagger) ? agrl_opts().conv3x3_half_stagger : 0;
+        hipLaunchKernelGGL(conv3x3_half_kernel, dim3(2 * p.nblocks * nNt), dim3(256), 0, (hipStream_t)stream, p, stagger, p.nblocks * nNt);
+        AGRL_CHECK_LAUNCH("agrl_conv3x3_packed_bn_act");
+        return 0;
+    }
     const int force_pb = agrl_opts().conv3x3_fat_pb;   // AGRL_CONV3X3_FAT_PB = 1 / 2: A/B
     if (agrl_opt_set(force_pb) ? force_pb == 2 : (p.nblocks / 2) * nNt >= 224) hipLaunchKernelGGL(conv3x3_fat_kernel<2>, dim3(((p.nblocks + 1) / 2) * nNt), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv3x3_fat_kernel<1>, dim3(p.nblocks * nNt), dim3(256), 0, (hipStream_t)stream, p);
