@@ -18,7 +18,9 @@
 //     agrl_conv2d_bn_act(residual=...) / agrl_conv1x1_bn_act_pool), result out row by row. POOL: the rounded activations' quarter
 //     sums (4 image rows) per lane, 16-lane shuffles, quarters through LDS, bins = sums of whole quarters (igemm_wide_kernel<16384>'s
 //     order). Measured, same box, inside a Bottleneck (conv1 and the 3x3 run before every timed call), HIP events, this / wide:
-//     POOLED 92.0 / 101.2 us (global branch), the model's dispatch; map stored 117.4 / 119.5 us: equal, not dispatched.
+//     POOLED 92.0 / 101.2 us (global branch), the model's dispatch; map stored 117.4 / 119.5 us: equal, not dispatched; WITHOUT a
+//     residual (layer 4's conv1s, tools/conv1x1_duo_vs_fat.py: this / conv1x1_fat_kernel / wide) 2048 -> 512 69.2 / 72.7 / 77.5 us,
+//     1024 -> 512 43.5 / 45.4 / 45.4: dispatched; 512 -> 256 on 32 x 16 maps 56 / 60.5 / 54: not.
 //     Ablations of the stored form (127 us with the accumulator-layout epilogue): no result stores 76, no residual loads 110, neither
 //     62, no MFMA 124 (!), no weight loads 107, no pixel DMA 114, one workgroup per CU 142. Timeline of a workgroup (s_memtime): 5.3 us
 //     from start to the first barrier (first loads), k-loop 9.0, residual wait 2.6, combine 4.5, stores 2.4.

@@ -307,13 +307,14 @@ def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None):
 
 
 def conv1x1_duo_enabled():
-    """AGRL_HIP_CONV1X1_DUO=0 runs the pool-fused last conv of a layer-4 branch through conv1x1_bn_act_pool (A/B; bit-identical)."""
+    """AGRL_HIP_CONV1X1_DUO=0 runs the pool-fused last conv of a layer-4 branch through conv1x1_bn_act_pool and layer 4's conv1s through
+    conv1x1_packed / conv_bn_act (A/B; bit-identical)."""
     return os.environ.get('AGRL_HIP_CONV1X1_DUO', '1') != '0'
 
 
 def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
     """act(x @ W^T + bias + residual) over pixel rows, weights from conv1x1_pack: conv3 / bn3 + identity shortcut + ReLU of a
-    Bottleneck (vmgn.py:56-64) through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip; equal in time to conv_bn_act: the model does not route it here). -> (N,H,W,Cout) 16-bit NHWC."""
+    Bottleneck (vmgn.py:56-64), or with ``residual=None`` a plain conv1 / bn1 / relu (vmgn.py:48-50), through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip; the model routes layer 4's conv1s here: 2048 -> 512 69 us against conv1x1_fat_kernel's 73; with a residual it measures equal to conv_bn_act and is not used). -> (N,H,W,Cout) 16-bit NHWC."""
     N, H, W, K = x.shape
     M = N * H * W
     assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * K * Cout
