@@ -20,7 +20,8 @@
 //     order). Measured, same box, inside a Bottleneck (conv1 and the 3x3 run before every timed call), HIP events, this / wide:
 //     POOLED 92.0 / 101.2 us (global branch), the model's dispatch; map stored 117.4 / 119.5 us: equal, not dispatched; WITHOUT a
 //     residual (layer 4's conv1s, tools/conv1x1_duo_vs_fat.py: this / conv1x1_fat_kernel / wide) 2048 -> 512 69.2 / 72.7 / 77.5 us,
-//     1024 -> 512 43.5 / 45.4 / 45.4: dispatched; 512 -> 256 on 32 x 16 maps 56 / 60.5 / 54: not.
+//     1024 -> 512 43.5 / 45.4 / 45.4: dispatched; 512 -> 256 on 32 x 16 maps 56 / 60.5 / 54: not; the TWO-SOURCE form (conv3 + downsample
+//     conv of a first block over [x | y2], agrl_conv1x1_packed_dual_duo) 167.1 us against conv1x1_fat_kernel's 185.2: dispatched.
 //     Ablations of the stored form (127 us with the accumulator-layout epilogue): no result stores 76, no residual loads 110, neither
 //     62, no MFMA 124 (!), no weight loads 107, no pixel DMA 114, one workgroup per CU 142. Timeline of a workgroup (s_memtime): 5.3 us
 //     from start to the first barrier (first loads), k-loop 9.0, residual wait 2.6, combine 4.5, stores 2.4.
@@ -40,7 +41,9 @@
 namespace {
 
 struct DuoParams {
-    const unsigned char* x;     // (M, K) 16-bit pixel rows
+    const unsigned char* x;     // (M, K1) 16-bit pixel rows
+    const unsigned char* x2;    // (M, K - K1) second source (the K axis is [x | x2]) or nullptr
+    int K1;                     // columns of x (= K without a second source)
     const unsigned char* wpk;   // packed weight streams (agrl_conv1x1_pack)
     const float* bias;          // (Cout)
     const unsigned char* res;   // (M, Cout) residual or nullptr
@@ -136,19 +139,22 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
 
     // ---- pixel staging: piece i = 2 j + h of this wave -> rows (wave + 4 j) * 8 .. + 7 of 64-channel half h; lane (lrow = lane >> 3,
     // lchk = lane & 7) fetches chunk lchk ^ swizzle(row) of its row (16-byte chunk c of row r at c ^ ((r >> 1) & 7))
-    unsigned roff[4];
+    unsigned roff[4], roff2[4];
     const int lrow = lane >> 3, lchk = lane & 7;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = (wave + 4 * j) * 8 + lrow;
         const int gm = min(m0 + row, p.M - 1);
-        roff[j] = (unsigned)gm * (unsigned)p.K * 2u + (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
+        const unsigned sw = (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
+        roff[j] = (unsigned)gm * (unsigned)p.K1 * 2u + sw;
+        roff2[j] = (unsigned)gm * (unsigned)(p.K - p.K1) * 2u + sw;
     }
-    const int nslab = p.K >> 7;
+    const int nslab = p.K >> 7, nslab1 = p.K1 >> 7;
     auto stage_piece = [&](int slab, int buf, auto i_c) {  // piece i of slab `slab` into buffer `buf`
         constexpr int I = decltype(i_c)::value, J = I >> 1, H = I & 1;
-        fat_dma(p.x + roff[J] + (size_t)(slab * 256 + H * 128),
-                __builtin_amdgcn_readfirstlane(lds0 + buf * DSLAB + H * DHALF + (wave + 4 * J) * 1024));
+        const bool second = slab >= nslab1;  // uniform: the slab lies in x2 (two-source form: conv3 + downsample conv as one GEMM)
+        const unsigned char* src = second ? p.x2 + roff2[J] + (size_t)((slab - nslab1) * 256 + H * 128) : p.x + roff[J] + (size_t)(slab * 256 + H * 128);
+        fat_dma(src, __builtin_amdgcn_readfirstlane(lds0 + buf * DSLAB + H * DHALF + (wave + 4 * J) * 1024));
     };
 
     // ---- pixel fragment b (rows 16 b + (lane & 15)) of k-step kk: half kk >> 1, chunk 4 (kk & 1) + (lane >> 4)
@@ -386,7 +392,7 @@ extern "C" int agrl_conv1x1_packed_res_bn_act(const void* x, const void* packed,
     p.bias = bias;
     p.res = reinterpret_cast<const unsigned char*>(residual);
     p.out = reinterpret_cast<unsigned char*>(out);
-    p.M = M; p.K = K; p.Cout = Cout; p.relu = relu;
+    p.M = M; p.K = K; p.K1 = K; p.Cout = Cout; p.relu = relu;
     return duo_launch(p, false, (hipStream_t)stream, "agrl_conv1x1_packed_res_bn_act");
 }
 
@@ -421,6 +427,25 @@ extern "C" int agrl_conv1x1_packed_res_pool(const void* x, const void* packed, c
     p.bias = bias;
     p.res = reinterpret_cast<const unsigned char*>(residual);
     p.out = nullptr;
-    p.M = N * 128; p.K = K; p.Cout = Cout; p.relu = relu;
+    p.M = N * 128; p.K = K; p.K1 = K; p.Cout = Cout; p.relu = relu;
     return duo_launch(p, true, (hipStream_t)stream, "agrl_conv1x1_packed_res_pool");
+}
+
+extern "C" int agrl_conv1x1_packed_dual_duo(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1,
+                                            int K2, int Cout, int relu, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && x2 && packed && bias && out, "agrl_conv1x1_packed_dual_duo: null pointer");
+    AGRL_CHECK_ARG(M > 0 && K1 > 0 && K1 % 128 == 0 && K2 > 0 && K2 % 128 == 0 && Cout > 0 && Cout % 256 == 0,
+                   "agrl_conv1x1_packed_dual_duo: needs K1, K2 %% 128 == 0 and Cout %% 256 == 0; got M=%d K1=%d K2=%d Cout=%d", M, K1, K2, Cout);
+    const size_t widest = (size_t)(K1 > Cout ? (K1 > K2 ? K1 : K2) : (Cout > K2 ? Cout : K2));
+    AGRL_CHECK_ARG((size_t)M * widest * 2 < (1ull << 32), "agrl_conv1x1_packed_dual_duo: maps beyond 4 GB are not addressed");
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)out) & 15) == 0,
+                   "agrl_conv1x1_packed_dual_duo: pointers must be 16-byte aligned");
+    DuoParams p{};
+    p.x = reinterpret_cast<const unsigned char*>(x);
+    p.x2 = reinterpret_cast<const unsigned char*>(x2);
+    p.wpk = reinterpret_cast<const unsigned char*>(packed);
+    p.bias = bias;
+    p.out = reinterpret_cast<unsigned char*>(out);
+    p.M = M; p.K = K1 + K2; p.K1 = K1; p.Cout = Cout; p.relu = relu;
+    return duo_launch(p, false, (hipStream_t)stream, "agrl_conv1x1_packed_dual_duo");
 }

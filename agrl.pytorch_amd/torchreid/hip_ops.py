@@ -288,7 +288,7 @@ def conv1x1_pack(w):
     return packed
 
 
-def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None):
+def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None, duo=False):
     """act([x | x2] @ W^T + bias) over pixel rows, weights from conv1x1_pack. vmgn.py:48-50 (conv1), :56-64 with x2 (conv3 +
     downsample conv of a first block as one GEMM: x = the block input, x2 = conv2's output). -> (N,H,W,Cout) 16-bit NHWC."""
     N, H, W, K1 = x.shape
@@ -302,7 +302,10 @@ def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None):
                             "bytes": 2.0 * (x.numel() + (0 if x2 is None else x2.numel()) + out.numel()) + packed.numel(),
                             "conv": (1, 1, K1 + K2, Cout, H, W)}
     with _dev(x):
-        call("agrl_conv1x1_packed_bn_act", ptr(x), ptr(x2), ptr(packed), ptr(bias), ptr(out), M, K1, K2, Cout, 1 if relu else 0, _stream(x))
+        if duo and x2 is not None:   # the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip), same packed weights, bit-identical
+            call("agrl_conv1x1_packed_dual_duo", ptr(x), ptr(x2), ptr(packed), ptr(bias), ptr(out), M, K1, K2, Cout, 1 if relu else 0, _stream(x))
+        else:
+            call("agrl_conv1x1_packed_bn_act", ptr(x), ptr(x2), ptr(packed), ptr(bias), ptr(out), M, K1, K2, Cout, 1 if relu else 0, _stream(x))
     return out
 
 

@@ -212,7 +212,7 @@ def _run_block(x, blk, pool=None):
     y = _conv2(y, blk)
     if (pool is None and 'dualp' in blk and ops.conv1x1_packed_enabled() and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0'
             and x.shape[:3] == y.shape[:3] and x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()):
-        return ops.conv1x1_packed(x, blk['dualp'], blk['dual'][1], blk['dual'][0].shape[0], True, x2=y)
+        return ops.conv1x1_packed(x, blk['dualp'], blk['dual'][1], blk['dual'][0].shape[0], True, x2=y, duo=ops.conv1x1_duo_enabled())   # (two workgroups per CU: 167 us against conv1x1_fat_kernel's 185)
     if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
         return ops.conv1x1_dual(x, y, blk['dual'][0], blk['dual'][1], True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)

@@ -177,6 +177,10 @@ int agrl_conv1x1_packed_res_bn_act(const void* x, const void* packed, const floa
 int agrl_conv1x1_packed_res_pool(const void* x, const void* packed, const float* bias, const void* residual, float* pool_out,
                                  void* pool_out_lp, int N, int H, int W, int K, int Cout, int relu, const int* splits,
                                  int n_splits, int mean, agrl_stream_t stream);
+/* agrl_conv1x1_packed_bn_act's two-source form (conv3 / bn3 + downsample conv / BN of a layer's first block as one GEMM over
+ * [x | x2], vmgn.py:56-64) through the same two-workgroups-per-CU kernel; same packed weights, bit-identical results. */
+int agrl_conv1x1_packed_dual_duo(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1,
+                                 int K2, int Cout, int relu, agrl_stream_t stream);
 
 /* Whole body of a layer-1 Bottleneck behind its first conv, fused with the head of the next block (bf16 only;
  * torchreid/models/vmgn.py:45-65: conv2/bn2/relu :52-54, conv3/bn3/+residual/relu :56-64 of block i, conv1/bn1/relu

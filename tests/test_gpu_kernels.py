@@ -360,6 +360,10 @@ def test_conv1x1_packed(case):
     d = None if other is None else (out.float() - other.float()).abs().max().item()
     print("conv1x1 packed", case, "vs fp32 %.3e | max |packed - other launch|" % e, d)
     assert other is None or torch.equal(out, other)
+    if K2:   # the two-source form through the two-workgroups-per-CU kernel (conv1x1_duo.hip): the same bits
+        assert torch.equal(ops.conv1x1_packed(dx, packed, b.to(DEV), Cout, relu, x2=dx2, duo=True), out)
+    else:
+        assert torch.equal(ops.conv1x1_packed_res(dx, packed, b.to(DEV), Cout, None, relu), out)
     with pytest.raises(_hip.HipKernelError):
         ops.call("agrl_conv1x1_packed_bn_act", ops.ptr(dx), None, ops.ptr(packed), ops.ptr(b.to(DEV)), ops.ptr(out), N * H * W, K1 + 64, 0, Cout, 1, None)
 

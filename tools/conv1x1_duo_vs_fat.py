@@ -34,3 +34,21 @@ for k, cout, hh, ww in ((2048, 512, 16, 8), (1024, 512, 16, 8), (512, 256, 32, 1
         for n, f in arms.items():
             t[n].append(timed(f))
     print("conv1x1 %4d->%4d @%dx%d equal %s  " % (k, cout, hh, ww, same) + "  ".join("%s %.1f us (min %.1f)" % (n, sorted(v)[len(v) // 2], min(v)) for n, v in t.items()))
+
+k1, k2, cout = 1024, 512, 2048
+x = torch.relu(torch.randn((256, 16, 8, k1), device=dev)).to(LP_DTYPE)
+x2 = torch.relu(torch.randn((256, 16, 8, k2), device=dev)).to(LP_DTYPE)
+w = (torch.randn((cout, k1 + k2), device=dev) / (k1 + k2) ** 0.5).to(LP_DTYPE)
+b = torch.randn((cout,), device=dev)
+packed = ops.conv1x1_pack(w)
+arms = {"duo": lambda: ops.conv1x1_packed(x, packed, b, cout, True, x2=x2, duo=True), "fat": lambda: ops.conv1x1_packed(x, packed, b, cout, True, x2=x2)}
+same = torch.equal(arms["duo"](), arms["fat"]())
+for _ in range(3):
+    for f in arms.values():
+        f()
+torch.cuda.synchronize()
+t = {n: [] for n in arms}
+for _ in range(rounds):
+    for n, f in arms.items():
+        t[n].append(timed(f))
+print("conv1x1 [1024|512]->2048 equal %s  " % same + "  ".join("%s %.1f us (min %.1f)" % (n, sorted(v)[len(v) // 2], min(v)) for n, v in t.items()))
