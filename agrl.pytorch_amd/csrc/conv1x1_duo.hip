@@ -18,7 +18,7 @@
 //     agrl_conv2d_bn_act(residual=...) / agrl_conv1x1_bn_act_pool), result out row by row. POOL: the rounded activations' quarter
 //     sums (4 image rows) per lane, 16-lane shuffles, quarters through LDS, bins = sums of whole quarters (igemm_wide_kernel<16384>'s
 //     order). Measured, same box, inside a Bottleneck (conv1 and the 3x3 run before every timed call), HIP events, this / wide:
-//     POOLED 92.0 / 101.2 us (global branch), the model's dispatch; map stored 117.4 / 119.5 us: equal, not dispatched; WITHOUT a
+//     POOLED 92.0 / 101.2 us (global branch), the model's dispatch; map stored 117.4 / 119.5 us (back to back 115.6 / 122.4): dispatched; WITHOUT a
 //     residual (layer 4's conv1s, tools/conv1x1_duo_vs_fat.py: this / conv1x1_fat_kernel / wide) 2048 -> 512 69.2 / 72.7 / 77.5 us,
 //     1024 -> 512 43.5 / 45.4 / 45.4: dispatched; 512 -> 256 on 32 x 16 maps 56 / 60.5 / 54: not; the TWO-SOURCE form (conv3 + downsample
 //     conv of a first block over [x | y2], agrl_conv1x1_packed_dual_duo) 167.1 us against conv1x1_fat_kernel's 185.2: dispatched.

@@ -221,7 +221,8 @@ def _run_block(x, blk, pool=None):
         if duo and tuple(y.shape[1:3]) == (16, 8):
             return ops.conv1x1_packed_res_pool(y, blk['c3p'], blk['c3'][1], blk['c3'][0].shape[0], shortcut, pool[0], pool[1], pool[2])
         return ops.conv1x1_bn_act_pool(y, blk['c3'][0], blk['c3'][1], shortcut, pool[0], pool[1], pool[2])
-    # (ops.conv1x1_packed_res, the same kernel with the map stored, measures equal to conv_bn_act -- 117 / 119.5 us -- and is not used)
+    if duo and os.environ.get('AGRL_HIP_CONV1X1_DUO_RES', '1') != '0':   # the same kernel with the map stored (in the step: the layer-4 pointwise family 0.968-0.981 ms with it, 0.984-0.993 without, three A/B pairs on one box)
+        return ops.conv1x1_packed_res(y, blk['c3p'], blk['c3'][1], blk['c3'][0].shape[0], shortcut)
     return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)
 
 
