@@ -317,7 +317,7 @@ def conv1x1_duo_enabled():
 
 def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
     """act(x @ W^T + bias + residual) over pixel rows, weights from conv1x1_pack: conv3 / bn3 + identity shortcut + ReLU of a
-    Bottleneck (vmgn.py:56-64), or with ``residual=None`` a plain conv1 / bn1 / relu (vmgn.py:48-50), through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip; the model routes layer 4's conv1s here: 2048 -> 512 69 us against conv1x1_fat_kernel's 73; with a residual 115.6 against conv_bn_act's 122.4 us back to back, 117 / 119.5 inside a block: also routed here, AGRL_HIP_CONV1X1_DUO_RES=0 = off). -> (N,H,W,Cout) 16-bit NHWC."""
+    Bottleneck (vmgn.py:56-64), or with ``residual=None`` a plain conv1 / bn1 / relu (vmgn.py:48-50), through the two-workgroups-per-CU kernel (csrc/conv1x1_duo.hip; layer 4's conv1s are faster here back to back -- 2048 -> 512 69 us against conv1x1_fat_kernel's 73 -- but not inside the step, and stay where they were; with a residual 115.6 against conv_bn_act's 122.4 us back to back, 117 / 119.5 inside a block: also routed here, AGRL_HIP_CONV1X1_DUO_RES=0 = off). -> (N,H,W,Cout) 16-bit NHWC."""
     N, H, W, K = x.shape
     M = N * H * W
     assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * K * Cout

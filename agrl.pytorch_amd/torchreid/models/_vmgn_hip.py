@@ -81,7 +81,7 @@ def _pack_stage(stage, dtype, seam=False):
                     blk['dualp'] = ops.conv1x1_pack(blk['dual'][0])     # the same GEMM through the four-wave kernel
         if dtype == ops.LP_DTYPE and ops.conv1x1_packed_supported(blk['c1'][0]) and blk['c1'][0].shape[3] >= 1024:
             # layer 4's 2048 -> 512 / 1024 -> 512 convs: the shapes where the packed-weight kernels are ahead of the 8-wave tile
-            # (_conv1: ops.conv1x1_packed_res without a residual -- two workgroups per CU: 69 / 43.5 us against 73 / 45 -- or ops.conv1x1_packed)
+            # (_conv1: ops.conv1x1_packed for 2048 -> 512; ops.conv1x1_packed_res without a residual is an A/B option)
             blk['c1p'] = ops.conv1x1_pack(blk['c1'][0])
         if (dtype == ops.LP_DTYPE and blk['ds'] is None and ops.conv1x1_packed_supported(blk['c3'][0])
                 and blk['c3'][0].shape[0] >= 2048):
@@ -159,7 +159,9 @@ def _conv2(y, blk):
 
 def _conv1(x, blk):
     """conv1 / bn1 / relu of a Bottleneck (vmgn.py:48-50)."""
-    if 'c1p' in blk and ops.conv1x1_duo_enabled() and x.is_contiguous():
+    # (conv1 through conv1x1_duo_kernel: ahead back to back -- 2048 -> 512 69 us against 73 -- but not inside the step: the six launches
+    # 12 us slower by events, step equal, three A/B pairs on one box; AGRL_HIP_CONV1X1_DUO_C1=1 turns it on)
+    if 'c1p' in blk and ops.conv1x1_duo_enabled() and x.is_contiguous() and os.environ.get('AGRL_HIP_CONV1X1_DUO_C1', '0') == '1':
         return ops.conv1x1_packed_res(x, blk['c1p'], blk['c1'][1], blk['c1'][0].shape[0], None, True)
     if 'c1p' in blk and ops.conv1x1_packed_enabled() and blk['c1'][0].shape[3] >= 2048:
         return ops.conv1x1_packed(x, blk['c1p'], blk['c1'][1], blk['c1'][0].shape[0], True)
