@@ -19,10 +19,11 @@ def load(path, counter):
             continue
         name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
         key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "conv1x1_fat_kernel", "conv1x1_duo_kernel", "bottleneck_")) and "pack_kernel" not in name else name.split("(")[0][-40:]
-        for dom in ("conv3x3_wide_kernel", "conv3x3_fat_kernel"):   # the dominant kernel is also reported on its own
+        for dom, alias in (("conv3x3_wide_kernel", "conv3x3_wide_kernel"), ("conv3x3_fat_kernel", "conv3x3_fat_kernel"),
+                           ("conv3x3_half_kernel", "conv3x3_fat_kernel")):   # the dominant kernel family (layers 3-4: fat<2> + half) on its own
             if dom in name:
-                per[dom][0] += float(row["Counter_Value"])
-                per[dom][1] += 1
+                per[alias][0] += float(row["Counter_Value"])
+                per[alias][1] += 1
         per[key][0] += float(row["Counter_Value"])
         per[key][1] += 1
     return per
