@@ -49,6 +49,9 @@ struct DuoParams {
     const unsigned char* res;   // (M, Cout) residual or nullptr
     unsigned char* out;         // (M, Cout) or nullptr (POOL only)
     int M, K, Cout, relu;
+    // strided first source (the stride-s 1x1 downsample conv of a first block): x is the (frames, Hi, Wi, K1) map and row m = (f, ho, wo)
+    // of the GEMM reads its pixel (f, s ho, s wo); gHoWo = 0: x holds the M rows themselves
+    int gHoWo, gWo, gS, gWi, gHiWi;
     // POOL
     float* pool_out;            // fp32 (frames, nparts, Cout)
     unsigned short* pool_out_lp;  // optional 16-bit copy
@@ -146,7 +149,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
         const int row = (wave + 4 * j) * 8 + lrow;
         const int gm = min(m0 + row, p.M - 1);
         const unsigned sw = (unsigned)((lchk ^ ((row >> 1) & 7)) << 4);
-        roff[j] = (unsigned)gm * (unsigned)p.K1 * 2u + sw;
+        unsigned srow = (unsigned)gm;
+        if (p.gHoWo) {
+            const unsigned f = (unsigned)gm / (unsigned)p.gHoWo, r = (unsigned)gm - f * (unsigned)p.gHoWo;
+            const unsigned ho = r / (unsigned)p.gWo, wo = r - ho * (unsigned)p.gWo;
+            srow = f * (unsigned)p.gHiWi + (ho * (unsigned)p.gWi + wo) * (unsigned)p.gS;
+        }
+        roff[j] = srow * (unsigned)p.K1 * 2u + sw;
         roff2[j] = (unsigned)gm * (unsigned)(p.K - p.K1) * 2u + sw;
     }
     const int nslab = p.K >> 7, nslab1 = p.K1 >> 7;
@@ -448,4 +457,31 @@ extern "C" int agrl_conv1x1_packed_dual_duo(const void* x, const void* x2, const
     p.out = reinterpret_cast<unsigned char*>(out);
     p.M = M; p.K = K1 + K2; p.K1 = K1; p.Cout = Cout; p.relu = relu;
     return duo_launch(p, false, (hipStream_t)stream, "agrl_conv1x1_packed_dual_duo");
+}
+
+// The same GEMM for the first block of a STRIDED layer (layers 2 / 3: conv2 and the downsample conv both have stride s, vmgn.py:56-64 with
+// the downsample of torchvision's _make_layer): x is the block input (N, Hi, Wi, K1), of which the 1x1 / stride-s / pad-0 downsample conv
+// reads pixel (s ho, s wo) for output pixel (ho, wo); x2 = conv2's output (N, Ho, Wo, K2), Ho = (Hi - 1) / s + 1. The shortcut map
+// (N, Ho, Wo, Cout) is neither written nor read back.
+extern "C" int agrl_conv1x1_packed_dual_strided(const void* x, const void* x2, const void* packed, const float* bias, void* out, int N,
+                                                int Hi, int Wi, int stride, int K1, int K2, int Cout, int relu, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && x2 && packed && bias && out, "agrl_conv1x1_packed_dual_strided: null pointer");
+    AGRL_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && stride >= 1, "agrl_conv1x1_packed_dual_strided: bad map %dx%dx%d stride %d", N, Hi, Wi, stride);
+    AGRL_CHECK_ARG(K1 > 0 && K1 % 128 == 0 && K2 > 0 && K2 % 128 == 0 && Cout > 0 && Cout % 256 == 0,
+                   "agrl_conv1x1_packed_dual_strided: needs K1, K2 %% 128 == 0 and Cout %% 256 == 0; got K1=%d K2=%d Cout=%d", K1, K2, Cout);
+    const int Ho = (Hi - 1) / stride + 1, Wo = (Wi - 1) / stride + 1;
+    const size_t M = (size_t)N * Ho * Wo;
+    AGRL_CHECK_ARG((size_t)N * Hi * Wi * K1 * 2 < (1ull << 32) && M * (size_t)(Cout > K2 ? Cout : K2) * 2 < (1ull << 32),
+                   "agrl_conv1x1_packed_dual_strided: maps beyond 4 GB are not addressed");
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)out) & 15) == 0,
+                   "agrl_conv1x1_packed_dual_strided: pointers must be 16-byte aligned");
+    DuoParams p{};
+    p.x = reinterpret_cast<const unsigned char*>(x);
+    p.x2 = reinterpret_cast<const unsigned char*>(x2);
+    p.wpk = reinterpret_cast<const unsigned char*>(packed);
+    p.bias = bias;
+    p.out = reinterpret_cast<unsigned char*>(out);
+    p.M = (int)M; p.K = K1 + K2; p.K1 = K1; p.Cout = Cout; p.relu = relu;
+    if (stride > 1) { p.gHoWo = Ho * Wo; p.gWo = Wo; p.gS = stride; p.gWi = Wi; p.gHiWi = Hi * Wi; }
+    return duo_launch(p, false, (hipStream_t)stream, "agrl_conv1x1_packed_dual_strided");
 }

@@ -67,6 +67,7 @@ SIGNATURES = {
     "agrl_conv1x1_packed_res_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_conv1x1_packed_res_pool": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _p],
     "agrl_conv1x1_packed_dual_duo": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "agrl_conv1x1_packed_dual_strided": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "agrl_conv3x3_pack": [_p, _p, _i, _i, _p],
     "agrl_conv3x3_packed_bn_act": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_block": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -309,6 +309,26 @@ def conv1x1_packed(x, packed, bias, Cout, relu=True, x2=None, duo=False):
     return out
 
 
+def conv1x1_packed_dual_strided(x, x2, packed, bias, Cout, stride, relu=True):
+    """relu(W3 x2 + b3 + Wds x[:, ::stride, ::stride] + bds) of the FIRST block of a strided layer (vmgn.py:56-64 with a stride-2
+    downsample conv) as one GEMM over [x sampled | x2]: x (N,Hi,Wi,K1) the block input, x2 (N,Ho,Wo,K2) conv2's output, packed =
+    conv1x1_pack([Wds | W3]), bias = bds + b3. The (N,Ho,Wo,Cout) shortcut map never exists. -> (N,Ho,Wo,Cout) 16-bit NHWC."""
+    N, Hi, Wi, K1 = x.shape
+    Ho, Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    K2 = x2.shape[3]
+    assert x.dtype == LP_DTYPE and x2.dtype == LP_DTYPE and x.is_contiguous() and x2.is_contiguous()
+    assert tuple(x2.shape[:3]) == (N, Ho, Wo) and packed.numel() == 2 * (K1 + K2) * Cout
+    out = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    M = N * Ho * Wo
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * (K1 + K2) * Cout, "bytes": 2.0 * (M * K1 + x2.numel() + out.numel()) + packed.numel(),
+                            "conv": (1, 1, K1 + K2, Cout, Ho, Wo)}
+    with _dev(x):
+        call("agrl_conv1x1_packed_dual_strided", ptr(x), ptr(x2), ptr(packed), ptr(bias), ptr(out), N, Hi, Wi, stride, K1, K2, Cout,
+             1 if relu else 0, _stream(x))
+    return out
+
+
 def conv1x1_duo_enabled():
     """AGRL_HIP_CONV1X1_DUO=0 runs the pool-fused last conv of a layer-4 branch through conv1x1_bn_act_pool and layer 4's conv1s through
     conv1x1_packed / conv_bn_act (A/B; bit-identical)."""

@@ -79,6 +79,13 @@ def _pack_stage(stage, dtype, seam=False):
                 if (ops.conv1x1_packed_supported(blk['dual'][0]) and blk['dual'][0].shape[1] >= 1536
                         and blk['ds'][0].shape[3] % 128 == 0 and blk['c3'][0].shape[3] % 128 == 0):   # K1, K2 % 128 each
                     blk['dualp'] = ops.conv1x1_pack(blk['dual'][0])     # the same GEMM through the four-wave kernel
+            if dtype == ops.LP_DTYPE and blk['ds_stride'] > 1 and blk['ds_stride'] == blk['stride']:
+                # first block of layers 2 / 3: the same one-GEMM form with the block input sampled at the stride (ops.conv1x1_packed_dual_strided)
+                cout = blk['c3'][0].shape[0]
+                dual_w = torch.cat([blk['ds'][0].view(cout, -1), blk['c3'][0].view(cout, -1)], dim=1).contiguous()
+                if (ops.conv1x1_packed_supported(dual_w) and blk['ds'][0].shape[3] % 128 == 0 and blk['c3'][0].shape[3] % 128 == 0):
+                    blk['dualps'] = ops.conv1x1_pack(dual_w)
+                    blk['dualps_bias'] = (blk['ds'][1] + blk['c3'][1]).contiguous()
         if dtype == ops.LP_DTYPE and ops.conv1x1_packed_supported(blk['c1'][0]) and blk['c1'][0].shape[3] >= 1024:
             # layer 4's 2048 -> 512 / 1024 -> 512 convs: the shapes where the packed-weight kernels are ahead of the 8-wave tile
             # (_conv1: ops.conv1x1_packed for 2048 -> 512; ops.conv1x1_packed_res without a residual is an A/B option)
@@ -194,6 +201,14 @@ def _run_trunk(a, blocks, fuse_tail=True):
             # first block of layer 1: the downsample conv rides along as a second k-tile (no shortcut map in HBM)
             a, z = ops.bottleneck_tail(y, blk['c3'][0], blk['c3'][1], None, nxt['c1'][0], nxt['c1'][1],
                                        shortcut=(a, blk['ds'][0], blk['ds'][1]))
+            continue
+        if ('dualps' in blk and ops.conv1x1_duo_enabled() and os.environ.get('AGRL_HIP_FUSE_DS_STRIDED', '1') != '0'
+                and a.is_contiguous() and y.is_contiguous() and a.dtype == y.dtype and a.shape[0] == y.shape[0]
+                and tuple(y.shape[1:3]) == tuple((d - 1) // blk['stride'] + 1 for d in a.shape[1:3])):
+            # first block of layers 2 / 3: conv3 + the stride-2 downsample conv as ONE GEMM over [a sampled | y]: the shortcut map is
+            # neither written nor read back (the next block's conv1 then runs on its own)
+            a = ops.conv1x1_packed_dual_strided(a, y, blk['dualps'], blk['dualps_bias'], blk['c3'][0].shape[0], blk['stride'], True)
+            z = None
             continue
         shortcut = a if blk['ds'] is None else ops.conv_bn_act(a, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
         if fuse_tail and nxt is not None and 'seam' in blk and (y.numel() // y.shape[-1]) % 128 == 0 and ops.seam_enabled():

@@ -181,6 +181,12 @@ int agrl_conv1x1_packed_res_pool(const void* x, const void* packed, const float*
  * [x | x2], vmgn.py:56-64) through the same two-workgroups-per-CU kernel; same packed weights, bit-identical results. */
 int agrl_conv1x1_packed_dual_duo(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1,
                                  int K2, int Cout, int relu, agrl_stream_t stream);
+/* The same GEMM for the first block of a STRIDED layer (layers 2 / 3 of the trunk: conv2 and the downsample conv both have stride
+ * `stride`; vmgn.py:56-64, downsample = conv1x1(stride) + BN): x is the block input (N, Hi, Wi, K1) -- output pixel (ho, wo) reads
+ * its pixel (stride ho, stride wo), the 1x1 / pad-0 conv's sampling --, x2 conv2's output (N, Ho, Wo, K2) with Ho = (Hi - 1) /
+ * stride + 1, out (N, Ho, Wo, Cout) = act([x_sampled | x2] @ W^T + bias). The shortcut map is neither written nor read back. */
+int agrl_conv1x1_packed_dual_strided(const void* x, const void* x2, const void* packed, const float* bias, void* out, int N, int Hi,
+                                     int Wi, int stride, int K1, int K2, int Cout, int relu, agrl_stream_t stream);
 
 /* Whole body of a layer-1 Bottleneck behind its first conv, fused with the head of the next block (bf16 only;
  * torchreid/models/vmgn.py:45-65: conv2/bn2/relu :52-54, conv3/bn3/+residual/relu :56-64 of block i, conv1/bn1/relu

@@ -368,6 +368,51 @@ def test_conv1x1_packed(case):
         ops.call("agrl_conv1x1_packed_bn_act", ops.ptr(dx), None, ops.ptr(packed), ops.ptr(b.to(DEV)), ops.ptr(out), N * H * W, K1 + 64, 0, Cout, 1, None)
 
 
+STRIDED_DUAL_CASES = [(8, 64, 32, 256, 128, 512, 2), (8, 32, 16, 512, 256, 1024, 2), (3, 7, 5, 128, 128, 256, 2), (2, 9, 6, 128, 256, 256, 3),
+                      (2, 6, 4, 128, 256, 256, 1)]
+
+
+@pytest.mark.parametrize("case", STRIDED_DUAL_CASES)
+def test_conv1x1_packed_dual_strided(case):
+    """First block of a strided layer (layers 2 / 3): conv3 + the stride-s 1x1 downsample conv as ONE GEMM over [block input sampled
+    at the stride | conv2's output] (conv1x1_duo.hip, agrl_conv1x1_packed_dual_strided) against the fp32 reference (two convs + add +
+    ReLU), bit for bit against the same kernel fed an explicitly gathered copy of the block input, and -- to the 16-bit rounding of
+    the shortcut map that the fused form no longer makes -- against the two launches it replaces. The trunk's two shapes, odd map
+    sizes with a ragged last tile (stride 2 and 3), stride 1. Every call twice."""
+    from torchreid import hip_ops as ops
+    N, Hi, Wi, K1, K2, Cout, s = case
+    Ho, Wo = (Hi - 1) // s + 1, (Wi - 1) // s + 1
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((N, K1, Hi, Wi), generator=g).relu().to(LP_DTYPE).float()
+    y = torch.randn((N, K2, Ho, Wo), generator=g).relu().to(LP_DTYPE).float()
+    wds = (torch.randn((Cout, K1, 1, 1), generator=g) / np.sqrt(K1)).to(LP_DTYPE).float()
+    w3 = (torch.randn((Cout, K2, 1, 1), generator=g) / np.sqrt(K2)).to(LP_DTYPE).float()
+    bds, b3 = torch.randn((Cout,), generator=g), torch.randn((Cout,), generator=g)
+    ref = F.relu(F.conv2d(x.to(DEV), wds.to(DEV), bias=bds.to(DEV), stride=s) + F.conv2d(y.to(DEV), w3.to(DEV), bias=b3.to(DEV)))
+    assert tuple(ref.shape) == (N, Cout, Ho, Wo)
+    dx, dy = nhwc(x, LP_DTYPE), nhwc(y, LP_DTYPE)
+    dwds = wds.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    dw3 = w3.permute(0, 2, 3, 1).contiguous().to(LP_DTYPE).to(DEV)
+    dual = torch.cat([dwds.view(Cout, -1), dw3.view(Cout, -1)], dim=1).contiguous()
+    packed = ops.conv1x1_pack(dual)
+    bias = (bds + b3).to(DEV)
+    out = ops.conv1x1_packed_dual_strided(dx, dy, packed, bias, Cout, s, True)
+    out_b = ops.conv1x1_packed_dual_strided(dx, dy, packed, bias, Cout, s, True)
+    gathered = ops.conv1x1_packed(dx[:, ::s, ::s].contiguous(), packed, bias, Cout, True, x2=dy, duo=True)
+    shortcut = ops.conv_bn_act(dx, dwds, bds.to(DEV), s, 0, False)
+    two = ops.conv_bn_act(dy, dw3, b3.to(DEV), 1, 0, True, residual=shortcut)
+    torch.cuda.synchronize()
+    e = rel_err(out.float().permute(0, 3, 1, 2).cpu(), ref.cpu())
+    e2 = rel_err(out.float().cpu(), two.float().cpu())
+    print("strided dual", case, "vs fp32 %.3e | vs the two launches %.3e" % (e, e2))
+    assert e < (3e-3 if LP_DTYPE == torch.float16 else 2e-2), e
+    assert e2 < (4e-3 if LP_DTYPE == torch.float16 else 3e-2), e2
+    assert torch.equal(out, out_b) and torch.equal(out, gathered)
+    with pytest.raises(_hip.HipKernelError):
+        ops.call("agrl_conv1x1_packed_dual_strided", ops.ptr(dx), ops.ptr(dy), ops.ptr(packed), ops.ptr(bias), ops.ptr(out), N, Hi, Wi, s,
+                 K1 + 64, K2, Cout, 1, None)
+
+
 DUO_CASES = [(256, 16, 8, 512, 2048, True, True), (1, 16, 8, 512, 2048, True, True), (3, 10, 6, 128, 256, True, False),
              (37, 16, 8, 256, 1024, True, True), (5, 16, 8, 384, 512, False, True)]
 

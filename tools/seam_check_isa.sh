@@ -3,7 +3,9 @@
 # name their AGPRs in inline asm; hipcc must therefore never touch an AGPR itself and never spill: this compiles the files for both
 # 16-bit types and fails if a kernel instance contains scratch accesses or any use of an AGPR (v_accvgpr_*, or an a-register operand) outside the asm blocks, if a
 # file yields NO kernel instance to check (a renamed kernel must not pass vacuously), or if a register budget is exceeded
-# (kernel:max = the allocation the occupancy the kernel is designed for allows).
+# (kernel:max = the allocation the occupancy the kernel is designed for allows). tools/ring_hazard_check.py then replays each kernel's
+# vector-memory queue and fails if any instruction names a VGPR whose asm-issued load is still in flight (a v_mov / re-use of a ring
+# register in front of the counted wait that covers it).
 # usage: tools/seam_check_isa.sh [EXTRA hipcc flags]  (exit 0 = clean); HIPCC overrides the compiler as in csrc/Makefile
 set -e
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
@@ -28,6 +30,8 @@ for f in bottleneck_seam:bottleneck_seam_kernel:512 conv3x3_fat:conv3x3_fat_kern
       if [ "$nscr" != 0 ] || [ "$nacc" != 0 ]; then rc=1; fi
       if [ -n "$vg" ] && [ "${vg##* }" -gt "$maxreg" ]; then echo "  register budget exceeded"; rc=1; fi
     done
+    python3 "$src/../../tools/ring_hazard_check.py" "$s" "${kern}" | sed "s/^/LP_F16=$lp /" || rc=1
+    if [ "${PIPESTATUS[0]}" != 0 ]; then rc=1; fi
     if [ "$found" = 0 ]; then echo "LP_F16=$lp $file.hip: no kernel matching $kern found -- nothing was checked"; rc=1; fi
     rm -f "$tmp"/*
   done
