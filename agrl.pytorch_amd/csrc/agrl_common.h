@@ -183,6 +183,7 @@ struct AgrlOpts {
     int conv3x3_n128;         // AGRL_CONV3X3_N128: conv3x3_wide_kernel with 128-channel tiles also where 256-channel ones apply
     int conv3x3_fat_pb;       // AGRL_CONV3X3_FAT_PB: 1 / 2 forces the pixel blocks per workgroup of conv3x3_fat_kernel (unset: 2 where that still covers the chip)
     int conv3x3_half, conv3x3_half_stagger;   // AGRL_CONV3X3_HALF (0 / 1), AGRL_CONV3X3_HALF_STAGGER (clocks): conv3x3_half_kernel on / off, its start delay
+    int stem_split_lds;       // AGRL_STEM_SPLIT_LDS: 0 = patch and conv tile share one LDS region (four barriers per tile; A/B)
     int stem_xcd_map;         // AGRL_STEM_XCD_MAP: 0 = the 16-bit stem's tiles in launch order (A/B); unset / 1: every frame on one XCD
     int distmat_tile_n;       // AGRL_DISTMAT_TILE_N: 192 / 256 forces the column width of the full distance matrix's tile (unset: by round count)
     int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library

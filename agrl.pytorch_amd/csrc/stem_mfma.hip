@@ -42,15 +42,20 @@ typedef __attribute__((address_space(1))) const void gbl_void_t;
 constexpr int CT_BYTES = (NPOS + 3) * 128;
 constexpr int REGION_BYTES = CT_BYTES > PATCH_BYTES ? CT_BYTES : PATCH_BYTES;
 
+// SPLIT: the patch and the conv tile in SEPARATE LDS regions (12.2 + 36.5 + 30 KB + biases = 78.9 KB: still two workgroups per CU) -- the
+// two barriers that guarded the overlay (sweep done -> conv tile may be written; pool done -> next patch may be written) disappear: a wave
+// that has finished pooling writes its pixels of the next patch while the others still pool, two barriers per tile instead of four.
+template <bool SPLIT>
 __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wpk,
                                                         const float* __restrict__ bias, lp16_t* __restrict__ out, int H,
                                                         int W, int CH, int CW, int PH, int PW, int tiles_w, int tiles_hw,
                                                         int ntiles, int xcd_map) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[REGION_BYTES + W_BYTES + 256];
+    constexpr int TILES_BYTES = SPLIT ? PATCH_BYTES + CT_BYTES : REGION_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILES_BYTES + W_BYTES + 256];
     unsigned char* s_patch = smem;
-    unsigned char* s_ct = smem;
-    unsigned char* s_w = smem + REGION_BYTES;
-    float* s_bias = reinterpret_cast<float*>(smem + REGION_BYTES + W_BYTES);  // 64 biases: LDS reads in the epilogue instead
+    unsigned char* s_ct = SPLIT ? smem + PATCH_BYTES : smem;
+    unsigned char* s_w = smem + TILES_BYTES;
+    float* s_bias = reinterpret_cast<float*>(smem + TILES_BYTES + W_BYTES);  // 64 biases: LDS reads in the epilogue instead
                                                                              // of global loads whose waits also cover the prefetch
 
     const int tid = threadIdx.x;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
                 for (int a = 0; a < 4; ++a)
                     acc[i][a] = mfma_lp16_16x16x32(wf[a], xf[i], acc[i][a]);
         }
-        __syncthreads();  // every wave is done with the patch: the conv tile may overlay it
+        if constexpr (!SPLIT) __syncthreads();  // every wave is done with the patch: the conv tile may overlay it
         int fr = frow, gg = g, tq = tid;
         asm volatile("" : "+v"(fr), "+v"(gg), "+v"(tq));  // epilogue / pooling addresses are recomputed per tile
 
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(NTH, 4) void stem_mfma_kernel(const float* __restri
                 *reinterpret_cast<uint4*>(out + (((size_t)n * PH + ph) * PW + pw) * 64 + cq * 8) = o;
             }
         }
-        __syncthreads();  // the conv tile is consumed: the next patch may overwrite it
+        if constexpr (!SPLIT) __syncthreads();  // the conv tile is consumed: the next patch may overwrite it
     }
 }
 }  // namespace
@@ -239,7 +244,12 @@ extern "C" int agrl_stem_conv_bn_relu_maxpool_lp16(const float* x, const void* w
     AGRL_CHECK_ARG(grid < (1ll << 31), "agrl_stem_lp16: grid too large");
     const int wgs = 512;  // two persistent workgroups per CU (67 KB of LDS each)
     const unsigned launch = (unsigned)(grid < wgs ? grid : wgs);
-    hipLaunchKernelGGL(stem_mfma_kernel, dim3(launch), dim3(NTH), 0, (hipStream_t)stream, x,
+    if (agrl_opts().stem_split_lds != 0)
+        hipLaunchKernelGGL(stem_mfma_kernel<true>, dim3(launch), dim3(NTH), 0, (hipStream_t)stream, x,
+                       (const unsigned char*)w_packed, bias, (lp16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w,
+                       (int)grid, agrl_opts().stem_xcd_map != 0);
+    else
+        hipLaunchKernelGGL(stem_mfma_kernel<false>, dim3(launch), dim3(NTH), 0, (hipStream_t)stream, x,
                        (const unsigned char*)w_packed, bias, (lp16_t*)out, H, W, CH, CW, PH, PW, tiles_w, tiles_h * tiles_w,
                        (int)grid, agrl_opts().stem_xcd_map != 0);
     AGRL_CHECK_LAUNCH("agrl_stem_lp16");
