@@ -711,6 +711,37 @@ def test_stem_bf16_mfma(shape):
     assert e < 5e-3  # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 48), (10, 64, 48), (33, 256, 128), (64, 128, 64)])
+def test_stem_16bit_tile_order_and_lds_forms(shape, monkeypatch):
+    """The 16-bit stem walks its tiles frame by frame per XCD from 8 frames on (round 5: HBM fetch 300 -> 101 MB per launch) and keeps
+    the patch and the conv tile in separate LDS regions (two barriers per tile): frame counts that give every XCD the same number of
+    frames, uneven ones (10, 33: XCDs with one frame more), a grid above the 512 persistent workgroups -- against the fp32 reference,
+    and bit for bit against the launch-order / overlaid-region forms (AGRL_STEM_XCD_MAP=0, AGRL_STEM_SPLIT_LDS=0)."""
+    from torchreid import hip_ops as ops
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn((N, 3, H, W), generator=g)
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.1
+    b = torch.randn((64,), generator=g) * 0.1
+    ref = F.max_pool2d(F.relu(F.conv2d(x.to(LP_DTYPE).float(), w.to(LP_DTYPE).float(), bias=b, stride=2, padding=3)), 3, 2, 1)
+    wpk = ops.pack_stem_weights_lp16(w.permute(0, 2, 3, 1).contiguous().to(DEV))
+    dx, db = x.to(DEV), b.to(DEV)
+    out = ops.stem_lp16(dx, wpk, db)
+    again = ops.stem_lp16(dx, wpk, db)
+    torch.cuda.synchronize()
+    e = rel_err(out.float().permute(0, 3, 1, 2), ref)
+    print("stem 16-bit", shape, "rel err %.3e" % e)
+    assert e < 5e-3 and torch.equal(out, again)
+    for var in ("AGRL_STEM_XCD_MAP", "AGRL_STEM_SPLIT_LDS"):
+        monkeypatch.setenv(var, "0")
+        _hip.reload_options()
+        other = ops.stem_lp16(dx, wpk, db)
+        torch.cuda.synchronize()
+        assert torch.equal(out, other), var
+        monkeypatch.delenv(var)
+        _hip.reload_options()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, LP_DTYPE])
 @pytest.mark.parametrize("cfg", [(2, 4, 16, 8, 2048, [4, 2, 1]), (1, 3, 14, 7, 512, [4, 2, 1]), (2, 2, 16, 8, 256, [8, 4, 2, 1]), (1, 2, 16, 8, 256, [4])])
 def test_part_pool(cfg, dtype):
