@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
     // ---- weight stream of this wave: fragment q of slab s at wpk + ((nt * 4 + wave) * nslab * DPS + s * DPS + q) KiB
     const unsigned char* wstream = p.wpk + (size_t)(nt * 4 + wave) * nslab * (DPS * 1024);
 #if DUO_ABL   // (profiling builds: with parts of the loop compiled out hipcc no longer proves the stream pointer uniform)
-    wstream = reinterpret_cast<const unsigned char*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)((size_t)wstream >> 32)) << 32) |
-                                                     __builtin_amdgcn_readfirstlane((unsigned)(size_t)wstream));
+    wstream = reinterpret_cast<const unsigned char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((size_t)wstream >> 32)) << 32) |
+                                                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(size_t)wstream));   // (the builtin returns a SIGNED int)
 #endif
     u32x4_t wr[DRING];
     auto issue_w = [&](auto slot_c, const unsigned char* slab_base, auto pos_c) {

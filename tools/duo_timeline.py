@@ -1,6 +1,7 @@
 """Phase timeline of conv1x1_duo_kernel from the profiling build (tools/duo_ablate.sh 64 -> lib/libagrl_hip_duoabl64.so):
 per-workgroup s_memtime stamps -> median phase durations, per-CU overlap of the two resident workgroups.
-usage: AGRL_HIP_LIB=.../libagrl_hip_duoabl64.so python tools/duo_timeline.py"""
+usage: AGRL_HIP_LIB=.../libagrl_hip_duoabl64.so python tools/duo_timeline.py [strided2 | strided3]   (default: conv3 + residual of layer 4;
+strided2 / strided3: the two-source first blocks of layers 2 / 3)"""
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd")):
@@ -22,7 +23,16 @@ w1 = (torch.randn((512, 1, 1, Cout), device=dev) / Cout ** 0.5).to(LP_DTYPE)
 w2 = (torch.randn((512, 3, 3, 512), device=dev) / (9 * 512) ** 0.5).to(LP_DTYPE)
 b1 = torch.randn((512,), device=dev)
 p1, p2 = ops.conv1x1_pack(w1), ops.conv3x3_pack(w2)
-nwg = frames * (Cout // 256)
+case = sys.argv[1] if len(sys.argv) > 1 else "res"
+if case in ("strided2", "strided3"):
+    hi, wi, k1, k2, co = (64, 32, 256, 128, 512) if case == "strided2" else (32, 16, 512, 256, 1024)
+    sa = torch.relu(torch.randn((frames, hi, wi, k1), device=dev)).to(LP_DTYPE)
+    sy = torch.relu(torch.randn((frames, hi // 2, wi // 2, k2), device=dev)).to(LP_DTYPE)
+    spk = ops.conv1x1_pack((torch.randn((co, 1, 1, k1 + k2), device=dev) / (k1 + k2) ** 0.5).to(LP_DTYPE))
+    sb = torch.randn((co,), device=dev)
+    nwg = frames * (hi // 2) * (wi // 2) // 128 * (co // 256)
+else:
+    nwg = frames * (Cout // 256)
 buf = torch.zeros((nwg, 12), dtype=torch.int64, device=dev)
 lib = _hip.lib()
 lib.agrl_duo_trace_buffer.argtypes = [ctypes.c_void_p]
@@ -31,7 +41,10 @@ for it in range(3):
     y1 = ops.conv1x1_packed(res, p1, b1, 512, True)
     y2 = ops.conv3x3_packed(y1, p2, b1, 512, True)
     buf.zero_()
-    ops.conv1x1_packed_res(x, packed, b, Cout, res)
+    if case in ("strided2", "strided3"):
+        ops.conv1x1_packed_dual_strided(sa, sy, spk, sb, co, 2, True)
+    else:
+        ops.conv1x1_packed_res(x, packed, b, Cout, res)
     torch.cuda.synchronize()
 t = buf.cpu().numpy().astype(np.int64)
 hw, xcc = t[:, 10], t[:, 11]
