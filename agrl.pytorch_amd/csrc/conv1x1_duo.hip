@@ -25,6 +25,9 @@
 //     Ablations of the stored form (127 us with the accumulator-layout epilogue): no result stores 76, no residual loads 110, neither
 //     62, no MFMA 124 (!), no weight loads 107, no pixel DMA 114, one workgroup per CU 142. Timeline of a workgroup (s_memtime): 5.3 us
 //     from start to the first barrier (first loads), k-loop 9.0, residual wait 2.6, combine 4.5, stores 2.4.
+//   * a weight ring of 12 fragments instead of 8 (248 / 252 registers; the ring then rotates through the 16-fragment slab and the slab body
+//     exists three times): bit-identical, layer 4's pointwise family 0.981-0.982 ms against 0.974-0.978 in the step (three A/B pairs, one
+//     box) -- no gain, not kept: the k-loop does not wait for its weights.
 //   * second form (git history, c2f7fb3): ONE persistent 8-wave workgroup per frame walking its eight channel tiles, four matrix
 //     waves (k-loop + combine, the fragment stream running on across tiles, an LDS arrival counter instead of s_barrier for the
 //     pixel buffers) + four memory waves bringing the residual into the image and streaming the result out under the next tile's

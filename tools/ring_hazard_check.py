@@ -12,8 +12,8 @@ order:
   * `s_waitcnt vmcnt(N)` retires all but the youngest N entries;
   * any other instruction that names (reads or writes) a VGPR of a still-pending load is a violation;
   * control flow: one execution path is walked -- unconditional branches are followed, every loop runs three iterations (first,
-    steady state, last) and is then left, the optional side of a forward diamond is executed; instructions the walk never reached are
-    counted in the report.
+    steady state, last) and is then left (by its backward branch falling through, or by a forward branch that jumps past the back-edge),
+    the optional side of a forward diamond inside a body is always executed; instructions the walk never reached are counted in the report.
 
 usage: ring_hazard_check.py FILE.s KERNEL_SYMBOL_REGEX   -> one line per kernel; exit 1 on a violation or when nothing matched."""
 import re
@@ -102,6 +102,7 @@ def check(prog):
     # way on the third, so that every loop runs three iterations (first, steady state, last) and is then left
     visits = {}
     seen = set()
+    back_edges = [(k, labels[p_[1]]) for k, p_ in enumerate(prog) if p_[0] == "branch" and p_[1] in labels and labels[p_[1]] < k]
     i, steps = 0, 0
     while i < len(prog) and steps < 50 * len(prog):
         steps += 1
@@ -114,7 +115,15 @@ def check(prog):
                 continue
             n = visits[i] = visits.get(i, 0) + 1
             backward = target < i
-            if backward == (n % 3 != 0):
+            if backward:
+                take = n % 3 != 0
+            else:
+                # a forward conditional branch is followed only where it LEAVES a loop (a back-edge lies between it and its target and
+                # closes a loop that contains it), and then on its third visit; a forward branch that merely skips code inside the loop body
+                # is never followed: skipping one optional part but not the next can be a path no execution takes
+                leaves = any(i < b < target and h <= i for b, h in back_edges)
+                take = leaves and n % 3 == 0
+            if take:
                 i = target
                 continue
         elif kind == "inst":
