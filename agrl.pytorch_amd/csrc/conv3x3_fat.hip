@@ -268,6 +268,8 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
 // (profiles/r05_conv3x3_fat_timeline.txt); two half-width workgroups share a CU's matrix pipes and hide part of each other's waits.
 // Same k order: bit-identical. Measured (rocprofv3 kernel durations, tools/half_trace.sh): layer 3 (256 -> 256) 33.7 us against
 // conv3x3_fat_kernel<1>'s 35.5 -- taken there; layer 4 (512 -> 512) 120.8 against conv3x3_fat_kernel<2>'s 115 -- not taken. Starting
+// Late in round 5 the same kernel took layer 2's 128 -> 128 convs (32 x 16 maps: `halves` = 1, the weights packed as the lower half of a 256-channel
+// tile, one workgroup per block): 37.5-39.0 us against conv3x3_patch_kernel<128>'s 45.2-45.9 (events, same box), step -0.6 %. Starting
 // the second resident round `stagger` clocks late (so that one's start-up and store burst would fall under the other's k-loop) makes
 // it SLOWER: 41.4 us by events without, 42.5-43.7 with 4 k .. 20 k clocks -- the default is 0.
 constexpr int HRING = 12;                // weight fragments in flight per wave (a slab = 36 = 3 ring turns)
@@ -295,7 +297,7 @@ struct HalfSchedOf {
     static constexpr HalfSched value = make_half_sched();
 };
 
-__global__ __launch_bounds__(256, 2) void conv3x3_half_kernel(const FatParams p, int stagger, int first) {
+__global__ __launch_bounds__(256, 2) void conv3x3_half_kernel(const FatParams p, int stagger, int first, int halves) {
     using SCHED = HalfSchedOf;
     using std::integral_constant;
     constexpr int NBF = 8;
@@ -318,8 +320,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_half_kernel(const FatParams p,
 
     // tile = (pixel block mt, 128-channel half ht of channel tile nt): the two halves of a block are `first` workgroups apart, i.e. in
     // different resident rounds (whichever CU they land on)
-    const int nNt = p.Cout >> 8;
-    const int per_half = gridDim.x >> 1;
+    // (halves == 1: a 128-channel conv -- layer 2 -- whose weights were packed as the lower half of a 256-channel tile: one workgroup per block)
+    const int nNt = halves == 1 ? 1 : p.Cout >> 8;
+    const int per_half = halves == 1 ? (int)gridDim.x : (int)(gridDim.x >> 1);
     const int half = (int)blockIdx.x >= per_half ? 1 : 0;
     int bid = (int)blockIdx.x - half * per_half;
     {
@@ -460,7 +463,7 @@ __global__ void conv3x3_fat_pack_kernel(const lp16_t* __restrict__ w, uint4* __r
     }
 }
 
-bool fat_shape_ok(int H, int W, int Cin, int Cout) { return H % 16 == 0 && W % 8 == 0 && Cin % 64 == 0 && Cin >= 128 && Cout % 256 == 0; }
+bool fat_shape_ok(int H, int W, int Cin, int Cout) { return H % 16 == 0 && W % 8 == 0 && Cin % 64 == 0 && Cin >= 128 && (Cout % 256 == 0 || Cout == 128); }
 
 }  // namespace
 
@@ -489,7 +492,7 @@ extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, con
                                           int Cout, int relu, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && packed && bias && out, "agrl_conv3x3_packed_bn_act: null pointer");
     AGRL_CHECK_ARG(N > 0 && fat_shape_ok(H, W, Cin, Cout),
-                   "agrl_conv3x3_packed_bn_act: needs 16 x 8-divisible maps, Cin %% 64 == 0 (>= 128), Cout %% 256 == 0; got %dx%d %d->%d", H, W, Cin, Cout);
+                   "agrl_conv3x3_packed_bn_act: needs 16 x 8-divisible maps, Cin %% 64 == 0 (>= 128), Cout %% 256 == 0 or Cout == 128; got %dx%d %d->%d", H, W, Cin, Cout);
     AGRL_CHECK_ARG((size_t)N * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 2 < (1ull << 32), "agrl_conv3x3_packed_bn_act: maps beyond 4 GB are not addressed");
     AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)out) & 15) == 0, "agrl_conv3x3_packed_bn_act: pointers must be 16-byte aligned");
     FatParams p;
@@ -499,6 +502,12 @@ extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, con
     p.out = reinterpret_cast<unsigned char*>(out);
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.nblocks = N * (H >> 4) * (W >> 3);
+    if (Cout == 128) {   // layer 2's 128 -> 128 convs: `packed` holds the weights as the lower half of one 256-channel tile (upper half zero,
+                         // never read); one half-width workgroup per 16 x 8 block, two or three resident per CU
+        hipLaunchKernelGGL(conv3x3_half_kernel, dim3(p.nblocks), dim3(256), 0, (hipStream_t)stream, p, 0, p.nblocks, 1);
+        AGRL_CHECK_LAUNCH("agrl_conv3x3_packed_bn_act");
+        return 0;
+    }
     const int nNt = Cout >> 8;
     // two pixel blocks per workgroup where that still gives every CU a workgroup, else one
     // one-block launches that would put ONE workgroup on a CU (layer 3): two half-width workgroups per block instead
@@ -511,7 +520,7 @@ extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, con
     const int want_half = agrl_opts().conv3x3_half;
     if (agrl_opt_set(want_half) ? want_half != 0 : ((p.nblocks / 2) * nNt < 224 && p.nblocks * nNt <= cus && p.nblocks * nNt >= cus / 2)) {
         const int stagger = agrl_opt_set(agrl_opts().conv3x3_half_stagger) ? agrl_opts().conv3x3_half_stagger : 0;
-        hipLaunchKernelGGL(conv3x3_half_kernel, dim3(2 * p.nblocks * nNt), dim3(256), 0, (hipStream_t)stream, p, stagger, p.nblocks * nNt);
+        hipLaunchKernelGGL(conv3x3_half_kernel, dim3(2 * p.nblocks * nNt), dim3(256), 0, (hipStream_t)stream, p, stagger, p.nblocks * nNt, 2);
         AGRL_CHECK_LAUNCH("agrl_conv3x3_packed_bn_act");
         return 0;
     }

@@ -231,15 +231,19 @@ def conv3x3_packed_enabled():
 
 def conv3x3_packed_supported(w_ohwi, H=None, W=None):
     """3x3 / stride 1 conv through the four-wave kernel with a pre-packed weight stream (csrc/conv3x3_fat.hip): 16-bit weights,
-    Cin % 64 == 0 (>= 128), Cout % 256 == 0 and -- when given -- maps made of whole 16 x 8 blocks."""
+    Cin % 64 == 0 (>= 128), Cout % 256 == 0 -- or Cout == 128 (layer 2: packed as the lower half of a 256-channel tile) -- and, when
+    given, maps made of whole 16 x 8 blocks."""
     return (w_ohwi.dtype == LP_DTYPE and w_ohwi.dim() == 4 and tuple(w_ohwi.shape[1:3]) == (3, 3) and w_ohwi.shape[3] % 64 == 0
-            and w_ohwi.shape[3] >= 128 and w_ohwi.shape[0] % 256 == 0 and (H is None or (H % 16 == 0 and W % 8 == 0)))
+            and w_ohwi.shape[3] >= 128 and (w_ohwi.shape[0] % 256 == 0 or w_ohwi.shape[0] == 128) and (H is None or (H % 16 == 0 and W % 8 == 0)))
 
 
 def conv3x3_pack(w_ohwi):
     """OHWI 3x3 weights re-ordered once into per-wave MFMA fragment streams (agrl_conv3x3_pack) -> uint8 tensor."""
     assert conv3x3_packed_supported(w_ohwi)
     Cout, Cin = w_ohwi.shape[0], w_ohwi.shape[3]
+    if Cout == 128:   # the lower half of one 256-channel tile; the upper half (zeros) is never read by the launch
+        w_ohwi = torch.cat([w_ohwi, torch.zeros_like(w_ohwi)], dim=0)
+        Cout = 256
     w_ohwi = w_ohwi.contiguous()
     nbytes = int(_hip.lib().agrl_conv3x3_packed_bytes(Cin, Cout))
     assert nbytes == 2 * w_ohwi.numel()
@@ -252,10 +256,10 @@ def conv3x3_pack(w_ohwi):
 def conv3x3_packed(x, packed, bias, Cout, relu=True):
     """relu(conv3x3(x) + bias), stride 1 / pad 1, weights from conv3x3_pack. vmgn.py:52-54. -> (N,H,W,Cout) 16-bit NHWC."""
     N, H, W, Cin = x.shape
-    assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * 9 * Cin * Cout
+    assert x.dtype == LP_DTYPE and x.is_contiguous() and packed.numel() == 2 * 9 * Cin * max(Cout, 256)
     out = torch.empty((N, H, W, Cout), dtype=x.dtype, device=x.device)
     if _hip.PROFILE is not None:
-        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * 9 * Cin * Cout, "bytes": 2.0 * (x.numel() + out.numel()) + packed.numel(),
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * 9 * Cin * Cout, "bytes": 2.0 * (x.numel() + out.numel()) + 2.0 * 9 * Cin * Cout,
                             "conv": (3, 1, Cin, Cout, H, W)}
     with _dev(x):
         call("agrl_conv3x3_packed_bn_act", ptr(x), ptr(packed), ptr(bias), ptr(out), N, H, W, Cin, Cout, 1 if relu else 0, _stream(x))

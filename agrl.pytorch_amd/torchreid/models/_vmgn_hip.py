@@ -159,7 +159,8 @@ def pack_weights(model, device, precision):
 def _conv2(y, blk):
     """conv2 / bn2 / relu of a Bottleneck (vmgn.py:52-54): the packed-weight kernel where it was packed and the map is made of
     whole 16 x 8 blocks, else the general conv."""
-    if 'c2p' in blk and y.shape[1] % 16 == 0 and y.shape[2] % 8 == 0 and ops.conv3x3_packed_enabled():
+    if ('c2p' in blk and y.shape[1] % 16 == 0 and y.shape[2] % 8 == 0 and ops.conv3x3_packed_enabled()
+            and (blk['c2'][0].shape[0] != 128 or os.environ.get('AGRL_HIP_CONV3X3_PACKED_L2', '1') != '0')):   # (layer 2's 128 -> 128: round 5, late)
         return ops.conv3x3_packed(y, blk['c2p'], blk['c2'][1], blk['c2'][0].shape[0], True)
     return ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
 

@@ -287,12 +287,13 @@ def test_bottleneck_seam(dims, frames):
 
 
 @pytest.mark.parametrize("case", [(1, 16, 8, 128, 256, True), (3, 16, 8, 256, 256, True), (5, 32, 16, 192, 512, False),
-                                  (250, 16, 8, 512, 512, True), (231, 16, 8, 256, 256, True)])
+                                  (250, 16, 8, 512, 512, True), (231, 16, 8, 256, 256, True), (7, 32, 16, 128, 128, True), (64, 32, 16, 128, 128, False)])
 def test_conv3x3_packed(case):
     """3x3 conv through the four-wave kernel with the pre-packed weight stream (conv3x3_fat.hip) against the fp32 reference and
     against conv_bn_act (same summation order: equal bit for bit). 1 frame = a single workgroup with an absent second block;
     5 frames of 32 x 16 = blocks with real neighbours on all sides (halo rows / columns from the map, zeros at the border);
-    250 frames x 512 channels takes the two-blocks-per-workgroup form, 231 an odd block count in it. Every call twice."""
+    250 frames x 512 channels takes the two-blocks-per-workgroup form, 231 an odd block count in it; 128 -> 128 on 32 x 16 maps (layer
+    2) runs as one half-width workgroup per block on the lower half of a 256-channel weight tile. Every call twice."""
     from torchreid import hip_ops as ops
     N, H, W, Cin, Cout, relu = case
     g = torch.Generator().manual_seed(sum(case[:5]))
