@@ -142,7 +142,10 @@ int agrl_bottleneck_seam(const void* y2, const void* packed, const float* b3, co
  * agrl_conv3x3_pack writes agrl_conv3x3_packed_bytes(Cin, Cout) = 2 * 9 * Cin * Cout bytes; agrl_conv3x3_packed_bn_act then
  * streams them global -> registers (no LDS staging of weights) while the LDS holds only the pixel halo patches. Needs maps made
  * of whole 16 x 8 blocks, Cin % 64 == 0 (>= 128), Cout % 256 == 0; other shapes are rejected (the caller runs them through
- * agrl_conv2d_bn_act). Same arithmetic as agrl_conv2d_bn_act: fp32 accumulation over (slab, tap, k) in that order, one rounding. */
+ * agrl_conv2d_bn_act). agrl_conv3x3_packed_bn_act also takes Cout == 128 (layer 2's convs) when `packed` was made by
+ * agrl_conv3x3_pack(Cin, 256) from the weights padded with 128 all-zero output channels (the lower half of one 256-channel tile;
+ * the upper half is never read; out and bias hold 128 channels). Same arithmetic as agrl_conv2d_bn_act: fp32 accumulation over
+ * (slab, tap, k) in that order, one rounding. */
 long long agrl_conv3x3_packed_bytes(int Cin, int Cout);
 int agrl_conv3x3_pack(const void* w_ohwi, void* packed, int Cin, int Cout, agrl_stream_t stream);
 int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin,
