@@ -20,7 +20,7 @@
 //     order). Measured, same box, inside a Bottleneck (conv1 and the 3x3 run before every timed call), HIP events, this / wide:
 //     POOLED 92.0 / 101.2 us (global branch), the model's dispatch; map stored 117.4 / 119.5 us (back to back 115.6 / 122.4): dispatched; WITHOUT a
 //     residual (layer 4's conv1s, tools/conv1x1_duo_vs_fat.py: this / conv1x1_fat_kernel / wide) 2048 -> 512 69.2 / 72.7 / 77.5 us,
-//     1024 -> 512 43.5 / 45.4 / 45.4 -- but inside the step the six conv1 launches are 12 us slower than before: not dispatched; 512 -> 256 on 32 x 16 maps 56 / 60.5 / 54: not; the TWO-SOURCE form (conv3 + downsample
+//     1024 -> 512 43.5 / 45.4 / 45.4 -- inside the step equal mid-round (six conv1 launches 12 us slower by events), 7-13 us per step AHEAD on the final tree (two boxes, eight A/B pairs): dispatched late in round 5; 512 -> 256 on 32 x 16 maps 56 / 60.5 / 54: not; the TWO-SOURCE form (conv3 + downsample
 //     conv of a first block over [x | y2], agrl_conv1x1_packed_dual_duo) 167.1 us against conv1x1_fat_kernel's 185.2: dispatched.
 //     Ablations of the stored form (127 us with the accumulator-layout epilogue): no result stores 76, no residual loads 110, neither
 //     62, no MFMA 124 (!), no weight loads 107, no pixel DMA 114, one workgroup per CU 142. Timeline of a workgroup (s_memtime): 5.3 us

@@ -167,9 +167,10 @@ def _conv2(y, blk):
 
 def _conv1(x, blk):
     """conv1 / bn1 / relu of a Bottleneck (vmgn.py:48-50)."""
-    # (conv1 through conv1x1_duo_kernel: ahead back to back -- 2048 -> 512 69 us against 73 -- but not inside the step: the six launches
-    # 12 us slower by events, step equal, three A/B pairs on one box; AGRL_HIP_CONV1X1_DUO_C1=1 turns it on)
-    if 'c1p' in blk and ops.conv1x1_duo_enabled() and x.is_contiguous() and os.environ.get('AGRL_HIP_CONV1X1_DUO_C1', '0') == '1':
+    # (layer 4's conv1s through conv1x1_duo_kernel: ahead back to back -- 2048 -> 512 69 us against 73 --; inside the step it measured equal
+    # in the middle of round 5 and, on the final tree, 7-13 us ahead per step on two boxes (eight A/B pairs, profiles/r05_ab_conv1_through_duo.txt):
+    # on; AGRL_HIP_CONV1X1_DUO_C1=0 = conv1x1_fat_kernel / igemm_wide_kernel)
+    if 'c1p' in blk and ops.conv1x1_duo_enabled() and x.is_contiguous() and os.environ.get('AGRL_HIP_CONV1X1_DUO_C1', '1') != '0':
         return ops.conv1x1_packed_res(x, blk['c1p'], blk['c1'][1], blk['c1'][0].shape[0], None, True)
     if 'c1p' in blk and ops.conv1x1_packed_enabled() and blk['c1'][0].shape[3] >= 2048:
         return ops.conv1x1_packed(x, blk['c1p'], blk['c1'][1], blk['c1'][0].shape[0], True)
