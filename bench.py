@@ -988,7 +988,7 @@ def main():
         if pw["launches"]:
             ach = pw["flops"] / (pw["ms"] * 1e-3) / 1e12
             result["roofline_pointwise_layer4"] = {
-                "bound": "mfma", "kernel": "1x1 convs of the two layer-4 branches (conv1x1_fat_kernel / igemm_wide_kernel + the pool-fused last conv, conv1x1_duo_kernel)",
+                "bound": "mfma", "kernel": "1x1 convs of the two layer-4 branches (conv1x1_duo_kernel: conv1s, conv3 + downsample, conv3 + residual, the pool-fused last conv; AGRL_HIP_CONV1X1_DUO* = 0: conv1x1_fat_kernel / igemm_wide_kernel)",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "launches_per_step": pw["launches"] // nprof, "ms_per_step": round(pw["ms"] / nprof, 4)}
 
