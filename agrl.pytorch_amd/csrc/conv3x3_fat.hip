@@ -524,8 +524,12 @@ extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, con
         AGRL_CHECK_LAUNCH("agrl_conv3x3_packed_bn_act");
         return 0;
     }
-    const int force_pb = agrl_opts().conv3x3_fat_pb;   // AGRL_CONV3X3_FAT_PB = 1 / 2: A/B
-    if (agrl_opt_set(force_pb) ? force_pb == 2 : (p.nblocks / 2) * nNt >= 224) hipLaunchKernelGGL(conv3x3_fat_kernel<2>, dim3(((p.nblocks + 1) / 2) * nNt), dim3(256), 0, (hipStream_t)stream, p);
+    // One pixel block per workgroup (240 registers: TWO workgroups per CU) unless AGRL_CONV3X3_FAT_PB=2 asks for the two-block form (one
+    // 460-register workgroup per CU, the default until late in round 5). Back to back the two forms of layer 4 measure the same (126.5-127.8
+    // against 126.3-128.2 us by events); INSIDE the step, where every launch starts cold behind a different kernel, the one-block form is
+    // ~5 us per launch ahead: step 3.508-3.540 against 3.536-3.573 ms, eight A/B pairs on two boxes (profiles/r05_ab_conv3x3_fat_pb.txt).
+    const int force_pb = agrl_opts().conv3x3_fat_pb;
+    if (agrl_opt_set(force_pb) && force_pb == 2) hipLaunchKernelGGL(conv3x3_fat_kernel<2>, dim3(((p.nblocks + 1) / 2) * nNt), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(conv3x3_fat_kernel<1>, dim3(p.nblocks * nNt), dim3(256), 0, (hipStream_t)stream, p);
     AGRL_CHECK_LAUNCH("agrl_conv3x3_packed_bn_act");
     return 0;

@@ -973,9 +973,9 @@ def main():
                   "avg_launch_us": round(1e3 * a["ms"] / a["launches"], 2), "ms_per_step": round(a["ms"] / nprof, 4)}
         dom = cls["dom"]
         if dom["launches"]:
-            # THE dominant kernel by time (profiles/*_bench_kernel_stats.csv): conv3x3_fat_kernel<1 | 2>
+            # THE dominant kernel by time (profiles/*_bench_kernel_stats.csv): conv3x3_fat_kernel<1> (layer 4) + conv3x3_half_kernel (layer 3)
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_fat_kernel<1> + <2> (3x3 stride-1 convs of layers 3-4: one 16 x 8 block x 256 channels per workgroup in layer 3, two in layer 4; csrc/conv3x3_fat.hip)" if ops.conv3x3_packed_enabled() else "conv3x3_wide_kernel<0, 128> + <0, 256> (csrc/conv3x3_wide.hip; AGRL_HIP_CONV3X3_PACKED=0)",
+            result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_fat_kernel<1> + conv3x3_half_kernel (3x3 stride-1 convs of layers 3-4: layer 4 one 16 x 8 block x 256 channels per four-wave workgroup, two workgroups per CU; layer 3 two half-width workgroups per block; csrc/conv3x3_fat.hip)" if ops.conv3x3_packed_enabled() else "conv3x3_wide_kernel<0, 128> + <0, 256> (csrc/conv3x3_wide.hip; AGRL_HIP_CONV3X3_PACKED=0)",
                                   "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                   "traffic": traffic, "traffic_source": traffic_src,
                                   "flops_per_launch": round(dom["flops"] / dom["launches"], 1),

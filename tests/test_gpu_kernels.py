@@ -288,11 +288,11 @@ def test_bottleneck_seam(dims, frames):
 
 @pytest.mark.parametrize("case", [(1, 16, 8, 128, 256, True), (3, 16, 8, 256, 256, True), (5, 32, 16, 192, 512, False),
                                   (250, 16, 8, 512, 512, True), (231, 16, 8, 256, 256, True), (7, 32, 16, 128, 128, True), (64, 32, 16, 128, 128, False)])
-def test_conv3x3_packed(case):
+def test_conv3x3_packed(case, monkeypatch):
     """3x3 conv through the four-wave kernel with the pre-packed weight stream (conv3x3_fat.hip) against the fp32 reference and
     against conv_bn_act (same summation order: equal bit for bit). 1 frame = a single workgroup with an absent second block;
     5 frames of 32 x 16 = blocks with real neighbours on all sides (halo rows / columns from the map, zeros at the border);
-    250 frames x 512 channels takes the two-blocks-per-workgroup form, 231 an odd block count in it; 128 -> 128 on 32 x 16 maps (layer
+    250 frames x 512 channels and 231 (an odd block count) also run forced into the two-blocks-per-workgroup form and the half-width form; 128 -> 128 on 32 x 16 maps (layer
     2) runs as one half-width workgroup per block on the lower half of a 256-channel weight tile. Every call twice."""
     from torchreid import hip_ops as ops
     N, H, W, Cin, Cout, relu = case
@@ -317,6 +317,15 @@ def test_conv3x3_packed(case):
     assert torch.equal(out, out_b)
     assert torch.equal(out, other)
     assert not ops.conv3x3_packed_supported(dw, 10, 6)
+    if Cout % 256 == 0:   # the other forms of the same kernel family: two blocks per workgroup (the default until late round 5), half-width workgroups
+        for var, val in (("AGRL_CONV3X3_FAT_PB", "2"), ("AGRL_CONV3X3_HALF", "1"), ("AGRL_CONV3X3_HALF", "0")):
+            monkeypatch.setenv(var, val)
+            _hip.reload_options()
+            form = ops.conv3x3_packed(dx, packed, b.to(DEV), Cout, relu)
+            torch.cuda.synchronize()
+            assert torch.equal(out, form), (var, val)
+            monkeypatch.delenv(var)
+        _hip.reload_options()
     with pytest.raises(_hip.HipKernelError):
         ops.call("agrl_conv3x3_packed_bn_act", ops.ptr(dx), ops.ptr(packed), ops.ptr(b.to(DEV)), ops.ptr(out), N, 10, 6, Cin, Cout, 1, None)
 

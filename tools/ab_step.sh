@@ -8,7 +8,8 @@ mkdir -p gpurun_out
 : > "$OUT"
 for i in $(seq 1 "$PAIRS"); do
   for v in "$ON" "$OFF"; do
-    env "$VAR=$v" python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-accuracy --no-config5 --no-config4 --no-modes --sustain-seconds 0 > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$VAR=$v FAILED" >> "$OUT"; tail -5 gpurun_out/ab_tmp.err >> "$OUT"; continue; }
+    if [ "$v" = unset ]; then E="-u $VAR"; else E="$VAR=$v"; fi   # "unset" = run without the variable
+    env $E python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-accuracy --no-config5 --no-config4 --no-modes --sustain-seconds 0 > gpurun_out/ab_tmp.json 2> gpurun_out/ab_tmp.err || { echo "$VAR=$v FAILED" >> "$OUT"; tail -5 gpurun_out/ab_tmp.err >> "$OUT"; continue; }
     python3 - "$VAR=$v" >> "$OUT" <<'PY'
 import json, sys
 d = json.loads(open('gpurun_out/ab_tmp.json').read().strip().splitlines()[-1])
