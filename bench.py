@@ -860,7 +860,9 @@ def main():
             result["config"]["allgather_bytes_per_rank"] = B * FEATURE_DIM * 4
         prof, _hip.PROFILE = _hip.PROFILE, None
         agg = {}
-        cls = {"dom": {"ms": 0.0, "launches": 0, "flops": 0.0}, "pw4": {"ms": 0.0, "launches": 0, "flops": 0.0}}
+        cls = {"dom": {"ms": 0.0, "launches": 0, "flops": 0.0}, "pw4": {"ms": 0.0, "launches": 0, "flops": 0.0},
+               "duo": {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0}}
+        DUO_CALLS = ("agrl_conv1x1_packed_res_bn_act", "agrl_conv1x1_packed_res_pool", "agrl_conv1x1_packed_dual_duo", "agrl_conv1x1_packed_dual_strided")
         for name, s_ev, e_ev, tag in prof:
             a = agg.setdefault(name, {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
             ms = s_ev.elapsed_time(e_ev)
@@ -883,6 +885,11 @@ def main():
                     cls[which]["ms"] += ms
                     cls[which]["launches"] += 1
                     cls[which]["flops"] += tag["flops"]
+                if lp and name in DUO_CALLS:   # every launch of conv1x1_duo_kernel (<false> + <true> in profiles/*_bench_kernel_stats.csv)
+                    cls["duo"]["ms"] += ms
+                    cls["duo"]["launches"] += 1
+                    cls["duo"]["flops"] += tag["flops"]
+                    cls["duo"]["bytes"] += tag["bytes"]
         kernels = {}
         for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
             sec = a["ms"] * 1e-3
@@ -952,7 +959,7 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         # HBM traffic per launch: NOT measured in this run -- PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command, tools/collect_profiles.sh) are committed under profiles/ and quoted with their source
-        traffic = fam_traffic = traffic_src = None
+        traffic = fam_traffic = traffic_src = duo_traffic = None
         for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
@@ -962,10 +969,12 @@ def main():
                     k3 = tj.get("other_kernels", {}).get("conv3x3_fat_kernel" if ops.conv3x3_packed_enabled() else "conv3x3_wide_kernel")
                     if k3:
                         traffic = k3["fetch_bytes_per_launch"] + (k3["write_bytes_per_launch"] or 0.0)
+                    kd = tj.get("other_kernels", {}).get("conv1x1_duo_kernel")
+                    duo_traffic = kd["fetch_bytes_per_launch"] + (kd["write_bytes_per_launch"] or 0.0) if kd else None
                     traffic_src = "profiles/%s (earlier rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)" % tname
                     break
                 except Exception:
-                    traffic = fam_traffic = None
+                    traffic = fam_traffic = duo_traffic = None
         family = {"bound": "mfma (layers 3-4) / hbm (layers 1-2)",
                   "kernel": "conv implicit-GEMM family (agrl_conv2d_bn_act + agrl_conv3x3_packed_bn_act + agrl_conv1x1_packed_bn_act + agrl_conv1x1_dual_bn_act + agrl_conv1x1_bn_act_pool / agrl_conv1x1_packed_res_pool + agrl_bottleneck_tail + agrl_bottleneck_block + agrl_bottleneck_seam)",
                   "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -982,6 +991,24 @@ def main():
                                   "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
                                   "launches_per_step": dom["launches"] // nprof, "ms_per_step": round(dom["ms"] / nprof, 4)}
             result["roofline_conv_family"] = family
+            # Which kernel is "the dominant one" is decided by THIS run's times: until late in round 5 the 3x3 family above; since all of
+            # layer 4's 1x1 GEMMs (and the strided first blocks of layers 2 / 3) run through conv1x1_duo_kernel, its 14 launches per step
+            # outweigh the 3x3 family's 11. `roofline` carries the larger one, both stay in the line under their own names.
+            duo = cls["duo"]
+            result["roofline_conv3x3"] = dict(result["roofline"])
+            if duo["launches"]:
+                ach_d = duo["flops"] / (duo["ms"] * 1e-3) / 1e12
+                result["roofline_conv1x1_duo"] = {
+                    "bound": "mfma", "kernel": "conv1x1_duo_kernel<false> + <true> (every 1x1 GEMM of layer 4 -- conv1s, conv3 + downsample, conv3 + residual stored / pooled -- and the two-source first blocks of layers 2 / 3: two co-resident four-wave workgroups per CU, 128 x 256 tiles; csrc/conv1x1_duo.hip)",
+                    "achieved": round(ach_d, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach_d / peak, 4),
+                    "traffic": duo_traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(duo["bytes"] / duo["launches"], 1),
+                    "flops_per_launch": round(duo["flops"] / duo["launches"], 1), "avg_launch_us": round(1e3 * duo["ms"] / duo["launches"], 2),
+                    "launches_per_step": duo["launches"] // nprof, "ms_per_step": round(duo["ms"] / nprof, 4),
+                    "hbm_frac_at_8tbs": round(duo["bytes"] / (duo["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                if duo["ms"] > dom["ms"]:
+                    result["roofline"] = dict(result["roofline_conv1x1_duo"])
+            result["roofline"]["dominant_by"] = "time in this run (HIP events around the C-ABI calls): %s" % (
+                "conv1x1_duo_kernel %.3f ms vs the 3x3 family %.3f ms per step" % (duo["ms"] / nprof, dom["ms"] / nprof))
         else:  # fp32 / split modes: one generic kernel serves every conv
             result["roofline"] = family
         pw = cls["pw4"]

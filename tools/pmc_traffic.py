@@ -20,7 +20,8 @@ def load(path, counter):
         name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
         key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "conv1x1_fat_kernel", "conv1x1_duo_kernel", "bottleneck_")) and "pack_kernel" not in name else name.split("(")[0][-40:]
         for dom, alias in (("conv3x3_wide_kernel", "conv3x3_wide_kernel"), ("conv3x3_fat_kernel", "conv3x3_fat_kernel"),
-                           ("conv3x3_half_kernel", "conv3x3_fat_kernel")):   # the dominant kernel family (layers 3-4: fat<2> + half) on its own
+                           ("conv3x3_half_kernel", "conv3x3_fat_kernel"),    # the 3x3 family (layers 2-4: fat + half) on its own
+                           ("conv1x1_duo_kernel", "conv1x1_duo_kernel")):    # every launch of the two-workgroups-per-CU 1x1 kernel (<false> + <true>)
             if dom in name:
                 per[alias][0] += float(row["Counter_Value"])
                 per[alias][1] += 1
@@ -35,7 +36,7 @@ write_b = wi[0] * 1024
 extra = {}
 for k in ("conv1x1_duo_kernel", "stem_mfma_kernel", "graph_propagate_stream_kernel", "gram_kernel", "graph_finalize_kernel", "graph_apply_stream_kernel", "graph_tracklet_kernel", "distmat_regq_kernel", "conv3x3_wide_kernel", "conv3x3_fat_kernel", "rank_topk_fast_kernel"):
     for kk in f:
-        if k in kk and not (k in ("conv3x3_wide_kernel", "conv3x3_fat_kernel") and kk != k):
+        if k in kk and not (k in ("conv3x3_wide_kernel", "conv3x3_fat_kernel", "conv1x1_duo_kernel") and kk != k):
             # one entry per instantiation (distmat_regq_kernel<2, 3, 16> = the step's 12 180-row gallery, <2, 4, 16> = the 8 x gallery)
             extra[kk if kk != k and "<" in kk else k] = {
                 "launches": f[kk][1], "fetch_bytes_per_launch": f[kk][0] * 1024 * 2.0 / max(f[kk][1], 1),
