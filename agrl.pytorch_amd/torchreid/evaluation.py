@@ -73,14 +73,16 @@ def _claim(pending, main):
 
 
 @torch.no_grad()
-def extract_features(model, batches, pool="avg", prefetch=True, sync_ranks=False):
+def extract_features(model, batches, pool="avg", prefetch=True, local_only=False, sync_ranks=None):
     """``batches`` yields (imgs, pids, camids, adj) like the reference's loaders; imgs is (b,S,3,H,W) or, for the
     dense samplers, (b,n,S,3,H,W) with adj (b,n,V,V). Returns (features (N,D) on the model's device, pids, camids).
 
-    No collective by default: the call is safe on one rank of an initialised process group (a rank-0-only ``evaluate``).
-    ``sync_ranks=True`` is for the sharded form, where EVERY rank extracts its slice and then meets the others in
-    ``match_and_rank``: the non-finite flag is all-reduced (MAX) -- by every rank, whatever device its model is on, so the
-    ranks cannot diverge -- and all of them raise together instead of one leaving the rest blocked in the next collective."""
+    Under an active process group (world > 1) the call is COLLECTIVE by default: every rank extracts its slice and then meets
+    the others in ``match_and_rank``, so the non-finite flag is all-reduced (MAX) -- by every rank, whatever device its model
+    is on -- and all of them raise together instead of one leaving the rest blocked in the next collective.
+    ``local_only=True`` is the explicit opt-out for a call that only THIS rank makes (a rank-0-only ``evaluate``): no
+    collective is issued and a non-finite embedding raises on this rank alone. (``sync_ranks``: the round-4 spelling,
+    ``sync_ranks=False`` == ``local_only=True``.)"""
     device = next(model.parameters()).device
     model.eval()
     feats, pids, camids = [], [], []
@@ -105,7 +107,9 @@ def extract_features(model, batches, pool="avg", prefetch=True, sync_ranks=False
     # One check per extraction, on the RAW model outputs (before the dense samplers' clip pooling): the fp16 build stores
     # activations with a range of 65504 -- a checkpoint whose activations leave it yields inf / nan embeddings, and ranking those
     # would be silent garbage. (Nothing on this path comes near the limit with the recipe or with trained ResNet50 statistics.)
-    sync = sync_ranks and parallel.world_size() > 1
+    if sync_ranks is not None:
+        local_only = not sync_ranks
+    sync = not local_only and parallel.world_size() > 1
     if nonfinite is not None or sync:
         flag = (nonfinite.to(torch.int32) if nonfinite is not None else torch.zeros((), dtype=torch.int32, device=out.device)).reshape(1)
         if sync:   # every rank takes part, also one whose features came from the CPU path (flag 0)
@@ -126,12 +130,16 @@ def _i32(a, device):
 
 @torch.no_grad()
 def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosine", max_rank=50,
-                   precision="fp32", return_topk=False, re_rank=False):
+                   precision="fp32", return_topk=False, re_rank=False, local_only=False):
     """Distance matrix + MARS ranking on the device. ``qf``: ALL query embeddings (m,D); ``gf``: this rank's gallery
     rows when a process group is active (rows ``shard_bounds(n, rank, world)`` of the gallery), else the whole
-    gallery. ``g_pids``/``g_camids`` always describe the WHOLE gallery. Returns (cmc ndarray (max_rank,), mAP float)."""
+    gallery. ``g_pids``/``g_camids`` always describe the WHOLE gallery. Returns (cmc ndarray (max_rank,), mAP float).
+    ``local_only=True``: ``gf`` is the WHOLE gallery and only this rank calls -- no rank offset, no candidate all-gather,
+    whatever process group is initialised."""
     device = qf.device
-    world = parallel.world_size()
+    world = 1 if local_only else parallel.world_size()
+    if local_only and gf.size(0) != len(g_pids):
+        raise ValueError("local_only=True needs the whole gallery: {} rows for {} labels".format(gf.size(0), len(g_pids)))
     n = len(g_pids)
     if max_rank > n:
         raise ValueError("max_rank={} exceeds the gallery size {}".format(max_rank, n))
@@ -158,7 +166,7 @@ def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosi
             return hip_distmat_topk_device(q, g, dist_metric, k, precision)
 
         idx, val = parallel.sharded_topk(qf.float().contiguous(), gf.float().contiguous(), lo, max_rank, dist_fn, topk_fn,
-                                         match_fn=match_fn if qf.is_cuda else None)
+                                         match_fn=match_fn if qf.is_cuda else None, local_only=local_only)
     ap, cmc = ops.rank_mars(idx.to(torch.int32).contiguous(), _i32(q_pids, device), _i32(q_camids, device),
                             _i32(g_pids, device), _i32(g_camids, device))
     ap = ap.cpu().numpy()
@@ -174,13 +182,14 @@ def match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric="cosi
 def evaluate(model, query_batches, gallery_batches, dist_metric="cosine", pool="avg", max_rank=50,
              ranks=(1, 5, 10, 20), verbose=False, re_rank=False):
     """Single-process form of the reference's ``test()``: returns (rank1, mAP) and, like the reference, can print the
-    CMC table. Issues no collective (callable from one rank of a process group, provided the gallery is whole: ``match_and_rank``
-    shards by rank as soon as a group is initialised). For the sharded form run ``extract_features(..., sync_ranks=True)`` on each
-    rank's slice and call ``match_and_rank`` on every rank."""
-    qf, q_pids, q_camids = extract_features(model, query_batches, pool)
-    gf, g_pids, g_camids = extract_features(model, gallery_batches, pool)
+    CMC table. This process extracts EVERY batch itself, so the gallery it ranks against is whole: all three stages run with
+    ``local_only=True`` -- no collective anywhere, no rank offset -- and the call is safe on one rank of an initialised process
+    group (``tests/test_parallel_gloo.py::test_rank0_only_evaluate``). For the sharded form every rank runs ``extract_features``
+    on its slice and then ``match_and_rank`` (both collective by default)."""
+    qf, q_pids, q_camids = extract_features(model, query_batches, pool, local_only=True)
+    gf, g_pids, g_camids = extract_features(model, gallery_batches, pool, local_only=True)
     cmc, mAP = match_and_rank(qf, q_pids, q_camids, gf, g_pids, g_camids, dist_metric, max_rank,
-                              getattr(model, "hip_precision", "fp32"), re_rank=re_rank)
+                              getattr(model, "hip_precision", "fp32"), re_rank=re_rank, local_only=True)
     if verbose:
         print("Results ----------")
         print("mAP: {:.2%}".format(mAP))

@@ -16,6 +16,7 @@ from ._hip import F32, LP16, LP_DTYPE, LP_NAME, METRIC_COSINE, METRIC_EUCLIDEAN,
 
 import contextlib
 import threading
+import weakref
 
 _MODE = threading.local()
 
@@ -723,14 +724,18 @@ def attn_tail(nodes, gsum, g_scale, g_shift, a_scale, a_shift, B, S, P, hw, want
 
 class QueryOperandCache:
     """What agrl_attn_tail left beside an embedding batch: its rows' squared norms and L2-normalised copy in the distance matrix's
-    operand type. ``lookup(emb, dtype)`` answers only for THE tensor the forward returned (same storage, shape and version)."""
+    operand type. ``lookup(emb, dtype)`` answers only for THE tensor object the forward returned -- identity through a weak
+    reference, not its address: once that tensor is freed the caching allocator may hand the same address to another (B, D) fp32
+    tensor whose ``_version`` is 0 as well (raw kernels never bump it), and an address-keyed cache would then serve the previous
+    batch's rows. The version is still compared so that an in-place edit of the live tensor misses."""
 
     def __init__(self, emb, query):
-        self.key = (emb.data_ptr(), tuple(emb.shape), emb._version, emb.device)
+        self.ref = weakref.ref(emb)
+        self.version = emb._version
         self.query = query
 
     def lookup(self, emb, dtype):
-        if self.key != (emb.data_ptr(), tuple(emb.shape), emb._version, emb.device) or self.query['normalized'].dtype != dtype:
+        if self.ref() is not emb or self.version != emb._version or self.query['normalized'].dtype != dtype:
             return None
         return self.query
 

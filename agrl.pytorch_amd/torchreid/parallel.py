@@ -88,7 +88,7 @@ def all_gather_ragged_rows(local, counts):
     return torch.cat([gathered[r, : counts[r]] for r in range(world)], dim=0)
 
 
-def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn, match_fn=None):
+def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn, match_fn=None, local_only=False):
     """Global top-k of every query against a gallery sharded by rows across ranks.
 
     ``distmat_fn(q, g) -> (m, n_local)`` and ``topk_fn(d, k) -> (idx (m,k') int, val (m,k'))`` (ascending
@@ -96,7 +96,8 @@ def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn, match_f
     given, replaces the pair for the local step (the fused distance + top-k that never writes the (m, n_local) matrix).
     Returns (idx (m,k) global gallery indices, val (m,k)), identical on every rank and identical to a single-GPU top-k of
     the full matrix: shards are contiguous and rank-ordered, so 'position in the concatenated candidate list' orders ties
-    exactly like 'global gallery index'."""
+    exactly like 'global gallery index'. ``local_only=True``: ``gallery_shard`` is the whole gallery and only this rank calls --
+    the local step's result is returned as it is, no collective."""
     k_local = min(k, gallery_shard.size(0))
     if match_fn is not None:
         idx, val = match_fn(q_all, gallery_shard, k_local)
@@ -104,7 +105,7 @@ def sharded_topk(q_all, gallery_shard, shard_lo, k, distmat_fn, topk_fn, match_f
         idx, val = topk_fn(distmat_fn(q_all, gallery_shard), k_local)
     idx = idx.to(torch.int64) + shard_lo
     world = world_size()
-    if not collectives_active():
+    if local_only or not collectives_active():
         return idx, val
     if k_local < k:  # a shard smaller than k: pad with +inf candidates
         pad = k - k_local

@@ -1044,6 +1044,41 @@ def test_distmat_wide_tile_f32out(shape, metric, monkeypatch):
     assert e < 1e-2 and d < 1e-6 and torch.isfinite(wide).all()
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("shape", [(1980, 12180, 512), (1000, 12002, 576), (700, 390, 512)])
+def test_distmat_wide_tile_192_columns(shape, metric, monkeypatch):
+    """Round-5 advice: the 256 x 192 instantiation of the fp32-output tile (igemm_wide_kernel<65536, 192>) had no direct test -- both
+    shapes above select the 256-column tile. Here: the MARS shape (1980 x 12 180: 512 tiles of 192 columns = two exact rounds, the
+    heuristic's own choice; 12 180 = 63 x 192 + 84, ragged), a second ragged N the heuristic also sends there, and a small matrix
+    on which the tile is FORCED (AGRL_DISTMAT_TILE_N=192) -- each against the 256-column tile (bit-identical: same k order per
+    output element), the tiled igemm form and the fp64 oracle."""
+    from torchreid.metrics.distance import hip_distmat_device
+    m, n, D = shape
+    g = torch.Generator().manual_seed(n + m)
+    q, gal = torch.randn((m, D), generator=g), torch.randn((n, D), generator=g)
+    ref = O.euclidean_squared(q.double(), gal.double()) if metric == "euclidean" else O.cosine(q.double(), gal.double())
+    qd, gd = q.to(DEV), gal.to(DEV)
+    auto = hip_distmat_device(qd, gd, metric, LP16)
+    out = {}
+    for tile in ("192", "256"):
+        monkeypatch.setenv("AGRL_DISTMAT_TILE_N", tile)
+        _hip.reload_options()
+        out[tile] = hip_distmat_device(qd, gd, metric, LP16)
+    monkeypatch.delenv("AGRL_DISTMAT_TILE_N")
+    monkeypatch.setenv("AGRL_DISTMAT_TILED", "1")
+    _hip.reload_options()
+    tiled = hip_distmat_device(qd, gd, metric, LP16)
+    monkeypatch.delenv("AGRL_DISTMAT_TILED")
+    _hip.reload_options()
+    torch.cuda.synchronize()
+    e = rel_err(out["192"], ref)
+    d = (out["192"] - tiled).abs().max().item() / tiled.abs().max().item()
+    print("distmat 256 x 192 tile", shape, metric, "vs fp64 %.3e, vs tiled %.3e, == 256-column tile %s" % (e, d, torch.equal(out["192"], out["256"])))
+    assert torch.isfinite(out["192"]).all() and e < 1e-2 and d < 1e-6
+    assert torch.equal(out["192"], out["256"])
+    assert torch.equal(auto, out["192"])
+
+
 def test_distmat_public_api_and_errors():
     from torchreid import metrics
     q, gal = torch.randn(7, 64), torch.randn(60, 64)

@@ -222,3 +222,90 @@ def test_bucketed_step_skips_parameters_without_gradient_like_the_plain_step():
         assert torch.equal(bucketed[k], b1[k]), k         # and by the bucketed one
     for k in plain:
         assert torch.allclose(plain[k].float(), bucketed[k].float(), rtol=1e-5, atol=1e-7), k
+
+
+class _StubModel(torch.nn.Module):
+    """(b, S, 3, H, W), adj -> (b, 8): stands in for the eval forward in the collective-discipline test below."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(1))
+
+    def forward(self, x, adj):
+        return x.flatten(1)[:, :8] * self.w
+
+
+def _local_only_worker(rank, world, port, tmp):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), "agrl.pytorch_amd"), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from torchreid import evaluation, parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env("gloo")
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn((6, 64), generator=g)
+    gallery = torch.randn((101, 64), generator=g)
+    batches = [(torch.randn((4, 2, 3, 4, 4), generator=g), np.arange(4), np.zeros(4), torch.zeros((4, 14, 14)))]
+    model = _StubModel()
+    # the default under a group is COLLECTIVE: both ranks call, both return (the MAX all-reduce of the non-finite flag pairs up)
+    f, _, _ = evaluation.extract_features(model, batches, prefetch=False)
+    assert f.shape == (4, 8)
+    if rank == 0:
+        # ... and local_only is the opt-out: rank 0 alone, whole gallery, no collective, no rank offset
+        f0, _, _ = evaluation.extract_features(model, batches, prefetch=False, local_only=True)
+        assert torch.equal(f0, f)
+        idx, val = parallel.sharded_topk(emb, gallery, 0, 20, O.cosine, _cpu_topk, local_only=True)
+        torch.save((idx, val), os.path.join(tmp, "local.pt"))
+    dist.barrier()   # rank 1 has been waiting here: a collective hidden in the local_only calls would have paired with it
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_local_only_calls_issue_no_collective_under_a_group(tmp_path):
+    """Round-5 advice: under an initialised group ``extract_features`` all-reduces its non-finite flag by default (every rank
+    raises together), and ``local_only=True`` -- what ``evaluation.evaluate`` passes to all three of its stages -- makes the
+    extraction and ``sharded_topk`` safe to call from ONE rank: no collective, global indices. (The device form of the same
+    check, with the real model and ``evaluate`` itself: tests/test_gpu_dist.py.)"""
+    mp.spawn(_local_only_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn((6, 64), generator=g)
+    gallery = torch.randn((101, 64), generator=g)
+    ref_idx, ref_val = _cpu_topk(O.cosine(emb, gallery), 20)
+    idx, val = torch.load(os.path.join(str(tmp_path), "local.pt"))
+    assert torch.equal(idx, ref_idx) and torch.allclose(val, ref_val, atol=1e-6)
+
+
+def test_query_operand_cache_is_keyed_on_identity_not_address():
+    """Round-5 review: QueryOperandCache used to key on (data_ptr, shape, _version, device). Free the embedding, let the
+    allocator hand the SAME address to a fresh tensor of the same shape (version 0 as well, filled by raw kernels that never
+    bump it) and it would have served the previous batch's normalised rows. Now: a weak reference, identity only. The recycled
+    address is produced deterministically here: two tensor objects over one arena, the contents rewritten behind torch's back."""
+    import ctypes
+    import gc
+    from torchreid import hip_ops as ops
+    arena = torch.zeros(32 * 64)
+    emb = arena.view(32, 64)
+    emb.copy_(torch.randn((32, 64)))
+    arena_version = arena._version
+    query = {"sqn": (emb * emb).sum(1), "normalized": emb / emb.norm(dim=1, keepdim=True)}
+    cache = ops.QueryOperandCache(emb, query)
+    old_key = (emb.data_ptr(), tuple(emb.shape), emb._version, emb.device)
+    assert cache.lookup(emb, torch.float32) is query
+    assert cache.lookup(emb, torch.float16) is None                 # other operand type
+    assert cache.lookup(emb.clone(), torch.float32) is None         # equal contents, other tensor
+    del emb
+    gc.collect()
+    assert cache.ref() is None
+    other = torch.randn((32, 64))
+    ctypes.memmove(arena.data_ptr(), other.data_ptr(), 32 * 64 * 4)  # what a raw kernel does: new rows, no version bump
+    fresh = arena.view(32, 64)                                       # 'the allocator handed out the same block again'
+    assert arena._version == arena_version and torch.equal(fresh, other)
+    assert (fresh.data_ptr(), tuple(fresh.shape), fresh._version, fresh.device) == old_key   # the round-5 key would have HIT
+    assert cache.lookup(fresh, torch.float32) is None, "stale rows served for a recycled address"
+    live = torch.randn((4, 8))
+    c2 = ops.QueryOperandCache(live, {"sqn": None, "normalized": live})
+    assert c2.lookup(live, torch.float32) is not None
+    live.add_(1.0)                                                   # in-place edit of the live tensor: version moves on
+    assert c2.lookup(live, torch.float32) is None
