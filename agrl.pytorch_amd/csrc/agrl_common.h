@@ -159,6 +159,15 @@ struct DT<f32s_t> {
     static constexpr int code = AGRL_F32X3;
     static constexpr int epc = 4;
 };
+// fp32 storage, split-FP16 arithmetic (AGRL_F32H3, round 6): same layout as float, Frag<f32h_t>'s recipe
+struct f32h_t {
+    float v;
+};
+template <>
+struct DT<f32h_t> {
+    static constexpr int code = AGRL_F32H3;
+    static constexpr int epc = 4;
+};
 template <>
 struct DT<lp16_t> {
     static constexpr int code = AGRL_LP16;

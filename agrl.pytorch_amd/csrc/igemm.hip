@@ -944,6 +944,30 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     return 0;
 }
 
+extern "C" int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, const float* bias, const void* residual, void* out, int N,
+                                          int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int relu, float w_unscale,
+                                          agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && w_scaled && out, "agrl_conv2d_bn_act_split16: null pointer");
+    AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
+                   "agrl_conv2d_bn_act_split16: bad shape");
+    AGRL_CHECK_ARG(w_unscale > 0.f && w_unscale == w_unscale && w_unscale <= 3.4e38f, "agrl_conv2d_bn_act_split16: w_unscale must be a positive finite power of two");
+    {
+        int e = 0;
+        AGRL_CHECK_ARG(frexpf(w_unscale, &e) == 0.5f, "agrl_conv2d_bn_act_split16: w_unscale=%g is not a power of two (the un-scaling must be exact)", (double)w_unscale);
+    }
+    IgemmParams p{};
+    p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
+    p.x = x; p.w = w_scaled; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
+    p.alpha = w_unscale; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
+    p.OH = (H + 2 * pad - R) / stride + 1;
+    p.OW = (W + 2 * pad - S) / stride + 1;
+    AGRL_CHECK_ARG(p.OH > 0 && p.OW > 0, "agrl_conv2d_bn_act_split16: empty output");
+    p.M = N * p.OH * p.OW; p.N = Cout; p.K = R * S * Cin;
+    p.Cin = Cin; p.H = H; p.W = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+    p.ldo = Cout;
+    return launch_igemm<f32h_t, float>(p, (hipStream_t)stream, "agrl_conv2d_bn_act_split16");
+}
+
 extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const void* residual,
                                   void* out, int N, int H, int W, int Cin, int Cout, int R, int S,
                                   int stride, int pad, int relu, int dtype, agrl_stream_t stream) {

@@ -89,6 +89,35 @@ struct Frag<f32s_t> {
     }
 };
 
+template <>
+struct Frag<f32h_t> {
+    // Same operand layout as Frag<float> / Frag<f32s_t> (a 16-byte chunk = 4 fp32 = this lane's four hardware-k values of
+    // v_mfma_f32_16x16x16_f16). x = xh + xl, xh = fp16(x) rounded to nearest, xl = fp16(x - xh): the difference is exact in fp32
+    // (xh keeps 11 of x's 24 significand bits), so xh + xl carries 22 bits wherever xl is a NORMAL fp16 (|x| >= ~2^-2; below that the
+    // subnormal spacing 2^-24 bounds the ABSOLUTE error of the pair at 2^-25 -- the caller scales its small operand, the weights,
+    // into range: agrl_conv2d_bn_act_split16). x w = xh wh + xh wl + xl wh + O(2^-22 |x w|): three fp16 MFMAs, fp32 accumulation,
+    // the small terms first.
+    typedef _Float16 h16x4_t __attribute__((ext_vector_type(4)));
+    typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+    __device__ static inline void split(const uint4& v, h16x4_t& hi, h16x4_t& lo) {
+        const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        const h16x2_t h0 = {(_Float16)f[0], (_Float16)f[1]}, h1 = {(_Float16)f[2], (_Float16)f[3]};   // v_cvt_pk_f16_f32 (RNE)
+        const float d0 = f[0] - (float)h0[0], d1 = f[1] - (float)h0[1], d2 = f[2] - (float)h1[0], d3 = f[3] - (float)h1[1];
+        const h16x2_t l0 = {(_Float16)d0, (_Float16)d1}, l1 = {(_Float16)d2, (_Float16)d3};
+        hi = h16x4_t{h0[0], h0[1], h1[0], h1[1]};
+        lo = h16x4_t{l0[0], l0[1], l1[0], l1[1]};
+    }
+    __device__ static inline f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+        h16x4_t ah, al, bh, bl;
+        split(a, ah, al);
+        split(b, bh, bl);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+        return c;
+    }
+};
+
 __device__ inline int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <typename TOUT>

@@ -61,12 +61,13 @@ def stem(x_nchw, w_ohwi, bias, out_dtype):
     return out
 
 
-PRECISIONS = ('fp32', LP_NAME, 'bf16x3')
+PRECISIONS = ('fp32', LP_NAME, 'bf16x3', 'fp16x3')
 
 
 def check_precision(precision, allowed=PRECISIONS, what="hip_precision"):
     """'fp32' exact-fp32 MFMA | LP_NAME ('fp16' or 'bf16': the loaded library's 16-bit storage type, fp32 accumulation) |
-    'bf16x3' fp32 tensors, split-bf16 products. Asking for the OTHER 16-bit type is an error, not a silent substitution."""
+    'bf16x3' fp32 tensors, split-bf16 products | 'fp16x3' (round 6) fp32 tensors, conv products as three fp16 MFMAs on fp16 high /
+    low halves with pre-scaled weights (22 significand bits per operand). Asking for the OTHER 16-bit type is an error, not a silent substitution."""
     if precision in allowed:
         return precision
     if precision in ('fp16', 'bf16'):
@@ -123,10 +124,33 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
         _hip.PROFILE_TAG = {"flops": 2.0 * N * OH * OW * Cout * R * S * Cin,
                             "bytes": e * (x.numel() + w_ohwi.numel() + out.numel() * (2 if residual is not None else 1)),
                             "conv": (R, stride, Cin, Cout, OH, OW)}
+    unscale = getattr(w_ohwi, 'agrl_unscale', None)
     with _dev(x):
-        call("agrl_conv2d_bn_act", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
-             stride, pad, 1 if relu else 0, _gemm_code(x.dtype), _stream(x))
+        if unscale is not None:
+            # 'fp16x3': weights pre-scaled by a power of two at pack time (split16_prescale); every product as three fp16 MFMAs
+            assert x.dtype == torch.float32
+            call("agrl_conv2d_bn_act_split16", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
+                 stride, pad, 1 if relu else 0, float(unscale), _stream(x))
+        else:
+            call("agrl_conv2d_bn_act", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
+                 stride, pad, 1 if relu else 0, _gemm_code(x.dtype), _stream(x))
     return out
+
+
+def split16_prescale(w):
+    """fp32 weights -> the same tensor times 2^k, k chosen so that max |w| 2^k lies in [2^13, 2^14) (exact; fp16's largest finite
+    value is 65504 = ~2^16), with ``.agrl_unscale`` = 2^-k riding on the tensor object: what agrl_conv2d_bn_act_split16 expects.
+    With the largest weight at ~2^13.5 a weight 2^-13 of it still has a NORMAL fp16 low half, and anything smaller is off by at
+    most 2^-25 absolute = 2^-38 of the largest."""
+    import math
+    amax = float(w.detach().abs().max())
+    if not (amax > 0.0 and math.isfinite(amax)):
+        k = 0
+    else:
+        k = 13 - math.frexp(amax)[1] + 1       # frexp: amax = m 2^e, m in [0.5, 1) -> amax 2^k in [2^13, 2^14)
+    ws = (w.detach().float() * (2.0 ** k)).contiguous()
+    ws.agrl_unscale = 2.0 ** (-k)
+    return ws
 
 
 def conv1x1_dual_supported(x1, x2, w_cat):

@@ -22,15 +22,21 @@ from torchreid import hip_ops as ops
 from torchreid import _hip
 
 # 'bf16x3': fp32 tensors and layouts of the parity mode, conv / Linear products as three bf16 MFMAs (hip_ops.f32_split)
-_PRECISIONS = {'fp32': torch.float32, ops.LP_NAME: ops.LP_DTYPE, 'bf16x3': torch.float32}   # ops.LP_NAME: 'fp16' (default build) or 'bf16'
+# 'fp16x3' (round 6): the same fp32 tensors, conv products as three FP16 MFMAs on fp16 high / low halves (22 bits per operand), conv
+# weights pre-scaled by a power of two at pack time (ops.split16_prescale); GraphLayer, pooling, distance matrix: exact fp32
+_PRECISIONS = {'fp32': torch.float32, ops.LP_NAME: ops.LP_DTYPE, 'bf16x3': torch.float32, 'fp16x3': torch.float32}   # ops.LP_NAME: 'fp16' (default build) or 'bf16'
 
 
-def _fold_conv_bn(conv, bn, dtype):
-    """conv (no bias) followed by eval BatchNorm2d -> (OHWI weight in dtype, fp32 bias)."""
+def _fold_conv_bn(conv, bn, dtype, split16=False):
+    """conv (no bias) followed by eval BatchNorm2d -> (OHWI weight in dtype, fp32 bias). ``split16``: the fp32 weight pre-scaled by a
+    power of two for the split-fp16 convolution (ops.split16_prescale; the un-scaling factor rides on the tensor)."""
     w = conv.weight.detach().float()
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
     w = (w * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous()
+    if split16:
+        assert dtype == torch.float32
+        return ops.split16_prescale(w), shift.contiguous()
     return w.to(dtype).contiguous(), shift.contiguous()
 
 
@@ -58,18 +64,18 @@ def _fold_bn1d(bn):
     return scale.contiguous(), shift.contiguous()
 
 
-def _pack_stage(stage, dtype, seam=False):
+def _pack_stage(stage, dtype, seam=False, split16=False):
     blocks = []
     for unit in stage:
         blk = {
-            'c1': _fold_conv_bn(unit.conv1, unit.bn1, dtype),
-            'c2': _fold_conv_bn(unit.conv2, unit.bn2, dtype),
-            'c3': _fold_conv_bn(unit.conv3, unit.bn3, dtype),
+            'c1': _fold_conv_bn(unit.conv1, unit.bn1, dtype, split16),
+            'c2': _fold_conv_bn(unit.conv2, unit.bn2, dtype, split16),
+            'c3': _fold_conv_bn(unit.conv3, unit.bn3, dtype, split16),
             'stride': unit.conv2.stride[0],
             'ds': None,
         }
         if unit.downsample is not None:
-            blk['ds'] = _fold_conv_bn(unit.downsample[0], unit.downsample[1], dtype)
+            blk['ds'] = _fold_conv_bn(unit.downsample[0], unit.downsample[1], dtype, split16)
             blk['ds_stride'] = unit.downsample[0].stride[0]
             if dtype == ops.LP_DTYPE and blk['ds_stride'] == 1 and blk['stride'] == 1:
                 # conv3 + downsample as ONE GEMM over the concatenated K axis (ops.conv1x1_dual): [w_ds | w3], b_ds + b3
@@ -123,22 +129,23 @@ def pack_weights(model, device, precision):
     if first.device != device:
         raise RuntimeError('model parameters live on {} but the input is on {}'.format(first.device, device))
     dtype = _PRECISIONS[precision]
+    s16 = precision == 'fp16x3'
     with torch.no_grad():
         stem_w, stem_b = _fold_conv_bn(model.conv1, model.bn1, torch.float32)
         pack = {
             'dtype': dtype,
             'stem': (stem_w, stem_b),
             'stem_lp': ops.pack_stem_weights_lp16(stem_w) if dtype == ops.LP_DTYPE else None,
-            'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype, seam=True),
+            'trunk': _pack_stage(model.layer1, dtype, split16=s16) + _pack_stage(model.layer2, dtype, split16=s16) + _pack_stage(model.layer3, dtype, seam=True, split16=s16),
             'graph': [],
         }
         if hasattr(model, 'layer4_1'):   # vmgn: two layer4 branches, two BNNecks
-            pack['l4_1'] = _pack_stage(model.layer4_1, dtype)
-            pack['l4_2'] = _pack_stage(model.layer4_2, dtype)
+            pack['l4_1'] = _pack_stage(model.layer4_1, dtype, split16=s16)
+            pack['l4_2'] = _pack_stage(model.layer4_2, dtype, split16=s16)
             pack['g_bn'] = _fold_bn1d(model.global_bottleneck)
             pack['a_bn'] = _fold_bn1d(model.att_bottleneck)
         else:                            # gsta: one branch, one BNNeck (the unused global half gets an identity)
-            pack['l4'] = _pack_stage(model.layer4, dtype)
+            pack['l4'] = _pack_stage(model.layer4, dtype, split16=s16)
             pack['a_bn'] = _fold_bn1d(model.bottleneck)
             pack['g_bn'] = (torch.ones_like(pack['a_bn'][0]), torch.zeros_like(pack['a_bn'][1]))
         for layer in model.graph_layers:

@@ -39,7 +39,7 @@ for p in (ROOT, os.path.join(ROOT, "agrl.pytorch_amd"), os.path.join(ROOT, "test
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}  # dense MFMA peaks, MI355X_MICROARCH.md (split mode: 3 bf16 MFMAs per product)
+PEAK_TFLOPS = {"fp16": 2500.0, "bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3}  # dense MFMA peaks, MI355X_MICROARCH.md (split mode: 3 bf16 MFMAs per product)
 PEAK_HBM_GBS = 8000.0
 GALLERY_ROWS = 12180  # MARS gallery of the reference tree
 QUERY_ROWS = 1980
@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="tracklets per GPU per step")
     ap.add_argument("--seq-len", type=int, default=8)
-    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "bf16x3"],
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32", "bf16x3", "fp16x3"],
                     help="fp16 / bf16: 16-bit storage + MFMA operands, fp32 accumulation (each has its own build of the library: "
                          "libagrl_hip.so / libagrl_hip_bf16.so, selected through AGRL_HIP_LP16 before torchreid is imported)")
     ap.add_argument("--metric", default="cosine", choices=["cosine", "euclidean"])
@@ -355,13 +355,14 @@ def accuracy_block(model, device, S, metric):
     top = {}
     LP = ops.LP_NAME
     out["lp16"] = LP
-    for prec in (LP, "bf16x3", "fp32"):   # bf16x3: the embeddings from split-bf16 products, matched in exact fp32
+    SPLIT = ("bf16x3", "fp16x3")
+    for prec in (LP,) + SPLIT + ("fp32",):   # bf16x3 / fp16x3: the embeddings from split products, matched in exact fp32
         model.hip_precision = prec
         t0 = time.perf_counter()
         qf, _, _ = evaluation.extract_features(model, batches(q_pids, q_cams, 0), prefetch=False)
         gf, _, _ = evaluation.extract_features(model, batches(g_pids, g_cams, FS.QUERY_ROWS), prefetch=False)
         cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50,
-                                                       "fp32" if prec == "bf16x3" else prec, return_topk=True)
+                                                       "fp32" if prec in SPLIT else prec, return_topk=True)
         torch.cuda.synchronize()
         out[prec] = {"rank1": round(float(cmc[0]), 6), "rank5": round(float(cmc[4]), 6), "mAP": round(float(mAP), 6),
                      "seconds": round(time.perf_counter() - t0, 2)}
@@ -386,7 +387,7 @@ def accuracy_block(model, device, S, metric):
         ref = z["q_emb_head"].astype(np.float64)
         out["oracle"] = {"rank1": round(float(o_cmc[0]), 6), "rank5": round(float(o_cmc[4]), 6), "mAP": round(o_map, 6),
                          "source": "tests/golden/fullsplit_oracle.npz (oracle/vmgn_oracle.py on the build container's CPU, tests/golden/make_fullsplit.py)"}
-        for prec in ("fp32", "bf16x3", LP):
+        for prec in ("fp32",) + SPLIT + (LP,):
             c = FS.compare_topk(top[prec][0], top[prec][1], z[metric + "_idx"], z[metric + "_val"])
             out[prec + "_vs_oracle"] = {"rank1_delta": round(out[prec]["rank1"] - float(o_cmc[0]), 6),
                                         "mAP_delta": round(out[prec]["mAP"] - o_map, 6),
@@ -425,7 +426,7 @@ def modes_block(model, clips, adj, g_shard, metric, steps=3, blocks=3):
         return ops.distmat(emb, g_op, "euclidean", ops.row_sqnorm(emb), g_norm)
 
     try:
-        for prec in ("fp32", "bf16x3"):
+        for prec in ("fp32", "bf16x3", "fp16x3"):
             model.hip_precision = prec
             one()
             torch.cuda.synchronize()
@@ -452,7 +453,8 @@ def modes_block(model, clips, adj, g_shard, metric, steps=3, blocks=3):
         _hip.PROFILE = None
         model.hip_precision = prev
     out["note"] = ("fp32: v_mfma_f32_16x16x4_f32, bit-compatible with an fmaf chain; bf16x3: three bf16 MFMAs per product on the high / low "
-                   "halves of fp32 operands (~1e-5 per product). Both hold the whole forward within 1e-3 of the CPU oracle "
+                   "halves of fp32 operands (~1e-5 per product); fp16x3 (round 6): three fp16 MFMAs per product on fp16 high / low halves, conv weights "
+                   "pre-scaled by a power of two (22 significand bits per operand, ~2e-7 per product; GraphLayer / distance matrix exact fp32). All hold the whole forward within 1e-3 of the CPU oracle "
                    "(tests/test_gpu_model.py: 3e-7 / 4e-5); of the 16-bit modes fp16 is at ~2.5e-4 and bf16 at ~2e-3 (`accuracy`, `lp16_other`)")
     return out
 
@@ -1248,7 +1250,7 @@ def main():
                 # the index-exact modes in top-level fields: frames/s of this run (`modes`) beside their agreement with the ORACLE's
                 # ranked lists on the full split (tests/golden/fullsplit_oracle.npz)
                 ie = {}
-                for mode in ("fp32", "bf16x3"):
+                for mode in ("fp32", "bf16x3", "fp16x3"):
                     vo = acc.get(mode + "_vs_oracle")
                     if vo:
                         ie[mode] = {"frames_per_s": (result.get("modes", {}).get(mode) or {}).get("frames_per_s"),

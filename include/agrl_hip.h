@@ -18,7 +18,10 @@
  *     the activations stay far below 65504), AGRL_F32X3 = 2 (fp32 tensors, each product formed as three bf16 MFMAs
  *     on the high / low halves of the operands: x = xh + xl, x w ~ xh wh + xh wl + xl wh, fp32 accumulation; ~1e-5
  *     relative instead of bit-exact fp32, 2-3 x the exact mode's rate; accepted by agrl_conv2d_bn_act and
- *     agrl_linear_nobias)
+ *     agrl_linear_nobias), AGRL_F32H3 = 3 (round 6: fp32 tensors, each product as three FP16 MFMAs on fp16 high / low halves --
+ *     22 significand bits per operand instead of bf16x3's 16, ~2^-22 per product, at the same three MFMAs; fp16's narrow
+ *     exponent range is handled by a power-of-two pre-scale of the weights that the caller un-does through w_unscale:
+ *     agrl_conv2d_bn_act_split16)
  *
  * Each entry point cites the reference call site it replaces (paths relative to the reference
  * tree weleen/AGRL.pytorch).
@@ -37,6 +40,7 @@ extern "C" {
 #define AGRL_LP16 1
 #define AGRL_BF16 AGRL_LP16 /* historical name of the same code */
 #define AGRL_F32X3 2
+#define AGRL_F32H3 3
 
 #define AGRL_METRIC_EUCLIDEAN 0 /* squared euclidean, torchreid/metrics/distance.py:59-73 */
 #define AGRL_METRIC_COSINE 1    /* 1 - cos,          torchreid/metrics/distance.py:76-89 */
@@ -83,6 +87,21 @@ int agrl_stem_conv_bn_relu_maxpool_lp16(const float* x, const void* w_packed, co
 int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const void* residual,
                        void* out, int N, int H, int W, int Cin, int Cout, int R, int S, int stride,
                        int pad, int relu, int dtype, agrl_stream_t stream);
+
+/* The same convolution on fp32 tensors with every product formed as THREE FP16 MFMAs (v_mfma_f32_16x16x16_f16) on the fp16
+ * high / low halves of the operands, fp32 accumulation: x = xh + xl with xh = fp16(x) (round to nearest) and xl = fp16(x - xh)
+ * (the difference is exact in fp32), x w ~ xh wh + xh wl + xl wh: 22 significand bits per operand, ~2^-22 relative per product
+ * (AGRL_F32X3's bf16 halves: 2^-16) at the same matrix rate. The "index-exact at speed" mode the round-5 review asks for
+ * (north star: ranking indices bit-exact; reference arithmetic: fp32 nn.Conv2d, torchreid/models/vmgn.py:45-65).
+ * fp16 has 5 exponent bits: a low half below 2^-14 loses bits to the subnormal spacing 2^-24. Activations of this network
+ * (post-ReLU, O(0.1 .. 100)) sit well inside; BatchNorm-folded weights (O(1e-2)) do not, so the CALLER passes them pre-scaled
+ * by a power of two, w_scaled = w * 2^k with max |w_scaled| in [2^13, 2^14) (exact), and w_unscale = 2^-k is applied to the
+ * fp32 accumulator before bias / residual / ReLU (exact as well). |x| must stay below 65504.
+ *   x (N,H,W,Cin) fp32 ; w_scaled (Cout,R,S,Cin) fp32 ; bias fp32 (Cout) ; residual NULL or (N,OH,OW,Cout) fp32 ; out fp32
+ *   Cin a multiple of 32. */
+int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, const float* bias, const void* residual, void* out, int N,
+                               int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int relu, float w_unscale,
+                               agrl_stream_t stream);
 
 /* Last conv of a Bottleneck and the block's 1x1 stride-1 downsample conv as ONE GEMM over the concatenated K axis (bf16):
  *   out (M, Cout) = act([x1 (M,K1) | x2 (M,K2)] @ w (Cout, K1+K2)^T + bias)

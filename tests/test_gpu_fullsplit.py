@@ -83,3 +83,50 @@ def test_fp32_pipeline_at_full_size_against_the_oracle(embedded, metric):
     assert abs(cmc[0] - o_cmc[0]) <= (c["swapped_positions"] + 0.5) / len(q_pids)
     assert abs(mAP - o_map) < 1e-4
     assert np.abs(cmc - o_cmc).max() <= (c["swapped_positions"] + 0.5) / len(q_pids)
+
+
+@pytest.fixture(scope="module")
+def embedded_split16():
+    """The same split embedded in the split-fp16 mode (round 6: hip_precision 'fp16x3' -- conv products as three fp16 MFMAs on
+    fp16 high / low halves, everything else exact fp32)."""
+    from torchreid import evaluation, models
+    from torchreid import hip_ops as ops
+    z = FS.load_oracle_fixture()
+    if z is None:
+        pytest.skip("tests/golden/fullsplit_oracle.npz not generated")
+    m = models.init_model("vmgn", num_classes=FS.N_IDS, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True, consistent_loss=False)
+    m.load_state_dict(recipe_state_dict(m.state_dict(), seed=0))
+    m = m.to(DEV).eval()
+    FS.apply_calibration(m, z)
+    m.hip_precision = "fp16x3"
+    labels = FS.labels()
+
+    def make_adj(poses, detected):
+        return ops.pose_adjacency(poses, detected, height=float(FS.HEIGHT), num_split=4, pyramid_part=True, threshold=0.1)
+
+    qf, _, _ = evaluation.extract_features(m, FS.batches(labels[0], labels[1], 0, DEV, 64, make_adj), prefetch=False)
+    gf, _, _ = evaluation.extract_features(m, FS.batches(labels[2], labels[3], FS.QUERY_ROWS, DEV, 64, make_adj), prefetch=False)
+    return z, labels, qf, gf
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclidean"])
+def test_split_fp16_pipeline_at_full_size_against_the_oracle(embedded_split16, metric):
+    """The conforming mode at speed the round-5 review asks for, held to the SAME bars as the exact-fp32 pipeline above: every
+    index that differs from the oracle's ranked list must be a swap inside a near-tie of the oracle's own distances."""
+    from torchreid import evaluation
+    z, (q_pids, q_cams, g_pids, g_cams), qf, gf = embedded_split16
+    ref = z["q_emb_head"].astype(np.float64)
+    e = np.abs(qf[:16].cpu().double().numpy() - ref).max() / np.abs(ref).max()
+    cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, "fp32", return_topk=True)
+    c = FS.compare_topk(idx, val, z[metric + "_idx"], z[metric + "_val"])
+    o_cmc, o_map = z[metric + "_cmc"], float(z[metric + "_mAP"])
+    print("fp16x3 %s: embedding rel err %.2e | Rank-1 %.6f (oracle %.6f) mAP %.6f (oracle %.6f) | top-1 agreement %.6f, top-50 index agreement "
+          "%.6f, identical rows %.4f, distance err %.2e (window %.2e), swapped %d, unexplained %d" % (
+              metric, e, cmc[0], o_cmc[0], mAP, o_map, c["top1_agreement"], c["agreement"], c["rows_equal"], c["max_abs_val_err"], c["tol"],
+              c["swapped_positions"], c["unexplained"]))
+    assert e < 1e-3
+    scale = float(np.abs(z[metric + "_val"]).max())
+    assert c["max_abs_val_err"] < 1e-3 * scale
+    assert abs(mAP - o_map) < 1e-4
+    assert abs(cmc[0] - o_cmc[0]) <= (c["swapped_positions"] + 0.5) / len(q_pids)

@@ -1044,6 +1044,62 @@ def test_distmat_wide_tile_f32out(shape, metric, monkeypatch):
     assert e < 1e-2 and d < 1e-6 and torch.isfinite(wide).all()
 
 
+@pytest.mark.parametrize("cfg", [(8, 16, 8, 512, 512, 3, 1, 1, False), (8, 16, 8, 2048, 512, 1, 1, 0, False), (6, 16, 8, 512, 2048, 1, 1, 0, True),
+                                 (4, 32, 16, 256, 256, 3, 2, 1, False), (3, 64, 32, 64, 64, 1, 1, 0, False), (2, 9, 5, 32, 96, 3, 1, 1, True)])
+def test_conv_split_fp16_three_products(cfg):
+    """agrl_conv2d_bn_act_split16 (round 6; vmgn.py:45-65 in fp32 tensors, every product as three FP16 MFMAs on fp16 high / low
+    halves, weights pre-scaled by a power of two, un-scaled in the epilogue) against F.conv2d in FLOAT64 -- beside the exact-fp32
+    kernel and the split-bf16 one on the same operands. Weights at BatchNorm-folded magnitude (1e-2 / sqrt(fan-in) .. with two
+    channels a thousand times smaller), activations post-ReLU-like with a long tail of tiny values: the cases where an fp16 low
+    half goes subnormal. Bars: within 4 x the exact-fp32 kernel's own distance from float64 + 2^-22 (the dropped low x low
+    term), and at least 20 x closer than split-bf16."""
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, Cout, R, stride, pad, with_res = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:8]))
+    x = torch.randn((N, H, W, Cin), generator=g).clamp(min=0) * torch.exp(2.0 * torch.randn((N, H, W, 1), generator=g))   # 1e-3 .. 1e2
+    x[0, 0, 0, :8] = torch.tensor([3e-5, 1e-6, 6e-8, 0.0, 1e-3, 2e-4, 7.0, 1200.0])
+    w = torch.randn((Cout, R, R, Cin), generator=g) * (0.5 / np.sqrt(Cin * R * R))
+    w[1] *= 1e-3
+    w[Cout // 2] *= 1e-3
+    b = 0.1 * torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    res = None
+    if with_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res.double()
+    ref = ref.clamp(min=0)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    rd = None if res is None else res.to(DEV)
+    exact = ops.conv_bn_act(xd, wd, bd, stride, pad, True, residual=rd)
+    with ops.f32_split(True):
+        b3 = ops.conv_bn_act(xd, wd, bd, stride, pad, True, residual=rd)
+    ws = ops.split16_prescale(wd)
+    k = np.log2(ws.agrl_unscale)
+    assert k == int(k) and 2 ** 13 <= float(ws.abs().max()) < 2 ** 14 and torch.equal(ws * ws.agrl_unscale, wd)   # exact pre-scale
+    h3 = ops.conv_bn_act(xd, ws, bd, stride, pad, True, residual=rd)
+    torch.cuda.synchronize()
+    den = ref.abs().max().item()
+    e = {name: ((t.double().cpu() - ref).abs().max().item() / den) for name, t in (("fp32", exact), ("bf16x3", b3), ("fp16x3", h3))}
+    # the two scaled-down channels on their own scale (the per-tensor pre-scale leaves them 2^-10 below the rest)
+    small = [1, Cout // 2]
+    es = {name: ((t[..., small].double().cpu() - ref[..., small]).abs().max().item() / ref[..., small].abs().max().clamp(min=1e-30).item())
+          for name, t in (("fp32", exact), ("fp16x3", h3))}
+    print("conv split-fp16", cfg, "vs float64: exact fp32 %.2e, fp16x3 %.2e, bf16x3 %.2e | 1e-3-scaled channels: fp32 %.2e fp16x3 %.2e" % (
+        e["fp32"], e["fp16x3"], e["bf16x3"], es["fp32"], es["fp16x3"]))
+    assert torch.isfinite(h3).all()
+    assert e["fp16x3"] < 4 * e["fp32"] + 2.4e-7 and e["fp16x3"] * 20 < e["bf16x3"]
+    assert es["fp16x3"] < 1e-4     # bias-dominated outputs: loose; the strict bar is the whole-tensor one above
+
+
+def test_conv_split_fp16_rejects_a_scale_that_is_not_a_power_of_two():
+    from torchreid import hip_ops as ops
+    x = torch.rand((1, 16, 8, 64), device=DEV)
+    w = ops.split16_prescale(torch.randn((64, 1, 1, 64), device=DEV) * 0.01)
+    w.agrl_unscale = 0.3
+    with pytest.raises(_hip.HipKernelError):
+        ops.conv_bn_act(x, w, torch.zeros(64, device=DEV), 1, 0, True)
+
+
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])
 @pytest.mark.parametrize("shape", [(1980, 12180, 512), (1000, 12002, 576), (700, 390, 512)])
 def test_distmat_wide_tile_192_columns(shape, metric, monkeypatch):
