@@ -60,6 +60,10 @@ struct DuoParams {
     unsigned short* pool_out_lp;  // optional 16-bit copy
     int pool_nparts, pool_mean;
     int pool_q0[16], pool_q1[16];  // bins in quarters (4 image rows) [q0, q1)
+    // split-fp16 planes (round 6, agrl_conv1x1_split16*): x / x2 / res / out hold three fp16 planes per pixel, [hi | lo 2^11 | hi] -- for the
+    // k-loop simply rows of 3 x the channels (K counts them); res / out: (M, 3 Cout). alpha un-does the weights' power-of-two pre-scale.
+    float alpha;
+    int planes;
 };
 
 #ifndef DUO_ABL
@@ -107,11 +111,14 @@ __device__ unsigned long long* g_duo_trace = nullptr;
 #define DUO_STAMP(k) do { } while (0)
 #endif
 
-template <bool POOL>
+template <bool POOL, bool PLANES = false>   // PLANES: the split-fp16 epilogue (its own instantiations: both epilogues in one kernel do not fit the 128 arch VGPRs beside the 128 asm-owned AGPRs)
 __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) {
     using SCHED = DuoSchedOf;
     using std::integral_constant;
     __shared__ __attribute__((aligned(16))) unsigned char smem_[2 * DSLAB];
+    // pooled planes form: the quarter sums of a pass are parked here (4 waves x [4 quarters][64 channels]) -- the wave's image is the
+    // residual planes' landing zone in both passes, and carrying all 64 sums per lane through them overflows the 128 arch VGPRs
+    __shared__ __attribute__((aligned(16))) float s_pool_[(POOL && PLANES) ? 4 * 256 : 4];
     lds_u8_t* const smem = (lds_u8_t*)smem_;
     const unsigned lds0 = (unsigned)(size_t)smem;
 
@@ -270,13 +277,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
         const int gm = min(m0 + row, p.M - 1);
         return (size_t)gm * p.Cout * 2 + colb + (size_t)((lchk ^ ((row >> 1) & 7)) << 4);
     };
-    if (has_res) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) fat_dma(p.res + row_off(i), __builtin_amdgcn_readfirstlane(lds0 + wave * 16384 + i * 1024));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    DUO_STAMP(5);
     const int cb = nt * 256 + wave * 64 + 8 * fchunk;
+    const float alpha = p.alpha;
     float psum[POOL ? 4 : 1][2][8];
     if constexpr (POOL) {
 #pragma unroll
@@ -286,6 +288,142 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) psum[q][j][e] = 0.f;
     }
+    if constexpr (PLANES) {
+        // ---- split-fp16 planes: the fp32 value v = alpha acc + bias (+ residual hi + residual lo 2^-11) (ReLU) leaves as fp16 hi = fp16(v)
+        // and lo = fp16((v - hi) 2^11). The wave's 16 KB image holds 64 rows at a time: hi rows in its lower half, lo rows in the upper
+        // half (same swizzled row layout), so two passes of 64 rows; the residual's two planes arrive in the same two halves by LDS-DMA
+        // and each cell pair is combined in place. POOL: the UNROUNDED v is pooled (what the fp32 reference pools, vmgn.py:298-308).
+        const size_t ld3 = (size_t)p.Cout * 3 * 2;   // bytes per pixel row of a planes tensor
+        const size_t plane = (size_t)p.Cout * 2;
+        // (opaque copies: hipcc would otherwise compute the sixteen request offsets before the k-loop and carry them through it, and
+        // the pooled instantiation then overflows its 128 arch VGPRs into AGPRs the asm blocks own)
+        int lrow_e = lrow, lchk_e = lchk;
+        asm volatile("" : "+v"(lrow_e), "+v"(lchk_e));
+        auto row_off3 = [&](int i) {  // piece i = rows 8 i + lrow of the TILE: byte offset of this lane's 16 bytes in plane 0 of res / out
+            const int row = 8 * i + lrow_e;
+            const int gm = min(m0 + row, p.M - 1);
+            return (size_t)gm * ld3 + colb + (size_t)((lchk_e ^ ((row >> 1) & 7)) << 4);
+        };
+        sfor<2>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            float ps[POOL ? 2 : 1][2][8];   // this pass's quarters 2 h, 2 h + 1
+            if constexpr (POOL) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ps[q][j][e] = 0.f;
+            }
+            if (has_res) {
+                // (scalar base + 32-bit lane offset: with 64-bit lane addresses for 16 requests beside the live pooling sums the
+                // instantiation would not fit its 128 arch VGPRs; the entry points bound every map by 4 GB)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned off = (unsigned)row_off3(8 * h + i);
+                    fat_dma_s(p.res, off, __builtin_amdgcn_readfirstlane(lds0 + wave * 16384 + i * 1024));
+                    fat_dma_s(p.res + plane, off, __builtin_amdgcn_readfirstlane(lds0 + wave * 16384 + 8192 + i * 1024));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            sfor<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j);
+                const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j + 4);
+                sfor<4>([&](auto bc) {
+                    constexpr int BL = decltype(bc)::value, B = 4 * h + BL;
+                    const f32x4_t lo = fat_read<(2 * j) * 8 + B>(), hi = fat_read<(2 * j + 1) * 8 + B>();
+                    float v[8] = {fmaf(alpha, lo[0], b0.x), fmaf(alpha, lo[1], b0.y), fmaf(alpha, lo[2], b0.z), fmaf(alpha, lo[3], b0.w),
+                                  fmaf(alpha, hi[0], b1.x), fmaf(alpha, hi[1], b1.y), fmaf(alpha, hi[2], b1.z), fmaf(alpha, hi[3], b1.w)};
+                    lds_u32x4_t* const cell_h = reinterpret_cast<lds_u32x4_t*>(wt + (xbase ^ (j * 64)) + BL * 2048);  // row 16 BL + frow of this pass
+                    lds_u32x4_t* const cell_l = reinterpret_cast<lds_u32x4_t*>(wt + 8192 + (xbase ^ (j * 64)) + BL * 2048);
+                    if (has_res) {
+                        float r[8];
+                        {
+                            const u32x4_t rl = *cell_l;
+                            const uint32_t wl4[4] = {rl.x, rl.y, rl.z, rl.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) unpack_lp16x2(wl4[e], r[2 * e], r[2 * e + 1]);
+                        }
+                        {
+                            const u32x4_t rh = *cell_h;
+                            const uint32_t wh4[4] = {rh.x, rh.y, rh.z, rh.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float a0, a1;
+                                unpack_lp16x2(wh4[e], a0, a1);
+                                v[2 * e] += fmaf(r[2 * e], 1.f / 2048.f, a0);       // hi + lo 2^-11: exact (22 bits)
+                                v[2 * e + 1] += fmaf(r[2 * e + 1], 1.f / 2048.f, a1);
+                            }
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
+                    }
+                    if constexpr (!POOL) {   // (the pooled plane form never writes the map: agrl_conv1x1_split16_pool passes no out)
+                      if (has_out) {
+                        uint32_t ph[4], pl[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ph[e] = pack_lp16x2(v[2 * e], v[2 * e + 1]);
+                            float a0, a1;
+                            unpack_lp16x2(ph[e], a0, a1);
+                            pl[e] = pack_lp16x2((v[2 * e] - a0) * 2048.f, (v[2 * e + 1] - a1) * 2048.f);
+                        }
+                        *cell_h = u32x4_t{ph[0], ph[1], ph[2], ph[3]};
+                        *cell_l = u32x4_t{pl[0], pl[1], pl[2], pl[3]};
+                      }
+                    }
+                    if constexpr (POOL) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ps[BL >> 1][j][e] += v[e];
+                    }
+                });
+            });
+            if constexpr (!POOL)
+            if (has_out) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4_t vh = *reinterpret_cast<const lds_u32x4_t*>(wt + i * 1024 + lane * 16);
+                    const u32x4_t vl = *reinterpret_cast<const lds_u32x4_t*>(wt + 8192 + i * 1024 + lane * 16);
+                    if (m0 + 8 * (8 * h + i) + lrow < p.M) {
+                        unsigned char* o = p.out + row_off3(8 * h + i);
+                        *reinterpret_cast<u32x4_t*>(o) = vh;
+                        *reinterpret_cast<u32x4_t*>(o + plane) = vl;
+                        *reinterpret_cast<u32x4_t*>(o + 2 * plane) = vh;
+                    }
+                }
+            }
+            if constexpr (POOL) {   // sum over the 16 pixel lanes of a fragment (same f), park the quarter sums (igemm_wide_kernel<16384>'s order)
+                float* const s_w = s_pool_ + wave * 256;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float t = ps[q][j][e];
+                            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                            ps[q][j][e] = t;
+                        }
+                        if (frow == 0) {
+                            float* d = s_w + (2 * h + q) * 64 + 8 * fchunk + 32 * j;
+                            *reinterpret_cast<float4*>(d) = make_float4(ps[q][j][0], ps[q][j][1], ps[q][j][2], ps[q][j][3]);
+                            *reinterpret_cast<float4*>(d + 4) = make_float4(ps[q][j][4], ps[q][j][5], ps[q][j][6], ps[q][j][7]);
+                        }
+                    }
+            }
+            // the image is re-filled by the next pass's DMA: every LDS read of this pass must have returned first
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        });
+    } else {
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) fat_dma(p.res + row_off(i), __builtin_amdgcn_readfirstlane(lds0 + wave * 16384 + i * 1024));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    DUO_STAMP(5);
     sfor<2>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j);
@@ -293,7 +431,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
         sfor<8>([&](auto bc) {
             constexpr int B = decltype(bc)::value;
             const f32x4_t lo = fat_read<(2 * j) * 8 + B>(), hi = fat_read<(2 * j + 1) * 8 + B>();
-            float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+            float v[8] = {fmaf(alpha, lo[0], b0.x), fmaf(alpha, lo[1], b0.y), fmaf(alpha, lo[2], b0.z), fmaf(alpha, lo[3], b0.w),
+                          fmaf(alpha, hi[0], b1.x), fmaf(alpha, hi[1], b1.y), fmaf(alpha, hi[2], b1.z), fmaf(alpha, hi[3], b1.w)};   // (alpha = 1: acc + b bit for bit)
             lds_u32x4_t* const cell = reinterpret_cast<lds_u32x4_t*>(wt + (xbase ^ (j * 64)) + B * 2048);  // row 16 B + frow, chunk 4 j + f
             if (has_res) {
                 const u32x4_t r = *cell;
@@ -332,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
             if (m0 + 8 * i + lrow < p.M) *reinterpret_cast<u32x4_t*>(p.out + row_off(i)) = v;
         }
     }
+    }  // (!p.planes)
     DUO_STAMP(7);
 #if DUO_ABL & 64
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -342,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
         // pixel lanes of a fragment (same f), park the quarter sums in LDS (the head of the wave's own image: its row reads above
         // are issued, and the LDS serves a wave in order); every output bin is a sum of whole quarters.
         float* const s_w = reinterpret_cast<float*>(smem_ + wave * 16384);  // [4 quarters][64 channels of this wave]
+        if constexpr (!PLANES) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -358,13 +499,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
                     *reinterpret_cast<float4*>(d + 4) = make_float4(psum[q][j][4], psum[q][j][5], psum[q][j][6], psum[q][j][7]);
                 }
             }
+        }
         __syncthreads();
         const int P = p.pool_nparts;
         for (int o = tid; o < P * 256; o += 256) {
             const int c = o & 255, part = o >> 8;
             const int q0 = p.pool_q0[part], q1 = p.pool_q1[part];
             float t = 0.f;
-            for (int q = q0; q < q1; ++q) t += reinterpret_cast<const float*>(smem_ + (c >> 6) * 16384)[q * 64 + (c & 63)];
+            for (int q = q0; q < q1; ++q)
+                t += PLANES ? s_pool_[(c >> 6) * 256 + q * 64 + (c & 63)] : reinterpret_cast<const float*>(smem_ + (c >> 6) * 16384)[q * 64 + (c & 63)];
             if (p.pool_mean) t *= 1.f / (float)((q1 - q0) * 32);
             const size_t oi = ((size_t)mt * P + part) * p.Cout + nt * 256 + c;
             p.pool_out[oi] = t;
@@ -374,10 +517,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
 }
 
 int duo_launch(DuoParams& p, bool pool, hipStream_t stream, const char* who) {
+    if (!p.planes) p.alpha = 1.f;   // the 16-bit entry points: acc + bias, bit for bit what round 5 computed
     const int grid = ((p.M + DROWS - 1) / DROWS) * (p.Cout >> 8);
     constexpr int dyn = (DUO_ABL & 32) ? 48 * 1024 : 0;
-    if (pool) hipLaunchKernelGGL(conv1x1_duo_kernel<true>, dim3(grid), dim3(256), dyn, stream, p);
-    else hipLaunchKernelGGL(conv1x1_duo_kernel<false>, dim3(grid), dim3(256), dyn, stream, p);
+    if (p.planes) {
+        if (pool) hipLaunchKernelGGL((conv1x1_duo_kernel<true, true>), dim3(grid), dim3(256), dyn, stream, p);
+        else hipLaunchKernelGGL((conv1x1_duo_kernel<false, true>), dim3(grid), dim3(256), dyn, stream, p);
+    } else if (pool) hipLaunchKernelGGL((conv1x1_duo_kernel<true, false>), dim3(grid), dim3(256), dyn, stream, p);
+    else hipLaunchKernelGGL((conv1x1_duo_kernel<false, false>), dim3(grid), dim3(256), dyn, stream, p);
     AGRL_CHECK_LAUNCH(who);
     return 0;
 }
@@ -487,4 +634,111 @@ extern "C" int agrl_conv1x1_packed_dual_strided(const void* x, const void* x2, c
     p.M = (int)M; p.K = K1 + K2; p.K1 = K1; p.Cout = Cout; p.relu = relu;
     if (stride > 1) { p.gHoWo = Ho * Wo; p.gWo = Wo; p.gS = stride; p.gWi = Wi; p.gHiWi = Hi * Wi; }
     return duo_launch(p, false, (hipStream_t)stream, "agrl_conv1x1_packed_dual_strided");
+}
+
+// ---- split-fp16 planes (round 6: the conforming mode at speed; torchreid/models/vmgn.py:45-65 in fp32-equivalent arithmetic) ----------
+// Every activation tensor is (M, 3 C) fp16 per pixel [hi | lo 2^11 | hi], hi = fp16(v), lo = fp16((v - hi) 2^11); `packed` is
+// agrl_conv1x1_pack of the fp16 weight (Cout, 3 K) = [wh | wh 2^-11 | wl] of w 2^k (hip_ops.split16_plane_weights): the unchanged k-loop
+// then sums xh wh + xl wh + xh wl -- 22 significand bits per operand -- into one fp32 accumulator, which the epilogue un-scales by
+// w_unscale = 2^-k. K3 / K1_3 / K2_3 count the plane channels (3 x the true ones).
+static int duo_split16_common(DuoParams& p, const void* x, const void* packed, const float* bias, int M, int K3, int Cout, int relu,
+                              float w_unscale, const char* who) {
+    AGRL_CHECK_ARG(agrl_lp16_is_f16(), "%s: the split planes are fp16 (load libagrl_hip.so, not the bf16 build)", who);
+    AGRL_CHECK_ARG(x && packed && bias, "%s: null pointer", who);
+    AGRL_CHECK_ARG(M > 0 && K3 > 0 && K3 % 384 == 0 && Cout > 0 && Cout % 256 == 0, "%s: needs K3 %% 384 == 0 (3 planes of whole 128-channel slabs) and Cout %% 256 == 0; got M=%d K3=%d Cout=%d", who, M, K3, Cout);
+    AGRL_CHECK_ARG((size_t)M * (size_t)(K3 > 3 * Cout ? K3 : 3 * Cout) * 2 < (1ull << 32), "%s: maps beyond 4 GB are not addressed", who);
+    AGRL_CHECK_ARG(w_unscale > 0.f && w_unscale <= 3.4e38f, "%s: w_unscale must be a positive finite power of two", who);
+    {
+        int e = 0;
+        AGRL_CHECK_ARG(frexpf(w_unscale, &e) == 0.5f, "%s: w_unscale=%g is not a power of two", who, (double)w_unscale);
+    }
+    p.x = reinterpret_cast<const unsigned char*>(x);
+    p.wpk = reinterpret_cast<const unsigned char*>(packed);
+    p.bias = bias;
+    p.M = M; p.K = K3; p.K1 = K3; p.Cout = Cout; p.relu = relu;
+    p.alpha = w_unscale; p.planes = 1;
+    return 0;
+}
+
+extern "C" int agrl_conv1x1_split16(const void* x, const void* packed, const float* bias, const void* residual, void* out, int M, int K3,
+                                    int Cout, int relu, float w_unscale, agrl_stream_t stream) {
+    DuoParams p{};
+    if (int rc = duo_split16_common(p, x, packed, bias, M, K3, Cout, relu, w_unscale, "agrl_conv1x1_split16")) return rc;
+    AGRL_CHECK_ARG(out, "agrl_conv1x1_split16: null pointer");
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)out) & 15) == 0, "agrl_conv1x1_split16: pointers must be 16-byte aligned");
+    p.res = reinterpret_cast<const unsigned char*>(residual);
+    p.out = reinterpret_cast<unsigned char*>(out);
+    return duo_launch(p, false, (hipStream_t)stream, "agrl_conv1x1_split16");
+}
+
+extern "C" int agrl_conv1x1_split16_dual(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1_3,
+                                         int K2_3, int Cout, int relu, float w_unscale, agrl_stream_t stream) {
+    DuoParams p{};
+    AGRL_CHECK_ARG(x2 && out && K1_3 > 0 && K1_3 % 384 == 0 && K2_3 > 0 && K2_3 % 384 == 0, "agrl_conv1x1_split16_dual: needs two sources of whole plane triples (K %% 384 == 0)");
+    if (int rc = duo_split16_common(p, x, packed, bias, M, K1_3 + K2_3, Cout, relu, w_unscale, "agrl_conv1x1_split16_dual")) return rc;
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)out) & 15) == 0, "agrl_conv1x1_split16_dual: pointers must be 16-byte aligned");
+    p.x2 = reinterpret_cast<const unsigned char*>(x2);
+    p.K1 = K1_3;
+    p.out = reinterpret_cast<unsigned char*>(out);
+    return duo_launch(p, false, (hipStream_t)stream, "agrl_conv1x1_split16_dual");
+}
+
+extern "C" int agrl_conv1x1_split16_pool(const void* x, const void* packed, const float* bias, const void* residual, float* pool_out, int N,
+                                         int H, int W, int K3, int Cout, int relu, const int* splits, int n_splits, int mean, float w_unscale,
+                                         agrl_stream_t stream) {
+    DuoParams p{};
+    AGRL_CHECK_ARG(pool_out && splits, "agrl_conv1x1_split16_pool: null pointer");
+    AGRL_CHECK_ARG(H == 16 && W == 8 && N > 0, "agrl_conv1x1_split16_pool: a frame must be 16 x 8 pixels (got %dx%d)", H, W);
+    if (int rc = duo_split16_common(p, x, packed, bias, N * 128, K3, Cout, relu, w_unscale, "agrl_conv1x1_split16_pool")) return rc;
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)pool_out) & 15) == 0, "agrl_conv1x1_split16_pool: pointers must be 16-byte aligned");
+    int P = 0;
+    for (int i = 0; i < n_splits; ++i) {
+        const int n = splits[i];
+        AGRL_CHECK_ARG(n > 0 && P + n <= 16, "agrl_conv1x1_split16_pool: at most 16 bins");
+        for (int j = 0; j < n; ++j) {
+            const int r0 = (j * H) / n, r1 = ((j + 1) * H + n - 1) / n;
+            AGRL_CHECK_ARG((r0 & 3) == 0 && (r1 & 3) == 0, "agrl_conv1x1_split16_pool: bins must be made of whole 4-row quarters (split %d)", n);
+            p.pool_q0[P] = r0 >> 2;
+            p.pool_q1[P] = r1 >> 2;
+            ++P;
+        }
+    }
+    p.pool_nparts = P; p.pool_mean = mean;
+    p.pool_out = pool_out;
+    p.pool_out_lp = nullptr;
+    p.res = reinterpret_cast<const unsigned char*>(residual);
+    p.out = nullptr;
+    return duo_launch(p, true, (hipStream_t)stream, "agrl_conv1x1_split16_pool");
+}
+
+// fp32 (rows, C) -> the three fp16 planes (rows, 3 C) = [hi | lo 2^11 | hi] the split16 kernels consume: the seam between the fp32-tensor
+// part of the conforming mode (stem .. first block of layer 3, agrl_conv2d_bn_act_split16) and its plane part.
+__global__ __launch_bounds__(256) void split16_planes_kernel(const float4* __restrict__ x, uint2* __restrict__ out, long long groups, int c4) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < groups; t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / c4;
+        const int g = (int)(t - row * c4);
+        const float4 v = x[t];
+        const uint32_t h0 = pack_lp16x2(v.x, v.y), h1 = pack_lp16x2(v.z, v.w);
+        float a, b, c, d;
+        unpack_lp16x2(h0, a, b);
+        unpack_lp16x2(h1, c, d);
+        const uint2 hi = make_uint2(h0, h1);
+        const uint2 lo = make_uint2(pack_lp16x2((v.x - a) * 2048.f, (v.y - b) * 2048.f), pack_lp16x2((v.z - c) * 2048.f, (v.w - d) * 2048.f));
+        uint2* o = out + row * 3 * c4 + g;
+        o[0] = hi;
+        o[c4] = lo;
+        o[2 * c4] = hi;
+    }
+}
+
+extern "C" int agrl_split16_planes(const float* x, void* out, long long rows, int C, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(agrl_lp16_is_f16(), "agrl_split16_planes: the split planes are fp16 (load libagrl_hip.so, not the bf16 build)");
+    AGRL_CHECK_ARG(x && out && rows > 0 && C > 0 && C % 4 == 0, "agrl_split16_planes: needs C %% 4 == 0 (got rows=%lld C=%d)", rows, C);
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "agrl_split16_planes: pointers must be 16-byte aligned");
+    const long long groups = rows * (C / 4);
+    const int grid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split16_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<uint2*>(out), groups, C / 4);
+    AGRL_CHECK_LAUNCH("agrl_split16_planes");
+    return 0;
 }

@@ -38,9 +38,26 @@ struct FatParams {
     const unsigned char* x;     // (F, H, W, Cin) 16-bit NHWC
     const unsigned char* wpk;   // packed weight streams (agrl_conv3x3_pack)
     const float* bias;          // (Cout)
-    unsigned char* out;         // (F, H, W, Cout)
+    unsigned char* out;         // (F, H, W, Cout); split planes: (F, H, W, 3 Cout) = [hi | lo 2^11 | hi] per pixel
     int H, W, Cin, Cout, nblocks, relu;
+    float alpha;                // out = act(alpha acc + bias): 1, or the power of two that un-does the split-fp16 mode's weight pre-scale
+    int planes;                 // 1: write the fp32 result as fp16 planes [hi | (v - hi) 2^11 | hi] (agrl_conv3x3_packed_split16)
 };
+
+// fp32 -> the split-fp16 planes of round 6's conforming mode: hi = fp16(v) (round to nearest), lo = fp16((v - hi) 2^11) -- the difference is
+// exact in fp32, the scale keeps lo a NORMAL fp16 wherever hi is one (the consumer's weight segment for the lo plane carries the 2^-11)
+__device__ __forceinline__ void split16_pack8(const float v[8], uint4& hi, uint4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = pack_lp16x2(v[2 * e], v[2 * e + 1]);
+        float a, b;
+        unpack_lp16x2(h[e], a, b);
+        l[e] = pack_lp16x2((v[2 * e] - a) * 2048.f, (v[2 * e + 1] - b) * 2048.f);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
 
 #ifndef FAT_ABL
 #define FAT_ABL 0  // timing ablations (results wrong): 1 no weight loads in the loop, 2 no patch DMA, 4 no LDS reads, 8 no MFMA; 16: phase stamps (s_memtime, results right; agrl_fat3_trace_buffer, tools/fat3_timeline.py)
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
 
     // ---- epilogue: + bias, ReLU, round once; lane (f, pixel) holds channels 64 wave + 32 j + 8 f .. + 7 of (b, j): 16-byte stores
     const int cb = nt * 256 + wave * 64 + 8 * fchunk;
+    const float alpha = p.alpha;
     sfor<2>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j);
@@ -239,7 +257,9 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
         sfor<NBF>([&](auto bc) {
             constexpr int B = decltype(bc)::value;
             const f32x4_t lo = fat_read<(2 * j) * NBF + B>(), hi = fat_read<(2 * j + 1) * NBF + B>();
-            float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+            // (alpha = 1: fmaf(1, acc, b) == acc + b, the round-5 results bit for bit)
+            float v[8] = {fmaf(alpha, lo[0], b0.x), fmaf(alpha, lo[1], b0.y), fmaf(alpha, lo[2], b0.z), fmaf(alpha, lo[3], b0.w),
+                          fmaf(alpha, hi[0], b1.x), fmaf(alpha, hi[1], b1.y), fmaf(alpha, hi[2], b1.z), fmaf(alpha, hi[3], b1.w)};
             if (p.relu) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
@@ -249,8 +269,17 @@ __global__ __launch_bounds__(256) void conv3x3_fat_kernel(const FatParams p) {
                 block_origin(B >> 3, img, oy0, ox0);
                 const int m = (B & 7) * 16 + fp;
                 const size_t gm = ((size_t)img * p.H + oy0 + (m >> 3)) * p.W + ox0 + (m & 7);
-                *reinterpret_cast<uint4*>(p.out + (gm * p.Cout + cb + 32 * j) * 2) =
-                    make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
+                if (p.planes) {
+                    uint4 ph, pl;
+                    split16_pack8(v, ph, pl);
+                    unsigned char* o = p.out + (gm * 3 * p.Cout + cb + 32 * j) * 2;
+                    *reinterpret_cast<uint4*>(o) = ph;
+                    *reinterpret_cast<uint4*>(o + (size_t)p.Cout * 2) = pl;
+                    *reinterpret_cast<uint4*>(o + (size_t)p.Cout * 4) = ph;
+                } else {
+                    *reinterpret_cast<uint4*>(p.out + (gm * p.Cout + cb + 32 * j) * 2) =
+                        make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
+                }
             }
         });
     });
@@ -427,18 +456,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_half_kernel(const FatParams p,
     const int cb = nt * 256 + grp * 64 + 32 * (wave & 1) + 8 * fchunk;
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb);
     const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cb + 4);
+    const float alpha = p.alpha;
     sfor<NBF>([&](auto bc) {
         constexpr int B = decltype(bc)::value;
         const f32x4_t lo = fat_read<B>(), hi = fat_read<NBF + B>();
-        float v[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+        float v[8] = {fmaf(alpha, lo[0], b0.x), fmaf(alpha, lo[1], b0.y), fmaf(alpha, lo[2], b0.z), fmaf(alpha, lo[3], b0.w),
+                      fmaf(alpha, hi[0], b1.x), fmaf(alpha, hi[1], b1.y), fmaf(alpha, hi[2], b1.z), fmaf(alpha, hi[3], b1.w)};
         if (p.relu) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
         }
         const int m = B * 16 + fp;
         const size_t gm = ((size_t)img * p.H + oy0 + (m >> 3)) * p.W + ox0 + (m & 7);
-        *reinterpret_cast<uint4*>(p.out + (gm * p.Cout + cb) * 2) =
-            make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
+        if (p.planes) {
+            uint4 ph, pl;
+            split16_pack8(v, ph, pl);
+            unsigned char* o = p.out + (gm * 3 * p.Cout + cb) * 2;
+            *reinterpret_cast<uint4*>(o) = ph;
+            *reinterpret_cast<uint4*>(o + (size_t)p.Cout * 2) = pl;
+            *reinterpret_cast<uint4*>(o + (size_t)p.Cout * 4) = ph;
+        } else {
+            *reinterpret_cast<uint4*>(p.out + (gm * p.Cout + cb) * 2) =
+                make_uint4(pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7]));
+        }
     });
 }
 
@@ -488,8 +528,29 @@ extern "C" int agrl_conv3x3_pack(const void* w_ohwi, void* packed, int Cin, int 
     return 0;
 }
 
+static int fat3_launch(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin, int Cout, int relu,
+                       float alpha, int planes, agrl_stream_t stream);
+
 extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin,
                                           int Cout, int relu, agrl_stream_t stream) {
+    return fat3_launch(x, packed, bias, out, N, H, W, Cin, Cout, relu, 1.f, 0, stream);
+}
+
+// Split-fp16 planes (round 6, the conforming mode at speed): x is (N, H, W, Cin3) fp16 with Cin3 = 3 Cin_true laid out per pixel as
+// [hi | lo 2^11 | hi]; `packed` = agrl_conv3x3_pack of the fp16 OHWI weight (Cout, 3, 3, Cin3) = [wh | wh 2^-11 | wl] per tap (w
+// pre-scaled by a power of two, hip_ops.split16_plane_weights): the unchanged k-loop then sums xh wh + xl wh + xh wl into ONE fp32
+// accumulator; the epilogue un-scales (w_unscale), adds the bias, applies ReLU and writes the result as the same three planes
+// (N, H, W, 3 Cout). vmgn.py:52-54.
+extern "C" int agrl_conv3x3_packed_split16(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin3,
+                                           int Cout, int relu, float w_unscale, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(agrl_lp16_is_f16(), "agrl_conv3x3_packed_split16: the split planes are fp16 (load libagrl_hip.so, not the bf16 build)");
+    AGRL_CHECK_ARG(Cin3 % 3 == 0 && w_unscale > 0.f, "agrl_conv3x3_packed_split16: Cin3 = 3 x channels, w_unscale > 0");
+    AGRL_CHECK_ARG((size_t)N * H * W * 3 * (size_t)Cout * 2 < (1ull << 32), "agrl_conv3x3_packed_split16: maps beyond 4 GB are not addressed");
+    return fat3_launch(x, packed, bias, out, N, H, W, Cin3, Cout, relu, w_unscale, 1, stream);
+}
+
+static int fat3_launch(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin, int Cout, int relu,
+                       float alpha, int planes, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && packed && bias && out, "agrl_conv3x3_packed_bn_act: null pointer");
     AGRL_CHECK_ARG(N > 0 && fat_shape_ok(H, W, Cin, Cout),
                    "agrl_conv3x3_packed_bn_act: needs 16 x 8-divisible maps, Cin %% 64 == 0 (>= 128), Cout %% 256 == 0 or Cout == 128; got %dx%d %d->%d", H, W, Cin, Cout);
@@ -501,6 +562,7 @@ extern "C" int agrl_conv3x3_packed_bn_act(const void* x, const void* packed, con
     p.bias = bias;
     p.out = reinterpret_cast<unsigned char*>(out);
     p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+    p.alpha = alpha; p.planes = planes;
     p.nblocks = N * (H >> 4) * (W >> 3);
     if (Cout == 128) {   // layer 2's 128 -> 128 convs: `packed` holds the weights as the lower half of one 256-channel tile (upper half zero,
                          // never read); one half-width workgroup per 16 x 8 block, two or three resident per CU

@@ -53,4 +53,13 @@ __device__ __forceinline__ void fat_dma(const unsigned char* src, unsigned lds_w
                  : "memory");
 }
 
+// the same with a scalar base and a 32-bit lane offset (one VGPR per request instead of two)
+__device__ __forceinline__ void fat_dma_s(const unsigned char* sbase, unsigned voff, unsigned lds_wave_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_wave_addr)
+                 : "memory");
+}
+
 }  // namespace

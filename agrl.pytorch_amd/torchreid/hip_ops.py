@@ -153,6 +153,98 @@ def split16_prescale(w):
     return ws
 
 
+# ---- split-fp16 PLANES (round 6): the conforming mode at speed -- include/agrl_hip.h, "Split-fp16 PLANES" ----------------------
+def split16_planes_available():
+    """The plane kernels exist in the fp16 build of the library only."""
+    return LP_NAME == 'fp16'
+
+
+def split16_plane_weights(w, segments=None):
+    """fp32 weights (Cout, K) / OHWI (Cout, R, S, Cin) -> (fp16 tensor with 3 x the innermost axis = [wh | wh 2^-11 | wl] of w 2^k,
+    2^-k): the operand the plane kernels multiply with activation planes [xh | xl 2^11 | xh] -- xh wh + xl wh + xh wl in one
+    accumulator. k as in split16_prescale (max |w| 2^k in [2^13, 2^14)); ONE k for the whole tensor, also for the two-source form
+    (``segments`` = [K1, K2]: the innermost axis is [W1 | W2] and each source gets its own plane triple, [W1 triple | W2 triple])."""
+    ws = split16_prescale(w)
+    parts = []
+    for seg in torch.split(ws, segments or [ws.shape[-1]], dim=-1):
+        wh = seg.to(torch.float16)
+        wl = (seg - wh.float()).to(torch.float16)
+        wh_s = (wh.float() * (2.0 ** -11)).to(torch.float16)
+        parts += [wh, wh_s, wl]
+    return torch.cat(parts, dim=-1).contiguous(), ws.agrl_unscale
+
+
+def to_split16_planes(x):
+    """fp32 (..., C) -> fp16 (..., 3 C) = [hi | lo 2^11 | hi] (agrl_split16_planes)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0
+    Cc = x.shape[-1]
+    out = torch.empty(tuple(x.shape[:-1]) + (3 * Cc,), dtype=torch.float16, device=x.device)
+    with _dev(x):
+        call("agrl_split16_planes", ptr(x), ptr(out), x.numel() // Cc, Cc, _stream(x))
+    return out
+
+
+def from_split16_planes(x3):
+    """planes (..., 3 C) -> fp32 (..., C) = hi + lo 2^-11 (exact): tests and the stage-by-stage parity hooks (torch arithmetic: not
+    on the product path)."""
+    Cc = x3.shape[-1] // 3
+    return x3[..., :Cc].float() + x3[..., Cc:2 * Cc].float() * (2.0 ** -11)
+
+
+def conv1x1_split16(x3, packed, unscale, bias, Cout, residual3=None, relu=True, x2=None):
+    """1x1 conv on planes: act(w_unscale [x3 | x2] @ W3^T + bias + residual) -> planes (N,H,W,3 Cout). vmgn.py:48-50, :56-64."""
+    N, H, W, K3 = x3.shape
+    K23 = 0 if x2 is None else x2.shape[3]
+    M = N * H * W
+    assert x3.dtype == torch.float16 and x3.is_contiguous() and packed.numel() == 2 * (K3 + K23) * Cout
+    assert residual3 is None or (residual3.dtype == torch.float16 and residual3.is_contiguous() and tuple(residual3.shape) == (N, H, W, 3 * Cout))
+    out = torch.empty((N, H, W, 3 * Cout), dtype=torch.float16, device=x3.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * Cout * (K3 + K23) / 3, "mfma_flops": 2.0 * M * Cout * (K3 + K23),
+                            "bytes": 2.0 * (x3.numel() + (0 if x2 is None else x2.numel()) + out.numel() + (0 if residual3 is None else residual3.numel())) + packed.numel()}
+    with _dev(x3):
+        if x2 is None:
+            call("agrl_conv1x1_split16", ptr(x3), ptr(packed), ptr(bias), ptr(residual3), ptr(out), M, K3, Cout, 1 if relu else 0,
+                 float(unscale), _stream(x3))
+        else:
+            assert residual3 is None and x2.dtype == torch.float16 and x2.is_contiguous() and tuple(x2.shape[:3]) == (N, H, W)
+            call("agrl_conv1x1_split16_dual", ptr(x3), ptr(x2), ptr(packed), ptr(bias), ptr(out), M, K3, K23, Cout, 1 if relu else 0,
+                 float(unscale), _stream(x3))
+    return out
+
+
+def conv1x1_split16_pool(x3, packed, unscale, bias, Cout, residual3, splits, mean, relu=True):
+    """Last conv of a layer-4 branch on planes with the frame pooling in the epilogue (the unrounded fp32 values are pooled; no map).
+    -> pooled fp32 (F, P, Cout). vmgn.py:56-64 + :298-308."""
+    N, H, W, K3 = x3.shape
+    assert x3.dtype == torch.float16 and x3.is_contiguous() and (H, W) == (16, 8) and packed.numel() == 2 * K3 * Cout
+    assert residual3 is None or (residual3.dtype == torch.float16 and residual3.is_contiguous() and tuple(residual3.shape) == (N, H, W, 3 * Cout))
+    P = int(sum(splits))
+    pooled = torch.empty((N, P, Cout), dtype=torch.float32, device=x3.device)
+    arr = (C.c_int * len(splits))(*[int(s_) for s_ in splits])
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * Cout * K3 / 3, "mfma_flops": 2.0 * N * H * W * Cout * K3,
+                            "bytes": 2.0 * (x3.numel() + (residual3.numel() if residual3 is not None else 0)) + packed.numel() + 4.0 * pooled.numel()}
+    with _dev(x3):
+        call("agrl_conv1x1_split16_pool", ptr(x3), ptr(packed), ptr(bias), ptr(residual3), ptr(pooled), N, H, W, K3, Cout,
+             1 if relu else 0, arr, len(splits), 1 if mean else 0, float(unscale), _stream(x3))
+    return pooled
+
+
+def conv3x3_split16(x3, packed, unscale, bias, Cout, relu=True):
+    """relu(conv3x3(x) + bias), stride 1 / pad 1, on planes -> planes (N,H,W,3 Cout). vmgn.py:52-54."""
+    N, H, W, Cin3 = x3.shape
+    assert x3.dtype == torch.float16 and x3.is_contiguous() and packed.numel() == 2 * 9 * Cin3 * Cout
+    out = torch.empty((N, H, W, 3 * Cout), dtype=torch.float16, device=x3.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * H * W * Cout * 9 * Cin3 / 3, "mfma_flops": 2.0 * N * H * W * Cout * 9 * Cin3,
+                            "bytes": 2.0 * (x3.numel() + out.numel()) + packed.numel()}
+    with _dev(x3):
+        call("agrl_conv3x3_packed_split16", ptr(x3), ptr(packed), ptr(bias), ptr(out), N, H, W, Cin3, Cout, 1 if relu else 0,
+             float(unscale), _stream(x3))
+    return out
+
+
 def conv1x1_dual_supported(x1, x2, w_cat):
     """The two-source pointwise GEMM exists for bf16, K1 == 2 K2, K1 % 64 == 0, Cout % 256 == 0 (layer-4 first blocks)."""
     K1, K2 = x1.shape[-1], x2.shape[-1]

@@ -156,11 +156,97 @@ def pack_weights(model, device, precision):
                 'gamma': float(layer.gamma), 'slope': float(layer.relu.negative_slope),
                 'use_pose': bool(layer.use_pose), 'learn_graph': bool(layer.learn_graph),
             })
+    if s16 and ops.split16_planes_available() and hasattr(model, 'layer4_1') and os.environ.get('AGRL_HIP_SPLIT16_PLANES', '1') != '0':
+        # the conforming mode at speed: behind layer 3's first block every Bottleneck runs on split-fp16 PLANES through the throughput
+        # mode's four-wave kernels (ops.conv1x1_split16 / conv3x3_split16); the stem .. layer 3's first block keep fp32 tensors and the
+        # in-loop split (agrl_conv2d_bn_act_split16)
+        first = len(model.layer1) + len(model.layer2) + 1
+        with torch.no_grad():
+            ok = all(_pack_planes(blk) for blk in pack['trunk'][first:] + pack['l4_1'] + pack['l4_2'])
+        pack['planes_from'] = first if ok else None
     if dtype == ops.LP_DTYPE:
         check_packed_range(pack)
     pack['fingerprint'] = _fingerprint(model)
     model._hip_packs[key] = pack
     return pack
+
+
+def _pack_planes(blk):
+    """The split-fp16 plane operands of one Bottleneck (blk: fp32 folded weights, pre-scaled for the in-loop split) -> blk['p3'];
+    False when a shape does not fit the four-wave kernels (the caller then keeps the whole model on the in-loop split)."""
+    def true_w(pair):
+        return pair[0] * pair[0].agrl_unscale    # undo the per-tensor pre-scale (exact)
+
+    w1, w2, w3 = true_w(blk['c1']), true_w(blk['c2']), true_w(blk['c3'])
+    K1, K3c, mid, cout = w1.shape[3], w3.shape[3], w1.shape[0], w3.shape[0]
+    if blk['stride'] != 1 or mid % 256 or cout % 256 or K1 % 128 or K3c % 128 or tuple(w2.shape[1:3]) != (3, 3) or w2.shape[3] % 64:
+        return False
+    p3 = {}
+    t, u = ops.split16_plane_weights(w1.view(mid, K1))
+    p3['c1'] = (ops.conv1x1_pack(t), u, blk['c1'][1], mid)
+    t, u = ops.split16_plane_weights(w2)
+    p3['c2'] = (ops.conv3x3_pack(t), u, blk['c2'][1], w2.shape[0])
+    if blk['ds'] is not None:
+        if blk['ds_stride'] != 1:
+            return False
+        wd = true_w(blk['ds'])
+        Kd = wd.shape[3]
+        if Kd % 128:
+            return False
+        t, u = ops.split16_plane_weights(torch.cat([wd.view(cout, Kd), w3.view(cout, K3c)], dim=1), segments=[Kd, K3c])
+        p3['dual'] = (ops.conv1x1_pack(t), u, (blk['ds'][1] + blk['c3'][1]).contiguous(), cout)
+    else:
+        t, u = ops.split16_plane_weights(w3.view(cout, K3c))
+        p3['c3'] = (ops.conv1x1_pack(t), u, blk['c3'][1], cout)
+    blk['p3'] = p3
+    return True
+
+
+def _run_block_planes(x3, blk, pool=None):
+    """One Bottleneck on split-fp16 planes (x3: (F,h,w,3 C) fp16 = [hi | lo 2^11 | hi]); ``pool`` = (splits, mean): the frame pooling
+    in the last conv's epilogue, returns the pooled fp32 tensor instead of the map. vmgn.py:45-65."""
+    p3 = blk['p3']
+    y = ops.conv1x1_split16(x3, p3['c1'][0], p3['c1'][1], p3['c1'][2], p3['c1'][3])
+    y = ops.conv3x3_split16(y, p3['c2'][0], p3['c2'][1], p3['c2'][2], p3['c2'][3])
+    if 'dual' in p3:
+        assert pool is None
+        d = p3['dual']
+        return ops.conv1x1_split16(x3, d[0], d[1], d[2], d[3], x2=y)
+    c = p3['c3']
+    if pool is not None:
+        return ops.conv1x1_split16_pool(y, c[0], c[1], c[2], c[3], x3, pool[0], pool[1])
+    return ops.conv1x1_split16(y, c[0], c[1], c[2], c[3], residual3=x3)
+
+
+def hip_features_pooled_planes(model, frames, pack, splits):
+    """The conv stages of the conforming mode ('fp16x3') at speed: stem .. layer 3's first block on fp32 tensors (in-loop split),
+    everything behind it on split-fp16 planes with the pooling fused into the last conv of each layer-4 branch.
+    -> gsum (F,C), nodes (F,P,C) fp32, None, hw -- or None when the planes do not apply (frames other than 256 x 128)."""
+    first = pack.get('planes_from')
+    if first is None or pack['l4_1'][0]['stride'] != 1:
+        return None
+    H, W = frames.shape[2], frames.shape[3]
+    h4, w4 = H, W
+    for _ in range(4):
+        h4, w4 = (h4 + 1) // 2, (w4 + 1) // 2
+    if (h4, w4) != (16, 8):
+        return None
+    a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+    a = _run_trunk(a, pack['trunk'][:first], False)
+    a3 = ops.to_split16_planes(a)
+    del a
+    for blk in pack['trunk'][first:]:
+        a3 = _run_block_planes(a3, blk)
+    splits = list(splits)
+    x = a3
+    for blk in pack['l4_1'][:-1]:
+        x = _run_block_planes(x, blk)
+    gsum = _run_block_planes(x, pack['l4_1'][-1], pool=([1], False))
+    x = a3
+    for blk in pack['l4_2'][:-1]:
+        x = _run_block_planes(x, blk)
+    nodes = _run_block_planes(x, pack['l4_2'][-1], pool=(splits, True))
+    return gsum.view(gsum.shape[0], gsum.shape[2]), nodes, None, 128
 
 
 def _conv2(y, blk):
@@ -357,6 +443,8 @@ def hip_forward(model, x, adj, return_feats=False, stages=None):
         frames = x.reshape(B * S, Cc, H, W)
         commute = gcn_commute_enabled(model)
         fused = hip_features_pooled(model, frames, pack, model.total_split_list, want_lp=not commute) if model.hip_fuse_pool else None
+        if fused is None and pack.get('planes_from') is not None:
+            fused = hip_features_pooled_planes(model, frames, pack, model.total_split_list)
         if fused is not None:
             gsum, nodes, nodes_lp, hw = fused
             C = nodes.shape[-1]

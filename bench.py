@@ -412,7 +412,8 @@ def modes_block(model, clips, adj, g_shard, metric, steps=3, blocks=3):
     from torchreid import hip_ops as ops
     prev = model.hip_precision
     B, S = clips.shape[:2]
-    fam = ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block", "agrl_conv1x1_dual_bn_act")
+    fam = ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block", "agrl_conv1x1_dual_bn_act",
+           "agrl_conv2d_bn_act_split16", "agrl_conv1x1_split16", "agrl_conv1x1_split16_dual", "agrl_conv1x1_split16_pool", "agrl_conv3x3_packed_split16")
     out = {}
     if metric == "cosine":
         g_op, g_norm = ops.row_l2_normalize(g_shard, True, torch.float32), None

@@ -103,6 +103,33 @@ int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, const float*
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int relu, float w_unscale,
                                agrl_stream_t stream);
 
+/* ---- Split-fp16 PLANES (round 6): the conforming mode at speed --------------------------------------------------------------
+ * The same arithmetic class as agrl_conv2d_bn_act_split16 (x w ~ xh wh + xl wh + xh wl, 22 significand bits per operand, fp32
+ * accumulation) with the operands split ONCE -- weights at pack time, activations in the producing kernel's epilogue -- so that the
+ * k-loops of the throughput mode's four-wave kernels run unchanged: no VALU split between the MFMAs.
+ *   activation tensor : (rows, 3 C) fp16 per pixel = [hi | lo 2^11 | hi], hi = fp16(v), lo = fp16((v - hi) 2^11) (normal wherever hi is)
+ *   weight tensor     : fp16 (Cout, [R, S,] 3 K) = [wh | wh 2^-11 | wl] of w 2^k (k: max |w| 2^k in [2^13, 2^14)), packed with
+ *                       agrl_conv1x1_pack / agrl_conv3x3_pack as any fp16 weight of that shape
+ *   epilogue          : v = w_unscale acc + bias (+ residual hi + residual lo 2^-11), ReLU, written as the three planes again;
+ *                       the pooled form pools the unrounded v
+ * fp16 build only (agrl_lp16_is_f16()). Replaces, for the first Bottlenecks behind layer 3's first block and all of layer 4,
+ * torchreid/models/vmgn.py:45-65 / :288-289 in the reference's own fp32 accuracy class (tests/test_gpu_fullsplit.py: every index that
+ * differs from the CPU oracle's ranked lists is a swap inside a near-tie, as for the exact-fp32 mode). */
+int agrl_split16_planes(const float* x, void* out, long long rows, int C, agrl_stream_t stream);   /* fp32 (rows, C) -> planes (rows, 3 C) */
+/* 1x1 conv (+ residual planes) on planes: x (M, K3), residual NULL or (M, 3 Cout), out (M, 3 Cout); K3 % 384 == 0, Cout % 256 == 0 */
+int agrl_conv1x1_split16(const void* x, const void* packed, const float* bias, const void* residual, void* out, int M, int K3,
+                         int Cout, int relu, float w_unscale, agrl_stream_t stream);
+/* conv3 + stride-1 downsample conv of a first block as one GEMM over [x | x2] (vmgn.py:56-64), all planes */
+int agrl_conv1x1_split16_dual(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1_3,
+                              int K2_3, int Cout, int relu, float w_unscale, agrl_stream_t stream);
+/* last conv of a layer-4 branch with the frame pooling of vmgn.py:298-308 in the epilogue: pool_out fp32 (N, nparts, Cout), no map */
+int agrl_conv1x1_split16_pool(const void* x, const void* packed, const float* bias, const void* residual, float* pool_out, int N,
+                              int H, int W, int K3, int Cout, int relu, const int* splits, int n_splits, int mean, float w_unscale,
+                              agrl_stream_t stream);
+/* 3x3 stride-1 pad-1 conv on planes: x (N, H, W, Cin3), out (N, H, W, 3 Cout); 16 x 8-divisible maps, Cin3 % 192 == 0, Cout % 256 == 0 */
+int agrl_conv3x3_packed_split16(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin3,
+                                int Cout, int relu, float w_unscale, agrl_stream_t stream);
+
 /* Last conv of a Bottleneck and the block's 1x1 stride-1 downsample conv as ONE GEMM over the concatenated K axis (bf16):
  *   out (M, Cout) = act([x1 (M,K1) | x2 (M,K2)] @ w (Cout, K1+K2)^T + bias)
  * torchreid/models/vmgn.py:56-64 for the first block of a stage: bn3(conv3(y2)) + downsample(x) with both BatchNorms

@@ -175,7 +175,7 @@ def bench_size_oracle():
     return m, x, adj, parts
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16x3", 1e-3), ("fp16x3", 1e-4), (LP16, LP_STAGE_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16x3", 1e-3), ("fp16x3", 1e-3), (LP16, LP_STAGE_TOL)])
 def test_vmgn_eval_at_benchmarked_size_stage_by_stage(bench_size_oracle, precision, tol):
     """B = 32, S = 8: the dispatch bench.py times (256 x 256 / 256 x 128 wide tiles, persistent forms, the two-block 3x3
     kernel, pool-fused last convs -- chosen by tile counts that B <= 5 never reaches) against the oracle, stage by stage:
