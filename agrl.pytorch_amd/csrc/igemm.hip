@@ -225,6 +225,37 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         constexpr int PPG = (DPT + GROUPS - 1) / GROUPS;
         const unsigned char* sa = smem + cur * BUF_BYTES;
         const unsigned char* sb = sa + A_BYTES;
+        if constexpr (DT<TIN>::code == AGRL_F32H3) {
+            // split-fp16: both k-halves of the tile feed ONE K = 32 MFMA triple per fragment pair (Frag<f32h_t>::mma32)
+            uint4 xh[FM], xl[FM], wh[FN], wl[FN];
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int row = wm * (BM / WM) + b * 16 + frow;
+                Frag<f32h_t>::split8(*reinterpret_cast<const uint4*>(sa + lds_off(row, fchunk)),
+                                     *reinterpret_cast<const uint4*>(sa + lds_off(row, 4 + fchunk)), xh[b], xl[b]);
+            }
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int row = wn * (BN / 2) + a * 16 + frow;
+                Frag<f32h_t>::split8(*reinterpret_cast<const uint4*>(sb + lds_off(row, fchunk)),
+                                     *reinterpret_cast<const uint4*>(sb + lds_off(row, 4 + fchunk)), wh[a], wl[a]);
+            }
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                if (do_stage) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int q = 0; q < PPG; ++q) {
+                            const int idx = (kk * FN + a) * PPG + q;
+                            if (idx < DPT) stage_piece(fill, idx);
+                        }
+                }
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b] = Frag<f32h_t>::mma32(wh[a], wl[a], xh[b], xl[b], acc[a][b]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             uint4 xf[FM], wf[FN];
@@ -1119,7 +1150,7 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
                                      float keep, float gamma, float slope, float* out, int M, int K, int Nout, int in_dtype,
                                      agrl_stream_t stream) {
     AGRL_CHECK_ARG(p_op && w && f && bn_scale && bn_shift && out, "agrl_graph_linear_mix: null pointer");
-    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3 || in_dtype == AGRL_F32H3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
     AGRL_CHECK_ARG((Nout % 4) == 0 && ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0),
                    "agrl_graph_linear_mix: Nout %% 4 == 0 and 16-byte aligned f / out / scale / shift required");
     // 16-bit operands: the kernel shaped for this problem (graph_gemm.hip) where it applies
@@ -1138,6 +1169,8 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
     p.nmajor = agrl_opts().graph_linear_mmajor ? 0 : 1;   // AGRL_GRAPH_LINEAR_MMAJOR=1: A/B switch
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
     if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
+    // split-fp16 (round 6): w holds the weight times a power of two 2^k (max |w| 2^k in [2^13, 2^14)); the caller folds 2^-k into bn_scale (exact)
+    if (in_dtype == AGRL_F32H3) return launch_igemm<f32h_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
     return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
 }
 

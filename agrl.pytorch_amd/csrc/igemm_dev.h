@@ -116,6 +116,30 @@ struct Frag<f32h_t> {
         c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
         return c;
     }
+    // The K = 32 form (igemm_kernel's k-loop for this type): the two 16-byte chunks a lane reads of a 128-byte k-tile (k-chunks g and
+    // 4 + g, g = lane >> 4) make ONE 8-element operand of v_mfma_f32_16x16x32_f16 -- the lane's hardware-k slots 0-3 take the first
+    // chunk, 4-7 the second, the same assignment for both operands -- so a k-tile costs three MFMAs per fragment pair instead of six
+    // at the same cycles each (the K = 16 instructions of the gfx90a generation run at half the gfx950 rate).
+    __device__ static inline void split8(const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
+        const float f[8] = {__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w),
+                            __uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z), __uint_as_float(c1.w)};
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const h16x2_t hh = {(_Float16)f[2 * e], (_Float16)f[2 * e + 1]};
+            const h16x2_t ll = {(_Float16)(f[2 * e] - (float)hh[0]), (_Float16)(f[2 * e + 1] - (float)hh[1])};
+            h[e] = __builtin_bit_cast(uint32_t, hh);
+            l[e] = __builtin_bit_cast(uint32_t, ll);
+        }
+        hi = make_uint4(h[0], h[1], h[2], h[3]);
+        lo = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+    __device__ static inline f32x4_t mma32(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x4_t c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, al), __builtin_bit_cast(f16x8_t, bh), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bl), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, ah), __builtin_bit_cast(f16x8_t, bh), c, 0, 0, 0);
+        return c;
+    }
 };
 
 __device__ inline int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }

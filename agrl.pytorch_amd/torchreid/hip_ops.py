@@ -154,6 +154,39 @@ def split16_prescale(w):
 
 
 # ---- split-fp16 PLANES (round 6): the conforming mode at speed -- include/agrl_hip.h, "Split-fp16 PLANES" ----------------------
+def pack_stem_weights_split16(w_ohwi):
+    """(64,7,7,3) fp32 OHWI (BN folded) -> (wh_packed, wl_packed, w_unscale): the fp16 high / low halves of w 2^k, each in the 16-bit
+    stem's (64, 240) layout (per filter row 8 taps x 4 channels, zero padded, 480-byte rows)."""
+    assert tuple(w_ohwi.shape) == (64, 7, 7, 3)
+    ws = split16_prescale(w_ohwi)
+    w4 = torch.zeros((64, 7, 8, 4), dtype=torch.float32, device=w_ohwi.device)
+    w4[:, :, :7, :3] = ws
+    wh = w4.to(torch.float16)
+    wl = (w4 - wh.float()).to(torch.float16)
+    out = []
+    for t in (wh, wl):
+        packed = torch.zeros((64, 240), dtype=torch.float16, device=w_ohwi.device)
+        packed[:, :224] = t.view(64, 224)
+        out.append(packed.contiguous())
+    return out[0], out[1], ws.agrl_unscale
+
+
+def stem_split16(x_nchw, wh_packed, wl_packed, unscale, bias):
+    """Split-fp16 stem: (N,3,H,W) fp32 NCHW -> (N,PH,PW,64) fp32 NHWC (agrl_stem_split16). vmgn.py:281-284."""
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.size(1) == 3
+    x_nchw = x_nchw.contiguous()
+    N, _, H, W = x_nchw.shape
+    CH, CW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = (CH + 2 - 3) // 2 + 1, (CW + 2 - 3) // 2 + 1
+    out = torch.empty((N, PH, PW, 64), dtype=torch.float32, device=x_nchw.device)
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * N * CH * CW * 64 * 147, "bytes": 4.0 * x_nchw.numel() + 4.0 * out.numel() + 4.0 * wh_packed.numel(),
+                            "conv": (7, 2, 3, 64, PH, PW)}
+    with _dev(x_nchw):
+        call("agrl_stem_split16", ptr(x_nchw), ptr(wh_packed), ptr(wl_packed), ptr(bias), ptr(out), N, H, W, float(unscale), _stream(x_nchw))
+    return out
+
+
 def split16_planes_available():
     """The plane kernels exist in the fp16 build of the library only."""
     return LP_NAME == 'fp16'
@@ -731,9 +764,14 @@ def graph_linear_mix(p_op, w, f, bn_scale, bn_shift, gamma, slope, keep=None):
     out = torch.empty_like(f)
     if _hip.PROFILE is not None:
         _hip.PROFILE_TAG = {"flops": 2.0 * B * V * K * Nout, "bytes": p_op.element_size() * (p_op.numel() + w.numel()) + 8.0 * f.numel()}
+    code = _gemm_code(p_op.dtype)
+    unscale = getattr(w, 'agrl_unscale', None)
+    if unscale is not None:   # 'fp16x3': w pre-scaled by a power of two (split16_prescale); bn_scale must already carry the 2^-k
+        assert p_op.dtype == torch.float32 and getattr(bn_scale, 'agrl_folded_unscale', None) == unscale
+        code = _hip.F32H3
     with _dev(f):
         call("agrl_graph_linear_mix", ptr(p_op.contiguous()), ptr(w), ptr(f.contiguous()), ptr(bn_scale), ptr(bn_shift), float(keep), float(gamma),
-             float(slope), ptr(out), B * V, K, Nout, _gemm_code(p_op.dtype), _stream(f))
+             float(slope), ptr(out), B * V, K, Nout, code, _stream(f))
     return out
 
 

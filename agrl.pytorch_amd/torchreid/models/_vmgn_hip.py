@@ -114,6 +114,11 @@ def _pack_stage(stage, dtype, seam=False, split16=False):
     return blocks
 
 
+def K_OK(w):
+    """The in-loop split GEMM needs whole 32-element k-tiles."""
+    return w.dim() == 2 and w.shape[1] % 32 == 0
+
+
 def _fingerprint(model):
     return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
 
@@ -136,6 +141,7 @@ def pack_weights(model, device, precision):
             'dtype': dtype,
             'stem': (stem_w, stem_b),
             'stem_lp': ops.pack_stem_weights_lp16(stem_w) if dtype == ops.LP_DTYPE else None,
+            'stem_s16': ops.pack_stem_weights_split16(stem_w) if s16 else None,   # conforming mode: the stem in split-fp16 arithmetic
             'trunk': _pack_stage(model.layer1, dtype, split16=s16) + _pack_stage(model.layer2, dtype, split16=s16) + _pack_stage(model.layer3, dtype, seam=True, split16=s16),
             'graph': [],
         }
@@ -150,8 +156,15 @@ def pack_weights(model, device, precision):
             pack['g_bn'] = (torch.ones_like(pack['a_bn'][0]), torch.zeros_like(pack['a_bn'][1]))
         for layer in model.graph_layers:
             scale, shift = _fold_bn1d(layer.bn)
+            gw = layer.linear.weight.detach().to(dtype).contiguous()
+            if s16 and K_OK(gw):
+                # the GraphLayer's Linear in the split-fp16 arithmetic as well (182 -> ~70 us per layer at 32 tracklets): weight times
+                # 2^k, the 2^-k folded into the BatchNorm scale the GEMM's epilogue multiplies the accumulator with (exact)
+                gw = ops.split16_prescale(gw)
+                scale = (scale * gw.agrl_unscale).contiguous()
+                scale.agrl_folded_unscale = gw.agrl_unscale
             pack['graph'].append({
-                'w': layer.linear.weight.detach().to(dtype).contiguous(),
+                'w': gw,
                 'scale': scale, 'shift': shift,
                 'gamma': float(layer.gamma), 'slope': float(layer.relu.negative_slope),
                 'use_pose': bool(layer.use_pose), 'learn_graph': bool(layer.learn_graph),
@@ -231,7 +244,7 @@ def hip_features_pooled_planes(model, frames, pack, splits):
         h4, w4 = (h4 + 1) // 2, (w4 + 1) // 2
     if (h4, w4) != (16, 8):
         return None
-    a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+    a = ops.stem_split16(frames, pack['stem_s16'][0], pack['stem_s16'][1], pack['stem_s16'][2], pack['stem'][1])
     a = _run_trunk(a, pack['trunk'][:first], False)
     a3 = ops.to_split16_planes(a)
     del a
@@ -342,6 +355,8 @@ def hip_featuremaps(model, frames, pack):
     """(F,3,H,W) fp32 NCHW -> x4_1, x4_2 NHWC (F,h,w,2048). reference vmgn.py:280-290."""
     if pack['stem_lp'] is not None:
         a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1])
+    elif pack.get('stem_s16') is not None:
+        a = ops.stem_split16(frames, pack['stem_s16'][0], pack['stem_s16'][1], pack['stem_s16'][2], pack['stem'][1])
     else:
         a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
     a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))

@@ -1010,7 +1010,8 @@ def main():
         for fam in ("agrl_conv2d_bn_act", "agrl_conv1x1_bn_act_pool", "agrl_bottleneck_tail", "agrl_bottleneck_block",
                     "agrl_conv1x1_dual_bn_act", "agrl_conv3x3_packed_bn_act", "agrl_conv1x1_packed_bn_act", "agrl_bottleneck_seam",
                     "agrl_conv1x1_packed_res_pool", "agrl_conv1x1_packed_res_bn_act", "agrl_conv1x1_packed_dual_duo",
-                    "agrl_conv1x1_packed_dual_strided"):
+                    "agrl_conv1x1_packed_dual_strided", "agrl_conv2d_bn_act_split16", "agrl_conv1x1_split16", "agrl_conv1x1_split16_dual",
+                    "agrl_conv1x1_split16_pool", "agrl_conv3x3_packed_split16"):
             if fam in agg:
                 for key in a:
                     a[key] += agg[fam][key]

@@ -78,6 +78,12 @@ int agrl_stem_conv_bn_relu_maxpool(const float* x, const float* w, const float* 
 int agrl_stem_conv_bn_relu_maxpool_lp16(const float* x, const void* w_packed, const float* bias,
                                         void* out, int N, int H, int W, agrl_stream_t stream);
 
+/* The stem in the split-fp16 arithmetic (round 6, conforming mode): the same fused conv 7x7/2 + BN + ReLU + maxpool 3x3/2 with every
+ * product as three fp16 MFMAs on fp16 high / low halves (x split in the kernel; w 2^k split by the host into wh / wl, each in the
+ * 16-bit stem's packed (64, 240) form), fp32 accumulation, fp32 NHWC output (N, PH, PW, 64). vmgn.py:281-284. */
+int agrl_stem_split16(const float* x, const void* wh_packed, const void* wl_packed, const float* bias, float* out, int N, int H,
+                      int W, float w_unscale, agrl_stream_t stream);
+
 /* Implicit-GEMM convolution (1x1 or 3x3, stride 1|2) + folded BN + optional residual + optional
  * ReLU, NHWC in / NHWC out. One call == one (conv, bn[, +residual][, relu]) group of
  * Bottleneck.forward, torchreid/models/vmgn.py:45-65 (and the downsample branch :58-59).

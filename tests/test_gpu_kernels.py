@@ -1108,6 +1108,33 @@ def test_fp16_mfma_keeps_subnormal_operands():
     assert torch.all(out.float() == 0.0625)
 
 
+@pytest.mark.parametrize("shape", [(3, 256, 128), (2, 64, 32), (1, 37, 23), (2, 130, 70)])
+def test_stem_split16_matches_float64(shape):
+    """agrl_stem_split16 (round 6: the stem as three fp16 MFMAs per product, fp32 out; vmgn.py:281-284) against conv 7x7/2 + ReLU +
+    maxpool 3x3/2 in FLOAT64 and beside the exact-fp32 stem (agrl_stem_conv_bn_relu_maxpool): image borders, ragged tiles, a weight row
+    a thousand times smaller than the rest."""
+    from torchreid import hip_ops as ops
+    N, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn((N, 3, H, W), generator=g)
+    w = torch.randn((64, 7, 7, 3), generator=g) * 0.08
+    w[5] *= 1e-3
+    b = 0.2 * torch.randn(64, generator=g)
+    y = F.conv2d(x.double(), w.permute(0, 3, 1, 2).double(), b.double(), stride=2, padding=3).clamp(min=0)
+    ref = F.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    exact = ops.stem(xd, wd, bd, torch.float32)
+    wh, wl, u = ops.pack_stem_weights_split16(wd)
+    got = ops.stem_split16(xd, wh, wl, u, bd)
+    torch.cuda.synchronize()
+    den = ref.abs().max().item()
+    e32 = (exact.double().cpu() - ref).abs().max().item() / den
+    e16 = (got.double().cpu() - ref).abs().max().item() / den
+    print("stem split16", shape, "vs float64: exact fp32 %.2e, split fp16 %.2e" % (e32, e16))
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    assert e16 < 4 * e32 + 2.4e-7
+
+
 def _planes_ref(x3):
     from torchreid import hip_ops as ops
     return ops.from_split16_planes(x3).double().cpu()

@@ -47,7 +47,7 @@ for r in range(reps):
     ci = 0
     for i, (name, s, e, tag) in enumerate(prof):
         label = name
-        if name == "agrl_conv2d_bn_act":
+        if name in ("agrl_conv2d_bn_act", "agrl_conv2d_bn_act_split16"):
             label = shapes[ci]
             ci += 1
         key = (i, label)
