@@ -125,8 +125,11 @@ def test_split_fp16_pipeline_at_full_size_against_the_oracle(embedded_split16, m
           "%.6f, identical rows %.4f, distance err %.2e (window %.2e), swapped %d, unexplained %d" % (
               metric, e, cmc[0], o_cmc[0], mAP, o_map, c["top1_agreement"], c["agreement"], c["rows_equal"], c["max_abs_val_err"], c["tol"],
               c["swapped_positions"], c["unexplained"]))
-    assert e < 1e-3
+    assert e < 1e-4                                            # measured 1.5-1.8e-5 (the exact-fp32 pipeline: 1.3e-5); north star: 1e-3
     scale = float(np.abs(z[metric + "_val"]).max())
-    assert c["max_abs_val_err"] < 1e-3 * scale
+    assert c["max_abs_val_err"] < 1e-4 * scale
+    assert c["unexplained"] == 0                               # every differing index is a swap inside a near-tie: the exact mode's bar
+    assert c["agreement"] > 0.995 and c["top1_agreement"] >= 0.998   # measured 0.9985-0.9989 / 0.9990-1.0 (exact fp32: 0.9988 / 1.0)
     assert abs(mAP - o_map) < 1e-4
     assert abs(cmc[0] - o_cmc[0]) <= (c["swapped_positions"] + 0.5) / len(q_pids)
+    assert np.abs(cmc - o_cmc).max() <= (c["swapped_positions"] + 0.5) / len(q_pids)
