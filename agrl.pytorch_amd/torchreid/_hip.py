@@ -181,9 +181,15 @@ def lib():
     return _lib
 
 
+RELOAD_HOOKS = []   # host-side caches of environment switches (hip_ops.switch) register their invalidation here
+
+
 def reload_options():
-    """Make the library re-read its AGRL_* tuning switches from the environment (they are read once at load time)."""
+    """Make the library re-read its AGRL_* tuning switches from the environment (they are read once at load time), and drop the
+    host side's cached switches with them."""
     lib().agrl_reload_options()
+    for hook in RELOAD_HOOKS:
+        hook()
 
 
 def available() -> bool:

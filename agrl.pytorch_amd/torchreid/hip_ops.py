@@ -33,6 +33,26 @@ def f32_split(on=True):
         _MODE.split = prev
 
 
+_SWITCHES = {}
+
+
+def switch(name, default='1'):
+    """A Python-side tuning switch (AGRL_HIP_*), read from the environment ONCE and cached like the library's own options:
+    ``_hip.reload_options()`` (what the A/B tools and the tests call after changing the environment) drops the cache. Round-5 review:
+    the dispatch predicates used to call os.environ.get 17 times per Bottleneck of every forward."""
+    v = _SWITCHES.get(name)
+    if v is None:
+        v = _SWITCHES[name] = os.environ.get(name, default)
+    return v
+
+
+def switch_on(name, default='1'):
+    return switch(name, default) != '0'
+
+
+_hip.RELOAD_HOOKS.append(_SWITCHES.clear)
+
+
 def _gemm_code(dt):
     if dt == torch.float32 and getattr(_MODE, 'split', False):
         return _hip.F32X3
@@ -282,7 +302,7 @@ def conv1x1_dual_supported(x1, x2, w_cat):
     """The two-source pointwise GEMM exists for bf16, K1 == 2 K2, K1 % 64 == 0, Cout % 256 == 0 (layer-4 first blocks)."""
     K1, K2 = x1.shape[-1], x2.shape[-1]
     return (x1.dtype == LP_DTYPE and x2.dtype == LP_DTYPE and K1 == 2 * K2 and K1 % 64 == 0
-            and w_cat.shape[0] % 256 == 0 and x1.shape[:-1] == x2.shape[:-1] and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0')
+            and w_cat.shape[0] % 256 == 0 and x1.shape[:-1] == x2.shape[:-1] and switch_on('AGRL_HIP_FUSE_DS'))
 
 
 def conv1x1_dual(x1, x2, w_cat, bias, relu=True):
@@ -328,7 +348,7 @@ SEAM_SHAPES = ((256, 1024, 256), (512, 2048, 512), (256, 1024, 512))
 
 def seam_enabled():
     """AGRL_HIP_FUSE_SEAM=0 runs the layer-3 seams as two launches (A/B)."""
-    return os.environ.get('AGRL_HIP_FUSE_SEAM', '1') != '0'
+    return switch_on('AGRL_HIP_FUSE_SEAM')
 
 
 def bottleneck_seam_supported(w3, w1_next, pixels=None):
@@ -336,7 +356,7 @@ def bottleneck_seam_supported(w3, w1_next, pixels=None):
     when ``pixels`` is given -- a pixel count made of whole 128-pixel tiles (16 x 8 frames)."""
     return (w3.dtype == LP_DTYPE and w1_next.dtype == LP_DTYPE and w3.dim() == 4 and tuple(w3.shape[1:3]) == (1, 1)
             and (w3.shape[3], w3.shape[0], w1_next.shape[0]) in SEAM_SHAPES and tuple(w1_next.shape[1:]) == (1, 1, w3.shape[0])
-            and (pixels is None or pixels % 128 == 0) and os.environ.get('AGRL_HIP_FUSE_SEAM', '1') != '0')
+            and (pixels is None or pixels % 128 == 0) and switch_on('AGRL_HIP_FUSE_SEAM'))
 
 
 def bottleneck_seam_pack(w3, w1_next):
@@ -376,7 +396,7 @@ def bottleneck_seam(y2, packed, b3, residual, b1_next, dims):
 
 def conv3x3_packed_enabled():
     """AGRL_HIP_CONV3X3_PACKED=0 runs the layer-3 / layer-4 3x3 convs through conv_bn_act (A/B; bit-identical results)."""
-    return os.environ.get('AGRL_HIP_CONV3X3_PACKED', '1') != '0'
+    return switch_on('AGRL_HIP_CONV3X3_PACKED')
 
 
 def conv3x3_packed_supported(w_ohwi, H=None, W=None):
@@ -418,7 +438,7 @@ def conv3x3_packed(x, packed, bias, Cout, relu=True):
 
 def conv1x1_packed_enabled():
     """AGRL_HIP_CONV1X1_PACKED=0 runs the layer-3 / layer-4 1x1 convs through conv_bn_act / conv1x1_dual (A/B; bit-identical)."""
-    return os.environ.get('AGRL_HIP_CONV1X1_PACKED', '1') != '0'
+    return switch_on('AGRL_HIP_CONV1X1_PACKED')
 
 
 def conv1x1_packed_supported(w):
@@ -486,7 +506,7 @@ def conv1x1_packed_dual_strided(x, x2, packed, bias, Cout, stride, relu=True):
 def conv1x1_duo_enabled():
     """AGRL_HIP_CONV1X1_DUO=0 runs the pool-fused last conv of a layer-4 branch through conv1x1_bn_act_pool and layer 4's conv1s through
     conv1x1_packed / conv_bn_act (A/B; bit-identical)."""
-    return os.environ.get('AGRL_HIP_CONV1X1_DUO', '1') != '0'
+    return switch_on('AGRL_HIP_CONV1X1_DUO')
 
 
 def conv1x1_packed_res(x, packed, bias, Cout, residual, relu=True):
@@ -530,7 +550,7 @@ def bottleneck_tail_supported(y2, w3, w1_next, shortcut_conv=None):
     """The fused conv3(+residual) -> next conv1 kernel exists for the layer-1 and layer-2 shapes in bf16. ``shortcut_conv`` =
     (weight, stride) of the block's downsample conv when the residual is to be computed in the same pass."""
     if (y2.dtype == LP_DTYPE and tuple(w3.shape) == (512, 1, 1, 128) and tuple(w1_next.shape) == (128, 1, 1, 512)
-            and shortcut_conv is None and os.environ.get('AGRL_HIP_FUSE_TAIL_L2', '1') != '0'):
+            and shortcut_conv is None and switch_on('AGRL_HIP_FUSE_TAIL_L2')):
         return True  # layer-2 form (weights resident in registers)
     ok = (y2.dtype == LP_DTYPE and tuple(w3.shape) == (256, 1, 1, 64)
           and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)))
@@ -570,7 +590,7 @@ def bottleneck_tail(y2, w3, b3, residual, w1_next, b1_next, shortcut=None):
 def bottleneck_block_supported(z, w2, stride, w3, w1_next, shortcut_conv=None):
     """The fused 3x3 -> conv3(+shortcut) -> next conv1 kernel exists for the layer-1 shapes in bf16 (stride-1 3x3,
     8 x 8-divisible maps). ``shortcut_conv`` as in bottleneck_tail_supported."""
-    if os.environ.get('AGRL_HIP_FUSE_BLOCK', '1') == '0':
+    if (not switch_on('AGRL_HIP_FUSE_BLOCK')):
         return False
     ok = (z.dtype == LP_DTYPE and stride == 1 and tuple(w2.shape) == (64, 3, 3, 64) and tuple(w3.shape) == (256, 1, 1, 64)
           and tuple(w1_next.shape) in ((64, 1, 1, 256), (128, 1, 1, 256)) and z.shape[1] % 8 == 0 and z.shape[2] % 8 == 0)
@@ -846,10 +866,10 @@ def attn_tail_supported(S, P, Cc, B=None):
     ok = Cc % 4 == 0 and (((S * P + 3) & ~3) + 2 * Cc + 4) * 4 <= 64 * 1024
     if B is None or not ok:
         return ok
-    force = os.environ.get('AGRL_HIP_FUSE_ATTN_TAIL')
-    if force is not None:
+    force = switch('AGRL_HIP_FUSE_ATTN_TAIL', '')
+    if force != '':
         return force != '0'
-    return B >= int(os.environ.get('AGRL_HIP_ATTN_TAIL_MIN_B', '224'))
+    return B >= int(switch('AGRL_HIP_ATTN_TAIL_MIN_B', '224'))
 
 
 def attn_tail(nodes, gsum, g_scale, g_shift, a_scale, a_shift, B, S, P, hw, want_feats=False, query_dtype=None, want_node_sqn=False):

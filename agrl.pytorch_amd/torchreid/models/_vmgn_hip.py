@@ -169,7 +169,7 @@ def pack_weights(model, device, precision):
                 'gamma': float(layer.gamma), 'slope': float(layer.relu.negative_slope),
                 'use_pose': bool(layer.use_pose), 'learn_graph': bool(layer.learn_graph),
             })
-    if s16 and ops.split16_planes_available() and hasattr(model, 'layer4_1') and os.environ.get('AGRL_HIP_SPLIT16_PLANES', '1') != '0':
+    if s16 and ops.split16_planes_available() and hasattr(model, 'layer4_1') and ops.switch_on('AGRL_HIP_SPLIT16_PLANES'):
         # the conforming mode at speed: behind layer 3's first block every Bottleneck runs on split-fp16 PLANES through the throughput
         # mode's four-wave kernels (ops.conv1x1_split16 / conv3x3_split16); the stem .. layer 3's first block keep fp32 tensors and the
         # in-loop split (agrl_conv2d_bn_act_split16)
@@ -266,7 +266,7 @@ def _conv2(y, blk):
     """conv2 / bn2 / relu of a Bottleneck (vmgn.py:52-54): the packed-weight kernel where it was packed and the map is made of
     whole 16 x 8 blocks, else the general conv."""
     if ('c2p' in blk and y.shape[1] % 16 == 0 and y.shape[2] % 8 == 0 and ops.conv3x3_packed_enabled()
-            and (blk['c2'][0].shape[0] != 128 or os.environ.get('AGRL_HIP_CONV3X3_PACKED_L2', '1') != '0')):   # (layer 2's 128 -> 128: round 5, late)
+            and (blk['c2'][0].shape[0] != 128 or ops.switch_on('AGRL_HIP_CONV3X3_PACKED_L2'))):   # (layer 2's 128 -> 128: round 5, late)
         return ops.conv3x3_packed(y, blk['c2p'], blk['c2'][1], blk['c2'][0].shape[0], True)
     return ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True)
 
@@ -276,7 +276,7 @@ def _conv1(x, blk):
     # (layer 4's conv1s through conv1x1_duo_kernel: ahead back to back -- 2048 -> 512 69 us against 73 --; inside the step it measured equal
     # in the middle of round 5 and, on the final tree, 7-13 us ahead per step on two boxes (eight A/B pairs, profiles/r05_ab_conv1_through_duo.txt):
     # on; AGRL_HIP_CONV1X1_DUO_C1=0 = conv1x1_fat_kernel / igemm_wide_kernel)
-    if 'c1p' in blk and ops.conv1x1_duo_enabled() and x.is_contiguous() and os.environ.get('AGRL_HIP_CONV1X1_DUO_C1', '1') != '0':
+    if 'c1p' in blk and ops.conv1x1_duo_enabled() and x.is_contiguous() and ops.switch_on('AGRL_HIP_CONV1X1_DUO_C1'):
         return ops.conv1x1_packed_res(x, blk['c1p'], blk['c1'][1], blk['c1'][0].shape[0], None, True)
     if 'c1p' in blk and ops.conv1x1_packed_enabled() and blk['c1'][0].shape[3] >= 2048:
         return ops.conv1x1_packed(x, blk['c1p'], blk['c1'][1], blk['c1'][0].shape[0], True)
@@ -310,7 +310,7 @@ def _run_trunk(a, blocks, fuse_tail=True):
             a, z = ops.bottleneck_tail(y, blk['c3'][0], blk['c3'][1], None, nxt['c1'][0], nxt['c1'][1],
                                        shortcut=(a, blk['ds'][0], blk['ds'][1]))
             continue
-        if ('dualps' in blk and ops.conv1x1_duo_enabled() and os.environ.get('AGRL_HIP_FUSE_DS_STRIDED', '1') != '0'
+        if ('dualps' in blk and ops.conv1x1_duo_enabled() and ops.switch_on('AGRL_HIP_FUSE_DS_STRIDED')
                 and a.is_contiguous() and y.is_contiguous() and a.dtype == y.dtype and a.shape[0] == y.shape[0]
                 and tuple(y.shape[1:3]) == tuple((d - 1) // blk['stride'] + 1 for d in a.shape[1:3])):
             # first block of layers 2 / 3: conv3 + the stride-2 downsample conv as ONE GEMM over [a sampled | y]: the shortcut map is
@@ -335,7 +335,7 @@ def _run_block(x, blk, pool=None):
     return the pooled tensors instead of the activation map (which is then never written to HBM)."""
     y = _conv1(x, blk)
     y = _conv2(y, blk)
-    if (pool is None and 'dualp' in blk and ops.conv1x1_packed_enabled() and os.environ.get('AGRL_HIP_FUSE_DS', '1') != '0'
+    if (pool is None and 'dualp' in blk and ops.conv1x1_packed_enabled() and ops.switch_on('AGRL_HIP_FUSE_DS')
             and x.shape[:3] == y.shape[:3] and x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()):
         return ops.conv1x1_packed(x, blk['dualp'], blk['dual'][1], blk['dual'][0].shape[0], True, x2=y, duo=ops.conv1x1_duo_enabled())   # (two workgroups per CU: 167 us against conv1x1_fat_kernel's 185)
     if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
@@ -346,7 +346,7 @@ def _run_block(x, blk, pool=None):
         if duo and tuple(y.shape[1:3]) == (16, 8):
             return ops.conv1x1_packed_res_pool(y, blk['c3p'], blk['c3'][1], blk['c3'][0].shape[0], shortcut, pool[0], pool[1], pool[2])
         return ops.conv1x1_bn_act_pool(y, blk['c3'][0], blk['c3'][1], shortcut, pool[0], pool[1], pool[2])
-    if duo and os.environ.get('AGRL_HIP_CONV1X1_DUO_RES', '1') != '0':   # the same kernel with the map stored (in the step: the layer-4 pointwise family 0.968-0.981 ms with it, 0.984-0.993 without, three A/B pairs on one box)
+    if duo and ops.switch_on('AGRL_HIP_CONV1X1_DUO_RES'):   # the same kernel with the map stored (in the step: the layer-4 pointwise family 0.968-0.981 ms with it, 0.984-0.993 without, three A/B pairs on one box)
         return ops.conv1x1_packed_res(y, blk['c3p'], blk['c3'][1], blk['c3'][0].shape[0], shortcut)
     return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)
 
@@ -405,7 +405,7 @@ def gcn_commute_enabled(model=None):
     import os
     if model is not None and hasattr(model, 'hip_gcn_commute'):
         return bool(model.hip_gcn_commute)
-    return os.environ.get('AGRL_HIP_GCN_COMMUTE', '1') != '0'
+    return ops.switch_on('AGRL_HIP_GCN_COMMUTE')
 
 
 def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, commute=True):

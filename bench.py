@@ -1020,7 +1020,7 @@ def main():
         # HBM traffic per launch: NOT measured in this run -- PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
         # runs of this same command, tools/collect_profiles.sh) are committed under profiles/ and quoted with their source
         traffic = fam_traffic = traffic_src = duo_traffic = None
-        for tname in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+        for tname in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 try:

@@ -305,3 +305,20 @@ def test_host_side_helpers_without_gpu():
     assert torch.equal(pool_clips(f, 1), f)
     assert torch.equal(pool_clips(f, 3, "avg"), torch.stack([f[0:3].mean(0), f[3:6].mean(0)]))
     assert torch.equal(pool_clips(f, 3, "max"), torch.stack([f[0:3].max(0)[0], f[3:6].max(0)[0]]))
+
+
+def test_host_side_switches_are_cached_until_reload(monkeypatch):
+    """Round-5 review (dispatch sprawl): the Python-side AGRL_HIP_* switches are read from the environment once, like the library's
+    own, instead of once per Bottleneck of every forward; _hip.reload_options() drops the cache together with the library's."""
+    from torchreid import _hip
+    from torchreid import hip_ops as ops
+    _hip.reload_options()
+    monkeypatch.delenv("AGRL_HIP_FUSE_SEAM", raising=False)
+    assert ops.switch_on("AGRL_HIP_FUSE_SEAM") and ops.seam_enabled()
+    monkeypatch.setenv("AGRL_HIP_FUSE_SEAM", "0")
+    assert ops.seam_enabled()                      # cached: the forward's dispatch does not touch os.environ
+    _hip.reload_options()
+    assert not ops.seam_enabled()
+    monkeypatch.delenv("AGRL_HIP_FUSE_SEAM")
+    _hip.reload_options()
+    assert ops.seam_enabled()

@@ -218,7 +218,9 @@ def test_query_operand_from_the_tail_kernel_equals_the_separate_launches(world, 
     (no extra launch) and are bit-identical to agrl_row_l2_normalize / agrl_row_sqnorm on it; any other tensor (a clone, a gathered
     batch) takes the separate launches; the distance matrix is the same either way."""
     from torchreid import hip_ops as ops
+    from torchreid import _hip
     monkeypatch.setenv("AGRL_HIP_FUSE_ATTN_TAIL", "1")   # (the model takes the one-launch tail from 224 tracklets per GPU on its own)
+    _hip.reload_options()                                # (the host side caches its switches like the library does)
     m = world["model"]
     x, adj = synthetic_clips(4, S, seed=21).to(DEV), synthetic_adj(4, S, seed=21).to(DEV)
     gal = torch.randn((300, 4096), device=DEV)
@@ -235,7 +237,9 @@ def test_query_operand_from_the_tail_kernel_equals_the_separate_launches(world, 
                 g_op = ops.row_l2_normalize(gal, True, dt)
                 assert torch.equal(ops.distmat(q_op, g_op, "cosine"), ops.distmat(q_ref, g_op, "cosine"))
         monkeypatch.setenv("AGRL_HIP_FUSE_ATTN_TAIL", "0")
+        _hip.reload_options()
         emb3 = m(x, adj)                                   # the three-launch tail: the same embedding bit for bit, no operand cache
         monkeypatch.setenv("AGRL_HIP_FUSE_ATTN_TAIL", "1")
+        _hip.reload_options()
         assert torch.equal(emb3, emb) and m._hip_query is None
     m.hip_precision = "fp32"

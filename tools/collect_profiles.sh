@@ -2,10 +2,10 @@
 # Round profile collection on the GPU box (run through gpurun): kernel-trace summary + the two PMC traffic passes of
 # the SAME bench command, then the bench line itself. Outputs under gpurun_out/prof_<round>/; copy the summaries into profiles/.
 export TMPDIR=/tmp
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/prof_$R
 mkdir -p $O
-CMD="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-accuracy --no-config5 --no-config4 --no-modes --sustain-seconds 0"
+CMD="bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-accuracy --no-config5 --no-config4 --no-modes --no-host-issue --sustain-seconds 0"
 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python3 $CMD > $O/bench_under_rocprof.json 2> $O/trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 $CMD > /dev/null 2> $O/fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 $CMD > /dev/null 2> $O/write.err
