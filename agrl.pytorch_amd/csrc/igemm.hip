@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
     // lane L -> row + (L>>3), physical chunk L&7, which holds global chunk (L&7) ^ ((row>>1)&7).
     const int lrow = lane >> 3;
     const int lchk = lane & 7;
-    int a_ih0[AJ], a_iw0[AJ], a_nbase[AJ], a_coff[AJ];
+    int a_ih0[AJ], a_iw0[AJ], a_nbase[AJ], a_coff[AJ], a_gm[AJ];
     bool a_ok[AJ];
     const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         a_ih0[j] = oh * p.stride - p.pad;
         a_iw0[j] = ow * p.stride - p.pad;
         a_nbase[j] = n * p.H * p.W;
+        a_gm[j] = gmc;
         a_coff[j] = (lchk ^ ((row >> 1) & 7)) * EPC;
     }
     size_t b_off[BJ];
@@ -123,6 +124,19 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         if (idx < AJ) {
             const int j = idx;
             unsigned char* sa = smem + buf * BUF_BYTES + wave * (BM / NW) * 128;
+            if (p.x2) {
+                // two-source pointwise form (round 6; conv3 + the block's downsample conv as ONE GEMM over [x sampled at the stride | x2],
+                // vmgn.py:56-64 -- the shortcut map is neither written nor read back): k-columns [0, K1) come from x (row length K1,
+                // pixel (oh * stride, ow * stride)), [K1, K) from x2 (row length K - K1, the output pixel itself). Uniform branch.
+                if (c0 < p.K1) {
+                    const size_t off = ((size_t)(a_nbase[j] + a_ih0[j] * p.W + a_iw0[j]) * p.K1 + c0 + a_coff[j]) * sizeof(TIN);
+                    dma16(a_ok[j] ? xg + off : zsrc, sa + j * 1024);
+                } else {
+                    const size_t off = ((size_t)a_gm[j] * (p.Cin - p.K1) + (c0 - p.K1) + a_coff[j]) * sizeof(TIN);
+                    dma16(a_ok[j] ? reinterpret_cast<const unsigned char*>(p.x2) + off : zsrc, sa + j * 1024);
+                }
+                return;
+            }
             const int ih = a_ih0[j] + tap_r;
             const int iw = a_iw0[j] + tap_s;
             const bool ok = a_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
@@ -997,6 +1011,33 @@ extern "C" int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, c
     p.Cin = Cin; p.H = H; p.W = W; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
     p.ldo = Cout;
     return launch_igemm<f32h_t, float>(p, (hipStream_t)stream, "agrl_conv2d_bn_act_split16");
+}
+
+// conv3 + the 1x1 stride-s downsample conv of a first Bottleneck as ONE split-fp16 GEMM over [x sampled at the stride | x2] (vmgn.py:56-64
+// with both BatchNorms folded: w_scaled = [w_downsample | w_conv3] 2^k per output channel, bias = b_downsample + b_conv3). fp32 tensors:
+// x (N, H, W, K1) the block input, x2 (N, OH, OW, K2) conv2's output, out (N, OH, OW, Cout); OH = (H - 1) / stride + 1. The
+// conforming mode's counterpart of agrl_conv1x1_packed_dual_strided: the fp32 shortcut map (537 MB in layer 1) no longer exists.
+extern "C" int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scaled, const float* bias, void* out, int N, int H,
+                                         int W, int stride, int K1, int K2, int Cout, int relu, float w_unscale, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(x && x2 && w_scaled && out, "agrl_conv1x1_dual_split16: null pointer");
+    AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && stride >= 1 && K1 > 0 && K2 > 0 && Cout > 0, "agrl_conv1x1_dual_split16: bad shape");
+    AGRL_CHECK_ARG(K1 % 32 == 0 && K2 % 32 == 0, "agrl_conv1x1_dual_split16: K1 and K2 must be multiples of 32 (got %d, %d)", K1, K2);
+    AGRL_CHECK_ARG((((uintptr_t)x2) & 15) == 0, "agrl_conv1x1_dual_split16: x2 must be 16-byte aligned");
+    AGRL_CHECK_ARG(w_unscale > 0.f && w_unscale <= 3.4e38f, "agrl_conv1x1_dual_split16: w_unscale must be a positive finite power of two");
+    {
+        int e = 0;
+        AGRL_CHECK_ARG(frexpf(w_unscale, &e) == 0.5f, "agrl_conv1x1_dual_split16: w_unscale=%g is not a power of two", (double)w_unscale);
+    }
+    IgemmParams p{};
+    p.x = x; p.x2 = x2; p.K1 = K1; p.stats = nullptr;
+    p.w = w_scaled; p.colv = bias; p.rowv = nullptr; p.res = nullptr; p.out = out;
+    p.alpha = w_unscale; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
+    p.OH = (H - 1) / stride + 1;
+    p.OW = (W - 1) / stride + 1;
+    p.M = N * p.OH * p.OW; p.N = Cout; p.K = K1 + K2;
+    p.Cin = K1 + K2; p.H = H; p.W = W; p.R = 1; p.S = 1; p.stride = stride; p.pad = 0;
+    p.ldo = Cout;
+    return launch_igemm<f32h_t, float>(p, (hipStream_t)stream, "agrl_conv1x1_dual_split16");
 }
 
 extern "C" int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const void* residual,

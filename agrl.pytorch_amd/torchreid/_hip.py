@@ -57,6 +57,7 @@ SIGNATURES = {
     "agrl_stem_conv_bn_relu_maxpool": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_stem_conv_bn_relu_maxpool_lp16": [_p, _p, _p, _p, _i, _i, _i, _p],
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "agrl_conv1x1_dual_split16": [_p, _p, _p, _p, _p] + [_i] * 8 + [_f, _p],
     "agrl_stem_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "agrl_split16_planes": [_p, _p, C.c_longlong, _i, _p],
     "agrl_conv1x1_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -157,6 +157,27 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
     return out
 
 
+def conv1x1_dual_split16(x, x2, w_cat, bias, stride, relu=True):
+    """relu([x sampled at the stride | x2] @ w_cat^T + bias) in the split-fp16 arithmetic on fp32 tensors: a first Bottleneck's conv3 + its
+    1x1 stride-s downsample conv in one GEMM (vmgn.py:56-64). x (N,H,W,K1) block input, x2 (N,OH,OW,K2) conv2's output, w_cat (Cout,
+    K1+K2) pre-scaled (split16_prescale of the concatenation: ONE power of two for both halves) -> (N,OH,OW,Cout) fp32."""
+    N, H, W, K1 = x.shape
+    K2 = x2.shape[3]
+    Cout = w_cat.shape[0]
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    assert x.dtype == torch.float32 and x2.dtype == torch.float32 and x.is_contiguous() and x2.is_contiguous()
+    assert tuple(x2.shape[:3]) == (N, OH, OW) and tuple(w_cat.shape) == (Cout, K1 + K2) and hasattr(w_cat, 'agrl_unscale')
+    out = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    if _hip.PROFILE is not None:
+        M = N * OH * OW
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * Cout * (K1 + K2), "bytes": 4.0 * (M * (K1 + K2) + w_cat.numel() + out.numel()),
+                            "conv": (1, stride, K1 + K2, Cout, OH, OW)}
+    with _dev(x):
+        call("agrl_conv1x1_dual_split16", ptr(x), ptr(x2), ptr(w_cat), ptr(bias), ptr(out), N, H, W, stride, K1, K2, Cout,
+             1 if relu else 0, float(w_cat.agrl_unscale), _stream(x))
+    return out
+
+
 def split16_prescale(w):
     """fp32 weights -> the same tensor times 2^k, k chosen so that max |w| 2^k lies in [2^13, 2^14) (exact; fp16's largest finite
     value is 65504 = ~2^16), with ``.agrl_unscale`` = 2^-k riding on the tensor object: what agrl_conv2d_bn_act_split16 expects.

@@ -77,6 +77,14 @@ def _pack_stage(stage, dtype, seam=False, split16=False):
         if unit.downsample is not None:
             blk['ds'] = _fold_conv_bn(unit.downsample[0], unit.downsample[1], dtype, split16)
             blk['ds_stride'] = unit.downsample[0].stride[0]
+            if split16 and blk['ds_stride'] == blk['stride'] and blk['ds'][0].shape[3] % 32 == 0 and blk['c3'][0].shape[3] % 32 == 0:
+                # conforming mode: conv3 + downsample as ONE in-loop split GEMM over [block input sampled at the stride | conv2's output]
+                # (ops.conv1x1_dual_split16): the fp32 shortcut map -- 537 MB written and read back in layer 1 -- no longer exists
+                cout = blk['c3'][0].shape[0]
+                wd = blk['ds'][0] * blk['ds'][0].agrl_unscale
+                w3 = blk['c3'][0] * blk['c3'][0].agrl_unscale
+                blk['dual16'] = (ops.split16_prescale(torch.cat([wd.view(cout, -1), w3.view(cout, -1)], dim=1).contiguous()),
+                                 (blk['ds'][1] + blk['c3'][1]).contiguous())
             if dtype == ops.LP_DTYPE and blk['ds_stride'] == 1 and blk['stride'] == 1:
                 # conv3 + downsample as ONE GEMM over the concatenated K axis (ops.conv1x1_dual): [w_ds | w3], b_ds + b3
                 cout = blk['c3'][0].shape[0]
@@ -318,6 +326,10 @@ def _run_trunk(a, blocks, fuse_tail=True):
             a = ops.conv1x1_packed_dual_strided(a, y, blk['dualps'], blk['dualps_bias'], blk['c3'][0].shape[0], blk['stride'], True)
             z = None
             continue
+        if 'dual16' in blk and ops.switch_on('AGRL_HIP_SPLIT16_DUAL') and a.is_contiguous() and y.is_contiguous():
+            a = ops.conv1x1_dual_split16(a, y, blk['dual16'][0], blk['dual16'][1], blk['stride'], True)
+            z = None
+            continue
         shortcut = a if blk['ds'] is None else ops.conv_bn_act(a, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
         if fuse_tail and nxt is not None and 'seam' in blk and (y.numel() // y.shape[-1]) % 128 == 0 and ops.seam_enabled():
             a, z = ops.bottleneck_seam(y, blk['seam'], blk['c3'][1], shortcut, nxt['c1'][1], blk['seam_dims'])
@@ -340,6 +352,8 @@ def _run_block(x, blk, pool=None):
         return ops.conv1x1_packed(x, blk['dualp'], blk['dual'][1], blk['dual'][0].shape[0], True, x2=y, duo=ops.conv1x1_duo_enabled())   # (two workgroups per CU: 167 us against conv1x1_fat_kernel's 185)
     if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
         return ops.conv1x1_dual(x, y, blk['dual'][0], blk['dual'][1], True)
+    if pool is None and 'dual16' in blk and ops.switch_on('AGRL_HIP_SPLIT16_DUAL') and x.is_contiguous() and y.is_contiguous():
+        return ops.conv1x1_dual_split16(x, y, blk['dual16'][0], blk['dual16'][1], blk['stride'], True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
     duo = 'c3p' in blk and blk['ds'] is None and ops.conv1x1_duo_enabled() and shortcut.is_contiguous() and y.is_contiguous()
     if pool is not None:

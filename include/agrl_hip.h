@@ -109,6 +109,13 @@ int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, const float*
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int relu, float w_unscale,
                                agrl_stream_t stream);
 
+/* conv3 + the 1x1 stride-s downsample conv of a first Bottleneck as ONE split-fp16 GEMM over [x sampled at the stride | x2]
+ * (torchreid/models/vmgn.py:56-64, both BatchNorms folded): fp32 tensors, arithmetic of agrl_conv2d_bn_act_split16. x (N,H,W,K1) the
+ * block input, x2 (N,OH,OW,K2) conv2's output, w_scaled (Cout, K1+K2) = [w_downsample | w_conv3] 2^k, bias = b_downsample + b_conv3,
+ * out (N,OH,OW,Cout) fp32, OH = (H-1)/stride+1. The fp32 shortcut map is neither written nor read back. K1, K2 multiples of 32. */
+int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scaled, const float* bias, void* out, int N, int H, int W,
+                              int stride, int K1, int K2, int Cout, int relu, float w_unscale, agrl_stream_t stream);
+
 /* ---- Split-fp16 PLANES (round 6): the conforming mode at speed --------------------------------------------------------------
  * The same arithmetic class as agrl_conv2d_bn_act_split16 (x w ~ xh wh + xl wh + xh wl, 22 significand bits per operand, fp32
  * accumulation) with the operands split ONCE -- weights at pack time, activations in the producing kernel's epilogue -- so that the

@@ -1257,6 +1257,36 @@ def test_conv3x3_split16_planes(cfg):
     assert e < 2e-6
 
 
+@pytest.mark.parametrize("cfg", [(4, 64, 32, 64, 64, 256, 1), (3, 64, 32, 256, 128, 512, 2), (5, 32, 16, 512, 256, 1024, 2), (2, 16, 8, 1024, 512, 2048, 1),
+                                 (2, 9, 7, 32, 64, 96, 2)])
+def test_conv1x1_dual_split16_matches_the_two_convs(cfg):
+    """agrl_conv1x1_dual_split16 (round 6): conv3 + the stride-s 1x1 downsample conv of a first Bottleneck as ONE in-loop split GEMM over
+    [block input sampled at the stride | conv2's output] (vmgn.py:56-64) against float64, and against the two split convs it replaces
+    (downsample conv -> shortcut map -> conv3 + residual): layers 1-4's first-block shapes, an odd map."""
+    from torchreid import hip_ops as ops
+    N, H, W, K1, K2, Cout, stride = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.randn((N, H, W, K1), generator=g).clamp(min=0)
+    y = torch.randn((N, OH, OW, K2), generator=g).clamp(min=0)
+    wd = torch.randn((Cout, 1, 1, K1), generator=g) * (0.7 / np.sqrt(K1))
+    w3 = torch.randn((Cout, 1, 1, K2), generator=g) * (0.7 / np.sqrt(K2))
+    bd, b3 = 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    xs = x[:, ::stride, ::stride, :]
+    ref = (xs.double() @ wd.view(Cout, K1).double().t() + y.double() @ w3.view(Cout, K2).double().t() + (bd + b3).double()).clamp(min=0)
+    xd, yd = x.to(DEV), y.to(DEV)
+    wcat = ops.split16_prescale(torch.cat([wd.view(Cout, K1), w3.view(Cout, K2)], dim=1).to(DEV))
+    got = ops.conv1x1_dual_split16(xd, yd, wcat, (bd + b3).to(DEV), stride, True)
+    short = ops.conv_bn_act(xd, ops.split16_prescale(wd.to(DEV)), bd.to(DEV), stride, 0, False)
+    two = ops.conv_bn_act(yd, ops.split16_prescale(w3.to(DEV)), b3.to(DEV), 1, 0, True, residual=short)
+    torch.cuda.synchronize()
+    den = ref.abs().max().item()
+    e1 = (got.double().cpu() - ref).abs().max().item() / den
+    e2 = (two.double().cpu() - ref).abs().max().item() / den
+    print("dual split16", cfg, "vs float64: one GEMM %.2e, two convs %.2e" % (e1, e2))
+    assert tuple(got.shape) == (N, OH, OW, Cout) and e1 < 2e-6 and e1 < 2 * e2 + 3e-7
+
+
 def test_conv_split_fp16_rejects_a_scale_that_is_not_a_power_of_two():
     from torchreid import hip_ops as ops
     x = torch.rand((1, 16, 8, 64), device=DEV)
