@@ -19,7 +19,7 @@ import torch
 
 from torchreid import hip_ops as ops
 from torchreid import _hip
-from torchreid.models._vmgn_hip import (_PRECISIONS, _fingerprint, _fold_bn1d, _fold_conv_bn, _pack_stage, _run_block, _run_trunk,
+from torchreid.models._vmgn_hip import (_PRECISIONS, run_stem, _fingerprint, _fold_bn1d, _fold_conv_bn, _pack_stage, _run_block, _run_trunk,
                                          check_packed_range)
 
 
@@ -33,6 +33,7 @@ def pack_weights(model, device, precision):
     if first.device != device:
         raise RuntimeError('model parameters live on {} but the input is on {}'.format(first.device, device))
     dtype = _PRECISIONS[precision]
+    s16 = precision == 'fp16x3'
     pam = model.pam_layer
     with torch.no_grad():
         stem_w, stem_b = _fold_conv_bn(model.conv1, model.bn1, torch.float32)
@@ -41,8 +42,12 @@ def pack_weights(model, device, precision):
             'dtype': dtype,
             'stem': (stem_w, stem_b),
             'stem_lp': ops.pack_stem_weights_lp16(stem_w) if dtype == ops.LP_DTYPE else None,
-            'trunk': _pack_stage(model.layer1, dtype) + _pack_stage(model.layer2, dtype) + _pack_stage(model.layer3, dtype, seam=True),
-            'l4': _pack_stage(model.layer4, dtype),
+            'stem_s16': ops.pack_stem_weights_split16(stem_w) if s16 else None,
+            # ('fp16x3': the conv trunk in the split-fp16 arithmetic -- pre-scaled weights, agrl_conv2d_bn_act_split16 -- as in vmgn / gsta;
+            # the attention module, the graph layers and the tail stay exact fp32)
+            'trunk': (_pack_stage(model.layer1, dtype, split16=s16) + _pack_stage(model.layer2, dtype, split16=s16)
+                      + _pack_stage(model.layer3, dtype, seam=True, split16=s16)),
+            'l4': _pack_stage(model.layer4, dtype, split16=s16),
             # stacked query / key conv as one OHWI weight (2*Cq, 1, 1, C) + bias; value conv as a Linear weight (C, C) + bias
             'qk_w': torch.cat([pam.query_conv.weight, pam.key_conv.weight], 0).detach().float().permute(0, 2, 3, 1).contiguous().to(dtype),
             'qk_b': torch.cat([pam.query_conv.bias, pam.key_conv.bias], 0).detach().float().contiguous(),
@@ -80,7 +85,7 @@ def hip_forward_ganet(model, x, adj, stages=None):
     splits = list(model.total_split_list)
     with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
-        a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+        a = run_stem(frames, pack)
         a = _run_trunk(a, pack['trunk'], model.hip_fuse_tail)
         for blk in pack['l4']:
             a = _run_block(a, blk)

@@ -365,14 +365,19 @@ def _run_block(x, blk, pool=None):
     return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut)
 
 
+def run_stem(frames, pack):
+    """conv1 / bn1 / relu / maxpool (vmgn.py:281-284) in the pack's arithmetic: the 16-bit MFMA stem, the split-fp16 one of the conforming
+    mode, or the exact-fp32 one."""
+    if pack['stem_lp'] is not None:
+        return ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1])
+    if pack.get('stem_s16') is not None:
+        return ops.stem_split16(frames, pack['stem_s16'][0], pack['stem_s16'][1], pack['stem_s16'][2], pack['stem'][1])
+    return ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+
+
 def hip_featuremaps(model, frames, pack):
     """(F,3,H,W) fp32 NCHW -> x4_1, x4_2 NHWC (F,h,w,2048). reference vmgn.py:280-290."""
-    if pack['stem_lp'] is not None:
-        a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1])
-    elif pack.get('stem_s16') is not None:
-        a = ops.stem_split16(frames, pack['stem_s16'][0], pack['stem_s16'][1], pack['stem_s16'][2], pack['stem'][1])
-    else:
-        a = ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+    a = run_stem(frames, pack)
     a = _run_trunk(a, pack['trunk'], getattr(model, 'hip_fuse_tail', True))
     x4_1 = a
     for blk in pack['l4_1']:
@@ -525,7 +530,7 @@ def hip_forward_gsta(model, x, adj):
     splits = list(model.total_split_list)
     with torch.no_grad(), ops.f32_split(model.hip_precision == 'bf16x3'):
         frames = x.reshape(B * S, Cc, H, W)
-        a = ops.stem_lp16(frames, pack['stem_lp'], pack['stem'][1]) if lp else ops.stem(frames, pack['stem'][0], pack['stem'][1], pack['dtype'])
+        a = run_stem(frames, pack)
         a = _run_trunk(a, pack['trunk'], model.hip_fuse_tail)
         hw = (a.shape[1] // pack['l4'][0]['stride']) * (a.shape[2] // pack['l4'][0]['stride'])
         if lp and model.hip_fuse_pool and a.shape[1] * a.shape[2] == 128 and pack['l4'][0]['stride'] == 1:

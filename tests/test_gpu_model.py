@@ -66,7 +66,7 @@ def test_vmgn_eval_fp32_matches_oracle(cfg):
 
 @pytest.mark.parametrize("cfg", [(3, 5, 128, 64, 4, True), (2, 16, 256, 128, 4, True), (1, 1, 256, 128, 4, True),
                                  (2, 4, 256, 128, 2, True), (2, 4, 256, 128, 4, False), (5, 3, 192, 96, 4, True)])
-@pytest.mark.parametrize("precision,tol", [(LP16, LP_EMBED_TOL), ("fp32", 1e-3)])
+@pytest.mark.parametrize("precision,tol", [(LP16, LP_EMBED_TOL), ("fp32", 1e-3), ("fp16x3", 1e-4)])
 def test_vmgn_eval_shape_variants(cfg, precision, tol):
     """Frame sizes / clip lengths / split counts off the bench configuration: every dispatch (fused pooling or not, wide
     or narrow tiles, streaming or LDS message pass, fused layer-1 tails) must agree with the oracle."""
@@ -104,7 +104,7 @@ def test_vmgn_eval_16_bit_mode_close_and_ranking_preserved():
     assert d_ref[0].argmin().item() == 1 and d_got[0].argmin().item() == 1
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), (LP16, LP_EMBED_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), (LP16, LP_EMBED_TOL), ("fp16x3", 1e-4)])
 def test_gsta_sibling_eval_matches_oracle(precision, tol):
     """``gsta`` (single layer4 branch, one BNNeck) through the same HIP kernels vs oracle.gsta_eval (pinned on the
     reference's gsta.py by tests/golden/gsta_b2s4.npz)."""
@@ -127,7 +127,7 @@ def test_gsta_sibling_eval_matches_oracle(precision, tol):
         assert err < tol
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16x3", 1e-3), (LP16, LP_EMBED_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16x3", 1e-3), ("fp16x3", 1e-4), (LP16, LP_EMBED_TOL)])
 @pytest.mark.parametrize("variant", ["default_gammas", "pam_on", "pam_and_graph_on"])
 def test_ganet_sibling_eval_matches_oracle(variant, precision, tol):
     """``ganet`` (position-attention part nodes, diagonal-masked graph layers, concatenated outputs) through the HIP kernels
