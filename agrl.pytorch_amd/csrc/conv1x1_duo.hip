@@ -516,6 +516,297 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
     }
 }
 
+// ---- PERSISTENT form (round 6, 16-bit non-plane entry points): 2 workgroups per CU walk the tiles, and the software pipeline of the
+// k-loop runs on ACROSS tiles -- during a tile's second-last slab the pieces that used to be dummies (the slab's own rows again) bring
+// the NEXT tile's slab 0 into the buffer that has just been freed, and during its last slab the weight ring refills with the next
+// tile's first eight fragments instead of re-reading slab 0. The epilogue works in the OTHER buffer only (the last slab's): 4 wave
+// images of 8 KB = 64 rows x 128 B, two passes of 64 rows (the plane epilogue's scheme), so the prefetched slab survives it. What a
+// tile of the one-shot form spends before its first barrier (5.3 of 23.8 us: first pixel rows and weight fragments arriving behind
+// the co-resident workgroup's traffic, profiles/r05_duo_timeline.txt) is requested a whole slab + an epilogue ahead here. Results bit-identical
+// (same k order, same epilogue arithmetic). Every counted wait of the one-shot form stays valid: a wait "at most N operations outstanding"
+// only ever meets MORE already-retired operations in this order, never fewer.
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void conv1x1_duo_persist_kernel(const DuoParams p, int ntiles) {
+    using SCHED = DuoSchedOf;
+    using std::integral_constant;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_[2 * DSLAB];
+    __shared__ __attribute__((aligned(16))) float s_pool_[POOL ? 4 * 256 : 4];
+    lds_u8_t* const smem = (lds_u8_t*)smem_;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const int nNt = p.Cout >> 8;
+    const int nslab = p.K >> 7, nslab1 = p.K1 >> 7;
+
+    // virtual block id -> tile, the one-shot form's XCD map over ALL tiles (gridDim.x is a multiple of 8: a workgroup's tiles keep its XCD)
+    auto tile_of = [&](int vb, int& mt_, int& nt_) {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = vb & 7, within = vb >> 3;
+        const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + within;
+        mt_ = b / nNt;
+        nt_ = b - mt_ * nNt;
+    };
+    // byte offset of this lane's 16 bytes of pixel row (wave + 4 j) * 8 + lrow of the tile at m0_ in source 1 (second = false) / source 2
+    // (by value, element by element: an array handed to a lambda by reference lives in scratch, and a scratch access is a vector-memory
+    // operation that would sit in the counted vmcnt queue)
+    auto roff_of = [&](int m0_, int j, bool second, int lrow_, int lchk_) -> unsigned {   // (lrow_ / lchk_: opaque copies at the per-tile call
+        // sites, so that hipcc recomputes the row terms there instead of carrying them through the k-loop: the kernel sits at its 128 arch VGPRs)
+        const int row = (wave + 4 * j) * 8 + lrow_;
+        const int gm = min(m0_ + row, p.M - 1);
+        const unsigned sw = (unsigned)((lchk_ ^ ((row >> 1) & 7)) << 4);
+        if (second) return (unsigned)gm * (unsigned)(p.K - p.K1) * 2u + sw;
+        unsigned srow = (unsigned)gm;
+        if (p.gHoWo) {
+            const unsigned f = (unsigned)gm / (unsigned)p.gHoWo, r = (unsigned)gm - f * (unsigned)p.gHoWo;
+            const unsigned ho = r / (unsigned)p.gWo, wo = r - ho * (unsigned)p.gWo;
+            srow = f * (unsigned)p.gHiWi + (ho * (unsigned)p.gWi + wo) * (unsigned)p.gS;
+        }
+        return srow * (unsigned)p.K1 * 2u + sw;
+    };
+    int vb = blockIdx.x, mt, nt;
+    tile_of(vb, mt, nt);
+    int m0 = mt * DROWS;
+    unsigned roff[4], roff2[4], roffd[4];   // roffd: next tile's source-1 offsets minus this tile's
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        roff[j] = roff_of(m0, j, false, lrow, lchk);
+        roff2[j] = roff_of(m0, j, true, lrow, lchk);
+        roffd[j] = 0u;
+    }
+    auto stage_piece = [&](int slab, int buf, auto i_c, bool nx) {  // piece i of slab `slab` (nx: of the NEXT tile's slab 0) into buffer `buf`
+        constexpr int I = decltype(i_c)::value, J = I >> 1, H = I & 1;
+        const bool second = !nx && slab >= nslab1;
+        // (next tile's offset as current + delta: a select between two array elements becomes a select of ADDRESSES in LLVM, which pins
+        // both arrays in scratch -- and a scratch access is a vector-memory operation in the counted queue)
+        const unsigned ro1 = roff[J] + (nx ? roffd[J] : 0u);
+        const unsigned char* src = second ? p.x2 + roff2[J] + (size_t)((slab - nslab1) * 256 + H * 128)
+                                          : p.x + ro1 + (size_t)(slab * 256 + H * 128);
+        fat_dma(src, __builtin_amdgcn_readfirstlane(lds0 + buf * DSLAB + H * DHALF + (wave + 4 * J) * 1024));
+    };
+    const int xbase = frow * 128 + ((fchunk ^ ((frow >> 1) & 7)) << 4);
+    auto stream_of = [&](int nt_) { return p.wpk + (size_t)(nt_ * 4 + wave) * nslab * (DPS * 1024); };
+    const unsigned char* wstream = stream_of(nt);
+    u32x4_t wr[DRING];
+    auto issue_w = [&](auto slot_c, const unsigned char* slab_base, auto pos_c) {
+        constexpr int SLOT = decltype(slot_c)::value, POS = decltype(pos_c)::value;
+        fat_gload<(POS & 3) * 1024>(wr[SLOT], lane16, slab_base + (POS & ~3) * 1024);
+    };
+    asm volatile("" ::: "a127");
+
+    // ---- prologue of the FIRST tile (the one-shot form's)
+    sfor<DPPW>([&](auto ic) { stage_piece(0, 0, ic, false); });
+    sfor<DRING>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        issue_w(ic, wstream, ic);
+        sfor<dpieces_at(I + DRING)>([&](auto jc) {
+            stage_piece(1, 1, integral_constant<int, dpiece_first(I + DRING) + decltype(jc)::value>{}, false);
+        });
+    });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DRING + DPPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int par = 0;   // buffer of the current tile's slab 0
+    auto ldx = [&](const lds_u8_t* sp, auto ks_c, auto b_c) {
+        constexpr int KS = decltype(ks_c)::value, B = decltype(b_c)::value;
+        const lds_u8_t* a = sp + (xbase ^ ((KS & 1) * 64));
+        return *reinterpret_cast<const lds_u32x4_t*>(a + (KS >> 1) * DHALF + B * 2048);
+    };
+    const bool has_res = p.res != nullptr;
+    const bool has_out = !POOL || p.out != nullptr;
+    const float alpha = p.alpha;
+    for (;;) {
+        sfor<32>([&](auto qc) { fat_zero<decltype(qc)::value>(); });
+        const int vbn = vb + (int)gridDim.x;
+        const bool has_next = vbn < ntiles;
+        int mtn = mt, ntn = nt;
+        const unsigned char* wstream_n = wstream;
+        if (has_next) {
+            tile_of(vbn, mtn, ntn);
+            int lr = lrow, lc = lchk;
+            asm volatile("" : "+v"(lr), "+v"(lc));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) roffd[j] = roff_of(mtn * DROWS, j, false, lr, lc) - roff[j];
+            wstream_n = stream_of(ntn);
+        }
+        u32x4_t xf[8];
+        sfor<8>([&](auto bc) { xf[decltype(bc)::value] = ldx(smem + par * DSLAB, integral_constant<int, 0>{}, bc); });
+        for (int slab = 0; slab < nslab; ++slab) {
+            const bool more = slab + 1 < nslab;
+            const unsigned char* ws = wstream + (size_t)slab * (DPS * 1024);
+            const unsigned char* wsn = more ? wstream + (size_t)(slab + 1) * (DPS * 1024) : wstream_n;   // last slab: the NEXT tile's first ring
+            const bool nx = has_next && slab + 2 == nslab;                   // second-last slab: the next tile's slab 0 ...
+            const int ahead = nx ? 0 : (slab + 2 < nslab ? slab + 2 : slab);  // ... (last slab, last tile: dummies -- the slab's own rows again)
+            const int cur = (slab + par) & 1;
+            const lds_u8_t* sp = smem + cur * DSLAB;
+            const lds_u8_t* spn = smem + (cur ^ 1) * DSLAB;
+            sfor<DPS>([&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                constexpr int KS = P >> 2, A = P & 3, SL = P % DRING;
+                fat_wait<SCHED::value.allowed[P]>(wr[SL]);
+                if constexpr (P == DBARRIER_AT) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                sfor<8>([&](auto bc) {
+                    constexpr int B = decltype(bc)::value;
+                    fat_mfma<A * 8 + B>(wr[SL], xf[B]);
+                    if constexpr (A == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (KS + 1 < 4) xf[B] = ldx(sp, integral_constant<int, KS + 1>{}, bc);
+                        else xf[B] = ldx(spn, integral_constant<int, 0>{}, bc);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int Q = P + DRING;
+                if constexpr (Q >= DPS) issue_w(integral_constant<int, SL>{}, wsn, integral_constant<int, Q - DPS>{});
+                else issue_w(integral_constant<int, SL>{}, ws, integral_constant<int, Q>{});
+                sfor<dpieces_at(P)>([&](auto ic) { stage_piece(ahead, cur, integral_constant<int, dpiece_first(P) + decltype(ic)::value>{}, nx); });
+            });
+        }
+        // the next tile's first ring and its slab 0 (or the dummies of the last tile) are still landing
+#pragma unroll
+        for (int i = 0; i < DRING; ++i) asm volatile("" : "+v"(wr[i]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < DRING; ++i) asm volatile("" : "+v"(wr[i]));
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __syncthreads();  // every wave is past its last fragment read of the LAST slab's buffer: it becomes the image area
+
+        // ---- epilogue in the last slab's buffer: wave image 8 KB = 64 rows x 128 B (the pixel buffers' swizzled row layout), two passes
+        const int bufE = (nslab - 1 + par) & 1;
+        lds_u8_t* const wt = smem + bufE * DSLAB + wave * 8192;
+        const unsigned ldsE = lds0 + bufE * DSLAB + wave * 8192;
+        const size_t colb = (size_t)(nt * 256 + wave * 64) * 2;
+        const int cb = nt * 256 + wave * 64 + 8 * fchunk;
+        int lrow_e = lrow, lchk_e = lchk;
+        asm volatile("" : "+v"(lrow_e), "+v"(lchk_e));
+        auto row_off = [&](int i) {
+            const int row = 8 * i + lrow_e;
+            const int gm = min(m0 + row, p.M - 1);
+            return (unsigned)((size_t)gm * p.Cout * 2 + colb + (size_t)((lchk_e ^ ((row >> 1) & 7)) << 4));
+        };
+        sfor<2>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            float ps[POOL ? 2 : 1][2][8];
+            if constexpr (POOL) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ps[q][j][e] = 0.f;
+            }
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fat_dma_s(p.res, row_off(8 * h + i), __builtin_amdgcn_readfirstlane(ldsE + i * 1024));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            sfor<2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j);
+                const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cb + 32 * j + 4);
+                sfor<4>([&](auto bc) {
+                    constexpr int BL = decltype(bc)::value, B = 4 * h + BL;
+                    const f32x4_t lo = fat_read<(2 * j) * 8 + B>(), hi = fat_read<(2 * j + 1) * 8 + B>();
+                    float v[8] = {fmaf(alpha, lo[0], b0.x), fmaf(alpha, lo[1], b0.y), fmaf(alpha, lo[2], b0.z), fmaf(alpha, lo[3], b0.w),
+                                  fmaf(alpha, hi[0], b1.x), fmaf(alpha, hi[1], b1.y), fmaf(alpha, hi[2], b1.z), fmaf(alpha, hi[3], b1.w)};
+                    lds_u32x4_t* const cell = reinterpret_cast<lds_u32x4_t*>(wt + (xbase ^ (j * 64)) + BL * 2048);
+                    if (has_res) {
+                        const u32x4_t r = *cell;
+                        const uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float l, hh;
+                            unpack_lp16x2(w4[e], l, hh);
+                            v[2 * e] += l;
+                            v[2 * e + 1] += hh;
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = relu_nan(v[e]);
+                    }
+                    const u32x4_t pk = {pack_lp16x2(v[0], v[1]), pack_lp16x2(v[2], v[3]), pack_lp16x2(v[4], v[5]), pack_lp16x2(v[6], v[7])};
+                    if (has_out) *cell = pk;
+                    if constexpr (POOL) {  // pool the rounded activations (what a separate pooling pass would read)
+                        const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float l, hh;
+                            unpack_lp16x2(w4[e], l, hh);
+                            ps[BL >> 1][j][2 * e] += l;
+                            ps[BL >> 1][j][2 * e + 1] += hh;
+                        }
+                    }
+                });
+            });
+            if (has_out) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4_t v = *reinterpret_cast<const lds_u32x4_t*>(wt + i * 1024 + lane * 16);
+                    if (m0 + 8 * (8 * h + i) + lrow < p.M) *reinterpret_cast<u32x4_t*>(p.out + row_off(8 * h + i)) = v;
+                }
+            }
+            if constexpr (POOL) {
+                float* const s_w = s_pool_ + wave * 256;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float t = ps[q][j][e];
+                            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                            ps[q][j][e] = t;
+                        }
+                        if (frow == 0) {
+                            float* d = s_w + (2 * h + q) * 64 + 8 * fchunk + 32 * j;
+                            *reinterpret_cast<float4*>(d) = make_float4(ps[q][j][0], ps[q][j][1], ps[q][j][2], ps[q][j][3]);
+                            *reinterpret_cast<float4*>(d + 4) = make_float4(ps[q][j][4], ps[q][j][5], ps[q][j][6], ps[q][j][7]);
+                        }
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is re-filled by the next pass's DMA
+        });
+        if constexpr (POOL) {
+            __syncthreads();
+            const int P = p.pool_nparts;
+            for (int o = tid; o < P * 256; o += 256) {
+                const int c = o & 255, part = o >> 8;
+                const int q0 = p.pool_q0[part], q1 = p.pool_q1[part];
+                float t = 0.f;
+                for (int q = q0; q < q1; ++q) t += s_pool_[(c >> 6) * 256 + q * 64 + (c & 63)];
+                if (p.pool_mean) t *= 1.f / (float)((q1 - q0) * 32);
+                const size_t oi = ((size_t)mt * P + part) * p.Cout + nt * 256 + c;
+                p.pool_out[oi] = t;
+                if (p.pool_out_lp) p.pool_out_lp[oi] = f32_to_lp16(t);
+            }
+        }
+        if (!has_next) break;
+        // ---- on to the next tile: its slab 0 sits in the other buffer, its first ring in wr[]; slab 1 goes where the images were
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();   // every wave has read its image rows (and the pooled sums): the buffer is free
+        vb = vbn; mt = mtn; nt = ntn; m0 = mt * DROWS;
+        int lr2 = lrow, lc2 = lchk;
+        asm volatile("" : "+v"(lr2), "+v"(lc2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            roff[j] += roffd[j];
+            roff2[j] = roff_of(m0, j, true, lr2, lc2);
+        }
+        wstream = wstream_n;
+        par = (nslab + par) & 1;
+        sfor<DPPW>([&](auto ic) { stage_piece(nslab > 1 ? 1 : 0, par ^ 1, ic, false); });
+    }
+}
+
 int duo_launch(DuoParams& p, bool pool, hipStream_t stream, const char* who) {
     if (!p.planes) p.alpha = 1.f;   // the 16-bit entry points: acc + bias, bit for bit what round 5 computed
     const int grid = ((p.M + DROWS - 1) / DROWS) * (p.Cout >> 8);
@@ -523,6 +814,11 @@ int duo_launch(DuoParams& p, bool pool, hipStream_t stream, const char* who) {
     if (p.planes) {
         if (pool) hipLaunchKernelGGL((conv1x1_duo_kernel<true, true>), dim3(grid), dim3(256), dyn, stream, p);
         else hipLaunchKernelGGL((conv1x1_duo_kernel<false, true>), dim3(grid), dim3(256), dyn, stream, p);
+    } else if (agrl_opts().duo_persist == 1 && (p.K >> 7) >= 2 && grid > 512) {
+        // AGRL_DUO_PERSIST=1 (round 6, A/B): two persistent workgroups per CU, the next tile's first slab and weight ring requested
+        // during the current tile's last slabs (conv1x1_duo_persist_kernel)
+        if (pool) hipLaunchKernelGGL((conv1x1_duo_persist_kernel<true>), dim3(512), dim3(256), 0, stream, p, grid);
+        else hipLaunchKernelGGL((conv1x1_duo_persist_kernel<false>), dim3(512), dim3(256), 0, stream, p, grid);
     } else if (pool) hipLaunchKernelGGL((conv1x1_duo_kernel<true, false>), dim3(grid), dim3(256), dyn, stream, p);
     else hipLaunchKernelGGL((conv1x1_duo_kernel<false, false>), dim3(grid), dim3(256), dyn, stream, p);
     AGRL_CHECK_LAUNCH(who);

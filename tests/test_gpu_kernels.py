@@ -461,6 +461,65 @@ def test_conv1x1_packed_res(case):
         ops.call("agrl_conv1x1_packed_res_bn_act", ops.ptr(dx), ops.ptr(packed), ops.ptr(b.to(DEV)), None, ops.ptr(out), N * H * W, K + 64, Cout, 1, None)
 
 
+@pytest.mark.parametrize("case", ["res", "plain_k2048", "plain_k1024", "dual", "strided_l2", "strided_l3", "pool_parts", "pool_sum", "ragged"])
+def test_conv1x1_duo_persistent_form_is_bit_identical(case, monkeypatch):
+    """AGRL_DUO_PERSIST=1 (round 6: conv1x1_duo_persist_kernel -- two persistent workgroups per CU, the next tile's first slab and weight
+    ring requested during the current tile's last slabs, the epilogue in two 64-row passes inside ONE pixel buffer) against the one-shot
+    form on every shape the step sends through conv1x1_duo.hip, and a ragged tile count with an odd number of slabs (the buffer parity
+    flips from tile to tile): equal BIT FOR BIT, every call twice (the second run starts with warm caches: other timing, same answer)."""
+    from torchreid import hip_ops as ops
+    g = torch.Generator().manual_seed(len(case))
+
+    def rnd(shape, scale=1.0, relu=False):
+        t = torch.randn(shape, generator=g) * scale
+        return (t.relu() if relu else t).to(LP_DTYPE).to(DEV)
+
+    def run():
+        if case == "res":          # conv3 + residual stored (512 -> 2048, 2048 tiles)
+            x, w, b, r = rnd((256, 16, 8, 512), relu=True), rnd((2048, 512), 0.05), rnd((2048,)).float(), rnd((256, 16, 8, 2048))
+            pk = ops.conv1x1_pack(w)
+            return [ops.conv1x1_packed_res(x, pk, b, 2048, r, True)]
+        if case in ("plain_k2048", "plain_k1024"):   # layer 4's conv1s (no residual; 512 tiles: exactly one per slot -> engages only above 512)
+            K = 2048 if case == "plain_k2048" else 1024
+            x, w, b = rnd((520, 16, 8, K), relu=True), rnd((512, K), 0.03), rnd((512,)).float()
+            pk = ops.conv1x1_pack(w)
+            return [ops.conv1x1_packed_res(x, pk, b, 512, None, True)]
+        if case == "dual":         # conv3 + downsample of layer 4's first block over [1024 | 512]
+            x, y, w, b = rnd((256, 16, 8, 1024), relu=True), rnd((256, 16, 8, 512), relu=True), rnd((2048, 1536), 0.03), rnd((2048,)).float()
+            pk = ops.conv1x1_pack(w)
+            return [ops.conv1x1_packed(x, pk, b, 2048, True, x2=y, duo=True)]
+        if case in ("strided_l2", "strided_l3"):
+            N, Hi, Wi, K1, K2, Cout = (64, 64, 32, 256, 128, 512) if case == "strided_l2" else (128, 32, 16, 512, 256, 1024)
+            x, y = rnd((N, Hi, Wi, K1), relu=True), rnd((N, Hi // 2, Wi // 2, K2), relu=True)
+            w, b = rnd((Cout, K1 + K2), 0.04), rnd((Cout,)).float()
+            pk = ops.conv1x1_pack(w)
+            return [ops.conv1x1_packed_dual_strided(x, y, pk, b, Cout, 2, True)]
+        if case in ("pool_parts", "pool_sum"):
+            x, w, b, r = rnd((256, 16, 8, 512), relu=True), rnd((2048, 512), 0.05), rnd((2048,)).float(), rnd((256, 16, 8, 2048))
+            pk = ops.conv1x1_pack(w)
+            splits, mean = ([4, 2, 1], True) if case == "pool_parts" else ([1], False)
+            return list(ops.conv1x1_packed_res_pool(x, pk, b, 2048, r, splits, mean, True))
+        # ragged: 131 frames x 100 px (M = 13100: a partial last tile), K = 384 (three slabs: odd), Cout = 1280 (five channel tiles)
+        x, w, b, r = rnd((131, 10, 10, 384), relu=True), rnd((1280, 384), 0.05), rnd((1280,)).float(), rnd((131, 10, 10, 1280))
+        pk = ops.conv1x1_pack(w)
+        return [ops.conv1x1_packed_res(x, pk, b, 1280, r, False)]
+
+    g.manual_seed(len(case))
+    ref = run()
+    monkeypatch.setenv("AGRL_DUO_PERSIST", "1")
+    _hip.reload_options()
+    g.manual_seed(len(case))
+    got = run()
+    g.manual_seed(len(case))
+    got2 = run()
+    monkeypatch.delenv("AGRL_DUO_PERSIST")
+    _hip.reload_options()
+    torch.cuda.synchronize()
+    for a, b_, c in zip(ref, got, got2):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b_) and torch.equal(a, c), (case, (a.float() - b_.float()).abs().max().item())
+
+
 @pytest.mark.parametrize("cfg", [(256, 512, 2048, [4, 2, 1], True), (256, 512, 2048, [1], False), (3, 128, 256, [4, 2, 1], True),
                                  (9, 256, 512, [2, 1], True)])
 def test_conv1x1_packed_res_pool(cfg):

@@ -14,7 +14,7 @@ src=$PWD
 tmp=$(mktemp -d)
 trap 'rm -rf "$tmp"' EXIT
 rc=0
-for f in bottleneck_seam:bottleneck_seam_kernel:512 conv3x3_fat:conv3x3_fat_kernelILi1E:256 conv3x3_fat:conv3x3_fat_kernelILi2E:512 conv3x3_fat:conv3x3_half_kernel:256 conv1x1_fat:conv1x1_fat:512 conv1x1_duo:conv1x1_duo_kernel:256; do
+for f in bottleneck_seam:bottleneck_seam_kernel:512 conv3x3_fat:conv3x3_fat_kernelILi1E:256 conv3x3_fat:conv3x3_fat_kernelILi2E:512 conv3x3_fat:conv3x3_half_kernel:256 conv1x1_fat:conv1x1_fat:512 conv1x1_duo:conv1x1_duo_kernel:256 conv1x1_duo:conv1x1_duo_persist_kernel:256; do
   IFS=: read -r file kern maxreg <<< "$f"
   for lp in 1 0; do
     (cd "$tmp" && "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DAGRL_LP_F16=$lp "$@" -I"$src" -c "$src/$file.hip" -o x.o -save-temps=obj 2>/dev/null)
