@@ -814,9 +814,12 @@ int duo_launch(DuoParams& p, bool pool, hipStream_t stream, const char* who) {
     if (p.planes) {
         if (pool) hipLaunchKernelGGL((conv1x1_duo_kernel<true, true>), dim3(grid), dim3(256), dyn, stream, p);
         else hipLaunchKernelGGL((conv1x1_duo_kernel<false, true>), dim3(grid), dim3(256), dyn, stream, p);
-    } else if (agrl_opts().duo_persist == 1 && (p.K >> 7) >= 2 && grid > 512) {
-        // AGRL_DUO_PERSIST=1 (round 6, A/B): two persistent workgroups per CU, the next tile's first slab and weight ring requested
-        // during the current tile's last slabs (conv1x1_duo_persist_kernel)
+    } else if (agrl_opts().duo_persist != 0 && (p.K >> 7) >= 2 && grid > 512) {
+        // round 6: two persistent workgroups per CU, the next tile's first slab and weight ring requested during the current tile's last
+        // slabs (conv1x1_duo_persist_kernel; bit-identical). Same-box A/B of the whole step, four pairs: 3.440-3.454 against 3.457-3.461 ms
+        // (every run ahead of every one-shot run; per launch: conv3 + residual 98 -> 92 / 95 -> 90.5 us, the strided first blocks 83 -> 78 /
+        // 58 -> 54, pooled 98 -> 95; profiles/r06_ab_duo_persist.txt). AGRL_DUO_PERSIST=0: the one-shot form. Launches of <= 512 tiles
+        // (layer 4's conv1s: one tile per resident slot) have nothing to carry over and stay one-shot.
         if (pool) hipLaunchKernelGGL((conv1x1_duo_persist_kernel<true>), dim3(512), dim3(256), 0, stream, p, grid);
         else hipLaunchKernelGGL((conv1x1_duo_persist_kernel<false>), dim3(512), dim3(256), 0, stream, p, grid);
     } else if (pool) hipLaunchKernelGGL((conv1x1_duo_kernel<true, false>), dim3(grid), dim3(256), dyn, stream, p);

@@ -463,7 +463,7 @@ def test_conv1x1_packed_res(case):
 
 @pytest.mark.parametrize("case", ["res", "plain_k2048", "plain_k1024", "dual", "strided_l2", "strided_l3", "pool_parts", "pool_sum", "ragged"])
 def test_conv1x1_duo_persistent_form_is_bit_identical(case, monkeypatch):
-    """AGRL_DUO_PERSIST=1 (round 6: conv1x1_duo_persist_kernel -- two persistent workgroups per CU, the next tile's first slab and weight
+    """The default dispatch since round 6 (conv1x1_duo_persist_kernel; AGRL_DUO_PERSIST=0 is the one-shot form it is compared with) -- two persistent workgroups per CU, the next tile's first slab and weight
     ring requested during the current tile's last slabs, the epilogue in two 64-row passes inside ONE pixel buffer) against the one-shot
     form on every shape the step sends through conv1x1_duo.hip, and a ragged tile count with an odd number of slabs (the buffer parity
     flips from tile to tile): equal BIT FOR BIT, every call twice (the second run starts with warm caches: other timing, same answer)."""
@@ -504,16 +504,16 @@ def test_conv1x1_duo_persistent_form_is_bit_identical(case, monkeypatch):
         pk = ops.conv1x1_pack(w)
         return [ops.conv1x1_packed_res(x, pk, b, 1280, r, False)]
 
+    monkeypatch.setenv("AGRL_DUO_PERSIST", "0")
+    _hip.reload_options()
     g.manual_seed(len(case))
     ref = run()
-    monkeypatch.setenv("AGRL_DUO_PERSIST", "1")
+    monkeypatch.delenv("AGRL_DUO_PERSIST")   # the default since the A/B of round 6: persistent
     _hip.reload_options()
     g.manual_seed(len(case))
     got = run()
     g.manual_seed(len(case))
     got2 = run()
-    monkeypatch.delenv("AGRL_DUO_PERSIST")
-    _hip.reload_options()
     torch.cuda.synchronize()
     for a, b_, c in zip(ref, got, got2):
         assert torch.isfinite(a.float()).all()
