@@ -7,7 +7,7 @@ FETCH_SIZE / WRITE_SIZE are in KiB (x1024); on gfx950 FETCH_SIZE counts 128-byte
 coalesced reads (MI355X_MICROARCH.md, HBM section) -> the read side is doubled."""
 import csv, json, sys, collections
 fetch_csv, write_csv, steps, prec = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
-out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r05.json"
+out_path = sys.argv[5] if len(sys.argv) > 5 else "profiles/traffic_r06.json"
 if steps == "auto":
     steps = sum(1 for row in csv.DictReader(open(fetch_csv)) if row["Counter_Name"] == "FETCH_SIZE" and "stem_mfma_kernel" in row["Kernel_Name"])
     assert steps > 0, "no stem_mfma_kernel launch in %s" % fetch_csv
@@ -18,10 +18,11 @@ def load(path, counter):
         if row["Counter_Name"] != counter:
             continue
         name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "conv1x1_fat_kernel", "conv1x1_duo_kernel", "bottleneck_")) and "pack_kernel" not in name else name.split("(")[0][-40:]
+        key = "igemm" if any(t in name for t in ("igemm", "conv3x3", "conv1x1_fat_kernel", "conv1x1_duo_kernel", "conv1x1_duo_persist_kernel", "bottleneck_")) and "pack_kernel" not in name else name.split("(")[0][-40:]
         for dom, alias in (("conv3x3_wide_kernel", "conv3x3_wide_kernel"), ("conv3x3_fat_kernel", "conv3x3_fat_kernel"),
                            ("conv3x3_half_kernel", "conv3x3_fat_kernel"),    # the 3x3 family (layers 2-4: fat + half) on its own
-                           ("conv1x1_duo_kernel", "conv1x1_duo_kernel")):    # every launch of the two-workgroups-per-CU 1x1 kernel (<false> + <true>)
+                           ("conv1x1_duo_kernel", "conv1x1_duo_kernel"),     # every launch of the two-workgroups-per-CU 1x1 kernel (<false> + <true>) ...
+                           ("conv1x1_duo_persist_kernel", "conv1x1_duo_kernel")):   # ... in its one-shot and its persistent form (round 6)
             if dom in name:
                 per[alias][0] += float(row["Counter_Value"])
                 per[alias][1] += 1
