@@ -195,6 +195,7 @@ struct AgrlOpts {
     int stem_split_lds;       // AGRL_STEM_SPLIT_LDS: 0 = patch and conv tile share one LDS region (four barriers per tile; A/B)
     int stem_xcd_map;         // AGRL_STEM_XCD_MAP: 0 = the 16-bit stem's tiles in launch order (A/B); unset / 1: every frame on one XCD
     int distmat_tile_n;       // AGRL_DISTMAT_TILE_N: 192 / 256 forces the column width of the full distance matrix's tile (unset: by round count)
+    int split16_ns;           // AGRL_SPLIT16_NS: 2 / 3 forces the LDS ring depth of the in-loop split-fp16 GEMM (unset: 3 for 64-channel tiles, else 2)
     int duo_persist;          // AGRL_DUO_PERSIST: 0 = the 16-bit 1x1 GEMMs of conv1x1_duo.hip through the one-shot form (unset / 1: persistent, round 6)
     int igemm_dbg, conv3x3_dbg;  // ablation masks: parsed only in an -DAGRL_ABLATE build, 0 in the shipped library
 };

@@ -40,6 +40,7 @@ static AgrlOpts load_opts() {
     o.conv3x3_n128 = opt_flag("AGRL_CONV3X3_N128");
     o.distmat_tile_n = opt_int("AGRL_DISTMAT_TILE_N");
     o.duo_persist = opt_int("AGRL_DUO_PERSIST");
+    o.split16_ns = opt_int("AGRL_SPLIT16_NS");
     o.stem_xcd_map = opt_int("AGRL_STEM_XCD_MAP");
     o.stem_split_lds = opt_int("AGRL_STEM_SPLIT_LDS");
     o.conv3x3_fat_pb = opt_int("AGRL_CONV3X3_FAT_PB");

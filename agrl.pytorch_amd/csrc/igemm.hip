@@ -981,6 +981,21 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
         }
     }
     if (!done) {
+        if constexpr (DT<TIN>::code == AGRL_F32H3) {
+            // split-fp16: the matrix work of a k-tile is ~5 x shorter than in the exact mode, so the k-tile in flight behind the one being
+            // multiplied no longer covers the HBM / L2 round trip: a three-slot ring where it keeps two workgroups on a CU (round 6)
+            // Measured per launch (profiles/r06_split16_ring_depth.txt): the 64-channel tiles (72 KB of LDS: still two workgroups per CU)
+            // gain 4-10 % -- 3x3 64 -> 64 248 -> 238 us, 256 -> 64 164 -> 149 --, the 128-channel tiles (96 KB: ONE workgroup per CU) lose
+            // 20-45 % (3x3 128 -> 128 171 -> 219, 128 -> 512 180 -> 258): three slots for the narrow tiles only. AGRL_SPLIT16_NS = 2 / 3 forces it.
+            const int ns = agrl_opt_set(agrl_opts().split16_ns) ? agrl_opts().split16_ns : (narrow ? 3 : 2);
+            if (ns == 3) {
+                if (narrow) { if (bm == 64) LAUNCH_IG(64, 64, false, 3); else LAUNCH_IG(128, 64, false, 3); }
+                else { if (bm == 64) LAUNCH_IG(64, 128, false, 3); else LAUNCH_IG(128, 128, false, 3); }
+                done = true;
+            }
+        }
+    }
+    if (!done) {
         if (narrow) LAUNCH_NS(64, false); else LAUNCH_NS(128, false);
     }
 #undef LAUNCH_NS
