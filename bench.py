@@ -15,14 +15,19 @@ distance matrix against the rank's gallery shard. Inputs are resident in HBM bef
 
 Rank 0 prints ONE JSON line: value = whole-job frames/s (all ranks) over EXACTLY --steps steps, plus
   sustained_value : the same step repeated for >= 2 s (the chip runs at its power limit; a 74 ms burst flatters it)
-  roofline        : the dominant kernel (3x3 implicit-GEMM conv of layers 3-4, MFMA-bound): algorithmic flops per
-                    launch / average launch duration from HIP events on the launch stream, vs the dense MFMA peak
+  roofline        : the dominant kernel (conv1x1_duo_kernel / conv1x1_duo_persist_kernel: every 1x1 GEMM of layer 4 and the two-source
+                    first blocks of layers 2 / 3; bound to this kernel in every run): algorithmic flops per launch / average launch
+                    duration from HIP events on the launch stream, vs the dense MFMA peak; the 3x3 family: roofline_conv3x3
+  host_issue      : wall time to ENQUEUE a step with nothing waited for, and the same in fresh children restricted to 1/8 of the
+                    host's CPUs (eager and HIP-graph form)
   roofline_*      : conv family, layer-4 pointwise convs, GCN message pass (the WHOLE SURVEY 8(d) unit: sim +
                     normalise + mix + G h + BN + LeakyReLU + residual), distance matrix -- the HBM-bound ones with
                     the read-stream yardstick of this chip at the same byte count beside them
   accuracy        : Rank-1 / mAP of the 16-bit mode and exact fp32 on the 625-identity 1980 x 12180 split of tests/fullsplit.py, both held
                     against the CPU oracle's committed result for the same split (tests/golden/fullsplit_oracle.npz)
-  modes           : the same step timed in the two precision modes that meet the 1e-3 / bit-exact-ranking bar (fp32, bf16x3)
+  modes           : the same step timed in exact fp32, bf16x3 and fp16x3 (round 6: the conforming mode at speed -- split-fp16 products,
+                    ranking indices equal to the oracle's up to its own near-ties); index_exactness_by_mode puts their frames/s beside
+                    their agreement with the oracle's ranked lists
   config5         : the full-eval distance matrix 1980 x 12180 x 4096 + top-50 + MARS AP/CMC, timed
   cpu_baseline    : the CPU oracle (oracle/vmgn_oracle.py, torch CPU kernels) on this host, B = 32, best thread count
 """
