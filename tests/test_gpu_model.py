@@ -347,3 +347,11 @@ def test_16_bit_build_with_undamped_batchnorm_statistics():
     print("undamped BatchNorm statistics: trunk half %s max rel err %.3e, fp32 %.3e; graph half %.3e / %.3e" % (LP16, e, e32, eg, eg32))
     assert torch.isfinite(got).all() and e32 < 1e-3 and e < LP_EMBED_TOL
     assert eg32 < 5e-2 and eg < 1e-1
+    # the conforming mode in the same regime: activations up to 13.7 k sit 5 x below fp16's range (the high half), their low halves
+    # times 2^11 below 2^15 -- the split planes and the in-loop split hold the exact mode's accuracy there too
+    m.hip_precision = "fp16x3"
+    got3 = m(x.to(DEV), adj.to(DEV))
+    torch.cuda.synchronize()
+    e3 = rel(got3[:, :C], ref[:, :C])
+    print("undamped BatchNorm statistics: trunk half fp16x3 max rel err %.3e (exact fp32 %.3e)" % (e3, e32))
+    assert torch.isfinite(got3).all() and e3 < 4 * e32 + 1e-6
