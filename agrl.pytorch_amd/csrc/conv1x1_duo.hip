@@ -1041,3 +1041,39 @@ extern "C" int agrl_split16_planes(const float* x, void* out, long long rows, in
     AGRL_CHECK_LAUNCH("agrl_split16_planes");
     return 0;
 }
+
+// fp32 (rows, C) -> the WEIGHT-side plane triple (rows, 3 C) = [h | h 2^-11 | l] of x * scale (scale a power of two: exact), h = fp16(x scale),
+// l = fp16(x scale - h): the operand that meets activation planes [xh | xl 2^11 | xh] in a k-loop (gallery rows of agrl_distmat_split16; the
+// conv weights are packed by the host at pack time, hip_ops.split16_plane_weights: the same arithmetic).
+__global__ __launch_bounds__(256) void split16_weight_planes_kernel(const float4* __restrict__ x, uint2* __restrict__ out, long long groups, int c4, float scale) {
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < groups; t += (long long)gridDim.x * blockDim.x) {
+        const long long row = t / c4;
+        const int g = (int)(t - row * c4);
+        float4 v = x[t];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        const uint32_t h0 = pack_lp16x2(v.x, v.y), h1 = pack_lp16x2(v.z, v.w);
+        float a, b, c, d;
+        unpack_lp16x2(h0, a, b);
+        unpack_lp16x2(h1, c, d);
+        uint2* o = out + row * 3 * c4 + g;
+        o[0] = make_uint2(h0, h1);
+        o[c4] = make_uint2(pack_lp16x2(a * (1.f / 2048.f), b * (1.f / 2048.f)), pack_lp16x2(c * (1.f / 2048.f), d * (1.f / 2048.f)));
+        o[2 * c4] = make_uint2(pack_lp16x2(v.x - a, v.y - b), pack_lp16x2(v.z - c, v.w - d));
+    }
+}
+
+extern "C" int agrl_split16_weight_planes(const float* x, void* out, long long rows, int C, float scale, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(agrl_lp16_is_f16(), "agrl_split16_weight_planes: the split planes are fp16 (load libagrl_hip.so, not the bf16 build)");
+    AGRL_CHECK_ARG(x && out && rows > 0 && C > 0 && C % 4 == 0, "agrl_split16_weight_planes: needs C %% 4 == 0 (got rows=%lld C=%d)", rows, C);
+    AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "agrl_split16_weight_planes: pointers must be 16-byte aligned");
+    {
+        int e = 0;
+        AGRL_CHECK_ARG(scale > 0.f && scale <= 3.4e38f && frexpf(scale, &e) == 0.5f, "agrl_split16_weight_planes: scale=%g is not a positive power of two", (double)scale);
+    }
+    const long long groups = rows * (C / 4);
+    const int grid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split16_weight_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
+                       reinterpret_cast<uint2*>(out), groups, C / 4, scale);
+    AGRL_CHECK_LAUNCH("agrl_split16_weight_planes");
+    return 0;
+}

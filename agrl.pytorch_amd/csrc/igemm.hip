@@ -1283,8 +1283,32 @@ extern "C" int agrl_gemm_nt_splitk(const void* x, const void* w, float* y, int M
     return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_gemm_nt_splitk");
 }
 
+static int distmat_impl(const void* q, const void* g, const float* qn, const float* gn, float* dist, int m, int n, int D, int ldd, int metric,
+                        int dtype, void* workspace, size_t workspace_bytes, float dot_scale, agrl_stream_t stream);
+
 extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist, int m, int n, int D,
                             int ldd, int metric, int dtype, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
+    return distmat_impl(q, g, qn, gn, dist, m, n, D, ldd, metric, dtype, workspace, workspace_bytes, 1.f, stream);
+}
+
+// The distance matrix in the split-fp16 arithmetic (round 6, the conforming mode; torchreid/metrics/distance.py:59-89): q3 (m, D3) and g3
+// (n, D3) are fp16 PLANE operands of D3 = 3 D columns -- queries [qh | ql 2^11 | qh] (agrl_split16_planes of the fp32 rows), gallery
+// [gh | gh 2^-11 | gl] of g 2^k (hip_ops.split16_plane_weights) -- so that the 16-bit kernels' plain dot product over D3 columns IS
+// qh gh + ql gh + qh gl, fp32-class (22 significand bits per operand), and g_unscale = 2^-k un-does the gallery's pre-scale inside the
+// epilogue's alpha. qn / gn (euclidean) are the fp32 squared norms of the TRUE rows. Same kernels, same dispatch as agrl_distmat.
+extern "C" int agrl_distmat_split16(const void* q3, const void* g3, const float* qn, const float* gn, float* dist, int m, int n, int D3,
+                                    int ldd, int metric, float g_unscale, void* workspace, size_t workspace_bytes, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(agrl_lp16_is_f16(), "agrl_distmat_split16: the split planes are fp16 (load libagrl_hip.so, not the bf16 build)");
+    AGRL_CHECK_ARG(D3 > 0 && D3 % 3 == 0 && g_unscale > 0.f && g_unscale <= 3.4e38f, "agrl_distmat_split16: D3 = 3 x columns, g_unscale a positive power of two");
+    {
+        int e = 0;
+        AGRL_CHECK_ARG(frexpf(g_unscale, &e) == 0.5f, "agrl_distmat_split16: g_unscale=%g is not a power of two", (double)g_unscale);
+    }
+    return distmat_impl(q3, g3, qn, gn, dist, m, n, D3, ldd, metric, AGRL_LP16, workspace, workspace_bytes, g_unscale, stream);
+}
+
+static int distmat_impl(const void* q, const void* g, const float* qn, const float* gn, float* dist, int m, int n, int D, int ldd, int metric,
+                        int dtype, void* workspace, size_t workspace_bytes, float dot_scale, agrl_stream_t stream) {
     AGRL_CHECK_ARG(q && g && dist, "agrl_distmat: null pointer");
     AGRL_CHECK_ARG(m > 0 && n > 0 && D > 0 && ldd >= n, "agrl_distmat: bad shape m=%d n=%d D=%d ldd=%d", m, n, D, ldd);
     AGRL_CHECK_ARG(dtype == AGRL_F32 || dtype == AGRL_LP16, "agrl_distmat: bad dtype %d", dtype);
@@ -1293,9 +1317,9 @@ extern "C" int agrl_distmat(const void* q, const void* g, const float* qn, const
     p.x = q; p.w = g; p.res = nullptr; p.out = dist; p.relu = 0; p.ksplit = 1; p.pool_nparts = 0;
     if (metric == AGRL_METRIC_EUCLIDEAN) {
         AGRL_CHECK_ARG(qn && gn, "agrl_distmat: euclidean needs the squared row norms");
-        p.alpha = -2.f; p.rowv = qn; p.colv = gn; p.rowc = 0.f;
+        p.alpha = -2.f * dot_scale; p.rowv = qn; p.colv = gn; p.rowc = 0.f;   // (dot_scale: 1, or the power of two of agrl_distmat_split16 -- exact)
     } else if (metric == AGRL_METRIC_COSINE) {
-        p.alpha = -1.f; p.rowv = nullptr; p.colv = nullptr; p.rowc = 1.f;
+        p.alpha = -1.f * dot_scale; p.rowv = nullptr; p.colv = nullptr; p.rowc = 1.f;
     } else {
         agrl_set_error("agrl_distmat: unknown metric %d", metric);
         return 1;

@@ -60,6 +60,7 @@ SIGNATURES = {
     "agrl_conv1x1_dual_split16": [_p, _p, _p, _p, _p] + [_i] * 8 + [_f, _p],
     "agrl_stem_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "agrl_split16_planes": [_p, _p, C.c_longlong, _i, _p],
+    "agrl_split16_weight_planes": [_p, _p, C.c_longlong, _i, _f, _p],
     "agrl_conv1x1_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "agrl_conv1x1_split16_dual": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "agrl_conv1x1_split16_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _f, _p],
@@ -101,6 +102,7 @@ SIGNATURES = {
     "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_attn_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "agrl_distmat_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, C.c_size_t, _p],
     "agrl_distmat": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p],
     "agrl_pose_adjacency": [_p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _p],
     "agrl_re_ranking_workspace": [_i, _i, _i],   # returns size_t (restype patched after loading)

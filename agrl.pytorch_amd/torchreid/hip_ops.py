@@ -258,6 +258,36 @@ def to_split16_planes(x):
     return out
 
 
+def to_split16_weight_planes(x, scale):
+    """fp32 (rows, C) -> fp16 (rows, 3 C) = [h | h 2^-11 | l] of x * scale (a power of two), on the device (agrl_split16_weight_planes):
+    the gallery side of distmat_split16."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and x.shape[1] % 4 == 0
+    out = torch.empty((x.shape[0], 3 * x.shape[1]), dtype=torch.float16, device=x.device)
+    with _dev(x):
+        call("agrl_split16_weight_planes", ptr(x), ptr(out), x.shape[0], x.shape[1], float(scale), _stream(x))
+    return out
+
+
+def distmat_split16(q3, g3, metric, g_unscale, qn=None, gn=None, out=None):
+    """q3 (m, 3D) query planes, g3 (n, 3D) gallery weight planes -> fp32 (m, n) distance matrix in the split-fp16 arithmetic
+    (agrl_distmat_split16). distance.py:59-89."""
+    m, D3 = q3.shape
+    n = g3.shape[0]
+    assert g3.shape[1] == D3 and q3.dtype == torch.float16 and g3.dtype == torch.float16
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=q3.device)
+    code = METRIC_EUCLIDEAN if metric == "euclidean" else METRIC_COSINE
+    if _hip.PROFILE is not None:
+        _hip.PROFILE_TAG = {"flops": 2.0 * m * n * D3 / 3, "mfma_flops": 2.0 * m * n * D3, "bytes": 2.0 * (m + n) * D3 + 4.0 * m * n}
+    ws = None
+    if (-(-m // 64)) * (-(-n // 128)) < 256:
+        ws = torch.empty((8 * m * n,), dtype=torch.float32, device=q3.device)
+    with _dev(q3):
+        call("agrl_distmat_split16", ptr(q3), ptr(g3), ptr(qn), ptr(gn), out.data_ptr(), m, n, D3, out.stride(0), code, float(g_unscale),
+             ptr(ws), 0 if ws is None else ws.numel() * 4, _stream(q3))
+    return out
+
+
 def from_split16_planes(x3):
     """planes (..., 3 C) -> fp32 (..., C) = hi + lo 2^-11 (exact): tests and the stage-by-stage parity hooks (torch arithmetic: not
     on the product path)."""

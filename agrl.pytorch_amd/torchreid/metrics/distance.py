@@ -18,7 +18,7 @@ import torch
 from torch.nn import functional as F
 
 # 'fp32' = exact-fp32 MFMA (parity mode); 'fp16' (or 'bf16' with the bf16 build of the library: hip_ops.LP_NAME) = 16-bit
-# operands, fp32 accumulation (throughput mode)
+# operands, fp32 accumulation (throughput mode); 'fp16x3' (round 6) = split-fp16 plane operands through the 16-bit kernels: fp32-class
 HIP_PRECISION = os.environ.get('AGRL_HIP_PRECISION', 'fp32')
 
 
@@ -59,6 +59,18 @@ def _hip_distmat(input1, input2, metric):
 def hip_distmat_device(q, g, metric, precision='fp32', out=None):
     """Device-resident form: q (m,d), g (n,d) fp32 CUDA tensors -> fp32 (m,n) on the same device."""
     from torchreid import hip_ops as ops
+    if precision == 'fp16x3' and ops.split16_planes_available() and q.size(1) % 64 == 0:
+        # the conforming mode (round 6): the 16-bit kernels on split-fp16 plane operands -- fp32-class distances (22 significand bits per
+        # operand, fp32 accumulation) at a third of the 16-bit rate instead of the exact-fp32 kernel's sixteenth
+        import math
+        if metric == 'euclidean':
+            qn, gn = ops.row_sqnorm(q), ops.row_sqnorm(g)
+            amax = float(g.abs().max())
+            k = (13 - math.frexp(amax)[1] + 1) if (amax > 0.0 and math.isfinite(amax)) else 0
+            return ops.distmat_split16(ops.to_split16_planes(q), ops.to_split16_weight_planes(g, 2.0 ** k), 'euclidean', 2.0 ** -k, qn, gn, out=out)
+        qh, gh = ops.row_l2_normalize(q, True, torch.float32), ops.row_l2_normalize(g, True, torch.float32)
+        # (unit rows: every entry is at most 1 in magnitude -> 2^13 puts the largest possible entry at 2^13)
+        return ops.distmat_split16(ops.to_split16_planes(qh), ops.to_split16_weight_planes(gh, 2.0 ** 13), 'cosine', 2.0 ** -13, out=out)
     lp = ops.is_lp16(precision)
     dt = ops.LP_DTYPE if lp else torch.float32
     km = ops.k_multiple(dt)

@@ -541,6 +541,16 @@ def config5_block(device, embeddings, metric):
             out["topk50_ms"] = round(t_topk, 3)
             out["topk50_gbs"] = round(4.0 * QUERY_ROWS * GALLERY_ROWS / (t_topk * 1e-3) / 1e9, 1)
             out["rank_mars_ms"] = round(t_mars, 3)
+            d_fp32 = d
+    if metric == "cosine" and ops.split16_planes_available():
+        # the conforming mode's distance matrix (round 6): the 16-bit kernels on split-fp16 plane operands -- fp32-class distances
+        q32, g32 = ops.row_l2_normalize(qf, True, torch.float32), ops.row_l2_normalize(gf, True, torch.float32)
+        (q3, g3), t_prep = timed(lambda: (ops.to_split16_planes(q32), ops.to_split16_weight_planes(g32, 2.0 ** 13)))
+        d3, t_mm = timed(lambda: ops.distmat_split16(q3, g3, "cosine", 2.0 ** -13))
+        out["fp16x3"] = {"prepare_ms": round(t_prep, 3), "distmat_ms": round(t_mm, 3), "tflops": round(flops / (t_mm * 1e-3) / 1e12, 1),
+                         "peak": round(PEAK_TFLOPS["fp16x3"], 1), "frac_of_mfma_peak": round(flops / (t_mm * 1e-3) / 1e12 / PEAK_TFLOPS["fp16x3"], 4),
+                         "max_abs_diff_vs_exact_fp32": float("%.3g" % (d3 - d_fp32).abs().max().item()),
+                         "top50_equals_exact_fp32": bool(torch.equal(ops.rank_topk(d3, 50)[0], ops.rank_topk(d_fp32, 50)[0]))}
     return out
 
 

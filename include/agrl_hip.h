@@ -129,6 +129,8 @@ int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scale
  * torchreid/models/vmgn.py:45-65 / :288-289 in the reference's own fp32 accuracy class (tests/test_gpu_fullsplit.py: every index that
  * differs from the CPU oracle's ranked lists is a swap inside a near-tie, as for the exact-fp32 mode). */
 int agrl_split16_planes(const float* x, void* out, long long rows, int C, agrl_stream_t stream);   /* fp32 (rows, C) -> planes (rows, 3 C) */
+/* fp32 (rows, C) -> the weight-side triple (rows, 3 C) = [h | h 2^-11 | l] of x * scale (scale a power of two): gallery rows of agrl_distmat_split16 */
+int agrl_split16_weight_planes(const float* x, void* out, long long rows, int C, float scale, agrl_stream_t stream);
 /* 1x1 conv (+ residual planes) on planes: x (M, K3), residual NULL or (M, 3 Cout), out (M, 3 Cout); K3 % 384 == 0, Cout % 256 == 0 */
 int agrl_conv1x1_split16(const void* x, const void* packed, const float* bias, const void* residual, void* out, int M, int K3,
                          int Cout, int relu, float w_unscale, agrl_stream_t stream);
@@ -428,6 +430,13 @@ int agrl_row_l2_normalize(const float* x, void* y, int R, int C, int ldy, int no
 int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn, float* dist,
                  int m, int n, int D, int ldd, int metric, int dtype, void* workspace,
                  size_t workspace_bytes, agrl_stream_t stream);
+
+/* The same distance matrix in the split-fp16 arithmetic of the conforming mode (round 6): q3 (m, D3) = [qh | ql 2^11 | qh] (agrl_split16_planes
+ * of the fp32 rows, L2-normalised first for cosine), g3 (n, D3) = [gh | gh 2^-11 | gl] of g 2^k, both fp16 with D3 = 3 D columns; the 16-bit
+ * kernels' dot product over D3 columns is then qh gh + ql gh + qh gl (22 significand bits per operand, fp32 accumulation) and g_unscale =
+ * 2^-k rides in the epilogue. qn / gn: fp32 squared norms of the true rows (euclidean). torchreid/metrics/distance.py:59-89. */
+int agrl_distmat_split16(const void* q3, const void* g3, const float* qn, const float* gn, float* dist, int m, int n, int D3,
+                         int ldd, int metric, float g_unscale, void* workspace, size_t workspace_bytes, agrl_stream_t stream);
 
 /* Per query row: the k smallest distances in ascending (distance, gallery index) order -- i.e.
  * np.argsort(dist[i])[:k] with ties broken towards the lower index -- torchreid/metrics/rank.py:170-172.

@@ -1390,6 +1390,33 @@ def test_distmat_wide_tile_192_columns(shape, metric, monkeypatch):
     assert torch.equal(auto, out["192"])
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+@pytest.mark.parametrize("shape", [(32, 12180, 4096), (1980, 3000, 4096), (256, 1523, 4096), (7, 60, 64), (37, 101, 128)])
+def test_distmat_split16_is_fp32_class(shape, metric):
+    """agrl_distmat_split16 (round 6: the 16-bit distance kernels -- streaming, tiled + split-K, the 256-column fp32-output tile -- on
+    split-fp16 plane operands, distance.py:59-89) against the fp64 oracle, beside the exact-fp32 kernel and the plain 16-bit one on the
+    same rows: fp32-class accuracy. The step's shape, a full-eval slab, an 8-GPU shard, tiny ragged ones."""
+    if LP16 != "fp16":
+        pytest.skip("fp16 build only")
+    from torchreid.metrics.distance import hip_distmat_device
+    m, n, D = shape
+    g = torch.Generator().manual_seed(m + n)
+    centers = torch.randn((16, D), generator=g)
+    q = centers[torch.randint(0, 16, (m,), generator=g)] + 0.5 * torch.randn((m, D), generator=g)
+    gal = centers[torch.randint(0, 16, (n,), generator=g)] + 0.5 * torch.randn((n, D), generator=g)
+    ref = O.euclidean_squared(q.double(), gal.double()) if metric == "euclidean" else O.cosine(q.double(), gal.double())
+    qd, gd = q.to(DEV), gal.to(DEV)
+    d3 = hip_distmat_device(qd, gd, metric, "fp16x3")
+    d32 = hip_distmat_device(qd, gd, metric, "fp32")
+    d16 = hip_distmat_device(qd, gd, metric, LP16)
+    torch.cuda.synchronize()
+    den = ref.abs().max().item()
+    e3, e32, e16 = [(t.double().cpu() - ref).abs().max().item() / den for t in (d3, d32, d16)]
+    print("distmat split16", shape, metric, "vs fp64: fp16x3 %.2e, exact fp32 %.2e, %s %.2e" % (e3, e32, LP16, e16))
+    assert d3.shape == (m, n) and torch.isfinite(d3).all()
+    assert e3 < 4 * e32 + 3e-7 and e3 * 50 < e16 + 1e-9
+
+
 def test_distmat_public_api_and_errors():
     from torchreid import metrics
     q, gal = torch.randn(7, 64), torch.randn(60, 64)
