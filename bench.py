@@ -367,7 +367,7 @@ def accuracy_block(model, device, S, metric):
         qf, _, _ = evaluation.extract_features(model, batches(q_pids, q_cams, 0), prefetch=False)
         gf, _, _ = evaluation.extract_features(model, batches(g_pids, g_cams, FS.QUERY_ROWS), prefetch=False)
         cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50,
-                                                       "fp32" if prec in SPLIT else prec, return_topk=True)
+                                                       "fp32" if prec == "bf16x3" else prec, return_topk=True)   # (fp16x3 matches in its own split-fp16 distance matrix)
         torch.cuda.synchronize()
         out[prec] = {"rank1": round(float(cmc[0]), 6), "rank5": round(float(cmc[4]), 6), "mAP": round(float(mAP), 6),
                      "seconds": round(time.perf_counter() - t0, 2)}

@@ -118,7 +118,8 @@ def test_split_fp16_pipeline_at_full_size_against_the_oracle(embedded_split16, m
     z, (q_pids, q_cams, g_pids, g_cams), qf, gf = embedded_split16
     ref = z["q_emb_head"].astype(np.float64)
     e = np.abs(qf[:16].cpu().double().numpy() - ref).max() / np.abs(ref).max()
-    cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, "fp32", return_topk=True)
+    # (the matching stage in the conforming mode's own arithmetic as well: agrl_distmat_split16 + top-k)
+    cmc, mAP, idx, val = evaluation.match_and_rank(qf, q_pids, q_cams, gf, g_pids, g_cams, metric, 50, "fp16x3", return_topk=True)
     c = FS.compare_topk(idx, val, z[metric + "_idx"], z[metric + "_val"])
     o_cmc, o_map = z[metric + "_cmc"], float(z[metric + "_mAP"])
     print("fp16x3 %s: embedding rel err %.2e | Rank-1 %.6f (oracle %.6f) mAP %.6f (oracle %.6f) | top-1 agreement %.6f, top-50 index agreement "
