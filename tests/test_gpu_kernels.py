@@ -461,7 +461,7 @@ def test_conv1x1_packed_res(case):
         ops.call("agrl_conv1x1_packed_res_bn_act", ops.ptr(dx), ops.ptr(packed), ops.ptr(b.to(DEV)), None, ops.ptr(out), N * H * W, K + 64, Cout, 1, None)
 
 
-@pytest.mark.parametrize("case", ["res", "plain_k2048", "plain_k1024", "dual", "strided_l2", "strided_l3", "pool_parts", "pool_sum", "ragged"])
+@pytest.mark.parametrize("case", ["res", "plain_k2048", "plain_k1024", "dual", "strided_l2", "strided_l3", "pool_parts", "pool_sum", "ragged", "two_slabs"])
 def test_conv1x1_duo_persistent_form_is_bit_identical(case, monkeypatch):
     """The default dispatch since round 6 (conv1x1_duo_persist_kernel; AGRL_DUO_PERSIST=0 is the one-shot form it is compared with) -- two persistent workgroups per CU, the next tile's first slab and weight
     ring requested during the current tile's last slabs, the epilogue in two 64-row passes inside ONE pixel buffer) against the one-shot
@@ -499,6 +499,10 @@ def test_conv1x1_duo_persistent_form_is_bit_identical(case, monkeypatch):
             pk = ops.conv1x1_pack(w)
             splits, mean = ([4, 2, 1], True) if case == "pool_parts" else ([1], False)
             return list(ops.conv1x1_packed_res_pool(x, pk, b, 2048, r, splits, mean, True))
+        if case == "two_slabs":    # K = 256: the shortest pipeline the persistent form takes (the next tile's slab 0 is requested during slab 0)
+            x, w, b, r = rnd((300, 16, 8, 256), relu=True), rnd((1024, 256), 0.06), rnd((1024,)).float(), rnd((300, 16, 8, 1024))
+            pk = ops.conv1x1_pack(w)
+            return [ops.conv1x1_packed_res(x, pk, b, 1024, r, True)]
         # ragged: 131 frames x 100 px (M = 13100: a partial last tile), K = 384 (three slabs: odd), Cout = 1280 (five channel tiles)
         x, w, b, r = rnd((131, 10, 10, 384), relu=True), rnd((1280, 384), 0.05), rnd((1280,)).float(), rnd((131, 10, 10, 1280))
         pk = ops.conv1x1_pack(w)
