@@ -1198,6 +1198,34 @@ def test_stem_split16_matches_float64(shape):
     assert e16 < 4 * e32 + 2.4e-7
 
 
+def test_split16_entry_points_validate_their_arguments():
+    """The plane entry points refuse what they cannot compute instead of computing something else: the bf16 build (the planes are fp16),
+    channel counts that are not whole plane triples of whole slabs, an un-scaling factor that is not a power of two."""
+    from torchreid import hip_ops as ops
+    x = torch.rand((4, 16, 8, 128), device=DEV)
+    if LP16 != "fp16":
+        with pytest.raises(_hip.HipKernelError):
+            ops.to_split16_planes(x)
+        with pytest.raises(_hip.HipKernelError):
+            ops.to_split16_weight_planes(x.view(-1, 128), 8.0)
+        return
+    x3 = ops.to_split16_planes(x)
+    w3, u = ops.split16_plane_weights(torch.randn((256, 128), device=DEV) * 0.05)
+    pk = ops.conv1x1_pack(w3)
+    b = torch.zeros(256, device=DEV)
+    out = ops.conv1x1_split16(x3, pk, u, b, 256)
+    assert tuple(out.shape) == (4, 16, 8, 768)
+    with pytest.raises(_hip.HipKernelError):   # 0.3 is not a power of two
+        ops.conv1x1_split16(x3, pk, 0.3, b, 256)
+    with pytest.raises(_hip.HipKernelError):   # K3 = 320 is not a whole number of plane triples of 128-channel slabs
+        ops.call("agrl_conv1x1_split16", ops.ptr(x3), ops.ptr(pk), ops.ptr(b), None, ops.ptr(out), 512, 320, 256, 1, 1.0, None)
+    with pytest.raises(_hip.HipKernelError):   # scale of the weight planes must be a power of two
+        ops.to_split16_weight_planes(x.view(-1, 128), 3.0)
+    with pytest.raises(_hip.HipKernelError):   # D3 must be a multiple of 3
+        q3 = torch.zeros((8, 128), dtype=torch.float16, device=DEV)
+        ops.call("agrl_distmat_split16", ops.ptr(q3), ops.ptr(q3), None, None, ops.ptr(torch.zeros((8, 8), device=DEV)), 8, 8, 128, 8, 1, 1.0, None, 0, None)
+
+
 def _planes_ref(x3):
     from torchreid import hip_ops as ops
     return ops.from_split16_planes(x3).double().cpu()
