@@ -169,6 +169,26 @@ def test_out_of_range_activations_fail_loudly_in_the_16_bit_mode(factor, message
         assert torch.isfinite(f).all()
 
 
+def test_out_of_range_activations_fail_loudly_in_the_conforming_mode():
+    """'fp16x3' carries activations as fp16 high / low halves (in the planes and inside the in-loop split): beyond 65504 the high half is
+    inf, the embedding non-finite, and extract_features refuses it -- in both builds of the library (the split is fp16 in either)."""
+    from torchreid import evaluation, models
+    m = models.init_model("vmgn", num_classes=4, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True)
+    sd = recipe_state_dict(m.state_dict(), seed=0)
+    sd["bn1.weight"] = sd["bn1.weight"] * 3e4
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.hip_precision = "fp16x3"
+    x, adj = synthetic_clips(2, 4, seed=3), synthetic_adj(2, 4, seed=3)
+    batch = [(x, np.zeros(2, dtype=np.int64), np.zeros(2, dtype=np.int64), adj)]
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        evaluation.extract_features(m, batch, prefetch=False)
+    m.hip_precision = "fp32"      # the exact mode has fp32's range: the same checkpoint passes
+    f, _, _ = evaluation.extract_features(m, batch, prefetch=False)
+    assert torch.isfinite(f).all()
+
+
 @pytest.mark.parametrize("sample", ["evenly", "dense"])
 @pytest.mark.parametrize("metric", ["cosine", "euclidean"])
 def test_device_pipeline_equals_the_reference_test_function(metric, sample):
