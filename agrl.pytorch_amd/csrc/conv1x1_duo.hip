@@ -64,13 +64,6 @@ struct DuoParams {
     // k-loop simply rows of 3 x the channels (K counts them); res / out: (M, 3 Cout). alpha un-does the weights' power-of-two pre-scale.
     float alpha;
     int planes;
-    // fp32 distance epilogue of the persistent form (agrl_distmat_packed: "pixel rows" = queries, "channels" = packed gallery rows):
-    // dist[m][n] = alpha acc + (rowv ? rowv[m] : rowc) + (colv ? colv[n] : 0), stored for m < M, n < n_valid; row stride ldf floats
-    float* outf;
-    const float* rowv;
-    const float* colv;
-    float rowc;
-    int n_valid, ldf;
 };
 
 #ifndef DUO_ABL
@@ -532,11 +525,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
 // the co-resident workgroup's traffic, profiles/r05_duo_timeline.txt) is requested a whole slab + an epilogue ahead here. Results bit-identical
 // (same k order, same epilogue arithmetic). Every counted wait of the one-shot form stays valid: a wait "at most N operations outstanding"
 // only ever meets MORE already-retired operations in this order, never fewer.
-typedef __attribute__((address_space(3))) f32x4_t lds_f32x4_t;
-
-template <bool POOL, bool F32OUT = false>
+template <bool POOL>
 __global__ __launch_bounds__(256, 2) void conv1x1_duo_persist_kernel(const DuoParams p, int ntiles) {
-    static_assert(!(POOL && F32OUT), "the distance epilogue has no pooling");
     using SCHED = DuoSchedOf;
     using std::integral_constant;
     __shared__ __attribute__((aligned(16))) unsigned char smem_[2 * DSLAB];
@@ -693,47 +683,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_persist_kernel(const DuoPa
         const int bufE = (nslab - 1 + par) & 1;
         lds_u8_t* const wt = smem + bufE * DSLAB + wave * 8192;
         const unsigned ldsE = lds0 + bufE * DSLAB + wave * 8192;
-        if constexpr (F32OUT) {
-            // fp32 distance tile: the wave's 128 rows x 64 columns leave in FOUR passes of 32 rows through its 8 KB image, rows of 256 B
-            // (64 floats), 16-byte chunk c of row r at c ^ (r & 15): the accumulator layout writes 8 different rows per store group
-            // (conflict-free with the XOR), a row leaves as 16 lanes x 16 B = one contiguous 256-byte segment.
-            int l_e = lane;
-            sfor<4>([&](auto hc) {
-                constexpr int h = decltype(hc)::value;
-                // (an opaque copy of the lane id per pass: the column / row terms are recomputed here instead of being carried through the
-                // k-loop or across the passes -- the instantiation sits at its 128 arch VGPRs with the next tile's weight ring live)
-                asm volatile("" : "+v"(l_e));
-                const int frow = l_e & 15, fchunk = l_e >> 4;
-                const int cbf = nt * 256 + wave * 64 + 8 * fchunk;      // this lane's 8 columns of (j, .): cbf + 32 j .. + 7
-                sfor<2>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    float cv[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) cv[e] = (p.colv && cbf + 32 * j + e < p.n_valid) ? p.colv[cbf + 32 * j + e] : 0.f;
-                    sfor<2>([&](auto bc) {
-                        constexpr int BL = decltype(bc)::value, B = 2 * h + BL;
-                        const f32x4_t lo = fat_read<(2 * j) * 8 + B>(), hi = fat_read<(2 * j + 1) * 8 + B>();
-                        const int r = 16 * BL + frow;                       // row inside the pass
-                        const int gm = m0 + 32 * h + r;
-                        const float rv = p.rowv ? p.rowv[min(gm, p.M - 1)] : p.rowc;
-                        const f32x4_t v0 = {fmaf(alpha, lo[0], rv + cv[0]), fmaf(alpha, lo[1], rv + cv[1]), fmaf(alpha, lo[2], rv + cv[2]), fmaf(alpha, lo[3], rv + cv[3])};
-                        const f32x4_t v1 = {fmaf(alpha, hi[0], rv + cv[4]), fmaf(alpha, hi[1], rv + cv[5]), fmaf(alpha, hi[2], rv + cv[6]), fmaf(alpha, hi[3], rv + cv[7])};
-                        const int c0 = 8 * j + 2 * fchunk;                  // 16-byte chunk of the first four columns
-                        *reinterpret_cast<lds_f32x4_t*>(wt + r * 256 + (((c0) ^ (r & 15)) << 4)) = v0;
-                        *reinterpret_cast<lds_f32x4_t*>(wt + r * 256 + (((c0 + 1) ^ (r & 15)) << 4)) = v1;
-                    });
-                });
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = 4 * i + (l_e >> 4), slot = l_e & 15;
-                    const f32x4_t v = *reinterpret_cast<const lds_f32x4_t*>(wt + r * 256 + (slot << 4));
-                    const int gm = m0 + 32 * h + r;
-                    const int gn = nt * 256 + wave * 64 + 4 * (slot ^ (r & 15));
-                    if (gm < p.M && gn + 3 < p.n_valid) *reinterpret_cast<f32x4_t*>(p.outf + (size_t)gm * p.ldf + gn) = v;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is rewritten by the next pass
-            });
-        } else {
         const size_t colb = (size_t)(nt * 256 + wave * 64) * 2;
         const int cb = nt * 256 + wave * 64 + 8 * fchunk;
         int lrow_e = lrow, lchk_e = lchk;
@@ -840,7 +789,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_persist_kernel(const DuoPa
                 if (p.pool_out_lp) p.pool_out_lp[oi] = f32_to_lp16(t);
             }
         }
-        }  // (!F32OUT)
         if (!has_next) break;
         // ---- on to the next tile: its slab 0 sits in the other buffer, its first ring in wr[]; slab 1 goes where the images were
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1127,38 +1075,5 @@ extern "C" int agrl_split16_weight_planes(const float* x, void* out, long long r
     hipLaunchKernelGGL(split16_weight_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
                        reinterpret_cast<uint2*>(out), groups, C / 4, scale);
     AGRL_CHECK_LAUNCH("agrl_split16_weight_planes");
-    return 0;
-}
-
-// The full query x gallery distance matrix (BASELINE configs[4]; torchreid/metrics/distance.py:59-89) through the persistent duo kernel:
-// "pixel rows" = the m query rows (16-bit, (m, D)), "channels" = the gallery, padded to n_pad = a multiple of 256 rows and re-ordered ONCE
-// by agrl_conv1x1_pack into per-wave fragment streams (a resident gallery is packed when it is loaded); fp32 distance epilogue
-// dist = alpha dot + qn[m] + gn[n] (euclidean: alpha -2) / 1 - dot (cosine), columns >= n never stored. Against the 8-wave LDS-ring tile
-// of igemm_wide.hip this form keeps two workgroups per CU and streams the gallery fragments global -> registers. n % 4 == 0, ldd % 4 == 0.
-extern "C" int agrl_distmat_packed(const void* q, const void* g_packed, const float* qn, const float* gn, float* dist, int m, int n, int n_pad,
-                                   int D, int ldd, int metric, agrl_stream_t stream) {
-    AGRL_CHECK_ARG(q && g_packed && dist, "agrl_distmat_packed: null pointer");
-    AGRL_CHECK_ARG(m > 0 && n > 0 && n_pad >= n && n_pad % 256 == 0 && D >= 256 && D % 128 == 0 && ldd >= n, "agrl_distmat_packed: needs n_pad %% 256 == 0 >= n, D %% 128 == 0 (>= 256); got m=%d n=%d n_pad=%d D=%d ldd=%d", m, n, n_pad, D, ldd);
-    AGRL_CHECK_ARG(n % 4 == 0 && ldd % 4 == 0 && (((uintptr_t)q | (uintptr_t)g_packed | (uintptr_t)dist) & 15) == 0, "agrl_distmat_packed: n and ldd multiples of 4, 16-byte aligned pointers");
-    AGRL_CHECK_ARG((size_t)m * D * 2 < (1ull << 32), "agrl_distmat_packed: queries beyond 4 GB are not addressed");
-    DuoParams p{};
-    p.x = reinterpret_cast<const unsigned char*>(q);
-    p.wpk = reinterpret_cast<const unsigned char*>(g_packed);
-    p.M = m; p.K = D; p.K1 = D; p.Cout = n_pad; p.relu = 0;
-    p.outf = dist; p.ldf = ldd; p.n_valid = n;
-    if (metric == AGRL_METRIC_EUCLIDEAN) {
-        AGRL_CHECK_ARG(qn && gn, "agrl_distmat_packed: euclidean needs the squared row norms");
-        p.alpha = -2.f; p.rowv = qn; p.colv = gn; p.rowc = 0.f;
-    } else if (metric == AGRL_METRIC_COSINE) {
-        p.alpha = -1.f; p.rowv = nullptr; p.colv = nullptr; p.rowc = 1.f;
-    } else {
-        agrl_set_error("agrl_distmat_packed: unknown metric %d", metric);
-        return 1;
-    }
-    p.planes = 1;   // (keeps duo_launch's alpha = 1 default off; the plane epilogue itself is not instantiated for this form)
-    const int ntiles = ((m + DROWS - 1) / DROWS) * (n_pad >> 8);
-    const int grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL((conv1x1_duo_persist_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, ntiles);
-    AGRL_CHECK_LAUNCH("agrl_distmat_packed");
     return 0;
 }

@@ -102,7 +102,6 @@ SIGNATURES = {
     "agrl_attn_pool_bnneck": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_attn_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_row_l2_normalize": [_p, _p, _i, _i, _i, _i, _i, _p],
-    "agrl_distmat_packed": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "agrl_distmat_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, C.c_size_t, _p],
     "agrl_distmat": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, C.c_size_t, _p],
     "agrl_pose_adjacency": [_p, _p, _p, _i, _i, _i, _i, C.c_float, C.c_float, _p],

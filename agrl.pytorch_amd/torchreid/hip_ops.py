@@ -1016,34 +1016,6 @@ def distmat(q, g, metric, qn=None, gn=None, out=None):
     return out
 
 
-def distmat_pack_gallery(g):
-    """16-bit gallery rows (n, D), prepared as for ``distmat`` (L2-normalised for cosine) -> (packed uint8 tensor, n_pad): padded to a
-    multiple of 256 rows and re-ordered once into the per-wave fragment streams of the persistent duo kernel (agrl_conv1x1_pack). Done
-    when a gallery becomes resident; ``distmat_packed`` then runs the full query x gallery matrix through it."""
-    n, D = g.shape
-    assert g.dtype == LP_DTYPE and D % 128 == 0
-    n_pad = -(-n // 256) * 256
-    if n_pad != n:
-        g = torch.cat([g, torch.zeros((n_pad - n, D), dtype=g.dtype, device=g.device)], dim=0)
-    return conv1x1_pack(g.contiguous()), n_pad
-
-
-def distmat_packed(q, g_packed, n, n_pad, metric, qn=None, gn=None, out=None):
-    """q (m, D) 16-bit queries against a gallery packed by distmat_pack_gallery -> fp32 (m, n) (agrl_distmat_packed): the FULL-eval form
-    (BASELINE configs[4]); equals ``distmat`` up to the order of the fp32 sums. distance.py:59-89."""
-    m, D = q.shape
-    assert q.dtype == LP_DTYPE and q.is_contiguous() and g_packed.numel() == 2 * n_pad * D and n % 4 == 0
-    if out is None:
-        out = torch.empty((m, n), dtype=torch.float32, device=q.device)
-    assert out.stride(1) == 1 and out.dtype == torch.float32 and out.stride(0) % 4 == 0
-    code = METRIC_EUCLIDEAN if metric == "euclidean" else METRIC_COSINE
-    if _hip.PROFILE is not None:
-        _hip.PROFILE_TAG = {"flops": 2.0 * m * n * D, "bytes": 2.0 * (m + n) * D + 4.0 * m * n}
-    with _dev(q):
-        call("agrl_distmat_packed", ptr(q), ptr(g_packed), ptr(qn), ptr(gn), out.data_ptr(), m, n, n_pad, D, out.stride(0), code, _stream(q))
-    return out
-
-
 def rank_topk(dist, k, idx_offset=0):
     """dist (m,n) fp32 -> idx int32 (m,k), val fp32 (m,k), ascending (distance, index). rank.py:170-172."""
     m, n = dist.shape

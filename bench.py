@@ -535,13 +535,6 @@ def config5_block(device, embeddings, metric):
             out[prec]["distmat_topk50_ms"] = round(t_f, 3)
             idx_s, _ = ops.rank_topk(d, 50)
             out[prec]["distmat_topk50_equals_separate"] = bool(torch.equal(idx_f, idx_s))
-        if prec == ops.LP_NAME and metric == "cosine":
-            # round 6: the same matrix through the persistent duo kernel with the gallery packed once into fragment streams
-            (packed, n_pad), t_pack = timed(lambda: ops.distmat_pack_gallery(gh))
-            dp, t_p = timed(lambda: ops.distmat_packed(qh, packed, GALLERY_ROWS, n_pad, "cosine"))
-            out[prec + "_packed_gallery"] = {"pack_ms_once_per_gallery": round(t_pack, 3), "distmat_ms": round(t_p, 3),
-                                             "tflops": round(flops / (t_p * 1e-3) / 1e12, 1), "frac_of_mfma_peak": round(flops / (t_p * 1e-3) / 1e12 / peak, 4),
-                                             "max_abs_diff_vs_distmat": float("%.3g" % (dp - d).abs().max().item())}
         if prec == "fp32":
             (idx, _), t_topk = timed(lambda: ops.rank_topk(d, 50))
             _, t_mars = timed(lambda: ops.rank_mars(idx, q_pids, q_cams, g_pids, g_cams))

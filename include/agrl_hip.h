@@ -431,13 +431,6 @@ int agrl_distmat(const void* q, const void* g, const float* qn, const float* gn,
                  int m, int n, int D, int ldd, int metric, int dtype, void* workspace,
                  size_t workspace_bytes, agrl_stream_t stream);
 
-/* The FULL query x gallery matrix (BASELINE configs[4]) with the gallery pre-packed: g_packed = agrl_conv1x1_pack of the 16-bit gallery
- * rows padded to n_pad (a multiple of 256; padding rows arbitrary, their columns are never stored). q (m, D) 16-bit; qn / gn fp32 squared
- * norms (euclidean) or NULL (cosine, rows L2-normalised); dist (m, ldd) fp32. n and ldd multiples of 4, D a multiple of 128. Same result
- * as agrl_distmat up to the order of the fp32 sums. torchreid/metrics/distance.py:59-89; what evaluate() builds per resident gallery. */
-int agrl_distmat_packed(const void* q, const void* g_packed, const float* qn, const float* gn, float* dist, int m, int n, int n_pad,
-                        int D, int ldd, int metric, agrl_stream_t stream);
-
 /* The same distance matrix in the split-fp16 arithmetic of the conforming mode (round 6): q3 (m, D3) = [qh | ql 2^11 | qh] (agrl_split16_planes
  * of the fp32 rows, L2-normalised first for cosine), g3 (n, D3) = [gh | gh 2^-11 | gl] of g 2^k, both fp16 with D3 = 3 D columns; the 16-bit
  * kernels' dot product over D3 columns is then qh gh + ql gh + qh gl (22 significand bits per operand, fp32 accumulation) and g_unscale =

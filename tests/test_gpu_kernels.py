@@ -1449,39 +1449,6 @@ def test_distmat_split16_is_fp32_class(shape, metric):
     assert e3 < 4 * e32 + 3e-7 and e3 * 5 < e16 + 1e-9    # (measured: 1.6e-6 .. 3.8e-6 against 1.3e-6 .. 3.3e-6 exact and 2.4e-5 .. 2.9e-5 in plain fp16)
 
 
-@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
-@pytest.mark.parametrize("shape", [(1980, 12180, 4096), (700, 3000, 512), (130, 1024, 256), (1, 260, 384)])
-def test_distmat_packed_gallery_form(shape, metric):
-    """agrl_distmat_packed (round 6: the full query x gallery matrix through the persistent duo kernel, gallery packed once into
-    fragment streams, fp32 distance epilogue; distance.py:59-89) against agrl_distmat on the same 16-bit operands (same products,
-    another order of the fp32 sums: <= 2e-6 of the largest distance) and the fp64 oracle: the MARS shape (48 gallery tiles, the last
-    one ragged: 12 180 = 47 x 256 + 148), a gallery that is not a multiple of 256, fewer queries than a tile, a single query."""
-    from torchreid import hip_ops as ops
-    m, n, D = shape
-    g = torch.Generator().manual_seed(m + n)
-    q, gal = torch.randn((m, D), generator=g), torch.randn((n, D), generator=g)
-    ref = O.euclidean_squared(q.double(), gal.double()) if metric == "euclidean" else O.cosine(q.double(), gal.double())
-    qd, gd = q.to(DEV), gal.to(DEV)
-    if metric == "euclidean":
-        qn, gn = ops.row_sqnorm(qd), ops.row_sqnorm(gd)
-        q16, g16 = ops.row_l2_normalize(qd, False, LP_DTYPE), ops.row_l2_normalize(gd, False, LP_DTYPE)
-    else:
-        qn = gn = None
-        q16, g16 = ops.row_l2_normalize(qd, True, LP_DTYPE), ops.row_l2_normalize(gd, True, LP_DTYPE)
-    base = ops.distmat(q16, g16, metric, qn, gn)
-    packed, n_pad = ops.distmat_pack_gallery(g16)
-    sentinel = torch.full((m, n + 4), -7.0, device=DEV)            # a row stride wider than n: nothing beyond column n - 1 may be written
-    got = ops.distmat_packed(q16, packed, n, n_pad, metric, qn, gn, out=sentinel[:, :n])
-    got_b = ops.distmat_packed(q16, packed, n, n_pad, metric, qn, gn)
-    torch.cuda.synchronize()
-    den = base.abs().max().item()
-    d = (got - base).abs().max().item() / den
-    e = rel_err(got, ref)
-    print("distmat packed", shape, metric, "vs agrl_distmat %.2e, vs fp64 %.2e" % (d, e))
-    assert torch.equal(got, got_b) and bool((sentinel[:, n:] == -7.0).all())
-    assert d < 2e-6 and e < 1e-2
-
-
 def test_distmat_public_api_and_errors():
     from torchreid import metrics
     q, gal = torch.randn(7, 64), torch.randn(60, 64)
