@@ -182,9 +182,9 @@ def pack_weights(model, device, precision):
         # .clone) would silently run as a 2^k-times-too-large exact-fp32 weight -- checked once per pack
         stages = pack['trunk'] + pack.get('l4_1', []) + pack.get('l4_2', []) + pack.get('l4', [])
         for blk in stages:
-            for key in ('c1', 'c2', 'c3', 'ds'):
-                if blk.get(key) is not None and not hasattr(blk[key][0], 'agrl_unscale'):
-                    raise RuntimeError("fp16x3 pack: %s lost its pre-scale attribute" % key)
+            for name in ('c1', 'c2', 'c3', 'ds'):
+                if blk.get(name) is not None and not hasattr(blk[name][0], 'agrl_unscale'):
+                    raise RuntimeError("fp16x3 pack: %s lost its pre-scale attribute" % name)
     if s16 and ops.split16_planes_available() and hasattr(model, 'layer4_1') and ops.switch_on('AGRL_HIP_SPLIT16_PLANES'):
         # the conforming mode at speed: behind layer 3's first block every Bottleneck runs on split-fp16 PLANES through the throughput
         # mode's four-wave kernels (ops.conv1x1_split16 / conv3x3_split16); the stem .. layer 3's first block keep fp32 tensors and the

@@ -322,3 +322,33 @@ def test_host_side_switches_are_cached_until_reload(monkeypatch):
     monkeypatch.delenv("AGRL_HIP_FUSE_SEAM")
     _hip.reload_options()
     assert ops.seam_enabled()
+
+
+def test_weight_packs_are_cached_per_precision(monkeypatch):
+    """pack_weights packs once per (device, precision) and answers from the cache while no parameter / buffer changed -- for every
+    precision mode (round 6: a loop variable in the fp16x3 pack once shadowed the cache key, and every forward re-packed: correct
+    results at half the speed, visible only in the bench line). Runs without a GPU: the in-loop form of fp16x3 packs with torch ops only."""
+    from unittest import mock
+    import torch
+    from recipe import recipe_state_dict
+    from torchreid import hip_ops as ops
+    from torchreid import models
+    from torchreid.models import _vmgn_hip as V
+    monkeypatch.setenv("AGRL_HIP_SPLIT16_PLANES", "0")   # (the plane packs go through the library's pack kernels: GPU only)
+    ops._SWITCHES.clear()
+    m = models.init_model("vmgn", num_classes=4, loss={"xent", "htri"}, last_stride=1, num_split=4, num_gb=2, num_scale=1,
+                          pyramid_part=True, use_pose=True, learn_graph=True)
+    m.load_state_dict(recipe_state_dict(m.state_dict(), seed=0))
+    m.eval()
+    dev = torch.device("cpu")
+    try:
+        with mock.patch("torch.cuda.current_device", return_value=0):
+            for prec in ("fp32", "bf16x3", "fp16x3"):
+                p1 = V.pack_weights(m, dev, prec)
+                assert V.pack_weights(m, dev, prec) is p1, prec
+                assert set(m._hip_packs) >= {(0, prec)} and all(isinstance(k, tuple) for k in m._hip_packs)
+            with torch.no_grad():
+                m.conv1.weight.mul_(1.0)                      # an in-place edit bumps the version: the pack is rebuilt
+            assert V.pack_weights(m, dev, "fp16x3") is not p1
+    finally:
+        ops._SWITCHES.clear()
