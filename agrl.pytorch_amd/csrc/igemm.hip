@@ -112,11 +112,13 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
     int tap_r = 0, tap_s = 0, c0 = 0;  // filter tap and channel offset of the tile being STAGED
     size_t kbyte = 0;                  // byte offset of that tile along K in the weight rows
     int nk = p.K / BKE;
+    [[maybe_unused]] int c_kt = 0;     // first k-tile of this workgroup
     if (p.ksplit > 1) {  // split-K (pointwise problems only): this workgroup owns k-tiles [z*nk/ks, (z+1)*nk/ks)
         const int per = nk / p.ksplit;
         c0 = blockIdx.y * per * BKE;
         kbyte = (size_t)blockIdx.y * per * 128;
         nk = per;
+        c_kt = blockIdx.y * per;
     }
 
     // one 1-KiB DMA piece of the k-tile being staged: pieces 0..AJ-1 are pixel rows, AJ..AJ+BJ-1 weight rows
@@ -242,17 +244,23 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         if constexpr (DT<TIN>::code == AGRL_F32H3) {
             // split-fp16: both k-halves of the tile feed ONE K = 32 MFMA triple per fragment pair (Frag<f32h_t>::mma32)
             uint4 xh[FM], xl[FM], wh[FN], wl[FN];
+            // (workgroup-uniform) the pixel rows of this k-tile were stored pre-split by the producing kernel's epilogue: operands as they stand
+            const bool a_pre = p.x2 ? ((c_kt + kt) * BKE >= p.K1 ? (p.a_pre & 2) : (p.a_pre & 1)) : (p.a_pre & 1);
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 const int row = wm * (BM / WM) + b * 16 + frow;
-                Frag<f32h_t>::split8(*reinterpret_cast<const uint4*>(sa + lds_off(row, fchunk)),
-                                     *reinterpret_cast<const uint4*>(sa + lds_off(row, 4 + fchunk)), xh[b], xl[b]);
+                const uint4 c0_ = *reinterpret_cast<const uint4*>(sa + lds_off(row, fchunk));
+                const uint4 c1_ = *reinterpret_cast<const uint4*>(sa + lds_off(row, 4 + fchunk));
+                if (a_pre) { xh[b] = c0_; xl[b] = c1_; }
+                else Frag<f32h_t>::split8(c0_, c1_, xh[b], xl[b]);
             }
+            // the weights arrive PRE-SPLIT (agrl_split16_weights_inloop): chunk g of a k-tile holds the fp16 high halves of this lane's eight
+            // k values, chunk 4 + g their low halves -- the same bytes as eight fp32, no VALU work per fragment
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
                 const int row = wn * (BN / 2) + a * 16 + frow;
-                Frag<f32h_t>::split8(*reinterpret_cast<const uint4*>(sb + lds_off(row, fchunk)),
-                                     *reinterpret_cast<const uint4*>(sb + lds_off(row, 4 + fchunk)), wh[a], wl[a]);
+                wh[a] = *reinterpret_cast<const uint4*>(sb + lds_off(row, fchunk));
+                wl[a] = *reinterpret_cast<const uint4*>(sb + lds_off(row, 4 + fchunk));
             }
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
@@ -351,6 +359,45 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
             }
         }
     } else {
+        if constexpr (DT<TIN>::code == AGRL_F32H3 && sizeof(TOUT) == 4) {
+            if (p.out_pre) {
+                // pre-split output (conv1 / conv2 of a Bottleneck: read by ONE consumer, as a GEMM operand). A lane's two fragments 2t, 2t + 1
+                // hold channels 4g..4g+3 and 16+4g..16+4g+3 of a 32-channel group: exactly lane group g's eight k values in the consumer
+                // -> fp16 halves formed here, once (the consumer's taps would each redo it), 16 bytes of hi at chunk g, lo at chunk 4 + g
+                unsigned char* ob = reinterpret_cast<unsigned char*>(p.out);
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
+                    if (gm >= p.M) continue;
+#pragma unroll
+                    for (int t = 0; t < FN / 2; ++t) {
+                        const int gn0 = n0 + wn * (BN / 2) + t * 32;
+                        if (gn0 >= p.N) continue;   // (N % 32 == 0: whole groups)
+                        uint32_t v[8];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float cv[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (p.colv) {
+                                const float4 c4 = *reinterpret_cast<const float4*>(p.colv + gn0 + h * 16 + fchunk * 4);
+                                cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float y = fmaf(p.alpha, acc[2 * t + h][b][r], cv[r]);
+                                if (p.relu) y = relu_nan(y);
+                                v[h * 4 + r] = __float_as_uint(y);
+                            }
+                        }
+                        uint4 hi, lo;
+                        Frag<f32h_t>::split8(make_uint4(v[0], v[1], v[2], v[3]), make_uint4(v[4], v[5], v[6], v[7]), hi, lo);
+                        unsigned char* dst = ob + ((size_t)gm * p.ldo + gn0) * 4 + fchunk * 16;
+                        *reinterpret_cast<uint4*>(dst) = hi;
+                        *reinterpret_cast<uint4*>(dst + 64) = lo;
+                    }
+                }
+                return;
+            }
+        }
         const bool vec_ok = p.vec_ok != 0;
         const bool do_stats = p.stats != nullptr;   // workgroup-uniform
         float st1[FN][4], st2[FN][4];
@@ -1005,12 +1052,46 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     return 0;
 }
 
+// The weight operand of the split-fp16 in-loop kernels: (rows, K) fp32, already scaled by the caller's power of two, -> the same
+// rows x K x 4 bytes with every 32-value k-tile stored as [hi of k 4c..4c+3 and 16+4c..16+4c+3 (8 fp16) for c = 0..3 | the low halves in
+// the same order]: the two 16-byte chunks lane group c reads of a k-tile ARE its operands of v_mfma_f32_16x16x32_f16.
+// hi = fp16(w) to nearest, lo = fp16(w - hi): the values Frag<f32h_t>::split8 would produce in the loop, produced once.
+namespace {
+__global__ void __launch_bounds__(256) split16_weights_inloop_kernel(const float4* __restrict__ w, uint4* __restrict__ out, long long groups) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < groups; g += (long long)gridDim.x * 256) {
+        const long long tile = g >> 2;
+        const int c = (int)(g & 3);
+        const float4 a = w[tile * 8 + c], b = w[tile * 8 + 4 + c];
+        const uint4 c0 = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
+        const uint4 c1 = make_uint4(__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w));
+        uint4 hi, lo;
+        Frag<f32h_t>::split8(c0, c1, hi, lo);
+        out[tile * 8 + c] = hi;
+        out[tile * 8 + 4 + c] = lo;
+    }
+}
+}  // namespace
+
+extern "C" int agrl_split16_weights_inloop(const float* w_scaled, void* out, long long rows, int K, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(w_scaled && out && rows > 0 && K > 0, "agrl_split16_weights_inloop: null pointer or empty shape");
+    AGRL_CHECK_ARG(K % 32 == 0, "agrl_split16_weights_inloop: K=%d must be a multiple of 32 (one k-tile)", K);
+    AGRL_CHECK_ARG((const void*)w_scaled != (const void*)out, "agrl_split16_weights_inloop: not in place");
+    AGRL_CHECK_ARG((((uintptr_t)w_scaled | (uintptr_t)out) & 15) == 0, "agrl_split16_weights_inloop: pointers must be 16-byte aligned");
+    const long long groups = rows * (K / 32) * 4;
+    const int grid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split16_weights_inloop_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(w_scaled),
+                       reinterpret_cast<uint4*>(out), groups);
+    AGRL_CHECK_LAUNCH("agrl_split16_weights_inloop");
+    return 0;
+}
+
 extern "C" int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, const float* bias, const void* residual, void* out, int N,
                                           int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int relu, float w_unscale,
-                                          agrl_stream_t stream) {
+                                          int x_presplit, int out_presplit, agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && w_scaled && out, "agrl_conv2d_bn_act_split16: null pointer");
     AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                    "agrl_conv2d_bn_act_split16: bad shape");
+    AGRL_CHECK_ARG(Cin % 32 == 0, "agrl_conv2d_bn_act_split16: Cin=%d must be a multiple of 32 (the pre-split weight k-tile)", Cin);
     AGRL_CHECK_ARG(w_unscale > 0.f && w_unscale == w_unscale && w_unscale <= 3.4e38f, "agrl_conv2d_bn_act_split16: w_unscale must be a positive finite power of two");
     {
         int e = 0;
@@ -1019,6 +1100,8 @@ extern "C" int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, c
     IgemmParams p{};
     p.x2 = nullptr; p.K1 = 0; p.stats = nullptr;
     p.x = x; p.w = w_scaled; p.colv = bias; p.rowv = nullptr; p.res = residual; p.out = out;
+    AGRL_CHECK_ARG(!out_presplit || (!residual && Cout % 32 == 0), "agrl_conv2d_bn_act_split16: a pre-split output takes no residual and Cout %% 32 == 0 (got %d)", Cout);
+    p.a_pre = x_presplit ? 1 : 0; p.out_pre = out_presplit ? 1 : 0;
     p.alpha = w_unscale; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
     p.OH = (H + 2 * pad - R) / stride + 1;
     p.OW = (W + 2 * pad - S) / stride + 1;
@@ -1034,7 +1117,8 @@ extern "C" int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, c
 // x (N, H, W, K1) the block input, x2 (N, OH, OW, K2) conv2's output, out (N, OH, OW, Cout); OH = (H - 1) / stride + 1. The
 // conforming mode's counterpart of agrl_conv1x1_packed_dual_strided: the fp32 shortcut map (537 MB in layer 1) no longer exists.
 extern "C" int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scaled, const float* bias, void* out, int N, int H,
-                                         int W, int stride, int K1, int K2, int Cout, int relu, float w_unscale, agrl_stream_t stream) {
+                                         int W, int stride, int K1, int K2, int Cout, int relu, float w_unscale, int x2_presplit,
+                                         agrl_stream_t stream) {
     AGRL_CHECK_ARG(x && x2 && w_scaled && out, "agrl_conv1x1_dual_split16: null pointer");
     AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && stride >= 1 && K1 > 0 && K2 > 0 && Cout > 0, "agrl_conv1x1_dual_split16: bad shape");
     AGRL_CHECK_ARG(K1 % 32 == 0 && K2 % 32 == 0, "agrl_conv1x1_dual_split16: K1 and K2 must be multiples of 32 (got %d, %d)", K1, K2);
@@ -1045,7 +1129,7 @@ extern "C" int agrl_conv1x1_dual_split16(const void* x, const void* x2, const vo
         AGRL_CHECK_ARG(frexpf(w_unscale, &e) == 0.5f, "agrl_conv1x1_dual_split16: w_unscale=%g is not a power of two", (double)w_unscale);
     }
     IgemmParams p{};
-    p.x = x; p.x2 = x2; p.K1 = K1; p.stats = nullptr;
+    p.x = x; p.x2 = x2; p.K1 = K1; p.stats = nullptr; p.a_pre = x2_presplit ? 2 : 0;
     p.w = w_scaled; p.colv = bias; p.rowv = nullptr; p.res = nullptr; p.out = out;
     p.alpha = w_unscale; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
     p.OH = (H - 1) / stride + 1;
@@ -1226,7 +1310,9 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
     p.nmajor = agrl_opts().graph_linear_mmajor ? 0 : 1;   // AGRL_GRAPH_LINEAR_MMAJOR=1: A/B switch
     if (in_dtype == AGRL_F32) return launch_igemm<float, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
     if (in_dtype == AGRL_F32X3) return launch_igemm<f32s_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
-    // split-fp16 (round 6): w holds the weight times a power of two 2^k (max |w| 2^k in [2^13, 2^14)); the caller folds 2^-k into bn_scale (exact)
+    // split-fp16 (round 6): w holds the weight times a power of two 2^k (max |w| 2^k in [2^13, 2^14)), pre-split by agrl_split16_weights_inloop;
+    // the caller folds 2^-k into bn_scale (exact)
+    if (in_dtype == AGRL_F32H3) AGRL_CHECK_ARG(K % 32 == 0, "agrl_graph_linear_mix: split-fp16 needs K %% 32 == 0 (got %d)", K);
     if (in_dtype == AGRL_F32H3) return launch_igemm<f32h_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
     return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
 }

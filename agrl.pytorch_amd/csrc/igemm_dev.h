@@ -37,6 +37,10 @@ struct IgemmParams {
     int nmajor = 0;  // XCD map: 1 = each XCD owns a contiguous range of N-TILES for all M-tiles (few pixel rows, large weight
                      // matrix: the XCD's weight slice stays in its 4 MB L2 and the small activation matrix is streamed per
                      // XCD); 0 = the N-tiles of one M-tile share an XCD (convs: large activations, small weights)
+    // split-fp16 in-loop kernels (AGRL_F32H3): activations that only ever feed a GEMM may be stored PRE-SPLIT, in the layout of
+    // agrl_split16_weights_inloop (per 32-channel group [8 x fp16 hi | 8 x fp16 lo] x 4 lane groups: the bytes of 32 fp32) -- the k-loop
+    // then has no VALU work for them. a_pre bit 0: x is pre-split, bit 1: x2 is; out_pre: write out in that layout (no residual)
+    int a_pre = 0, out_pre = 0;
     int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
 };
 

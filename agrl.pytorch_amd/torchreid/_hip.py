@@ -57,15 +57,16 @@ SIGNATURES = {
     "agrl_stem_conv_bn_relu_maxpool": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_stem_conv_bn_relu_maxpool_lp16": [_p, _p, _p, _p, _i, _i, _i, _p],
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "agrl_conv1x1_dual_split16": [_p, _p, _p, _p, _p] + [_i] * 8 + [_f, _p],
+    "agrl_conv1x1_dual_split16": [_p, _p, _p, _p, _p] + [_i] * 8 + [_f, _i, _p],
     "agrl_stem_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
     "agrl_split16_planes": [_p, _p, C.c_longlong, _i, _p],
     "agrl_split16_weight_planes": [_p, _p, C.c_longlong, _i, _f, _p],
+    "agrl_split16_weights_inloop": [_p, _p, C.c_longlong, _i, _p],
     "agrl_conv1x1_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "agrl_conv1x1_split16_dual": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "agrl_conv1x1_split16_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _f, _p],
     "agrl_conv3x3_packed_split16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p],
-    "agrl_conv2d_bn_act_split16": [_p, _p, _p, _p, _p] + [_i] * 10 + [_f, _p],
+    "agrl_conv2d_bn_act_split16": [_p, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _i, _p],
     "agrl_bottleneck_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "agrl_bottleneck_seam_packed_bytes": [_i, _i, _i],   # returns long long (restype patched after loading)
     "agrl_bottleneck_seam_pack": [_p, _p, _p, _i, _i, _i, _p],

@@ -130,8 +130,10 @@ def stem_lp16(x_nchw, w_packed, bias):
     return out
 
 
-def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
-    """NHWC conv (BN folded) [+ residual] [+ ReLU]. vmgn.py:45-65."""
+def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None, x_presplit=False, out_presplit=False):
+    """NHWC conv (BN folded) [+ residual] [+ ReLU]. vmgn.py:45-65. ``x_presplit`` / ``out_presplit`` ('fp16x3' weights only): the
+    input was / the output is to be stored with its fp16 halves already formed (agrl_conv2d_bn_act_split16: a tensor only a GEMM reads;
+    the same shape and bytes, not readable as fp32)."""
     N, H, W, Cin = x.shape
     Cout, R, S, Cin2 = w_ohwi.shape
     assert Cin == Cin2 and x.dtype == w_ohwi.dtype
@@ -147,26 +149,28 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None):
     unscale = getattr(w_ohwi, 'agrl_unscale', None)
     with _dev(x):
         if unscale is not None:
-            # 'fp16x3': weights pre-scaled by a power of two at pack time (split16_prescale); every product as three fp16 MFMAs
-            assert x.dtype == torch.float32
+            # 'fp16x3': weights pre-scaled by a power of two and pre-split at pack time (split16_inloop_weights); every product as three fp16 MFMAs
+            assert x.dtype == torch.float32 and getattr(w_ohwi, 'agrl_presplit', False), "fp16x3 weights come from split16_inloop_weights"
             call("agrl_conv2d_bn_act_split16", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
-                 stride, pad, 1 if relu else 0, float(unscale), _stream(x))
+                 stride, pad, 1 if relu else 0, float(unscale), 1 if x_presplit else 0, 1 if out_presplit else 0, _stream(x))
         else:
+            assert not (x_presplit or out_presplit), "pre-split activations exist in the 'fp16x3' arithmetic only"
             call("agrl_conv2d_bn_act", ptr(x), ptr(w_ohwi), ptr(bias), ptr(residual), ptr(out), N, H, W, Cin, Cout, R, S,
                  stride, pad, 1 if relu else 0, _gemm_code(x.dtype), _stream(x))
     return out
 
 
-def conv1x1_dual_split16(x, x2, w_cat, bias, stride, relu=True):
+def conv1x1_dual_split16(x, x2, w_cat, bias, stride, relu=True, x2_presplit=False):
     """relu([x sampled at the stride | x2] @ w_cat^T + bias) in the split-fp16 arithmetic on fp32 tensors: a first Bottleneck's conv3 + its
     1x1 stride-s downsample conv in one GEMM (vmgn.py:56-64). x (N,H,W,K1) block input, x2 (N,OH,OW,K2) conv2's output, w_cat (Cout,
-    K1+K2) pre-scaled (split16_prescale of the concatenation: ONE power of two for both halves) -> (N,OH,OW,Cout) fp32."""
+    K1+K2) from split16_inloop_weights of the concatenation (ONE power of two for both halves) -> (N,OH,OW,Cout) fp32. ``x2_presplit``: x2
+    was written by conv_bn_act(..., out_presplit=True)."""
     N, H, W, K1 = x.shape
     K2 = x2.shape[3]
     Cout = w_cat.shape[0]
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     assert x.dtype == torch.float32 and x2.dtype == torch.float32 and x.is_contiguous() and x2.is_contiguous()
-    assert tuple(x2.shape[:3]) == (N, OH, OW) and tuple(w_cat.shape) == (Cout, K1 + K2) and hasattr(w_cat, 'agrl_unscale')
+    assert tuple(x2.shape[:3]) == (N, OH, OW) and tuple(w_cat.shape) == (Cout, K1 + K2) and getattr(w_cat, 'agrl_presplit', False)
     out = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
     if _hip.PROFILE is not None:
         M = N * OH * OW
@@ -174,7 +178,7 @@ def conv1x1_dual_split16(x, x2, w_cat, bias, stride, relu=True):
                             "conv": (1, stride, K1 + K2, Cout, OH, OW)}
     with _dev(x):
         call("agrl_conv1x1_dual_split16", ptr(x), ptr(x2), ptr(w_cat), ptr(bias), ptr(out), N, H, W, stride, K1, K2, Cout,
-             1 if relu else 0, float(w_cat.agrl_unscale), _stream(x))
+             1 if relu else 0, float(w_cat.agrl_unscale), 1 if x2_presplit else 0, _stream(x))
     return out
 
 
@@ -192,6 +196,33 @@ def split16_prescale(w):
     ws = (w.detach().float() * (2.0 ** k)).contiguous()
     ws.agrl_unscale = 2.0 ** (-k)
     return ws
+
+
+def split16_inloop_weights(w):
+    """fp32 weights (.., K), K % 32 == 0 -> the weight operand of the kernels that split in the k-loop (conv_bn_act on 'fp16x3' weights,
+    conv1x1_dual_split16, graph_linear_mix): split16_prescale, then the fp16 high / low halves of every 32-value k-tile side by side
+    (the layout of agrl_split16_weights_inloop: the same shape and bytes, NOT readable as fp32 any more). ``.agrl_unscale`` = 2^-k and
+    ``.agrl_presplit`` ride on the tensor; ``.agrl_scaled`` keeps the scaled fp32 tensor for packers that derive other forms from it
+    (split16_true_weights)."""
+    ws = split16_prescale(w)
+    K = ws.shape[-1]
+    assert K % 32 == 0, "the in-loop split needs whole 32-element k-tiles (K = %d)" % K
+    # pack-time host logic in torch ops (any device; a C caller has agrl_split16_weights_inloop, byte-identical:
+    # tests/test_gpu_kernels.py::test_split16_inloop_weight_layout): (rows, tile, c, half, e) = lane group c's eight values of a k-tile
+    t = ws.view(-1, K // 32, 2, 4, 4).permute(0, 1, 3, 2, 4)
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+    out = torch.stack([hi, lo], dim=2).contiguous().view(torch.float32).view(ws.shape)
+    out.agrl_unscale = ws.agrl_unscale
+    out.agrl_presplit = True
+    out.agrl_scaled = ws
+    return out
+
+
+def split16_true_weights(t):
+    """The fp32 weights a split16_prescale / split16_inloop_weights tensor was made from (the power-of-two scale undone: exact)."""
+    src = t.agrl_scaled if getattr(t, 'agrl_presplit', False) else t
+    return src * t.agrl_unscale
 
 
 # ---- split-fp16 PLANES (round 6): the conforming mode at speed -- include/agrl_hip.h, "Split-fp16 PLANES" ----------------------
@@ -837,8 +868,8 @@ def graph_linear_mix(p_op, w, f, bn_scale, bn_shift, gamma, slope, keep=None):
         _hip.PROFILE_TAG = {"flops": 2.0 * B * V * K * Nout, "bytes": p_op.element_size() * (p_op.numel() + w.numel()) + 8.0 * f.numel()}
     code = _gemm_code(p_op.dtype)
     unscale = getattr(w, 'agrl_unscale', None)
-    if unscale is not None:   # 'fp16x3': w pre-scaled by a power of two (split16_prescale); bn_scale must already carry the 2^-k
-        assert p_op.dtype == torch.float32 and getattr(bn_scale, 'agrl_folded_unscale', None) == unscale
+    if unscale is not None:   # 'fp16x3': w pre-scaled by a power of two and pre-split (split16_inloop_weights); bn_scale must already carry the 2^-k
+        assert p_op.dtype == torch.float32 and getattr(bn_scale, 'agrl_folded_unscale', None) == unscale and getattr(w, 'agrl_presplit', False)
         code = _hip.F32H3
     with _dev(f):
         call("agrl_graph_linear_mix", ptr(p_op.contiguous()), ptr(w), ptr(f.contiguous()), ptr(bn_scale), ptr(bn_shift), float(keep), float(gamma),

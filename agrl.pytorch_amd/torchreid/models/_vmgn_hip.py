@@ -23,20 +23,20 @@ from torchreid import _hip
 
 # 'bf16x3': fp32 tensors and layouts of the parity mode, conv / Linear products as three bf16 MFMAs (hip_ops.f32_split)
 # 'fp16x3' (round 6): the same fp32 tensors, conv products as three FP16 MFMAs on fp16 high / low halves (22 bits per operand), conv
-# weights pre-scaled by a power of two at pack time (ops.split16_prescale); GraphLayer, pooling, distance matrix: exact fp32
+# weights pre-scaled by a power of two and pre-split at pack time (ops.split16_inloop_weights); GraphLayer, pooling, distance matrix: exact fp32
 _PRECISIONS = {'fp32': torch.float32, ops.LP_NAME: ops.LP_DTYPE, 'bf16x3': torch.float32, 'fp16x3': torch.float32}   # ops.LP_NAME: 'fp16' (default build) or 'bf16'
 
 
 def _fold_conv_bn(conv, bn, dtype, split16=False):
     """conv (no bias) followed by eval BatchNorm2d -> (OHWI weight in dtype, fp32 bias). ``split16``: the fp32 weight pre-scaled by a
-    power of two for the split-fp16 convolution (ops.split16_prescale; the un-scaling factor rides on the tensor)."""
+    power of two and pre-split for the split-fp16 convolution (ops.split16_inloop_weights; the un-scaling factor rides on the tensor)."""
     w = conv.weight.detach().float()
     scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
     shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
     w = (w * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous()
     if split16:
         assert dtype == torch.float32
-        return ops.split16_prescale(w), shift.contiguous()
+        return ops.split16_inloop_weights(w), shift.contiguous()
     return w.to(dtype).contiguous(), shift.contiguous()
 
 
@@ -81,9 +81,9 @@ def _pack_stage(stage, dtype, seam=False, split16=False):
                 # conforming mode: conv3 + downsample as ONE in-loop split GEMM over [block input sampled at the stride | conv2's output]
                 # (ops.conv1x1_dual_split16): the fp32 shortcut map -- 537 MB written and read back in layer 1 -- no longer exists
                 cout = blk['c3'][0].shape[0]
-                wd = blk['ds'][0] * blk['ds'][0].agrl_unscale
-                w3 = blk['c3'][0] * blk['c3'][0].agrl_unscale
-                blk['dual16'] = (ops.split16_prescale(torch.cat([wd.view(cout, -1), w3.view(cout, -1)], dim=1).contiguous()),
+                wd = ops.split16_true_weights(blk['ds'][0])
+                w3 = ops.split16_true_weights(blk['c3'][0])
+                blk['dual16'] = (ops.split16_inloop_weights(torch.cat([wd.view(cout, -1), w3.view(cout, -1)], dim=1).contiguous()),
                                  (blk['ds'][1] + blk['c3'][1]).contiguous())
             if dtype == ops.LP_DTYPE and blk['ds_stride'] == 1 and blk['stride'] == 1:
                 # conv3 + downsample as ONE GEMM over the concatenated K axis (ops.conv1x1_dual): [w_ds | w3], b_ds + b3
@@ -168,7 +168,7 @@ def pack_weights(model, device, precision):
             if s16 and K_OK(gw):
                 # the GraphLayer's Linear in the split-fp16 arithmetic as well (182 -> ~70 us per layer at 32 tracklets): weight times
                 # 2^k, the 2^-k folded into the BatchNorm scale the GEMM's epilogue multiplies the accumulator with (exact)
-                gw = ops.split16_prescale(gw)
+                gw = ops.split16_inloop_weights(gw)
                 scale = (scale * gw.agrl_unscale).contiguous()
                 scale.agrl_folded_unscale = gw.agrl_unscale
             pack['graph'].append({
@@ -178,13 +178,13 @@ def pack_weights(model, device, precision):
                 'use_pose': bool(layer.use_pose), 'learn_graph': bool(layer.learn_graph),
             })
     if s16:
-        # the un-scaling factor rides on the weight TENSOR OBJECT (ops.split16_prescale): a copy made behind its back (.to / .contiguous /
+        # the un-scaling factor rides on the weight TENSOR OBJECT (ops.split16_inloop_weights): a copy made behind its back (.to / .contiguous /
         # .clone) would silently run as a 2^k-times-too-large exact-fp32 weight -- checked once per pack
         stages = pack['trunk'] + pack.get('l4_1', []) + pack.get('l4_2', []) + pack.get('l4', [])
         for blk in stages:
             for name in ('c1', 'c2', 'c3', 'ds'):
-                if blk.get(name) is not None and not hasattr(blk[name][0], 'agrl_unscale'):
-                    raise RuntimeError("fp16x3 pack: %s lost its pre-scale attribute" % name)
+                if blk.get(name) is not None and not (hasattr(blk[name][0], 'agrl_unscale') and getattr(blk[name][0], 'agrl_presplit', False)):
+                    raise RuntimeError("fp16x3 pack: %s lost its pre-scale attributes" % name)
     if s16 and ops.split16_planes_available() and hasattr(model, 'layer4_1') and ops.switch_on('AGRL_HIP_SPLIT16_PLANES'):
         # the conforming mode at speed: behind layer 3's first block every Bottleneck runs on split-fp16 PLANES through the throughput
         # mode's four-wave kernels (ops.conv1x1_split16 / conv3x3_split16); the stem .. layer 3's first block keep fp32 tensors and the
@@ -193,6 +193,11 @@ def pack_weights(model, device, precision):
         with torch.no_grad():
             ok = all(_pack_planes(blk) for blk in pack['trunk'][first:] + pack['l4_1'] + pack['l4_2'])
         pack['planes_from'] = first if ok else None
+    if s16:
+        for blk in stages:   # the scaled fp32 copies were for the packers above
+            for name in ('c1', 'c2', 'c3', 'ds', 'dual16'):
+                if blk.get(name) is not None and hasattr(blk[name][0], 'agrl_scaled'):
+                    del blk[name][0].agrl_scaled
     if dtype == ops.LP_DTYPE:
         check_packed_range(pack)
     pack['fingerprint'] = _fingerprint(model)
@@ -204,7 +209,7 @@ def _pack_planes(blk):
     """The split-fp16 plane operands of one Bottleneck (blk: fp32 folded weights, pre-scaled for the in-loop split) -> blk['p3'];
     False when a shape does not fit the four-wave kernels (the caller then keeps the whole model on the in-loop split)."""
     def true_w(pair):
-        return pair[0] * pair[0].agrl_unscale    # undo the per-tensor pre-scale (exact)
+        return ops.split16_true_weights(pair[0])    # undo the per-tensor pre-scale (exact)
 
     w1, w2, w3 = true_w(blk['c1']), true_w(blk['c2']), true_w(blk['c3'])
     K1, K3c, mid, cout = w1.shape[3], w3.shape[3], w1.shape[0], w3.shape[0]
@@ -299,11 +304,32 @@ def _conv1(x, blk):
     return ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
 
 
+def _run_block_inloop(x, blk):
+    """One Bottleneck of the conforming mode on fp32 tensors (weights from ops.split16_inloop_weights): conv1's and conv2's outputs are read
+    by one GEMM each and never as numbers, so they are stored with their fp16 halves already formed -- the 3x3 conv's k-loop has no
+    VALU work left (bit-identical to splitting in the loop; AGRL_HIP_SPLIT16_PREACT=0 is that form)."""
+    pre = ops.switch_on('AGRL_HIP_SPLIT16_PREACT')
+    y = ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True, out_presplit=pre)
+    y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True, x_presplit=pre, out_presplit=pre)
+    if 'dual16' in blk and ops.switch_on('AGRL_HIP_SPLIT16_DUAL') and x.is_contiguous():
+        # conv3 + the downsample conv as ONE GEMM over [x sampled at the stride | y]: no shortcut map in HBM
+        return ops.conv1x1_dual_split16(x, y, blk['dual16'][0], blk['dual16'][1], blk['stride'], True, x2_presplit=pre)
+    shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
+    return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut, x_presplit=pre)
+
+
+def _is_inloop(blk):
+    return getattr(blk['c1'][0], 'agrl_presplit', False)
+
+
 def _run_trunk(a, blocks, fuse_tail=True):
     """layer1..layer3 Bottlenecks. Where the fused kernel exists (layer 1, bf16) the last conv of block i also
     produces the first conv of block i+1 from the tile it still holds in LDS (ops.bottleneck_tail)."""
     z = None  # conv1 output of the current block, when the previous block's tail already computed it
     for i, blk in enumerate(blocks):
+        if _is_inloop(blk):
+            a = _run_block_inloop(a, blk)
+            continue
         nxt = blocks[i + 1] if i + 1 < len(blocks) else None
         y = z if z is not None else ops.conv_bn_act(a, blk['c1'][0], blk['c1'][1], 1, 0, True)
         if fuse_tail and nxt is not None:
@@ -334,10 +360,6 @@ def _run_trunk(a, blocks, fuse_tail=True):
             a = ops.conv1x1_packed_dual_strided(a, y, blk['dualps'], blk['dualps_bias'], blk['c3'][0].shape[0], blk['stride'], True)
             z = None
             continue
-        if 'dual16' in blk and ops.switch_on('AGRL_HIP_SPLIT16_DUAL') and a.is_contiguous() and y.is_contiguous():
-            a = ops.conv1x1_dual_split16(a, y, blk['dual16'][0], blk['dual16'][1], blk['stride'], True)
-            z = None
-            continue
         shortcut = a if blk['ds'] is None else ops.conv_bn_act(a, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
         if fuse_tail and nxt is not None and 'seam' in blk and (y.numel() // y.shape[-1]) % 128 == 0 and ops.seam_enabled():
             a, z = ops.bottleneck_seam(y, blk['seam'], blk['c3'][1], shortcut, nxt['c1'][1], blk['seam_dims'])
@@ -353,6 +375,9 @@ def _run_trunk(a, blocks, fuse_tail=True):
 def _run_block(x, blk, pool=None):
     """One Bottleneck. ``pool`` = (splits, mean, want_lp): fuse the frame pooling into the last conv's epilogue and
     return the pooled tensors instead of the activation map (which is then never written to HBM)."""
+    if _is_inloop(blk):
+        assert pool is None
+        return _run_block_inloop(x, blk)
     y = _conv1(x, blk)
     y = _conv2(y, blk)
     if (pool is None and 'dualp' in blk and ops.conv1x1_packed_enabled() and ops.switch_on('AGRL_HIP_FUSE_DS')
@@ -360,8 +385,6 @@ def _run_block(x, blk, pool=None):
         return ops.conv1x1_packed(x, blk['dualp'], blk['dual'][1], blk['dual'][0].shape[0], True, x2=y, duo=ops.conv1x1_duo_enabled())   # (two workgroups per CU: 167 us against conv1x1_fat_kernel's 185)
     if pool is None and 'dual' in blk and ops.conv1x1_dual_supported(x, y, blk['dual'][0]):
         return ops.conv1x1_dual(x, y, blk['dual'][0], blk['dual'][1], True)
-    if pool is None and 'dual16' in blk and ops.switch_on('AGRL_HIP_SPLIT16_DUAL') and x.is_contiguous() and y.is_contiguous():
-        return ops.conv1x1_dual_split16(x, y, blk['dual16'][0], blk['dual16'][1], blk['stride'], True)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
     duo = 'c3p' in blk and blk['ds'] is None and ops.conv1x1_duo_enabled() and shortcut.is_contiguous() and y.is_contiguous()
     if pool is not None:

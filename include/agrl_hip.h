@@ -103,18 +103,34 @@ int agrl_conv2d_bn_act(const void* x, const void* w, const float* bias, const vo
  * (post-ReLU, O(0.1 .. 100)) sit well inside; BatchNorm-folded weights (O(1e-2)) do not, so the CALLER passes them pre-scaled
  * by a power of two, w_scaled = w * 2^k with max |w_scaled| in [2^13, 2^14) (exact), and w_unscale = 2^-k is applied to the
  * fp32 accumulator before bias / residual / ReLU (exact as well). |x| must stay below 65504.
- *   x (N,H,W,Cin) fp32 ; w_scaled (Cout,R,S,Cin) fp32 ; bias fp32 (Cout) ; residual NULL or (N,OH,OW,Cout) fp32 ; out fp32
- *   Cin a multiple of 32. */
+ * The weights are constants, so their halves are formed ONCE: w_scaled is the output of agrl_split16_weights_inloop (below), the
+ * same Cout x R x S x Cin x 4 bytes with the fp16 high and low halves of every 32-value k-tile side by side; the k-loop splits the
+ * activations only.
+ * An ACTIVATION that only ever feeds a GEMM (conv1's and conv2's outputs inside a Bottleneck, vmgn.py:48-54) can be kept pre-split
+ * the same way: out_presplit != 0 writes out in the layout of agrl_split16_weights_inloop (per pixel and 32-channel group 8 fp16 high
+ * halves x 4 lane groups, then the low halves: the bytes of 32 fp32; the halves are those the consumer's k-loop would form, so
+ * results are bit-identical), x_presplit != 0 says x is such a tensor. The 3x3 conv then re-splits nothing for its nine taps.
+ *   x (N,H,W,Cin) fp32 or pre-split ; w_scaled (Cout,R,S,Cin) x 4 bytes, pre-split ; bias fp32 (Cout) ; residual NULL or
+ *   (N,OH,OW,Cout) fp32 (not with out_presplit) ; out fp32 or pre-split (Cout % 32 == 0) ; Cin a multiple of 32. */
 int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, const float* bias, const void* residual, void* out, int N,
                                int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int relu, float w_unscale,
-                               agrl_stream_t stream);
+                               int x_presplit, int out_presplit, agrl_stream_t stream);
+
+/* The weight operand of the split-fp16 kernels that split in the k-loop (agrl_conv2d_bn_act_split16, agrl_conv1x1_dual_split16,
+ * agrl_graph_linear_mix with AGRL_F32H3): w_scaled (rows, K) fp32, ALREADY multiplied by the caller's power of two, -> out, rows x K x 4
+ * bytes: every 32-value k-tile of a row becomes [hi(k 4c..4c+3, 16+4c..16+4c+3) for c = 0..3 : 64 bytes | lo in the same order : 64 bytes],
+ * hi = fp16(w) to nearest, lo = fp16(w - hi) -- the two 16-byte chunks a lane group reads of a k-tile are its MFMA operands as they
+ * stand. rows = Cout (x R x S for a convolution: any leading shape with K = Cin innermost); K a multiple of 32; not in place. */
+int agrl_split16_weights_inloop(const float* w_scaled, void* out, long long rows, int K, agrl_stream_t stream);
 
 /* conv3 + the 1x1 stride-s downsample conv of a first Bottleneck as ONE split-fp16 GEMM over [x sampled at the stride | x2]
  * (torchreid/models/vmgn.py:56-64, both BatchNorms folded): fp32 tensors, arithmetic of agrl_conv2d_bn_act_split16. x (N,H,W,K1) the
- * block input, x2 (N,OH,OW,K2) conv2's output, w_scaled (Cout, K1+K2) = [w_downsample | w_conv3] 2^k, bias = b_downsample + b_conv3,
- * out (N,OH,OW,Cout) fp32, OH = (H-1)/stride+1. The fp32 shortcut map is neither written nor read back. K1, K2 multiples of 32. */
+ * block input, x2 (N,OH,OW,K2) conv2's output, w_scaled (Cout, K1+K2) = [w_downsample | w_conv3] 2^k pre-split
+ * (agrl_split16_weights_inloop), bias = b_downsample + b_conv3,
+ * out (N,OH,OW,Cout) fp32, OH = (H-1)/stride+1. The fp32 shortcut map is neither written nor read back. K1, K2 multiples of 32.
+ * x2_presplit != 0: x2 was written pre-split (agrl_conv2d_bn_act_split16 with out_presplit); x is always fp32. */
 int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scaled, const float* bias, void* out, int N, int H, int W,
-                              int stride, int K1, int K2, int Cout, int relu, float w_unscale, agrl_stream_t stream);
+                              int stride, int K1, int K2, int Cout, int relu, float w_unscale, int x2_presplit, agrl_stream_t stream);
 
 /* ---- Split-fp16 PLANES (round 6): the conforming mode at speed --------------------------------------------------------------
  * The same arithmetic class as agrl_conv2d_bn_act_split16 (x w ~ xh wh + xl wh + xh wl, 22 significand bits per operand, fp32
@@ -331,8 +347,9 @@ int agrl_graph_finalize_bits(const float* gram_part, int nz, const uint32_t* adj
  *   agrl_graph_linear_mix out = keep * f + gamma * LeakyReLU_slope( bn_scale * (P W^T) + bn_shift ): ONE GEMM (M = B V rows,
  *                         K -> Nout) whose register epilogue applies the folded eval BatchNorm1d, the LeakyReLU and the residual
  *                         mix with the layer input f (fp32 (M,Nout)); the Linear's output h never exists. p_op (M,K) and w (Nout,K)
- *                         in in_dtype (AGRL_F32 exact, AGRL_F32X3 split, AGRL_BF16); K a multiple of 32 (fp32) / 64 (bf16),
- *                         Nout % 4 == 0. The workgroup -> tile map keeps each XCD on its own slice of W (L2-resident). */
+ *                         in in_dtype (AGRL_F32 exact, AGRL_F32X3 split, AGRL_BF16; AGRL_F32H3: p_op fp32, w pre-scaled by a power of
+ *                         two whose inverse the caller folds into bn_scale, and pre-split by agrl_split16_weights_inloop); K a
+ *                         multiple of 32 (fp32) / 64 (bf16), Nout % 4 == 0. The workgroup -> tile map keeps each XCD on its own slice of W (L2-resident). */
 int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, int B, int V, int C, agrl_stream_t stream);
 /* agrl_graph_gram + agrl_graph_finalize + agrl_graph_apply for MANY tracklets per GPU, one workgroup per tracklet (use it when
  * B >= ~224, so that B workgroups fill the 256 CUs): Gram (exact fp32 MFMA) -> similarity -> row-L1 normalise -> mix with the pose

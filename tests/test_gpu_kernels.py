@@ -1139,7 +1139,9 @@ def test_conv_split_fp16_three_products(cfg):
     ws = ops.split16_prescale(wd)
     k = np.log2(ws.agrl_unscale)
     assert k == int(k) and 2 ** 13 <= float(ws.abs().max()) < 2 ** 14 and torch.equal(ws * ws.agrl_unscale, wd)   # exact pre-scale
-    h3 = ops.conv_bn_act(xd, ws, bd, stride, pad, True, residual=rd)
+    wp = ops.split16_inloop_weights(wd)
+    assert wp.agrl_unscale == ws.agrl_unscale and torch.equal(ops.split16_true_weights(wp), wd)
+    h3 = ops.conv_bn_act(xd, wp, bd, stride, pad, True, residual=rd)
     torch.cuda.synchronize()
     den = ref.abs().max().item()
     e = {name: ((t.double().cpu() - ref).abs().max().item() / den) for name, t in (("fp32", exact), ("bf16x3", b3), ("fp16x3", h3))}
@@ -1366,10 +1368,10 @@ def test_conv1x1_dual_split16_matches_the_two_convs(cfg):
     xs = x[:, ::stride, ::stride, :]
     ref = (xs.double() @ wd.view(Cout, K1).double().t() + y.double() @ w3.view(Cout, K2).double().t() + (bd + b3).double()).clamp(min=0)
     xd, yd = x.to(DEV), y.to(DEV)
-    wcat = ops.split16_prescale(torch.cat([wd.view(Cout, K1), w3.view(Cout, K2)], dim=1).to(DEV))
+    wcat = ops.split16_inloop_weights(torch.cat([wd.view(Cout, K1), w3.view(Cout, K2)], dim=1).to(DEV))
     got = ops.conv1x1_dual_split16(xd, yd, wcat, (bd + b3).to(DEV), stride, True)
-    short = ops.conv_bn_act(xd, ops.split16_prescale(wd.to(DEV)), bd.to(DEV), stride, 0, False)
-    two = ops.conv_bn_act(yd, ops.split16_prescale(w3.to(DEV)), b3.to(DEV), 1, 0, True, residual=short)
+    short = ops.conv_bn_act(xd, ops.split16_inloop_weights(wd.to(DEV)), bd.to(DEV), stride, 0, False)
+    two = ops.conv_bn_act(yd, ops.split16_inloop_weights(w3.to(DEV)), b3.to(DEV), 1, 0, True, residual=short)
     torch.cuda.synchronize()
     den = ref.abs().max().item()
     e1 = (got.double().cpu() - ref).abs().max().item() / den
@@ -1378,13 +1380,83 @@ def test_conv1x1_dual_split16_matches_the_two_convs(cfg):
     assert tuple(got.shape) == (N, OH, OW, Cout) and e1 < 2e-6 and e1 < 2 * e2 + 3e-7
 
 
+@pytest.mark.parametrize("cfg", [(3, 64, 32, 256, 64, 256, 1, False), (2, 64, 32, 64, 64, 256, 1, True), (3, 32, 16, 512, 128, 512, 1, False),
+                                 (2, 64, 32, 256, 128, 512, 2, True), (2, 32, 16, 512, 256, 1024, 2, True), (2, 11, 7, 160, 32, 160, 1, False),
+                                 (1, 9, 7, 64, 96, 128, 2, True)])
+def test_presplit_activations_are_bit_identical_to_splitting_in_the_loop(cfg):
+    """One Bottleneck of the conforming mode with conv1's / conv2's outputs stored PRE-SPLIT (agrl_conv2d_bn_act_split16 x_presplit /
+    out_presplit, agrl_conv1x1_dual_split16 x2_presplit) against the same three launches on fp32 tensors: the fp16 halves the epilogue
+    stores are those the consumer's k-loop would form, so every output must be equal bit for bit. Layer 1-3 shapes incl. the narrow
+    (64-channel) tiles, stride 2, first blocks through the two-source GEMM, ragged pixel counts; and the layout itself is checked against
+    the weight packer's (a pre-split activation row IS a pre-split weight row)."""
+    from torchreid import hip_ops as ops
+    N, H, W, Cin, mid, Cout, stride, first = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:7]))
+    x = (torch.randn((N, H, W, Cin), generator=g).clamp(min=0) * torch.exp(1.5 * torch.randn((N, H, W, 1), generator=g))).to(DEV)
+    mk = lambda co, r, ci: ops.split16_inloop_weights((torch.randn((co, r, r, ci), generator=g) * (0.8 / np.sqrt(ci * r * r))).to(DEV))
+    w1, w2, w3 = mk(mid, 1, Cin), mk(mid, 3, mid), mk(Cout, 1, mid)
+    b1, b2, b3 = (0.1 * torch.randn(c, generator=g).to(DEV) for c in (mid, mid, Cout))
+    outs = {}
+    for pre in (False, True):
+        y1 = ops.conv_bn_act(x, w1, b1, 1, 0, True, out_presplit=pre)
+        y2 = ops.conv_bn_act(y1, w2, b2, stride, 1, True, x_presplit=pre, out_presplit=pre)
+        if first:
+            wd = (torch.randn((Cout, Cin), generator=torch.Generator().manual_seed(7)) * (0.8 / np.sqrt(Cin))).to(DEV)
+            wcat = ops.split16_inloop_weights(torch.cat([wd, ops.split16_true_weights(w3).view(Cout, mid)], dim=1).contiguous())
+            out = ops.conv1x1_dual_split16(x, y2, wcat, b3, stride, True, x2_presplit=pre)
+        else:
+            assert stride == 1 and Cin == Cout
+            out = ops.conv_bn_act(y2, w3, b3, 1, 0, True, residual=x, x_presplit=pre)
+        outs[pre] = (y1, y2, out)
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[False][2]).all() and float(outs[False][2].abs().max()) > 0
+    assert torch.equal(outs[True][2], outs[False][2])
+    for i in (0, 1):      # the stored halves against the host packer's layout of the fp32 tensor (scale 1 here: compare the raw split)
+        t = outs[False][i]
+        K = t.shape[-1]
+        v = t.reshape(-1, K // 32, 2, 4, 4).permute(0, 1, 3, 2, 4)
+        hi = v.to(torch.float16)
+        lo = (v - hi.float()).to(torch.float16)
+        want = torch.stack([hi, lo], dim=2).contiguous().view(torch.int32).view(-1)
+        assert torch.equal(outs[True][i].view(torch.int32).view(-1), want)
+
+
 def test_conv_split_fp16_rejects_a_scale_that_is_not_a_power_of_two():
     from torchreid import hip_ops as ops
     x = torch.rand((1, 16, 8, 64), device=DEV)
-    w = ops.split16_prescale(torch.randn((64, 1, 1, 64), device=DEV) * 0.01)
+    w = ops.split16_inloop_weights(torch.randn((64, 1, 1, 64), device=DEV) * 0.01)
     w.agrl_unscale = 0.3
     with pytest.raises(_hip.HipKernelError):
         ops.conv_bn_act(x, w, torch.zeros(64, device=DEV), 1, 0, True)
+    with pytest.raises(AssertionError):    # scaled but not pre-split: the kernel would read fp32 bits as fp16 pairs
+        ops.conv_bn_act(x, ops.split16_prescale(torch.randn((64, 1, 1, 64), device=DEV) * 0.01), torch.zeros(64, device=DEV), 1, 0, True)
+
+
+def test_split16_inloop_weight_layout():
+    """agrl_split16_weights_inloop against its contract (include/agrl_hip.h): every 32-value k-tile of a row becomes
+    [hi(k 4c..4c+3, 16+4c..16+4c+3), c = 0..3 | lo in the same order], hi = fp16(w) to nearest, lo = fp16(w - hi) -- bytes compared,
+    incl. values whose low half is a subnormal fp16 and zeros; K not a multiple of 32 is refused."""
+    from torchreid import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn((24, 3, 3, 96), generator=g) * torch.exp(3.0 * torch.randn((24, 3, 3, 96), generator=g))
+    w[0, 0, 0, :4] = torch.tensor([0.0, 1e-7, 6.1e-5, -3.3e-6])
+    host = ops.split16_inloop_weights(w.to(DEV))           # the packers' torch form
+    ws = ops.split16_prescale(w)
+    wsd = ws.to(DEV)
+    got = torch.empty_like(wsd)                            # the C-ABI kernel
+    _hip.call("agrl_split16_weights_inloop", wsd.data_ptr(), got.data_ptr(), w.numel() // 96, 96, 0)
+    torch.cuda.synchronize()
+    assert host.agrl_unscale == ws.agrl_unscale and host.shape == w.shape and host.dtype == torch.float32 and torch.equal(
+        host.view(torch.int32), got.view(torch.int32))
+    t = ws.view(-1, 3, 2, 4, 4).permute(0, 1, 3, 2, 4).contiguous()      # (rows, tile, c, half, e): the lane group's eight values
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+    want = torch.stack([hi, lo], dim=2).contiguous()                       # (rows, tile, {hi, lo}, c, half, e)
+    assert torch.equal(got.cpu().view(torch.float16).view(-1), want.view(-1))
+    with pytest.raises(AssertionError):
+        ops.split16_inloop_weights(torch.randn((8, 48), device=DEV))
+    with pytest.raises(_hip.HipKernelError):
+        _hip.call("agrl_split16_weights_inloop", got.data_ptr(), got.data_ptr(), 8, 48, 0)
 
 
 @pytest.mark.parametrize("metric", ["euclidean", "cosine"])

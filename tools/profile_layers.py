@@ -28,10 +28,10 @@ shapes = []
 orig = ops.conv_bn_act
 
 
-def conv_logged(x_, w_, b_, stride, pad, relu, residual=None):
+def conv_logged(x_, w_, b_, stride, pad, relu, residual=None, **kw):
     shapes.append(("conv %dx%d s%d %4d->%4d @%dx%d%s" % (w_.shape[1], w_.shape[2], stride, w_.shape[3], w_.shape[0],
                                                         x_.shape[1], x_.shape[2], " +res" if residual is not None else "")))
-    return orig(x_, w_, b_, stride, pad, relu, residual)
+    return orig(x_, w_, b_, stride, pad, relu, residual, **kw)
 
 
 import torchreid.models._vmgn_hip as eng  # noqa: E402
