@@ -64,6 +64,11 @@ struct DuoParams {
     // k-loop simply rows of 3 x the channels (K counts them); res / out: (M, 3 Cout). alpha un-does the weights' power-of-two pre-scale.
     float alpha;
     int planes;
+    // plane PAIRS (round 6, late): a wide tensor (a block's input / output: the residual stream) holds [hi | lo 2^11] only -- the third
+    // plane repeats the first, and every kernel here is HBM-bound on exactly these tensors. x_pair: x is a pair of K1 / 3 channels and the
+    // K axis of its weights runs per 128-channel slab c as [hi_c | hi_c | lo_c] (against [wh_c | wl_c | wh_c 2^-11]): the repeated slab is
+    // requested again right behind its first use -- an L2 hit, not an HBM read. ro_pair: res / out are pairs, (M, 2 Cout).
+    int x_pair, ro_pair;
 };
 
 #ifndef DUO_ABL
@@ -165,14 +170,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
             const unsigned ho = r / (unsigned)p.gWo, wo = r - ho * (unsigned)p.gWo;
             srow = f * (unsigned)p.gHiWi + (ho * (unsigned)p.gWi + wo) * (unsigned)p.gS;
         }
-        roff[j] = srow * (unsigned)p.K1 * 2u + sw;
+        unsigned rowlen1 = (unsigned)p.K1;
+        if constexpr (PLANES) rowlen1 = p.x_pair ? (unsigned)p.K1 / 3u * 2u : (unsigned)p.K1;
+        roff[j] = srow * rowlen1 * 2u + sw;
         roff2[j] = (unsigned)gm * (unsigned)(p.K - p.K1) * 2u + sw;
     }
     const int nslab = p.K >> 7, nslab1 = p.K1 >> 7;
     auto stage_piece = [&](int slab, int buf, auto i_c) {  // piece i of slab `slab` into buffer `buf`
         constexpr int I = decltype(i_c)::value, J = I >> 1, H = I & 1;
         const bool second = slab >= nslab1;  // uniform: the slab lies in x2 (two-source form: conv3 + downsample conv as one GEMM)
-        const unsigned char* src = second ? p.x2 + roff2[J] + (size_t)((slab - nslab1) * 256 + H * 128) : p.x + roff[J] + (size_t)(slab * 256 + H * 128);
+        int slab1 = slab;
+        if constexpr (PLANES) {
+            if (p.x_pair) {   // (scalar) slab 3 c + r of the K axis -> slab c of the hi plane (r = 0, 1) or of the lo plane (r = 2)
+                const int c = slab / 3, r = slab - 3 * c;
+                slab1 = r == 2 ? nslab1 / 3 + c : c;
+            }
+        }
+        const unsigned char* src = second ? p.x2 + roff2[J] + (size_t)((slab - nslab1) * 256 + H * 128) : p.x + roff[J] + (size_t)(slab1 * 256 + H * 128);
         fat_dma(src, __builtin_amdgcn_readfirstlane(lds0 + buf * DSLAB + H * DHALF + (wave + 4 * J) * 1024));
     };
 
@@ -293,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
         // and lo = fp16((v - hi) 2^11). The wave's 16 KB image holds 64 rows at a time: hi rows in its lower half, lo rows in the upper
         // half (same swizzled row layout), so two passes of 64 rows; the residual's two planes arrive in the same two halves by LDS-DMA
         // and each cell pair is combined in place. POOL: the UNROUNDED v is pooled (what the fp32 reference pools, vmgn.py:298-308).
-        const size_t ld3 = (size_t)p.Cout * 3 * 2;   // bytes per pixel row of a planes tensor
+        const size_t ld3 = (size_t)p.Cout * (p.ro_pair ? 2 : 3) * 2;   // bytes per pixel row of a planes tensor (triple or pair)
         const size_t plane = (size_t)p.Cout * 2;
         // (opaque copies: hipcc would otherwise compute the sixteen request offsets before the k-loop and carry them through it, and
         // the pooled instantiation then overflows its 128 arch VGPRs into AGPRs the asm blocks own)
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_duo_kernel(const DuoParams p) 
                         unsigned char* o = p.out + row_off3(8 * h + i);
                         *reinterpret_cast<u32x4_t*>(o) = vh;
                         *reinterpret_cast<u32x4_t*>(o + plane) = vl;
-                        *reinterpret_cast<u32x4_t*>(o + 2 * plane) = vh;
+                        if (!p.ro_pair) *reinterpret_cast<u32x4_t*>(o + 2 * plane) = vh;
                     }
                 }
             }
@@ -941,7 +955,9 @@ extern "C" int agrl_conv1x1_packed_dual_strided(const void* x, const void* x2, c
 // then sums xh wh + xl wh + xh wl -- 22 significand bits per operand -- into one fp32 accumulator, which the epilogue un-scales by
 // w_unscale = 2^-k. K3 / K1_3 / K2_3 count the plane channels (3 x the true ones).
 static int duo_split16_common(DuoParams& p, const void* x, const void* packed, const float* bias, int M, int K3, int Cout, int relu,
-                              float w_unscale, const char* who) {
+                              float w_unscale, int layout, const char* who) {
+    AGRL_CHECK_ARG(layout >= 0 && layout <= 3, "%s: layout = %d (bit 0: x is a plane pair, bit 1: residual / out are pairs)", who, layout);
+    p.x_pair = layout & 1; p.ro_pair = (layout >> 1) & 1;
     AGRL_CHECK_ARG(agrl_lp16_is_f16(), "%s: the split planes are fp16 (load libagrl_hip.so, not the bf16 build)", who);
     AGRL_CHECK_ARG(x && packed && bias, "%s: null pointer", who);
     AGRL_CHECK_ARG(M > 0 && K3 > 0 && K3 % 384 == 0 && Cout > 0 && Cout % 256 == 0, "%s: needs K3 %% 384 == 0 (3 planes of whole 128-channel slabs) and Cout %% 256 == 0; got M=%d K3=%d Cout=%d", who, M, K3, Cout);
@@ -960,9 +976,9 @@ static int duo_split16_common(DuoParams& p, const void* x, const void* packed, c
 }
 
 extern "C" int agrl_conv1x1_split16(const void* x, const void* packed, const float* bias, const void* residual, void* out, int M, int K3,
-                                    int Cout, int relu, float w_unscale, agrl_stream_t stream) {
+                                    int Cout, int relu, float w_unscale, int layout, agrl_stream_t stream) {
     DuoParams p{};
-    if (int rc = duo_split16_common(p, x, packed, bias, M, K3, Cout, relu, w_unscale, "agrl_conv1x1_split16")) return rc;
+    if (int rc = duo_split16_common(p, x, packed, bias, M, K3, Cout, relu, w_unscale, layout, "agrl_conv1x1_split16")) return rc;
     AGRL_CHECK_ARG(out, "agrl_conv1x1_split16: null pointer");
     AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)out) & 15) == 0, "agrl_conv1x1_split16: pointers must be 16-byte aligned");
     p.res = reinterpret_cast<const unsigned char*>(residual);
@@ -971,10 +987,10 @@ extern "C" int agrl_conv1x1_split16(const void* x, const void* packed, const flo
 }
 
 extern "C" int agrl_conv1x1_split16_dual(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1_3,
-                                         int K2_3, int Cout, int relu, float w_unscale, agrl_stream_t stream) {
+                                         int K2_3, int Cout, int relu, float w_unscale, int layout, agrl_stream_t stream) {
     DuoParams p{};
     AGRL_CHECK_ARG(x2 && out && K1_3 > 0 && K1_3 % 384 == 0 && K2_3 > 0 && K2_3 % 384 == 0, "agrl_conv1x1_split16_dual: needs two sources of whole plane triples (K %% 384 == 0)");
-    if (int rc = duo_split16_common(p, x, packed, bias, M, K1_3 + K2_3, Cout, relu, w_unscale, "agrl_conv1x1_split16_dual")) return rc;
+    if (int rc = duo_split16_common(p, x, packed, bias, M, K1_3 + K2_3, Cout, relu, w_unscale, layout, "agrl_conv1x1_split16_dual")) return rc;
     AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)out) & 15) == 0, "agrl_conv1x1_split16_dual: pointers must be 16-byte aligned");
     p.x2 = reinterpret_cast<const unsigned char*>(x2);
     p.K1 = K1_3;
@@ -984,11 +1000,11 @@ extern "C" int agrl_conv1x1_split16_dual(const void* x, const void* x2, const vo
 
 extern "C" int agrl_conv1x1_split16_pool(const void* x, const void* packed, const float* bias, const void* residual, float* pool_out, int N,
                                          int H, int W, int K3, int Cout, int relu, const int* splits, int n_splits, int mean, float w_unscale,
-                                         agrl_stream_t stream) {
+                                         int layout, agrl_stream_t stream) {
     DuoParams p{};
     AGRL_CHECK_ARG(pool_out && splits, "agrl_conv1x1_split16_pool: null pointer");
     AGRL_CHECK_ARG(H == 16 && W == 8 && N > 0, "agrl_conv1x1_split16_pool: a frame must be 16 x 8 pixels (got %dx%d)", H, W);
-    if (int rc = duo_split16_common(p, x, packed, bias, N * 128, K3, Cout, relu, w_unscale, "agrl_conv1x1_split16_pool")) return rc;
+    if (int rc = duo_split16_common(p, x, packed, bias, N * 128, K3, Cout, relu, w_unscale, layout, "agrl_conv1x1_split16_pool")) return rc;
     AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)pool_out) & 15) == 0, "agrl_conv1x1_split16_pool: pointers must be 16-byte aligned");
     int P = 0;
     for (int i = 0; i < n_splits; ++i) {
@@ -1012,7 +1028,7 @@ extern "C" int agrl_conv1x1_split16_pool(const void* x, const void* packed, cons
 
 // fp32 (rows, C) -> the three fp16 planes (rows, 3 C) = [hi | lo 2^11 | hi] the split16 kernels consume: the seam between the fp32-tensor
 // part of the conforming mode (stem .. first block of layer 3, agrl_conv2d_bn_act_split16) and its plane part.
-__global__ __launch_bounds__(256) void split16_planes_kernel(const float4* __restrict__ x, uint2* __restrict__ out, long long groups, int c4) {
+__global__ __launch_bounds__(256) void split16_planes_kernel(const float4* __restrict__ x, uint2* __restrict__ out, long long groups, int c4, int nplanes) {
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < groups; t += (long long)gridDim.x * blockDim.x) {
         const long long row = t / c4;
         const int g = (int)(t - row * c4);
@@ -1023,21 +1039,22 @@ __global__ __launch_bounds__(256) void split16_planes_kernel(const float4* __res
         unpack_lp16x2(h1, c, d);
         const uint2 hi = make_uint2(h0, h1);
         const uint2 lo = make_uint2(pack_lp16x2((v.x - a) * 2048.f, (v.y - b) * 2048.f), pack_lp16x2((v.z - c) * 2048.f, (v.w - d) * 2048.f));
-        uint2* o = out + row * 3 * c4 + g;
+        uint2* o = out + row * nplanes * c4 + g;
         o[0] = hi;
         o[c4] = lo;
-        o[2 * c4] = hi;
+        if (nplanes == 3) o[2 * c4] = hi;
     }
 }
 
-extern "C" int agrl_split16_planes(const float* x, void* out, long long rows, int C, agrl_stream_t stream) {
+extern "C" int agrl_split16_planes(const float* x, void* out, long long rows, int C, int nplanes, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(nplanes == 2 || nplanes == 3, "agrl_split16_planes: nplanes = %d (3: [hi | lo 2^11 | hi], 2: the pair [hi | lo 2^11])", nplanes);
     AGRL_CHECK_ARG(agrl_lp16_is_f16(), "agrl_split16_planes: the split planes are fp16 (load libagrl_hip.so, not the bf16 build)");
     AGRL_CHECK_ARG(x && out && rows > 0 && C > 0 && C % 4 == 0, "agrl_split16_planes: needs C %% 4 == 0 (got rows=%lld C=%d)", rows, C);
     AGRL_CHECK_ARG((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "agrl_split16_planes: pointers must be 16-byte aligned");
     const long long groups = rows * (C / 4);
     const int grid = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
     hipLaunchKernelGGL(split16_planes_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(x),
-                       reinterpret_cast<uint2*>(out), groups, C / 4);
+                       reinterpret_cast<uint2*>(out), groups, C / 4, nplanes);
     AGRL_CHECK_LAUNCH("agrl_split16_planes");
     return 0;
 }

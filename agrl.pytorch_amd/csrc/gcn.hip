@@ -613,7 +613,10 @@ __global__ __launch_bounds__(64 * NWV) void graph_propagate_stream_kernel(
 // structure as graph_propagate_stream_kernel -- G by LDS-DMA at the head of the queue, one 16-byte load per lane per 4 graph
 // rows feeding four exact-fp32 MFMAs, the free channel <-> MFMA-row assignment chosen so that loads are whole cache lines --
 // minus the residual / BatchNorm operands: f crosses HBM once (V C 4 bytes per tracklet in, V C 2 or 4 out).
-template <int PS_NT, int NWV, bool LP>
+// MODE 0: fp32, 1: the 16-bit type, 2: fp32-sized rows PRE-SPLIT for the split-fp16 GEMM (AGRL_F32H3P: the layout of
+// agrl_split16_weights_inloop -- lane group kg's float4s 2 t, 2 t + 1 are exactly chunk kg of 32-channel group t, so the halves are
+// formed here, once, and agrl_graph_linear_mix's k-loop has no VALU work left)
+template <int PS_NT, int NWV, int MODE>
 __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const float* __restrict__ f, const float* __restrict__ G,
                                                                       float* __restrict__ out, lp16_t* __restrict__ out_lp, int C) {
     extern __shared__ __attribute__((aligned(16))) float s_g[];  // [16*NVF][V]
@@ -668,11 +671,26 @@ __global__ __launch_bounds__(64 * NWV) void graph_apply_stream_kernel(const floa
     for (int vf = 0; vf < NVF; ++vf) {
         const int v = vf * 16 + i16;
         if (v >= V) continue;
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint4 c0_ = make_uint4(__float_as_uint(acc[vf][0][2 * t]), __float_as_uint(acc[vf][1][2 * t]), __float_as_uint(acc[vf][2][2 * t]),
+                                             __float_as_uint(acc[vf][3][2 * t]));
+                const uint4 c1_ = make_uint4(__float_as_uint(acc[vf][0][2 * t + 1]), __float_as_uint(acc[vf][1][2 * t + 1]),
+                                             __float_as_uint(acc[vf][2][2 * t + 1]), __float_as_uint(acc[vf][3][2 * t + 1]));
+                uint4 hi, lo;
+                Frag<f32h_t>::split8(c0_, c1_, hi, lo);
+                unsigned char* dst = reinterpret_cast<unsigned char*>(out + (node0 + v) * C + c0 + 32 * t) + kg * 16;
+                *reinterpret_cast<uint4*>(dst) = hi;
+                *reinterpret_cast<uint4*>(dst + 64) = lo;
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float o0 = acc[vf][0][r], o1 = acc[vf][1][r], o2 = acc[vf][2][r], o3 = acc[vf][3][r];
-            if constexpr (LP) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_lp16x2(o0, o1), pack_lp16x2(o2, o3));
+            if constexpr (MODE == 1) *reinterpret_cast<uint2*>(out_lp + (node0 + v) * C + cl + 16 * r) = make_uint2(pack_lp16x2(o0, o1), pack_lp16x2(o2, o3));
             else *reinterpret_cast<float4*>(out + (node0 + v) * C + cl + 16 * r) = make_float4(o0, o1, o2, o3);
+        }
         }
     }
 }
@@ -1013,8 +1031,8 @@ extern "C" int agrl_graph_finalize_bits(const float* gram_part, int nz, const ui
 extern "C" int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, int B, int V, int C, agrl_stream_t stream) {
     AGRL_CHECK_ARG(G && f && out, "agrl_graph_apply: null pointer");
     AGRL_CHECK_ARG(B > 0 && V > 0 && C > 0, "agrl_graph_apply: bad shape");
-    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_LP16, "agrl_graph_apply: out dtype must be fp32 or bf16");
-    const bool lp = out_dtype == AGRL_LP16;
+    AGRL_CHECK_ARG(out_dtype == AGRL_F32 || out_dtype == AGRL_LP16 || out_dtype == AGRL_F32H3P, "agrl_graph_apply: out dtype must be fp32, the 16-bit type or AGRL_F32H3P");
+    const bool lp = out_dtype == AGRL_LP16, pre = out_dtype == AGRL_F32H3P;
     const bool aligned = ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)G) & 15) == 0);
     AGRL_CHECK_ARG(V <= 64 && (V % 4) == 0 && (C % 128) == 0 && aligned,
                    "agrl_graph_apply: the streaming form needs V <= 64, V %% 4 == 0, C %% 128 == 0, 16-byte aligned operands (V=%d C=%d); "
@@ -1026,11 +1044,13 @@ extern "C" int agrl_graph_apply(const float* G, const float* f, void* out, int o
 #define LAUNCH_GA(NT_)                                                                                                          \
     case NT_:                                                                                                                   \
         if (nwv == 4) {                                                                                                         \
-            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, true>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, nullptr, (lp16_t*)out, C); \
-            else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, false>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
+            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, 1>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, nullptr, (lp16_t*)out, C); \
+            else if (pre) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, 2>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C); \
+            else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 4, 0>), dim3(B, C / 256), dim3(256), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
         } else {                                                                                                                \
-            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, true>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, nullptr, (lp16_t*)out, C); \
-            else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, false>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
+            if (lp) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, 1>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, nullptr, (lp16_t*)out, C); \
+            else if (pre) hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, 2>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C); \
+            else hipLaunchKernelGGL((graph_apply_stream_kernel<NT_, 2, 0>), dim3(B, C / 128), dim3(128), lds_s, (hipStream_t)stream, f, G, (float*)out, nullptr, C);   \
         }                                                                                                                       \
         break
     switch (V4 >> 2) {

@@ -398,6 +398,44 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                 return;
             }
         }
+        if constexpr (DT<TIN>::code == AGRL_F32H3 && sizeof(TOUT) == 4 && kLpF16) {
+            if (p.out_planes) {
+                // the seam to the plane kernels (conv1x1_duo.hip): the finished fp32 value leaves as fp16 planes [hi | lo 2^11 (| hi)] --
+                // what agrl_split16_planes would make of the fp32 map, without the map (N % 4 == 0; no residual on this path)
+                _Float16* ob = reinterpret_cast<_Float16*>(p.out);
+                const size_t ldp = (size_t)p.out_planes * p.N;
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const int gm = m0 + wm * (BM / WM) + b * 16 + frow;
+                    if (gm >= p.M) continue;
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) {
+                        const int gn = n0 + wn * (BN / 2) + a * 16 + fchunk * 4;
+                        if (gn >= p.N) continue;
+                        float cv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (p.colv) {
+                            const float4 c4 = *reinterpret_cast<const float4*>(p.colv + gn);
+                            cv[0] = c4.x; cv[1] = c4.y; cv[2] = c4.z; cv[3] = c4.w;
+                        }
+                        uint32_t h[2], l[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            float y0 = fmaf(p.alpha, acc[a][b][2 * e], cv[2 * e]), y1 = fmaf(p.alpha, acc[a][b][2 * e + 1], cv[2 * e + 1]);
+                            if (p.relu) { y0 = relu_nan(y0); y1 = relu_nan(y1); }
+                            h[e] = pack_lp16x2(y0, y1);
+                            float a0, a1;
+                            unpack_lp16x2(h[e], a0, a1);
+                            l[e] = pack_lp16x2((y0 - a0) * 2048.f, (y1 - a1) * 2048.f);
+                        }
+                        _Float16* dst = ob + (size_t)gm * ldp + gn;
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(h[0], h[1]);
+                        *reinterpret_cast<uint2*>(dst + p.N) = make_uint2(l[0], l[1]);
+                        if (p.out_planes == 3) *reinterpret_cast<uint2*>(dst + 2 * (size_t)p.N) = make_uint2(h[0], h[1]);
+                    }
+                }
+                return;
+            }
+        }
         const bool vec_ok = p.vec_ok != 0;
         const bool do_stats = p.stats != nullptr;   // workgroup-uniform
         float st1[FN][4], st2[FN][4];
@@ -1118,7 +1156,9 @@ extern "C" int agrl_conv2d_bn_act_split16(const void* x, const void* w_scaled, c
 // conforming mode's counterpart of agrl_conv1x1_packed_dual_strided: the fp32 shortcut map (537 MB in layer 1) no longer exists.
 extern "C" int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scaled, const float* bias, void* out, int N, int H,
                                          int W, int stride, int K1, int K2, int Cout, int relu, float w_unscale, int x2_presplit,
-                                         agrl_stream_t stream) {
+                                         int out_planes, agrl_stream_t stream) {
+    AGRL_CHECK_ARG(out_planes == 0 || ((out_planes == 2 || out_planes == 3) && agrl_lp16_is_f16() && Cout % 4 == 0),
+                   "agrl_conv1x1_dual_split16: out_planes = %d (0: fp32 map; 2 / 3: split-fp16 planes, fp16 build, Cout %% 4 == 0)", out_planes);
     AGRL_CHECK_ARG(x && x2 && w_scaled && out, "agrl_conv1x1_dual_split16: null pointer");
     AGRL_CHECK_ARG(N > 0 && H > 0 && W > 0 && stride >= 1 && K1 > 0 && K2 > 0 && Cout > 0, "agrl_conv1x1_dual_split16: bad shape");
     AGRL_CHECK_ARG(K1 % 32 == 0 && K2 % 32 == 0, "agrl_conv1x1_dual_split16: K1 and K2 must be multiples of 32 (got %d, %d)", K1, K2);
@@ -1129,7 +1169,7 @@ extern "C" int agrl_conv1x1_dual_split16(const void* x, const void* x2, const vo
         AGRL_CHECK_ARG(frexpf(w_unscale, &e) == 0.5f, "agrl_conv1x1_dual_split16: w_unscale=%g is not a power of two", (double)w_unscale);
     }
     IgemmParams p{};
-    p.x = x; p.x2 = x2; p.K1 = K1; p.stats = nullptr; p.a_pre = x2_presplit ? 2 : 0;
+    p.x = x; p.x2 = x2; p.K1 = K1; p.stats = nullptr; p.a_pre = x2_presplit ? 2 : 0; p.out_planes = out_planes;
     p.w = w_scaled; p.colv = bias; p.rowv = nullptr; p.res = nullptr; p.out = out;
     p.alpha = w_unscale; p.rowc = 0.f; p.relu = relu; p.ksplit = 1; p.pool_nparts = 0;
     p.OH = (H - 1) / stride + 1;
@@ -1291,7 +1331,10 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
                                      float keep, float gamma, float slope, float* out, int M, int K, int Nout, int in_dtype,
                                      agrl_stream_t stream) {
     AGRL_CHECK_ARG(p_op && w && f && bn_scale && bn_shift && out, "agrl_graph_linear_mix: null pointer");
-    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3 || in_dtype == AGRL_F32H3, "agrl_graph_linear_mix: bad dtype %d", in_dtype);
+    AGRL_CHECK_ARG(in_dtype == AGRL_F32 || in_dtype == AGRL_LP16 || in_dtype == AGRL_F32X3 || in_dtype == AGRL_F32H3 || in_dtype == AGRL_F32H3P,
+                   "agrl_graph_linear_mix: bad dtype %d", in_dtype);
+    const bool p_presplit = in_dtype == AGRL_F32H3P;
+    if (p_presplit) in_dtype = AGRL_F32H3;
     AGRL_CHECK_ARG((Nout % 4) == 0 && ((((uintptr_t)f | (uintptr_t)out | (uintptr_t)bn_scale | (uintptr_t)bn_shift) & 15) == 0),
                    "agrl_graph_linear_mix: Nout %% 4 == 0 and 16-byte aligned f / out / scale / shift required");
     // 16-bit operands: the kernel shaped for this problem (graph_gemm.hip) where it applies
@@ -1313,7 +1356,10 @@ extern "C" int agrl_graph_linear_mix(const void* p_op, const void* w, const floa
     // split-fp16 (round 6): w holds the weight times a power of two 2^k (max |w| 2^k in [2^13, 2^14)), pre-split by agrl_split16_weights_inloop;
     // the caller folds 2^-k into bn_scale (exact)
     if (in_dtype == AGRL_F32H3) AGRL_CHECK_ARG(K % 32 == 0, "agrl_graph_linear_mix: split-fp16 needs K %% 32 == 0 (got %d)", K);
-    if (in_dtype == AGRL_F32H3) return launch_igemm<f32h_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
+    if (in_dtype == AGRL_F32H3) {
+        p.a_pre = p_presplit ? 1 : 0;
+        return launch_igemm<f32h_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
+    }
     return launch_igemm<lp16_t, float>(p, (hipStream_t)stream, "agrl_graph_linear_mix");
 }
 

@@ -41,6 +41,7 @@ struct IgemmParams {
     // agrl_split16_weights_inloop (per 32-channel group [8 x fp16 hi | 8 x fp16 lo] x 4 lane groups: the bytes of 32 fp32) -- the k-loop
     // then has no VALU work for them. a_pre bit 0: x is pre-split, bit 1: x2 is; out_pre: write out in that layout (no residual)
     int a_pre = 0, out_pre = 0;
+    int out_planes = 0;   // 2 / 3: write out as split-fp16 PLANES, (M, out_planes N) fp16 = [hi | lo 2^11 (| hi)] (the seam to the plane kernels)
     int dbg;     // ablation bits (AGRL_IGEMM_DBG, profiling only): 1 skip global stores, 4 skip epilogue phase 1, 8 skip steady-state DMA, 32 skip the DMA waits, 64 burst-issue DMA instead of interleaving
 };
 

@@ -18,6 +18,7 @@ import torch
 F32 = 0
 LP16 = 1   # the library's 16-bit storage type: fp16 (libagrl_hip.so) or bfloat16 (libagrl_hip_bf16.so)
 F32X3 = 2  # fp32 tensors, split-bf16 MFMA arithmetic (include/agrl_hip.h)
+F32H3P = 4  # F32H3 with the activation operand pre-split (graph_apply -> graph_linear_mix)
 F32H3 = 3  # fp32 tensors, split-FP16 MFMA arithmetic with pre-scaled weights (agrl_conv2d_bn_act_split16)
 METRIC_EUCLIDEAN = 0
 METRIC_COSINE = 1
@@ -57,14 +58,14 @@ SIGNATURES = {
     "agrl_stem_conv_bn_relu_maxpool": [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     "agrl_stem_conv_bn_relu_maxpool_lp16": [_p, _p, _p, _p, _i, _i, _i, _p],
     "agrl_conv2d_bn_act": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "agrl_conv1x1_dual_split16": [_p, _p, _p, _p, _p] + [_i] * 8 + [_f, _i, _p],
+    "agrl_conv1x1_dual_split16": [_p, _p, _p, _p, _p] + [_i] * 8 + [_f, _i, _i, _p],
     "agrl_stem_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _p],
-    "agrl_split16_planes": [_p, _p, C.c_longlong, _i, _p],
+    "agrl_split16_planes": [_p, _p, C.c_longlong, _i, _i, _p],
     "agrl_split16_weight_planes": [_p, _p, C.c_longlong, _i, _f, _p],
     "agrl_split16_weights_inloop": [_p, _p, C.c_longlong, _i, _p],
-    "agrl_conv1x1_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "agrl_conv1x1_split16_dual": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
-    "agrl_conv1x1_split16_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _f, _p],
+    "agrl_conv1x1_split16": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p],
+    "agrl_conv1x1_split16_dual": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p],
+    "agrl_conv1x1_split16_pool": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, C.POINTER(_i), _i, _i, _f, _i, _p],
     "agrl_conv3x3_packed_split16": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p],
     "agrl_conv2d_bn_act_split16": [_p, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _i, _p],
     "agrl_bottleneck_tail": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],

@@ -160,25 +160,28 @@ def conv_bn_act(x, w_ohwi, bias, stride, pad, relu, residual=None, x_presplit=Fa
     return out
 
 
-def conv1x1_dual_split16(x, x2, w_cat, bias, stride, relu=True, x2_presplit=False):
+def conv1x1_dual_split16(x, x2, w_cat, bias, stride, relu=True, x2_presplit=False, out_planes=0):
     """relu([x sampled at the stride | x2] @ w_cat^T + bias) in the split-fp16 arithmetic on fp32 tensors: a first Bottleneck's conv3 + its
     1x1 stride-s downsample conv in one GEMM (vmgn.py:56-64). x (N,H,W,K1) block input, x2 (N,OH,OW,K2) conv2's output, w_cat (Cout,
     K1+K2) from split16_inloop_weights of the concatenation (ONE power of two for both halves) -> (N,OH,OW,Cout) fp32. ``x2_presplit``: x2
-    was written by conv_bn_act(..., out_presplit=True)."""
+    was written by conv_bn_act(..., out_presplit=True). ``out_planes`` 2 / 3: the result leaves as split-fp16 planes (N,OH,OW,out_planes
+    Cout) fp16 -- to_split16_planes of the fp32 map, without the map."""
     N, H, W, K1 = x.shape
     K2 = x2.shape[3]
     Cout = w_cat.shape[0]
     OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
     assert x.dtype == torch.float32 and x2.dtype == torch.float32 and x.is_contiguous() and x2.is_contiguous()
     assert tuple(x2.shape[:3]) == (N, OH, OW) and tuple(w_cat.shape) == (Cout, K1 + K2) and getattr(w_cat, 'agrl_presplit', False)
-    out = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device)
+    assert out_planes in (0, 2, 3)
+    out = (torch.empty((N, OH, OW, out_planes * Cout), dtype=torch.float16, device=x.device) if out_planes
+           else torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device))
     if _hip.PROFILE is not None:
         M = N * OH * OW
-        _hip.PROFILE_TAG = {"flops": 2.0 * M * Cout * (K1 + K2), "bytes": 4.0 * (M * (K1 + K2) + w_cat.numel() + out.numel()),
+        _hip.PROFILE_TAG = {"flops": 2.0 * M * Cout * (K1 + K2), "bytes": 4.0 * (M * (K1 + K2) + w_cat.numel()) + out.numel() * out.element_size(),
                             "conv": (1, stride, K1 + K2, Cout, OH, OW)}
     with _dev(x):
         call("agrl_conv1x1_dual_split16", ptr(x), ptr(x2), ptr(w_cat), ptr(bias), ptr(out), N, H, W, stride, K1, K2, Cout,
-             1 if relu else 0, float(w_cat.agrl_unscale), 1 if x2_presplit else 0, _stream(x))
+             1 if relu else 0, float(w_cat.agrl_unscale), 1 if x2_presplit else 0, int(out_planes), _stream(x))
     return out
 
 
@@ -264,28 +267,37 @@ def split16_planes_available():
     return LP_NAME == 'fp16'
 
 
-def split16_plane_weights(w, segments=None):
+def split16_plane_weights(w, segments=None, pair_first=False):
     """fp32 weights (Cout, K) / OHWI (Cout, R, S, Cin) -> (fp16 tensor with 3 x the innermost axis = [wh | wh 2^-11 | wl] of w 2^k,
     2^-k): the operand the plane kernels multiply with activation planes [xh | xl 2^11 | xh] -- xh wh + xl wh + xh wl in one
     accumulator. k as in split16_prescale (max |w| 2^k in [2^13, 2^14)); ONE k for the whole tensor, also for the two-source form
-    (``segments`` = [K1, K2]: the innermost axis is [W1 | W2] and each source gets its own plane triple, [W1 triple | W2 triple])."""
+    (``segments`` = [K1, K2]: the innermost axis is [W1 | W2] and each source gets its own plane triple, [W1 triple | W2 triple]).
+    ``pair_first``: the first source is a plane PAIR [xh | xl 2^11] (include/agrl_hip.h, "Plane PAIRS"): its columns run per
+    128-channel slab c as [wh_c | wl_c | wh_c 2^-11], against the kernel's slab reads [xh_c | xh_c | xl_c]."""
     ws = split16_prescale(w)
     parts = []
-    for seg in torch.split(ws, segments or [ws.shape[-1]], dim=-1):
+    for i, seg in enumerate(torch.split(ws, segments or [ws.shape[-1]], dim=-1)):
         wh = seg.to(torch.float16)
         wl = (seg - wh.float()).to(torch.float16)
         wh_s = (wh.float() * (2.0 ** -11)).to(torch.float16)
-        parts += [wh, wh_s, wl]
+        if pair_first and i == 0:
+            assert seg.shape[-1] % 128 == 0
+            lead = tuple(seg.shape[:-1])
+            slabs = [t.reshape(lead + (-1, 128)) for t in (wh, wl, wh_s)]
+            parts.append(torch.stack(slabs, dim=-2).reshape(lead + (3 * seg.shape[-1],)))
+        else:
+            parts += [wh, wh_s, wl]
     return torch.cat(parts, dim=-1).contiguous(), ws.agrl_unscale
 
 
-def to_split16_planes(x):
-    """fp32 (..., C) -> fp16 (..., 3 C) = [hi | lo 2^11 | hi] (agrl_split16_planes)."""
-    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0
+def to_split16_planes(x, nplanes=3):
+    """fp32 (..., C) -> fp16 (..., 3 C) = [hi | lo 2^11 | hi], or with ``nplanes`` = 2 the pair (..., 2 C) = [hi | lo 2^11]
+    (agrl_split16_planes)."""
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] % 4 == 0 and nplanes in (2, 3)
     Cc = x.shape[-1]
-    out = torch.empty(tuple(x.shape[:-1]) + (3 * Cc,), dtype=torch.float16, device=x.device)
+    out = torch.empty(tuple(x.shape[:-1]) + (nplanes * Cc,), dtype=torch.float16, device=x.device)
     with _dev(x):
-        call("agrl_split16_planes", ptr(x), ptr(out), x.numel() // Cc, Cc, _stream(x))
+        call("agrl_split16_planes", ptr(x), ptr(out), x.numel() // Cc, Cc, nplanes, _stream(x))
     return out
 
 
@@ -319,41 +331,47 @@ def distmat_split16(q3, g3, metric, g_unscale, qn=None, gn=None, out=None):
     return out
 
 
-def from_split16_planes(x3):
-    """planes (..., 3 C) -> fp32 (..., C) = hi + lo 2^-11 (exact): tests and the stage-by-stage parity hooks (torch arithmetic: not
-    on the product path)."""
-    Cc = x3.shape[-1] // 3
+def from_split16_planes(x3, nplanes=3):
+    """planes (..., 3 C) (or a pair, (..., 2 C)) -> fp32 (..., C) = hi + lo 2^-11 (exact): tests and the stage-by-stage parity hooks
+    (torch arithmetic: not on the product path)."""
+    Cc = x3.shape[-1] // nplanes
     return x3[..., :Cc].float() + x3[..., Cc:2 * Cc].float() * (2.0 ** -11)
 
 
-def conv1x1_split16(x3, packed, unscale, bias, Cout, residual3=None, relu=True, x2=None):
-    """1x1 conv on planes: act(w_unscale [x3 | x2] @ W3^T + bias + residual) -> planes (N,H,W,3 Cout). vmgn.py:48-50, :56-64."""
-    N, H, W, K3 = x3.shape
+def conv1x1_split16(x3, packed, unscale, bias, Cout, residual3=None, relu=True, x2=None, layout=0):
+    """1x1 conv on planes: act(w_unscale [x3 | x2] @ W3^T + bias + residual) -> planes (N,H,W,3 Cout). vmgn.py:48-50, :56-64.
+    ``layout`` bit 0: x3 is a plane pair (N,H,W,2 K) with weights from split16_plane_weights(pair_first=True); bit 1: the residual
+    and the result are pairs (N,H,W,2 Cout). x2 is always a triple."""
+    N, H, W, Kx = x3.shape
+    K3 = Kx // 2 * 3 if layout & 1 else Kx     # the k-loop's columns
     K23 = 0 if x2 is None else x2.shape[3]
     M = N * H * W
+    no = 2 if layout & 2 else 3
     assert x3.dtype == torch.float16 and x3.is_contiguous() and packed.numel() == 2 * (K3 + K23) * Cout
-    assert residual3 is None or (residual3.dtype == torch.float16 and residual3.is_contiguous() and tuple(residual3.shape) == (N, H, W, 3 * Cout))
-    out = torch.empty((N, H, W, 3 * Cout), dtype=torch.float16, device=x3.device)
+    assert residual3 is None or (residual3.dtype == torch.float16 and residual3.is_contiguous() and tuple(residual3.shape) == (N, H, W, no * Cout))
+    out = torch.empty((N, H, W, no * Cout), dtype=torch.float16, device=x3.device)
     if _hip.PROFILE is not None:
         _hip.PROFILE_TAG = {"flops": 2.0 * M * Cout * (K3 + K23) / 3, "mfma_flops": 2.0 * M * Cout * (K3 + K23),
-                            "bytes": 2.0 * (x3.numel() + (0 if x2 is None else x2.numel()) + out.numel() + (0 if residual3 is None else residual3.numel())) + packed.numel()}
+                            "bytes": 2.0 * (x3.numel() + (0 if x2 is None else x2.numel()) + out.numel() + (0 if residual3 is None else residual3.numel() * 2 // no)) + packed.numel()}
     with _dev(x3):
         if x2 is None:
             call("agrl_conv1x1_split16", ptr(x3), ptr(packed), ptr(bias), ptr(residual3), ptr(out), M, K3, Cout, 1 if relu else 0,
-                 float(unscale), _stream(x3))
+                 float(unscale), int(layout), _stream(x3))
         else:
             assert residual3 is None and x2.dtype == torch.float16 and x2.is_contiguous() and tuple(x2.shape[:3]) == (N, H, W)
             call("agrl_conv1x1_split16_dual", ptr(x3), ptr(x2), ptr(packed), ptr(bias), ptr(out), M, K3, K23, Cout, 1 if relu else 0,
-                 float(unscale), _stream(x3))
+                 float(unscale), int(layout), _stream(x3))
     return out
 
 
-def conv1x1_split16_pool(x3, packed, unscale, bias, Cout, residual3, splits, mean, relu=True):
+def conv1x1_split16_pool(x3, packed, unscale, bias, Cout, residual3, splits, mean, relu=True, layout=0):
     """Last conv of a layer-4 branch on planes with the frame pooling in the epilogue (the unrounded fp32 values are pooled; no map).
     -> pooled fp32 (F, P, Cout). vmgn.py:56-64 + :298-308."""
     N, H, W, K3 = x3.shape
     assert x3.dtype == torch.float16 and x3.is_contiguous() and (H, W) == (16, 8) and packed.numel() == 2 * K3 * Cout
-    assert residual3 is None or (residual3.dtype == torch.float16 and residual3.is_contiguous() and tuple(residual3.shape) == (N, H, W, 3 * Cout))
+    assert not (layout & 1), "the pooled conv's input is conv2's output: a triple"
+    assert residual3 is None or (residual3.dtype == torch.float16 and residual3.is_contiguous()
+                                 and tuple(residual3.shape) == (N, H, W, (2 if layout & 2 else 3) * Cout))
     P = int(sum(splits))
     pooled = torch.empty((N, P, Cout), dtype=torch.float32, device=x3.device)
     arr = (C.c_int * len(splits))(*[int(s_) for s_ in splits])
@@ -362,7 +380,7 @@ def conv1x1_split16_pool(x3, packed, unscale, bias, Cout, residual3, splits, mea
                             "bytes": 2.0 * (x3.numel() + (residual3.numel() if residual3 is not None else 0)) + packed.numel() + 4.0 * pooled.numel()}
     with _dev(x3):
         call("agrl_conv1x1_split16_pool", ptr(x3), ptr(packed), ptr(bias), ptr(residual3), ptr(pooled), N, H, W, K3, Cout,
-             1 if relu else 0, arr, len(splits), 1 if mean else 0, float(unscale), _stream(x3))
+             1 if relu else 0, arr, len(splits), 1 if mean else 0, float(unscale), int(layout), _stream(x3))
     return pooled
 
 
@@ -806,17 +824,25 @@ def graph_propagate(f, h, G, bn_scale, bn_shift, gamma, slope, want_lp, keep=Non
     return out, out_lp
 
 
-def graph_apply_operand(G, f, out_dtype):
+def graph_apply_presplit_supported(f):
+    B, V, Cc = f.shape
+    return V <= 64 and V % 4 == 0 and Cc % 128 == 0
+
+
+def graph_apply_operand(G, f, out_dtype, presplit=False):
     """P = G f, (B,V,V) x (B,V,C) fp32 -> (B,V,C) in ``out_dtype`` (fp32 / bf16): the message pass applied to the layer INPUT,
-    written once as the operand of ``graph_linear_mix``. vmgn.py:168 with the Linear commuted behind it."""
+    written once as the operand of ``graph_linear_mix``. vmgn.py:168 with the Linear commuted behind it. ``presplit`` ('fp16x3'): the
+    fp32-sized rows hold the fp16 halves the GEMM's k-loop would form (graph_linear_mix(..., p_presplit=True))."""
     B, V, Cc = f.shape
     assert f.dtype == torch.float32 and G.dtype == torch.float32 and tuple(G.shape) == (B, V, V)
+    assert not presplit or (out_dtype == torch.float32 and graph_apply_presplit_supported(f))
     if V <= 64 and V % 4 == 0 and Cc % 128 == 0:
         out = torch.empty((B, V, Cc), dtype=out_dtype, device=f.device)
         if _hip.PROFILE is not None:
             _hip.PROFILE_TAG = {"flops": 2.0 * B * V * V * Cc, "bytes": 4.0 * (B * V * Cc + B * V * V) + out.element_size() * B * V * Cc}
         with _dev(f):
-            call("agrl_graph_apply", ptr(G.contiguous()), ptr(f.contiguous()), ptr(out), dtype_code(out_dtype), B, V, Cc, _stream(f))
+            call("agrl_graph_apply", ptr(G.contiguous()), ptr(f.contiguous()), ptr(out), _hip.F32H3P if presplit else dtype_code(out_dtype), B, V, Cc,
+                 _stream(f))
         return out
     # other node counts (V > 64: seq_len 16; V % 4 != 0): the general message-pass kernels with a unit BatchNorm
     key = (f.device, Cc)
@@ -855,7 +881,7 @@ def graph_tracklet_operand(f, adj, use_pose, learn_graph, out_dtype, want_graph=
     return P, G
 
 
-def graph_linear_mix(p_op, w, f, bn_scale, bn_shift, gamma, slope, keep=None):
+def graph_linear_mix(p_op, w, f, bn_scale, bn_shift, gamma, slope, keep=None, p_presplit=False):
     """out = keep f + gamma lrelu(bn((G f) W^T)): the Linear of a GraphLayer as ONE GEMM over P = G f with BatchNorm1d, LeakyReLU
     and the residual mix in its epilogue (vmgn.py:148, :168-172). p_op (B,V,K) fp32 / bf16, w (N,K) same dtype, f (B,V,N) fp32."""
     if keep is None:
@@ -870,7 +896,9 @@ def graph_linear_mix(p_op, w, f, bn_scale, bn_shift, gamma, slope, keep=None):
     unscale = getattr(w, 'agrl_unscale', None)
     if unscale is not None:   # 'fp16x3': w pre-scaled by a power of two and pre-split (split16_inloop_weights); bn_scale must already carry the 2^-k
         assert p_op.dtype == torch.float32 and getattr(bn_scale, 'agrl_folded_unscale', None) == unscale and getattr(w, 'agrl_presplit', False)
-        code = _hip.F32H3
+        code = _hip.F32H3P if p_presplit else _hip.F32H3
+    else:
+        assert not p_presplit
     with _dev(f):
         call("agrl_graph_linear_mix", ptr(p_op.contiguous()), ptr(w), ptr(f.contiguous()), ptr(bn_scale), ptr(bn_shift), float(keep), float(gamma),
              float(slope), ptr(out), B * V, K, Nout, code, _stream(f))

@@ -190,9 +190,11 @@ def pack_weights(model, device, precision):
         # mode's four-wave kernels (ops.conv1x1_split16 / conv3x3_split16); the stem .. layer 3's first block keep fp32 tensors and the
         # in-loop split (agrl_conv2d_bn_act_split16)
         first = len(model.layer1) + len(model.layer2) + 1
+        pairs = ops.switch_on('AGRL_HIP_SPLIT16_PAIRS')
         with torch.no_grad():
-            ok = all(_pack_planes(blk) for blk in pack['trunk'][first:] + pack['l4_1'] + pack['l4_2'])
+            ok = all(_pack_planes(blk, pairs) for blk in pack['trunk'][first:] + pack['l4_1'] + pack['l4_2'])
         pack['planes_from'] = first if ok else None
+        pack['planes_pairs'] = pairs
     if s16:
         for blk in stages:   # the scaled fp32 copies were for the packers above
             for name in ('c1', 'c2', 'c3', 'ds', 'dual16'):
@@ -205,9 +207,11 @@ def pack_weights(model, device, precision):
     return pack
 
 
-def _pack_planes(blk):
+def _pack_planes(blk, pairs=True):
     """The split-fp16 plane operands of one Bottleneck (blk: fp32 folded weights, pre-scaled for the in-loop split) -> blk['p3'];
-    False when a shape does not fit the four-wave kernels (the caller then keeps the whole model on the in-loop split)."""
+    False when a shape does not fit the four-wave kernels (the caller then keeps the whole model on the in-loop split).
+    ``pairs``: the block's input and output -- the wide tensors the 1x1 kernels are HBM-bound on -- are plane PAIRS [hi | lo 2^11]
+    (the third plane repeats the first: ops.split16_plane_weights(pair_first=True)); conv1's and conv2's outputs stay triples."""
     def true_w(pair):
         return ops.split16_true_weights(pair[0])    # undo the per-tensor pre-scale (exact)
 
@@ -215,8 +219,8 @@ def _pack_planes(blk):
     K1, K3c, mid, cout = w1.shape[3], w3.shape[3], w1.shape[0], w3.shape[0]
     if blk['stride'] != 1 or mid % 256 or cout % 256 or K1 % 128 or K3c % 128 or tuple(w2.shape[1:3]) != (3, 3) or w2.shape[3] % 64:
         return False
-    p3 = {}
-    t, u = ops.split16_plane_weights(w1.view(mid, K1))
+    p3 = {'pairs': bool(pairs)}
+    t, u = ops.split16_plane_weights(w1.view(mid, K1), pair_first=pairs)
     p3['c1'] = (ops.conv1x1_pack(t), u, blk['c1'][1], mid)
     t, u = ops.split16_plane_weights(w2)
     p3['c2'] = (ops.conv3x3_pack(t), u, blk['c2'][1], w2.shape[0])
@@ -227,7 +231,7 @@ def _pack_planes(blk):
         Kd = wd.shape[3]
         if Kd % 128:
             return False
-        t, u = ops.split16_plane_weights(torch.cat([wd.view(cout, Kd), w3.view(cout, K3c)], dim=1), segments=[Kd, K3c])
+        t, u = ops.split16_plane_weights(torch.cat([wd.view(cout, Kd), w3.view(cout, K3c)], dim=1), segments=[Kd, K3c], pair_first=pairs)
         p3['dual'] = (ops.conv1x1_pack(t), u, (blk['ds'][1] + blk['c3'][1]).contiguous(), cout)
     else:
         t, u = ops.split16_plane_weights(w3.view(cout, K3c))
@@ -240,16 +244,17 @@ def _run_block_planes(x3, blk, pool=None):
     """One Bottleneck on split-fp16 planes (x3: (F,h,w,3 C) fp16 = [hi | lo 2^11 | hi]); ``pool`` = (splits, mean): the frame pooling
     in the last conv's epilogue, returns the pooled fp32 tensor instead of the map. vmgn.py:45-65."""
     p3 = blk['p3']
-    y = ops.conv1x1_split16(x3, p3['c1'][0], p3['c1'][1], p3['c1'][2], p3['c1'][3])
+    xp, rop = (1, 2) if p3['pairs'] else (0, 0)   # layout bits: x3 is a pair / residual and result are pairs
+    y = ops.conv1x1_split16(x3, p3['c1'][0], p3['c1'][1], p3['c1'][2], p3['c1'][3], layout=xp)
     y = ops.conv3x3_split16(y, p3['c2'][0], p3['c2'][1], p3['c2'][2], p3['c2'][3])
     if 'dual' in p3:
         assert pool is None
         d = p3['dual']
-        return ops.conv1x1_split16(x3, d[0], d[1], d[2], d[3], x2=y)
+        return ops.conv1x1_split16(x3, d[0], d[1], d[2], d[3], x2=y, layout=xp | rop)
     c = p3['c3']
     if pool is not None:
-        return ops.conv1x1_split16_pool(y, c[0], c[1], c[2], c[3], x3, pool[0], pool[1])
-    return ops.conv1x1_split16(y, c[0], c[1], c[2], c[3], residual3=x3)
+        return ops.conv1x1_split16_pool(y, c[0], c[1], c[2], c[3], x3, pool[0], pool[1], layout=rop)
+    return ops.conv1x1_split16(y, c[0], c[1], c[2], c[3], residual3=x3, layout=rop)
 
 
 def hip_features_pooled_planes(model, frames, pack, splits):
@@ -266,8 +271,8 @@ def hip_features_pooled_planes(model, frames, pack, splits):
     if (h4, w4) != (16, 8):
         return None
     a = ops.stem_split16(frames, pack['stem_s16'][0], pack['stem_s16'][1], pack['stem_s16'][2], pack['stem'][1])
-    a = _run_trunk(a, pack['trunk'][:first], False)
-    a3 = ops.to_split16_planes(a)
+    a = _run_trunk(a, pack['trunk'][:first - 1], False)
+    a3 = _run_block_inloop(a, pack['trunk'][first - 1], out_planes=2 if pack.get('planes_pairs') else 3)
     del a
     for blk in pack['trunk'][first:]:
         a3 = _run_block_planes(a3, blk)
@@ -304,7 +309,7 @@ def _conv1(x, blk):
     return ops.conv_bn_act(x, blk['c1'][0], blk['c1'][1], 1, 0, True)
 
 
-def _run_block_inloop(x, blk):
+def _run_block_inloop(x, blk, out_planes=0):
     """One Bottleneck of the conforming mode on fp32 tensors (weights from ops.split16_inloop_weights): conv1's and conv2's outputs are read
     by one GEMM each and never as numbers, so they are stored with their fp16 halves already formed -- the 3x3 conv's k-loop has no
     VALU work left (bit-identical to splitting in the loop; AGRL_HIP_SPLIT16_PREACT=0 is that form)."""
@@ -313,9 +318,11 @@ def _run_block_inloop(x, blk):
     y = ops.conv_bn_act(y, blk['c2'][0], blk['c2'][1], blk['stride'], 1, True, x_presplit=pre, out_presplit=pre)
     if 'dual16' in blk and ops.switch_on('AGRL_HIP_SPLIT16_DUAL') and x.is_contiguous():
         # conv3 + the downsample conv as ONE GEMM over [x sampled at the stride | y]: no shortcut map in HBM
-        return ops.conv1x1_dual_split16(x, y, blk['dual16'][0], blk['dual16'][1], blk['stride'], True, x2_presplit=pre)
+        # (``out_planes``: the last block in front of the plane kernels writes their input layout itself)
+        return ops.conv1x1_dual_split16(x, y, blk['dual16'][0], blk['dual16'][1], blk['stride'], True, x2_presplit=pre, out_planes=out_planes)
     shortcut = x if blk['ds'] is None else ops.conv_bn_act(x, blk['ds'][0], blk['ds'][1], blk['ds_stride'], 0, False)
-    return ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut, x_presplit=pre)
+    out = ops.conv_bn_act(y, blk['c3'][0], blk['c3'][1], 1, 0, True, residual=shortcut, x_presplit=pre)
+    return ops.to_split16_planes(out, out_planes) if out_planes else out
 
 
 def _is_inloop(blk):
@@ -467,14 +474,18 @@ def hip_graph_layers(nodes, nodes_lp, adj, pack, stages=None, commute=True):
         if commute:
             # G (f W^T) = (G f) W^T: graph -> P = G f (written once, in the GEMM's operand dtype) -> ONE GEMM whose epilogue
             # applies BatchNorm1d + LeakyReLU + the residual mix. h never exists; f and out cross HBM once each.
+            pre = False
             if ops.graph_tracklet_operand_supported(nodes):   # many tracklets per GPU: one workgroup per tracklet, one launch
                 P, G = ops.graph_tracklet_operand(nodes, adj, g['use_pose'], g['learn_graph'], pack['dtype'], want_graph=stages is not None)
             else:
                 G = ops.graph_matrix(nodes, adj, g['use_pose'], g['learn_graph'])
-                P = ops.graph_apply_operand(G, nodes, pack['dtype'])
+                # conforming mode: P is read by the GEMM only -- written with its fp16 halves already formed
+                pre = (getattr(g['w'], 'agrl_presplit', False) and ops.graph_apply_presplit_supported(nodes)
+                       and ops.switch_on('AGRL_HIP_SPLIT16_PREACT'))
+                P = ops.graph_apply_operand(G, nodes, pack['dtype'], presplit=pre)
             if stages is not None:
                 stages['G%d' % i] = G
-            nodes = ops.graph_linear_mix(P, g['w'], nodes, g['scale'], g['shift'], g['gamma'], g['slope'])
+            nodes = ops.graph_linear_mix(P, g['w'], nodes, g['scale'], g['shift'], g['gamma'], g['slope'], p_presplit=pre)
             continue
         if lp and nodes_lp is None:   # A/B form entered without the pooled bf16 copy: native conversion kernel
             nodes_lp = ops.row_l2_normalize(nodes.view(B * V, C), False, ops.LP_DTYPE).view(B, V, C)

@@ -41,6 +41,8 @@ extern "C" {
 #define AGRL_BF16 AGRL_LP16 /* historical name of the same code */
 #define AGRL_F32X3 2
 #define AGRL_F32H3 3
+#define AGRL_F32H3P 4   /* AGRL_F32H3 with the activation operand already PRE-SPLIT (fp32-sized rows holding fp16 halves, the layout of
+                           agrl_split16_weights_inloop): agrl_graph_apply writes it, agrl_graph_linear_mix reads it */
 
 #define AGRL_METRIC_EUCLIDEAN 0 /* squared euclidean, torchreid/metrics/distance.py:59-73 */
 #define AGRL_METRIC_COSINE 1    /* 1 - cos,          torchreid/metrics/distance.py:76-89 */
@@ -128,9 +130,12 @@ int agrl_split16_weights_inloop(const float* w_scaled, void* out, long long rows
  * block input, x2 (N,OH,OW,K2) conv2's output, w_scaled (Cout, K1+K2) = [w_downsample | w_conv3] 2^k pre-split
  * (agrl_split16_weights_inloop), bias = b_downsample + b_conv3,
  * out (N,OH,OW,Cout) fp32, OH = (H-1)/stride+1. The fp32 shortcut map is neither written nor read back. K1, K2 multiples of 32.
- * x2_presplit != 0: x2 was written pre-split (agrl_conv2d_bn_act_split16 with out_presplit); x is always fp32. */
+ * x2_presplit != 0: x2 was written pre-split (agrl_conv2d_bn_act_split16 with out_presplit); x is always fp32.
+ * out_planes 2 / 3: the seam to the plane kernels below -- out leaves as split-fp16 planes (N,OH,OW,out_planes Cout) fp16 =
+ * [hi | lo 2^11 (| hi)], what agrl_split16_planes makes of the fp32 map, without the map (fp16 build); 0: the fp32 map. */
 int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scaled, const float* bias, void* out, int N, int H, int W,
-                              int stride, int K1, int K2, int Cout, int relu, float w_unscale, int x2_presplit, agrl_stream_t stream);
+                              int stride, int K1, int K2, int Cout, int relu, float w_unscale, int x2_presplit, int out_planes,
+                              agrl_stream_t stream);
 
 /* ---- Split-fp16 PLANES (round 6): the conforming mode at speed --------------------------------------------------------------
  * The same arithmetic class as agrl_conv2d_bn_act_split16 (x w ~ xh wh + xl wh + xh wl, 22 significand bits per operand, fp32
@@ -144,19 +149,25 @@ int agrl_conv1x1_dual_split16(const void* x, const void* x2, const void* w_scale
  * fp16 build only (agrl_lp16_is_f16()). Replaces, for the first Bottlenecks behind layer 3's first block and all of layer 4,
  * torchreid/models/vmgn.py:45-65 / :288-289 in the reference's own fp32 accuracy class (tests/test_gpu_fullsplit.py: every index that
  * differs from the CPU oracle's ranked lists is a swap inside a near-tie, as for the exact-fp32 mode). */
-int agrl_split16_planes(const float* x, void* out, long long rows, int C, agrl_stream_t stream);   /* fp32 (rows, C) -> planes (rows, 3 C) */
+/* Plane PAIRS: the third plane repeats the first, and the 1x1 kernels are HBM-bound on exactly the wide tensors of the residual stream
+ * (a Bottleneck's input / output). Those may be kept as (rows, 2 C) = [hi | lo 2^11] -- `layout` of the 1x1 entry points, bit 0: x is a
+ * pair, bit 1: residual and out are pairs (x2 and the 3x3 conv's tensors are always triples). The K axis of a pair's weights runs, per
+ * 128-channel slab c, as [wh_c | wl_c | wh_c 2^-11] against the kernel's reads [hi_c | hi_c | lo_c]: the repeated slab is requested
+ * again right behind its first use (an L2 hit). Same products, same accumulator: only the order of the k-steps differs. */
+int agrl_split16_planes(const float* x, void* out, long long rows, int C, int nplanes, agrl_stream_t stream);   /* fp32 (rows, C) -> planes (rows, nplanes C), nplanes 3 or 2 */
 /* fp32 (rows, C) -> the weight-side triple (rows, 3 C) = [h | h 2^-11 | l] of x * scale (scale a power of two): gallery rows of agrl_distmat_split16 */
 int agrl_split16_weight_planes(const float* x, void* out, long long rows, int C, float scale, agrl_stream_t stream);
-/* 1x1 conv (+ residual planes) on planes: x (M, K3), residual NULL or (M, 3 Cout), out (M, 3 Cout); K3 % 384 == 0, Cout % 256 == 0 */
+/* 1x1 conv (+ residual planes) on planes: x (M, K3) (a pair: (M, K3 / 3 * 2)), residual NULL or (M, 3 Cout), out (M, 3 Cout) (pairs:
+ * (M, 2 Cout)); K3 % 384 == 0 counts the k-loop's columns in either layout, Cout % 256 == 0 */
 int agrl_conv1x1_split16(const void* x, const void* packed, const float* bias, const void* residual, void* out, int M, int K3,
-                         int Cout, int relu, float w_unscale, agrl_stream_t stream);
+                         int Cout, int relu, float w_unscale, int layout, agrl_stream_t stream);
 /* conv3 + stride-1 downsample conv of a first block as one GEMM over [x | x2] (vmgn.py:56-64), all planes */
 int agrl_conv1x1_split16_dual(const void* x, const void* x2, const void* packed, const float* bias, void* out, int M, int K1_3,
-                              int K2_3, int Cout, int relu, float w_unscale, agrl_stream_t stream);
+                              int K2_3, int Cout, int relu, float w_unscale, int layout, agrl_stream_t stream);
 /* last conv of a layer-4 branch with the frame pooling of vmgn.py:298-308 in the epilogue: pool_out fp32 (N, nparts, Cout), no map */
 int agrl_conv1x1_split16_pool(const void* x, const void* packed, const float* bias, const void* residual, float* pool_out, int N,
                               int H, int W, int K3, int Cout, int relu, const int* splits, int n_splits, int mean, float w_unscale,
-                              agrl_stream_t stream);
+                              int layout, agrl_stream_t stream);
 /* 3x3 stride-1 pad-1 conv on planes: x (N, H, W, Cin3), out (N, H, W, 3 Cout); 16 x 8-divisible maps, Cin3 % 192 == 0, Cout % 256 == 0 */
 int agrl_conv3x3_packed_split16(const void* x, const void* packed, const float* bias, void* out, int N, int H, int W, int Cin3,
                                 int Cout, int relu, float w_unscale, agrl_stream_t stream);
@@ -341,14 +352,15 @@ int agrl_graph_finalize_bits(const float* gram_part, int nz, const uint32_t* adj
                              int learn_graph, int mask_diag, agrl_stream_t stream);
 
 /* GraphLayer with the Linear commuted behind the message pass: G (f W^T) = (G f) W^T (torchreid/models/vmgn.py:148, :168-172).
- *   agrl_graph_apply      P = G f, (B,V,V) x (B,V,C) fp32 -> (B,V,C) in out_dtype (AGRL_F32 / AGRL_BF16): the operand of the
+ *   agrl_graph_apply      P = G f, (B,V,V) x (B,V,C) fp32 -> (B,V,C) in out_dtype (AGRL_F32 / AGRL_BF16 / AGRL_F32H3P): the operand of the
  *                         GEMM below, written once. Streaming form: V <= 64, V % 4 == 0, C % 128 == 0 (other shapes: call
  *                         agrl_graph_propagate with h = f, unit scale, zero shift, keep 0, gamma 1, slope 1).
  *   agrl_graph_linear_mix out = keep * f + gamma * LeakyReLU_slope( bn_scale * (P W^T) + bn_shift ): ONE GEMM (M = B V rows,
  *                         K -> Nout) whose register epilogue applies the folded eval BatchNorm1d, the LeakyReLU and the residual
  *                         mix with the layer input f (fp32 (M,Nout)); the Linear's output h never exists. p_op (M,K) and w (Nout,K)
  *                         in in_dtype (AGRL_F32 exact, AGRL_F32X3 split, AGRL_BF16; AGRL_F32H3: p_op fp32, w pre-scaled by a power of
- *                         two whose inverse the caller folds into bn_scale, and pre-split by agrl_split16_weights_inloop); K a
+ *                         two whose inverse the caller folds into bn_scale, and pre-split by agrl_split16_weights_inloop; AGRL_F32H3P: the same with
+ *                         p_op pre-split too, as agrl_graph_apply writes it); K a
  *                         multiple of 32 (fp32) / 64 (bf16), Nout % 4 == 0. The workgroup -> tile map keeps each XCD on its own slice of W (L2-resident). */
 int agrl_graph_apply(const float* G, const float* f, void* out, int out_dtype, int B, int V, int C, agrl_stream_t stream);
 /* agrl_graph_gram + agrl_graph_finalize + agrl_graph_apply for MANY tracklets per GPU, one workgroup per tracklet (use it when

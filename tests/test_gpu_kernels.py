@@ -1220,7 +1220,9 @@ def test_split16_entry_points_validate_their_arguments():
     with pytest.raises(_hip.HipKernelError):   # 0.3 is not a power of two
         ops.conv1x1_split16(x3, pk, 0.3, b, 256)
     with pytest.raises(_hip.HipKernelError):   # K3 = 320 is not a whole number of plane triples of 128-channel slabs
-        ops.call("agrl_conv1x1_split16", ops.ptr(x3), ops.ptr(pk), ops.ptr(b), None, ops.ptr(out), 512, 320, 256, 1, 1.0, None)
+        ops.call("agrl_conv1x1_split16", ops.ptr(x3), ops.ptr(pk), ops.ptr(b), None, ops.ptr(out), 512, 320, 256, 1, 1.0, 0, None)
+    with pytest.raises(_hip.HipKernelError):   # layout bits beyond 3
+        ops.call("agrl_conv1x1_split16", ops.ptr(x3), ops.ptr(pk), ops.ptr(b), None, ops.ptr(out), 512, 384, 256, 1, 1.0, 4, None)
     with pytest.raises(_hip.HipKernelError):   # scale of the weight planes must be a power of two
         ops.to_split16_weight_planes(x.view(-1, 128), 3.0)
     with pytest.raises(_hip.HipKernelError):   # D3 must be a multiple of 3
@@ -1325,6 +1327,72 @@ def test_conv1x1_split16_planes(cfg):
     assert e < 2e-6
 
 
+@pytest.mark.parametrize("cfg", [(128 * 6, 2048, 512, "plain"), (128 * 5 + 40, 1024, 256, "plain"), (256 * 4, 512, 2048, "res"), (128 * 4 + 8, 256, 1024, "res"),
+                                 (128 * 6, (1024, 512), 2048, "dual"), (128 * 3 + 77, (1024, 256), 1024, "dual"), (5, 512, 2048, "pool")])
+def test_conv1x1_split16_plane_pairs(cfg):
+    """The plane-PAIR layout of the wide tensors (include/agrl_hip.h "Plane PAIRS": [hi | lo 2^11], the kernel reads the hi slab twice,
+    weights per 128-channel slab [wh | wl | wh 2^-11]) through agrl_conv1x1_split16 / _dual / _pool: conv1 (x a pair -> a triple), conv3 +
+    residual (x a triple, residual and result pairs), the two-source first block (x a pair, x2 a triple, result a pair), the pooled last conv
+    (residual a pair) -- against float64 on the values the planes hold, and against the all-triples launch (same products, another k order:
+    equal to fp32 summation roundoff). A pair IS the first two planes of the triple, checked bytewise."""
+    if LP16 != "fp16":
+        pytest.skip("fp16 build only")
+    from torchreid import hip_ops as ops
+    M, K, Cout, kind = cfg
+    g = torch.Generator().manual_seed(M + Cout + 1)
+    Ks = list(K) if isinstance(K, tuple) else [K]
+    if kind == "pool":
+        N, H, W = M, 16, 8
+        M = N * 128
+    xs = [(torch.randn((M, k_), generator=g).clamp(min=0) * torch.exp(1.5 * torch.randn((M, 1), generator=g))).to(DEV) for k_ in Ks]
+    w = (torch.randn((Cout, sum(Ks)), generator=g) * (0.7 / np.sqrt(sum(Ks)))).to(DEV)
+    bd = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    x3 = [ops.to_split16_planes(x_) for x_ in xs]
+    x2p = ops.to_split16_planes(xs[0], 2)
+    assert torch.equal(x2p, x3[0][:, :2 * Ks[0]].contiguous())
+    xv = torch.cat([_planes_ref(t) for t in x3], dim=1)
+    x_pair = kind in ("plain", "dual")
+    ro_pair = kind in ("res", "dual", "pool")
+    w3t, unscale = ops.split16_plane_weights(w, segments=Ks if len(Ks) > 1 else None)
+    w3p, unscale_p = ops.split16_plane_weights(w, segments=Ks if len(Ks) > 1 else None, pair_first=x_pair)
+    assert unscale == unscale_p and w3p.shape == w3t.shape
+    pk_t, pk_p = ops.conv1x1_pack(w3t), ops.conv1x1_pack(w3p)
+    ref = xv @ (w.double().cpu()).t() + bd.double().cpu()
+    layout = (1 if x_pair else 0) | (2 if ro_pair else 0)
+    xin = (x2p if x_pair else x3[0]).view(1, M, 1, -1)
+    r3 = r2 = None
+    if kind in ("res", "pool"):
+        r = torch.randn((M, Cout), generator=g).clamp(min=0).to(DEV)
+        r3, r2 = ops.to_split16_planes(r), ops.to_split16_planes(r, 2)
+        ref = ref + _planes_ref(r3)
+    ref = ref.clamp(min=0)
+    if kind == "pool":
+        splits = [4, 2, 1]
+        got = ops.conv1x1_split16_pool(x3[0].view(N, 16, 8, -1), pk_p, unscale, bd, Cout, r2.view(N, 16, 8, -1), splits, True, layout=layout)
+        tri = ops.conv1x1_split16_pool(x3[0].view(N, 16, 8, -1), pk_t, unscale, bd, Cout, r3.view(N, 16, 8, -1), splits, True)
+        torch.cuda.synchronize()
+        assert torch.equal(got, tri)      # (the k order is the triple's here: only the residual's row stride differs)
+        return
+    if kind == "dual":
+        got = ops.conv1x1_split16(xin, pk_p, unscale, bd, Cout, x2=x3[1].view(1, M, 1, -1), layout=layout)
+        tri = ops.conv1x1_split16(x3[0].view(1, M, 1, -1), pk_t, unscale, bd, Cout, x2=x3[1].view(1, M, 1, -1))
+    else:
+        got = ops.conv1x1_split16(xin, pk_p, unscale, bd, Cout, residual3=None if r2 is None else r2.view(1, M, 1, -1), layout=layout)
+        tri = ops.conv1x1_split16(x3[0].view(1, M, 1, -1), pk_t, unscale, bd, Cout, residual3=None if r3 is None else r3.view(1, M, 1, -1))
+    torch.cuda.synchronize()
+    no = 2 if ro_pair else 3
+    got, tri = got.view(M, no * Cout), tri.view(M, 3 * Cout)
+    if not ro_pair:
+        assert torch.equal(got[:, :Cout], got[:, 2 * Cout:])
+    den = ref.abs().max()
+    e = float((ops.from_split16_planes(got, no).double().cpu() - ref).abs().max() / den)
+    d = float((ops.from_split16_planes(got, no).double() - ops.from_split16_planes(tri).double()).abs().max().cpu() / den)
+    print("conv1x1 split16 pairs", cfg, "vs float64 %.2e, vs the triple launch %.2e" % (e, d))
+    assert e < 2e-6 and d < 2e-6
+    if kind == "res":      # same k order as the triple: bit-identical planes
+        assert torch.equal(got, tri[:, :2 * Cout].contiguous())
+
+
 @pytest.mark.parametrize("cfg", [(6, 16, 8, 512, 512), (5, 16, 8, 256, 256), (3, 32, 16, 128, 256)])
 def test_conv3x3_split16_planes(cfg):
     """agrl_conv3x3_packed_split16 (conv3x3_fat_kernel / conv3x3_half_kernel on split-fp16 planes; vmgn.py:52-54) against F.conv2d in
@@ -1419,6 +1487,55 @@ def test_presplit_activations_are_bit_identical_to_splitting_in_the_loop(cfg):
         lo = (v - hi.float()).to(torch.float16)
         want = torch.stack([hi, lo], dim=2).contiguous().view(torch.int32).view(-1)
         assert torch.equal(outs[True][i].view(torch.int32).view(-1), want)
+
+
+@pytest.mark.parametrize("cfg", [(3, 32, 16, 512, 256, 1024, 2), (2, 16, 8, 1024, 512, 2048, 1), (1, 9, 7, 64, 96, 128, 2)])
+def test_conv1x1_dual_split16_writes_the_planes_itself(cfg):
+    """agrl_conv1x1_dual_split16 with out_planes = 2 / 3 (the seam between the fp32-tensor part of the conforming mode and its plane part):
+    the planes must be exactly agrl_split16_planes of the fp32 map the same launch writes with out_planes = 0."""
+    if LP16 != "fp16":
+        pytest.skip("fp16 build only")
+    from torchreid import hip_ops as ops
+    N, H, W, K1, K2, Cout, stride = cfg
+    g = torch.Generator().manual_seed(sum(cfg) + 3)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.randn((N, H, W, K1), generator=g).clamp(min=0).to(DEV)
+    y = torch.randn((N, OH, OW, K2), generator=g).clamp(min=0).to(DEV)
+    wcat = ops.split16_inloop_weights((torch.randn((Cout, K1 + K2), generator=g) * (0.7 / np.sqrt(K1 + K2))).to(DEV))
+    b = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    full = ops.conv1x1_dual_split16(x, y, wcat, b, stride, True)
+    for n in (2, 3):
+        got = ops.conv1x1_dual_split16(x, y, wcat, b, stride, True, out_planes=n)
+        torch.cuda.synchronize()
+        assert got.dtype == torch.float16 and tuple(got.shape) == (N, OH, OW, n * Cout)
+        assert torch.equal(got, ops.to_split16_planes(full, n))
+
+
+@pytest.mark.parametrize("shape", [(32, 56, 2048), (3, 28, 2048), (5, 60, 256)])
+def test_graph_operand_presplit_is_bit_identical(shape):
+    """The GraphLayer's GEMM of the conforming mode with P = G f written PRE-SPLIT by agrl_graph_apply (AGRL_F32H3P) against the same
+    GEMM splitting P in its k-loop (AGRL_F32H3): equal bit for bit, and P's bytes are the host packer's layout of the fp32 P."""
+    from torchreid import hip_ops as ops
+    from recipe import synthetic_adj
+    B, V, C = shape
+    g = torch.Generator().manual_seed(B + V + C)
+    f = (torch.rand((B, 1, C), generator=g) + 0.02 * torch.randn((B, V, C), generator=g)).to(DEV)
+    adj = (synthetic_adj(B, V // 7, seed=V) if V % 7 == 0 else (torch.rand((B, V, V), generator=g) > 0.5).float()).to(DEV)
+    G = ops.graph_matrix(f, adj, True, True)
+    w = ops.split16_inloop_weights((torch.randn((C, C), generator=g) * 0.02).to(DEV))
+    scale = ((0.8 + 0.4 * torch.rand(C, generator=g)).to(DEV) * w.agrl_unscale).contiguous()
+    scale.agrl_folded_unscale = w.agrl_unscale
+    shift = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    P = ops.graph_apply_operand(G, f, torch.float32)
+    Pp = ops.graph_apply_operand(G, f, torch.float32, presplit=True)
+    a = ops.graph_linear_mix(P, w, f, scale, shift, 0.1, 0.1)
+    b = ops.graph_linear_mix(Pp, w, f, scale, shift, 0.1, 0.1, p_presplit=True)
+    torch.cuda.synchronize()
+    v = P.reshape(-1, C // 32, 2, 4, 4).permute(0, 1, 3, 2, 4)
+    hi = v.to(torch.float16)
+    want = torch.stack([hi, (v - hi.float()).to(torch.float16)], dim=2).contiguous().view(torch.int32).view(-1)
+    assert torch.equal(Pp.view(torch.int32).view(-1), want)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 def test_conv_split_fp16_rejects_a_scale_that_is_not_a_power_of_two():
