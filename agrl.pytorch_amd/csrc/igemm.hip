@@ -208,6 +208,25 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         }
     }
 
+    // split-fp16, short K (conv3 of layers 1-2: two to four k-tiles, then a residual as large as the result): the residual is requested
+    // NOW, behind the first k-tiles' DMA, instead of at the head of the epilogue -- one HBM round trip per tile less on the critical path.
+    // 64-row tiles only (FM = 1: 4 x FN registers; the 128-row tile has no room beside its 115)
+    constexpr bool RES_EARLY = DT<TIN>::code == AGRL_F32H3 && sizeof(TOUT) == 4 && !LDS_EPI && FM == 1;
+    f32x4_t rpre[RES_EARLY ? FN : 1];
+    bool res_early = false;
+    if constexpr (RES_EARLY) {
+        res_early = p.res != nullptr && p.vec_ok && !p.out_pre && !p.out_planes && !p.mix_f && nk <= 4;
+        if (res_early) {
+            const int gm = m0 + wm * (BM / WM) + (lane & 15);
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int gn = n0 + wn * (BN / 2) + a * 16 + (lane >> 4) * 4;
+                const bool ok = gm < p.M && gn + 3 < p.N;
+                rpre[a] = ok ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.res) + (size_t)gm * p.ldo + gn) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+
     // ---- main loop: NS-deep LDS ring, NS-1 k-tiles of DMA in flight, ONE raw barrier per k-tile and a COUNTED
     // vmcnt so the younger tiles' DMA stays in flight across the barrier (a plain __syncthreads() would drain it)
 #pragma unroll
@@ -476,7 +495,10 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                     }
                     if (resp) {
                         float rr[4];
-                        load4<TOUT>(resp + o, rr);
+                        if constexpr (RES_EARLY) {
+                            if (res_early) { rr[0] = rpre[a][0]; rr[1] = rpre[a][1]; rr[2] = rpre[a][2]; rr[3] = rpre[a][3]; }
+                            else load4<TOUT>(resp + o, rr);
+                        } else load4<TOUT>(resp + o, rr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += rr[r];
                     }
@@ -1010,6 +1032,7 @@ static int launch_igemm(const IgemmParams& p_in, hipStream_t stream, const char*
     // short K loops (<= 2 k-tiles) are pure load->store latency chains: 64-row tiles halve the LDS footprint so
     // three workgroups fit a CU
     int bm = (p.K / BKE) <= 2 ? 64 : 128;
+    // (split-fp16 conv3 of layer 2 -- four k-tiles, residual -- through 64-row tiles with the early residual request: 184-188 us against 167-170)
     if (cdiv(p.M, 128) * cdiv(p.N, narrow ? 64 : 128) < 400) bm = 64;  // too few 128-row tiles to fill 256 CUs twice
     const int grid = cdiv(p.M, bm) * cdiv(p.N, narrow ? 64 : 128);
     // 8-wave workgroups (4 x 2 wave grid) beat 4-wave ones by 3-14 % at equal tile size (A/B measured)
