@@ -352,3 +352,48 @@ def test_weight_packs_are_cached_per_precision(monkeypatch):
             assert V.pack_weights(m, dev, "fp16x3") is not p1
     finally:
         ops._SWITCHES.clear()
+
+
+def test_split16_weight_packers_follow_their_layout_contract():
+    """The host-side packers of the conforming mode against include/agrl_hip.h, element by element (no GPU: pack-time torch logic).
+    split16_inloop_weights: every 32-value k-tile of a row becomes [hi(k 4c..4c+3, 16+4c..16+4c+3), c = 0..3 | lo in the same order];
+    split16_plane_weights: [wh | wh 2^-11 | wl] per source, and with pair_first the first source per 128-channel slab [wh | wl | wh 2^-11];
+    both on w 2^k with max |w| 2^k in [2^13, 2^14), hi + lo reproducing w 2^k to 2^-21 of the largest weight."""
+    import numpy as np
+    import torch
+    from torchreid import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn((6, 64), generator=g) * 0.03
+    w[0, :3] = torch.tensor([0.0, 1e-9, -2e-7])
+    p = ops.split16_inloop_weights(w)
+    k = round(np.log2(1.0 / p.agrl_unscale))
+    ws = (w * 2.0 ** k).numpy()
+    assert 2 ** 13 <= np.abs(ws).max() < 2 ** 14 and p.agrl_presplit and tuple(p.shape) == (6, 64) and p.dtype == torch.float32
+    halves = p.numpy().view(np.float16).reshape(6, 2, 2, 4, 8)          # (row, tile, {hi, lo}, c, e)
+    for row in range(6):
+        for tile in range(2):
+            for c in range(4):
+                idx = [32 * tile + 4 * c + e for e in range(4)] + [32 * tile + 16 + 4 * c + e for e in range(4)]
+                hi = ws[row, idx].astype(np.float16)
+                lo = (ws[row, idx] - hi.astype(np.float32)).astype(np.float16)
+                assert np.array_equal(halves[row, tile, 0, c], hi) and np.array_equal(halves[row, tile, 1, c], lo)
+    assert torch.equal(ops.split16_true_weights(p), w)
+    # plane weights: a two-source tensor [W1 (256) | W2 (128)], triples and the pair form of the first source
+    w2 = torch.randn((4, 384), generator=g) * 0.05
+    t, u = ops.split16_plane_weights(w2, segments=[256, 128])
+    tp, up = ops.split16_plane_weights(w2, segments=[256, 128], pair_first=True)
+    assert u == up and t.dtype == torch.float16 and tuple(t.shape) == tuple(tp.shape) == (4, 3 * 384)
+    s2 = (w2 / u).numpy()
+    wh = s2.astype(np.float16)
+    wl = (s2 - wh.astype(np.float32)).astype(np.float16)
+    whs = (wh.astype(np.float32) * 2.0 ** -11).astype(np.float16)
+    tn, tpn = t.numpy(), tp.numpy()
+    assert np.array_equal(tn[:, :256], wh[:, :256]) and np.array_equal(tn[:, 256:512], whs[:, :256]) and np.array_equal(tn[:, 512:768], wl[:, :256])
+    assert np.array_equal(tn[:, 768:896], wh[:, 256:]) and np.array_equal(tn[:, 896:1024], whs[:, 256:]) and np.array_equal(tn[:, 1024:], wl[:, 256:])
+    for c in range(2):      # first source, slab c: [wh_c | wl_c | wh_c 2^-11]
+        base = 384 * c
+        assert np.array_equal(tpn[:, base:base + 128], wh[:, 128 * c:128 * c + 128])
+        assert np.array_equal(tpn[:, base + 128:base + 256], wl[:, 128 * c:128 * c + 128])
+        assert np.array_equal(tpn[:, base + 256:base + 384], whs[:, 128 * c:128 * c + 128])
+    assert np.array_equal(tpn[:, 768:], tn[:, 768:])       # the second source stays a triple
+    assert np.abs(wh.astype(np.float64) + wl.astype(np.float64) - s2).max() <= 2.0 ** -21 * np.abs(s2).max()
