@@ -208,25 +208,6 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
         }
     }
 
-    // split-fp16, short K (conv3 of layers 1-2: two to four k-tiles, then a residual as large as the result): the residual is requested
-    // NOW, behind the first k-tiles' DMA, instead of at the head of the epilogue -- one HBM round trip per tile less on the critical path.
-    // 64-row tiles only (FM = 1: 4 x FN registers; the 128-row tile has no room beside its 115)
-    constexpr bool RES_EARLY = DT<TIN>::code == AGRL_F32H3 && sizeof(TOUT) == 4 && !LDS_EPI && FM == 1;
-    f32x4_t rpre[RES_EARLY ? FN : 1];
-    bool res_early = false;
-    if constexpr (RES_EARLY) {
-        res_early = p.res != nullptr && p.vec_ok && !p.out_pre && !p.out_planes && !p.mix_f && nk <= 4;
-        if (res_early) {
-            const int gm = m0 + wm * (BM / WM) + (lane & 15);
-#pragma unroll
-            for (int a = 0; a < FN; ++a) {
-                const int gn = n0 + wn * (BN / 2) + a * 16 + (lane >> 4) * 4;
-                const bool ok = gm < p.M && gn + 3 < p.N;
-                rpre[a] = ok ? *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.res) + (size_t)gm * p.ldo + gn) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    }
-
     // ---- main loop: NS-deep LDS ring, NS-1 k-tiles of DMA in flight, ONE raw barrier per k-tile and a COUNTED
     // vmcnt so the younger tiles' DMA stays in flight across the barrier (a plain __syncthreads() would drain it)
 #pragma unroll
@@ -455,6 +436,62 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
                 return;
             }
         }
+        if constexpr (sizeof(TIN) == 4 && sizeof(TOUT) == 4) {
+            // fp32 result (+ fp32 residual) of the fp32-tensor convs (exact, split-bf16, split-fp16; measured on the split-fp16 ones) -- conv3 / conv3 + downsample of layers 1-2: two to twelve k-tiles, then a
+            // result and a residual of 268-537 MB each. Straight from the accumulator layout a wave instruction touches 16 rows with 64
+            // bytes each (half cache lines: with the ablation library the stores are 68 of 314 us in 64 -> 256 and, with the residual loads,
+            // 94 of 185 in 128 -> 512, profiles/r06_split16_inloop_ablation.txt). So, as the 16-bit epilogue above: alpha acc + bias is parked
+            // in the (now free) ring as a BM x BN fp32 image, 16-byte chunk c of row r at c ^ (r & (CPR - 1)); then every thread owns whole
+            // chunks of whole rows -- residual load, ReLU, store: a wave covers 1 KiB of consecutive row bytes per instruction.
+            constexpr int CPR32 = BN * 4 / 16, ROWB32 = BN * 4, RPT32 = 64 * NW / CPR32;
+            static_assert(BM * ROWB32 <= NS * BUF_BYTES, "the fp32 out image fits the ring");
+            const bool full = p.vec_ok && !p.mix_f && !p.stats && !p.rowv && p.ksplit <= 1 && n0 + BN <= p.N && (p.ldo & 3) == 0 &&
+                              ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.res)) & 15) == 0;   // workgroup-uniform
+            if (full) {
+                unsigned char* so = smem;
+                const int pch = tid % CPR32, r0 = tid / CPR32;
+                const float* __restrict__ resf = reinterpret_cast<const float*>(p.res);
+                float* __restrict__ outf = reinterpret_cast<float*>(p.out);
+                // the residual chunks this thread will add, requested now: their round trip runs under the parking of the tile and the barrier
+                float4 rpf[BM / RPT32];
+                const bool has_res = resf != nullptr && !(AGRL_DBG_BITS(p) & 2);
+                if (has_res) {
+#pragma unroll
+                    for (int i = 0; i < BM / RPT32; ++i) {
+                        const int row = r0 + i * RPT32;
+                        const int gm = m0 + row < p.M ? m0 + row : p.M - 1;
+                        rpf[i] = *reinterpret_cast<const float4*>(resf + (size_t)gm * p.ldo + n0 + ((pch ^ (row & (CPR32 - 1))) << 2));
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const int prow = wm * (BM / WM) + b * 16 + frow;
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) {
+                        const int c = wn * (BN / 2) + a * 16 + fchunk * 4;
+                        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.colv) cv = *reinterpret_cast<const float4*>(p.colv + n0 + c);
+                        const float4 v = make_float4(fmaf(p.alpha, acc[a][b][0], p.rowc + cv.x), fmaf(p.alpha, acc[a][b][1], p.rowc + cv.y),
+                                                     fmaf(p.alpha, acc[a][b][2], p.rowc + cv.z), fmaf(p.alpha, acc[a][b][3], p.rowc + cv.w));
+                        *reinterpret_cast<float4*>(so + prow * ROWB32 + (((c >> 2) ^ (prow & (CPR32 - 1))) << 4)) = v;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < BM / RPT32; ++i) {
+                    const int row = r0 + i * RPT32;
+                    const int gm = m0 + row;
+                    if (gm >= p.M) continue;
+                    const int gch = pch ^ (row & (CPR32 - 1));
+                    const size_t o = (size_t)gm * p.ldo + n0 + gch * 4;
+                    float4 v = *reinterpret_cast<const float4*>(so + row * ROWB32 + (pch << 4));
+                    if (has_res) { v.x += rpf[i].x; v.y += rpf[i].y; v.z += rpf[i].z; v.w += rpf[i].w; }
+                    if (p.relu) { v.x = relu_nan(v.x); v.y = relu_nan(v.y); v.z = relu_nan(v.z); v.w = relu_nan(v.w); }
+                    if (!(AGRL_DBG_BITS(p) & 1)) *reinterpret_cast<float4*>(outf + o) = v;
+                }
+                return;
+            }
+        }
         const bool vec_ok = p.vec_ok != 0;
         const bool do_stats = p.stats != nullptr;   // workgroup-uniform
         float st1[FN][4], st2[FN][4];
@@ -493,12 +530,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaf(p.alpha, acc[a][b][r], rv + cv[r]);
                     }
-                    if (resp) {
+                    if (resp && !(AGRL_DBG_BITS(p) & 2)) {
                         float rr[4];
-                        if constexpr (RES_EARLY) {
-                            if (res_early) { rr[0] = rpre[a][0]; rr[1] = rpre[a][1]; rr[2] = rpre[a][2]; rr[3] = rpre[a][3]; }
-                            else load4<TOUT>(resp + o, rr);
-                        } else load4<TOUT>(resp + o, rr);
+                        load4<TOUT>(resp + o, rr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += rr[r];
                     }
@@ -506,7 +540,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = relu_nan(v[r]);
                     }
-                    store4<TOUT>(outp + o, v);
+                    if (!(AGRL_DBG_BITS(p) & 1)) store4<TOUT>(outp + o, v);
                     if (do_stats) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { st1[a][r] += v[r]; st2[a][r] = fmaf(v[r], v[r], st2[a][r]); }
