@@ -445,6 +445,9 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(const IgemmParams p) {
             // chunks of whole rows -- residual load, ReLU, store: a wave covers 1 KiB of consecutive row bytes per instruction.
             constexpr int CPR32 = BN * 4 / 16, ROWB32 = BN * 4, RPT32 = 64 * NW / CPR32;
             static_assert(BM * ROWB32 <= NS * BUF_BYTES, "the fp32 out image fits the ring");
+            // (a PRE-SPLIT result, conv1 / conv2 of a split-fp16 Bottleneck, was tried on the same road -- halves formed in the parking pass, whole
+            // rows copied out -- and measured 25-30 us per step SLOWER than the register stores above, whose hi and lo chunks already complete
+            // a 128-byte line per 16-lane group within two instructions: same-box A/B of tools/profile_layers.py, 10.31 / 10.27 against 10.28 / 10.24 ms)
             const bool full = p.vec_ok && !p.mix_f && !p.stats && !p.rowv && p.ksplit <= 1 && n0 + BN <= p.N && (p.ldo & 3) == 0 &&
                               ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.res)) & 15) == 0;   // workgroup-uniform
             if (full) {
